@@ -1,0 +1,440 @@
+"""ctypes binding of the CPU oracle (oracle/libpg_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+
+PARITY UNPINNED: see oracle/pg_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpg_oracle.so")
+
+FRAC_BITS = 40
+W_CLAMP_LOG2 = 48
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (needs only oracle/*.c, no reference files)."""
+    srcs = [os.path.join(_HERE, f) for f in ("pg_oracle.c", "pg_oracle.h", "pgo_math.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s)
+    )
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_P = C.c_void_p
+_SZ = C.c_size_t
+
+
+def _declare(L):
+    L.pgo_tree_new.restype = _P
+    L.pgo_tree_free.argtypes = [_P]
+    L.pgo_tree_setup.argtypes = [_P, _P, _P, C.c_int, C.c_int, C.c_int]
+    L.pgo_tree_copy_from.argtypes = [_P, _P]
+    L.pgo_get_leaf_node_index.argtypes = [_P, _SZ, _P, _P, _P]
+    L.pgo_sample.argtypes = [_P, _SZ, _P, _P, _P, _P, _P, _P]
+    L.pgo_pdf.argtypes = [_P, _SZ, _P, _P, _P, _P]
+    L.pgo_sample_quadtree.argtypes = [_P, _SZ, _P, _P, _P, _P, _P]
+    L.pgo_pdf_quadtree.argtypes = [_P, _SZ, _P, _P, _P, _P]
+    L.pgo_add_data_propagate.argtypes = [_P, _SZ, _P, _P, _P, _P, _P, _P]
+    L.pgo_process_records.restype = _SZ
+    L.pgo_process_records.argtypes = [_SZ, _SZ] + [_P] * 16
+    for name in (
+        "pgo_finalize_accumulators",
+        "pgo_kd_refine",
+        "pgo_set_quadtree_refinement_threshold",
+        "pgo_refine_all_quadtree",
+        "pgo_clean_unused_quadtree",
+        "pgo_reset",
+    ):
+        getattr(L, name).argtypes = [_P]
+    L.pgo_set_refinement_threshold.argtypes = [_P, C.c_int]
+    L.pgo_refine_and_prepare.argtypes = [_P, _P, C.c_int]
+    for name in ("pgo_kd_size", "pgo_quad_size", "pgo_quad_roots"):
+        getattr(L, name).argtypes = [_P]
+        getattr(L, name).restype = _SZ
+    L.pgo_kd_max_leaf_size.argtypes = [_P]
+    L.pgo_kd_max_leaf_size.restype = C.c_double
+    for name in ("pgo_kd_max_depth", "pgo_quad_max_depth", "pgo_quad_store_nee"):
+        getattr(L, name).argtypes = [_P]
+        getattr(L, name).restype = C.c_int
+    L.pgo_kd_column.argtypes = [_P, C.c_char_p]
+    L.pgo_kd_column.restype = _P
+    L.pgo_quad_column.argtypes = [_P, C.c_char_p]
+    L.pgo_quad_column.restype = _P
+    L.pgo_tree_load.argtypes = (
+        [_P, _SZ] + [_P] * 8 + [C.c_double, C.c_int, _SZ, _P, _SZ] + [_P] * 10 + [C.c_int, C.c_int]
+    )
+    L.pgo_kd_split.argtypes = [_P, _SZ, _P]
+    L.pgo_quad_split.argtypes = [_P, _SZ, _P]
+    L.pgo_kd_all_leaves.argtypes = [_P, _P, _P]
+    L.pgo_quad_all_leaves.argtypes = [_P, _P, _P]
+    L.pgo_canonical_to_dir_v.argtypes = [_SZ, _P, _P]
+    L.pgo_dir_to_canonical_v.argtypes = [_SZ, _P, _P]
+    L.pgo_rng_seed.argtypes = [_SZ, C.c_uint32, C.c_uint32, _P, _P]
+    L.pgo_rng_next_f32.argtypes = [_SZ, _P, _P, _P]
+    L.pgo_quantize_v.argtypes = [_SZ, _P, _P, _P]
+    L.pgo_acc_to_float_v.argtypes = [_SZ, _P, _P, _P]
+    L.pgo_sincos_v.argtypes = [_SZ, _P, _P]
+    L.pgo_atan2_v.argtypes = [_SZ, _P, _P, _P]
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        assert a.shape == shape, (a.shape, shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _mask(active, n):
+    if active is None:
+        return None
+    m = np.ascontiguousarray(active, dtype=np.uint8)
+    assert m.shape == (n,)
+    return m
+
+
+# ---- scalar helper wrappers -------------------------------------------------
+
+def canonical_to_dir(p2):
+    p2 = _f32(p2)
+    n = p2.shape[1]
+    out = np.empty((3, n), np.float32)
+    lib().pgo_canonical_to_dir_v(n, _ptr(p2), _ptr(out))
+    return out
+
+
+def dir_to_canonical(d3):
+    d3 = _f32(d3)
+    n = d3.shape[1]
+    out = np.empty((2, n), np.float32)
+    lib().pgo_dir_to_canonical_v(n, _ptr(d3), _ptr(out))
+    return out
+
+
+def rng_seed(n, seed, lane0=0):
+    st = np.empty(n, np.uint64)
+    inc = np.empty(n, np.uint64)
+    lib().pgo_rng_seed(n, seed, lane0, _ptr(st), _ptr(inc))
+    return st, inc
+
+
+def rng_next_f32(state, inc):
+    out = np.empty(state.shape[0], np.float32)
+    lib().pgo_rng_next_f32(state.shape[0], _ptr(state), _ptr(inc), _ptr(out))
+    return out
+
+
+def quantize(w):
+    w = _f32(w)
+    lo = np.empty(w.shape[0], np.uint64)
+    hi = np.empty(w.shape[0], np.int64)
+    lib().pgo_quantize_v(w.shape[0], _ptr(w), _ptr(lo), _ptr(hi))
+    return lo, hi
+
+
+def acc_to_float(lo, hi):
+    lo = np.ascontiguousarray(lo, np.uint64)
+    hi = np.ascontiguousarray(hi, np.int64)
+    out = np.empty(lo.shape[0], np.float32)
+    lib().pgo_acc_to_float_v(lo.shape[0], _ptr(lo), _ptr(hi), _ptr(out))
+    return out
+
+
+def sincos(phi):
+    phi = _f32(phi)
+    s = np.empty_like(phi)
+    c = np.empty_like(phi)
+    lib().pgo_sincos_v(phi.shape[0], _ptr(phi), _ptr(s), _ptr(c))
+    return s, c
+
+
+def atan2(y, x):
+    y = _f32(y)
+    x = _f32(x)
+    out = np.empty_like(y)
+    lib().pgo_atan2_v(y.shape[0], _ptr(y), _ptr(x), _ptr(out))
+    return out
+
+
+def process_records(num_rays, max_depth, Lfinal, rec):
+    """rec: dict of dense columns (planar): active, position(3,S), direction(2,S), bsdf(3,S),
+    throughputBsdf(3,S), throughputRadiance(3,S), radiance_nee(3,S), direction_nee(2,S), woPdf(S)."""
+    S = num_rays * max_depth
+    Lfinal = _f32(Lfinal, (3, num_rays))
+    act = np.ascontiguousarray(rec["active"], np.uint8)
+    cols = {
+        k: _f32(rec[k])
+        for k in (
+            "position", "direction", "bsdf", "throughputBsdf", "throughputRadiance",
+            "radiance_nee", "direction_nee", "woPdf",
+        )
+    }
+    o = {
+        "position": np.zeros((3, S), np.float32),
+        "direction": np.zeros((2, S), np.float32),
+        "radiance": np.zeros(S, np.float32),
+        "woPdf": np.zeros(S, np.float32),
+        "direction_nee": np.zeros((2, S), np.float32),
+        "radiance_nee_lum": np.zeros(S, np.float32),
+    }
+    kept = lib().pgo_process_records(
+        num_rays, max_depth, _ptr(Lfinal), _ptr(act), _ptr(cols["position"]), _ptr(cols["direction"]),
+        _ptr(cols["bsdf"]), _ptr(cols["throughputBsdf"]), _ptr(cols["throughputRadiance"]),
+        _ptr(cols["radiance_nee"]), _ptr(cols["direction_nee"]), _ptr(cols["woPdf"]),
+        _ptr(o["position"]), _ptr(o["direction"]), _ptr(o["radiance"]), _ptr(o["woPdf"]),
+        _ptr(o["direction_nee"]), _ptr(o["radiance_nee_lum"]),
+    )
+    return {k: np.ascontiguousarray(v[..., :kept]) for k, v in o.items()}
+
+
+_KD_COLS = {
+    "bbox_min": (np.float32, 3), "bbox_max": (np.float32, 3), "depth": (np.uint32, 1),
+    "vertCount": (np.float32, 1), "isLeaf": (np.uint8, 1), "quadTreeRootIndex": (np.uint32, 1),
+    "child_left_index": (np.uint32, 1), "child_right_index": (np.uint32, 1), "count": (np.uint64, 1),
+}
+_Q_COLS = {
+    "bbox_min": (np.float32, 2), "bbox_max": (np.float32, 2), "depth": (np.uint32, 1),
+    "irradiance": (np.float32, 1), "isLeaf": (np.uint8, 1), "refinementThreshold": (np.float32, 1),
+    "child_1_index": (np.uint32, 1), "child_2_index": (np.uint32, 1), "child_3_index": (np.uint32, 1),
+    "child_4_index": (np.uint32, 1), "acc_lo": (np.uint64, 1), "acc_hi": (np.int64, 1),
+}
+
+
+class OracleTree:
+    """One SD-tree (KDTree + QuadTree forest) of the CPU restatement."""
+
+    def __init__(self):
+        self._h = lib().pgo_tree_new()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pgo_tree_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # --- lifecycle
+    def setup(self, bbox_min, bbox_max, kd_max_depth=10, quad_max_depth=30, store_nee=True):
+        bmin = _f32(bbox_min, (3,))
+        bmax = _f32(bbox_max, (3,))
+        lib().pgo_tree_setup(self._h, _ptr(bmin), _ptr(bmax), kd_max_depth, quad_max_depth, int(store_nee))
+
+    def copy_from(self, other: "OracleTree"):
+        lib().pgo_tree_copy_from(self._h, other._h)
+
+    # --- queries (positions/directions planar (3,n))
+    def get_leaf_node_index(self, p, active=None):
+        p = _f32(p)
+        n = p.shape[1]
+        out = np.empty(n, np.uint32)
+        lib().pgo_get_leaf_node_index(self._h, n, _ptr(p), _ptr(_mask(active, n)), _ptr(out))
+        return out
+
+    def sample(self, p, rng_state, rng_inc, active=None):
+        p = _f32(p)
+        n = p.shape[1]
+        d = np.empty((3, n), np.float32)
+        pdf = np.empty(n, np.float32)
+        lib().pgo_sample(self._h, n, _ptr(p), _ptr(rng_state), _ptr(rng_inc), _ptr(_mask(active, n)), _ptr(d), _ptr(pdf))
+        return d, pdf
+
+    def pdf(self, p, d, active=None):
+        p = _f32(p)
+        d = _f32(d)
+        n = p.shape[1]
+        pdf = np.empty(n, np.float32)
+        lib().pgo_pdf(self._h, n, _ptr(p), _ptr(d), _ptr(_mask(active, n)), _ptr(pdf))
+        return pdf
+
+    def sample_quadtree(self, root_index, rng_state, rng_inc, active=None):
+        r = np.ascontiguousarray(root_index, np.uint32)
+        n = r.shape[0]
+        d = np.empty((3, n), np.float32)
+        lib().pgo_sample_quadtree(self._h, n, _ptr(r), _ptr(rng_state), _ptr(rng_inc), _ptr(_mask(active, n)), _ptr(d))
+        return d
+
+    def pdf_quadtree(self, root_index, d, active=None):
+        r = np.ascontiguousarray(root_index, np.uint32)
+        d = _f32(d)
+        n = r.shape[0]
+        pdf = np.empty(n, np.float32)
+        lib().pgo_pdf_quadtree(self._h, n, _ptr(r), _ptr(d), _ptr(_mask(active, n)), _ptr(pdf))
+        return pdf
+
+    # --- splat
+    def add_data_propagate(self, position, direction, radiance, wo_pdf, direction_nee, radiance_nee_lum):
+        position = _f32(position)
+        m = position.shape[1]
+        direction = _f32(direction, (2, m))
+        radiance = _f32(radiance, (m,))
+        wo_pdf = _f32(wo_pdf, (m,))
+        direction_nee = _f32(direction_nee, (2, m))
+        radiance_nee_lum = _f32(radiance_nee_lum, (m,))
+        lib().pgo_add_data_propagate(
+            self._h, m, _ptr(position), _ptr(direction), _ptr(radiance), _ptr(wo_pdf),
+            _ptr(direction_nee), _ptr(radiance_nee_lum),
+        )
+
+    # --- refine steps
+    def finalize_accumulators(self):
+        lib().pgo_finalize_accumulators(self._h)
+
+    def set_refinement_threshold(self, iteration):
+        lib().pgo_set_refinement_threshold(self._h, iteration)
+
+    def kd_refine(self):
+        lib().pgo_kd_refine(self._h)
+
+    def set_quadtree_refinement_threshold(self):
+        lib().pgo_set_quadtree_refinement_threshold(self._h)
+
+    def refine_all_quadtree(self):
+        lib().pgo_refine_all_quadtree(self._h)
+
+    def clean_unused_quadtree(self):
+        lib().pgo_clean_unused_quadtree(self._h)
+
+    def reset(self):
+        lib().pgo_reset(self._h)
+
+    # --- forced splits (reference self-tests: kdtree.py:708-712, quadtree.py:1143-1152)
+    def kd_all_leaves(self):
+        out = np.empty(self.kd_size, np.uint32)
+        n = C.c_size_t(0)
+        lib().pgo_kd_all_leaves(self._h, _ptr(out), C.byref(n))
+        return out[: n.value].copy()
+
+    def quad_all_leaves(self):
+        out = np.empty(self.quad_size, np.uint32)
+        n = C.c_size_t(0)
+        lib().pgo_quad_all_leaves(self._h, _ptr(out), C.byref(n))
+        return out[: n.value].copy()
+
+    def kd_split(self, idx):
+        idx = np.ascontiguousarray(idx, np.uint32)
+        lib().pgo_kd_split(self._h, idx.shape[0], _ptr(idx))
+
+    def quad_split(self, idx):
+        idx = np.ascontiguousarray(idx, np.uint32)
+        lib().pgo_quad_split(self._h, idx.shape[0], _ptr(idx))
+
+    # --- export
+    @property
+    def kd_size(self):
+        return lib().pgo_kd_size(self._h)
+
+    @property
+    def quad_size(self):
+        return lib().pgo_quad_size(self._h)
+
+    @property
+    def quad_roots(self):
+        return lib().pgo_quad_roots(self._h)
+
+    def kd_column(self, name):
+        dt, w = _KD_COLS[name]
+        n = self.kd_size
+        p = lib().pgo_kd_column(self._h, name.encode())
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n * w,)).copy()
+        return a.reshape(n, w) if w > 1 else a
+
+    def quad_column(self, name):
+        if name == "rootNodeIndex":
+            n = self.quad_roots
+            p = lib().pgo_quad_column(self._h, b"rootNodeIndex")
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+        dt, w = _Q_COLS[name]
+        n = self.quad_size
+        p = lib().pgo_quad_column(self._h, name.encode())
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n * w,)).copy()
+        return a.reshape(n, w) if w > 1 else a
+
+    def export(self) -> dict:
+        """The reference's 23-key npz schema (kdtree.py:575-602), plus exact accumulators."""
+        L = lib()
+        d = {
+            "kdtree_maxLeafSize": np.float64(L.pgo_kd_max_leaf_size(self._h)),
+            "kdtree_maxDepth": np.int64(L.pgo_kd_max_depth(self._h)),
+            "quadtree_maxDepth": np.int64(L.pgo_quad_max_depth(self._h)),
+            "quadtree_isStoreNEERadiance": np.bool_(L.pgo_quad_store_nee(self._h)),
+        }
+        for k in ("bbox_min", "bbox_max", "depth", "vertCount", "isLeaf", "quadTreeRootIndex",
+                  "child_left_index", "child_right_index"):
+            v = self.kd_column(k)
+            d["kdtree_" + k] = v.astype(bool) if k == "isLeaf" else v
+        d["quadtree_rootNodeIndex"] = self.quad_column("rootNodeIndex")
+        for k in ("bbox_min", "bbox_max", "depth", "irradiance", "isLeaf", "refinementThreshold",
+                  "child_1_index", "child_2_index", "child_3_index", "child_4_index"):
+            v = self.quad_column(k)
+            d["quadtree_" + k] = v.astype(bool) if k == "isLeaf" else v
+        return d
+
+    def load(self, d: dict):
+        """Inverse of export() (kdtree.py:156-170)."""
+        kb0 = _f32(d["kdtree_bbox_min"]); kb1 = _f32(d["kdtree_bbox_max"])
+        kdepth = np.ascontiguousarray(d["kdtree_depth"], np.uint32)
+        kvc = _f32(d["kdtree_vertCount"])
+        kleaf = np.ascontiguousarray(d["kdtree_isLeaf"], np.uint8)
+        kq = np.ascontiguousarray(d["kdtree_quadTreeRootIndex"], np.uint32)
+        kl = np.ascontiguousarray(d["kdtree_child_left_index"], np.uint32)
+        kr = np.ascontiguousarray(d["kdtree_child_right_index"], np.uint32)
+        qroot = np.ascontiguousarray(d["quadtree_rootNodeIndex"], np.uint32)
+        qb0 = _f32(d["quadtree_bbox_min"]); qb1 = _f32(d["quadtree_bbox_max"])
+        qdepth = np.ascontiguousarray(d["quadtree_depth"], np.uint32)
+        qirr = _f32(d["quadtree_irradiance"])
+        qleaf = np.ascontiguousarray(d["quadtree_isLeaf"], np.uint8)
+        qthr = _f32(d["quadtree_refinementThreshold"])
+        qc = [np.ascontiguousarray(d["quadtree_child_%d_index" % i], np.uint32) for i in (1, 2, 3, 4)]
+        lib().pgo_tree_load(
+            self._h, kdepth.shape[0], _ptr(kb0), _ptr(kb1), _ptr(kdepth), _ptr(kvc), _ptr(kleaf), _ptr(kq),
+            _ptr(kl), _ptr(kr), float(d["kdtree_maxLeafSize"]), int(d["kdtree_maxDepth"]), qroot.shape[0],
+            _ptr(qroot), qdepth.shape[0], _ptr(qb0), _ptr(qb1), _ptr(qdepth), _ptr(qirr), _ptr(qleaf), _ptr(qthr),
+            _ptr(qc[0]), _ptr(qc[1]), _ptr(qc[2]), _ptr(qc[3]), int(d["quadtree_maxDepth"]),
+            int(bool(d["quadtree_isStoreNEERadiance"])),
+        )
+
+
+class OracleSDTreePair:
+    """sdTree_prev / sdTree_current pair with the integrator's refine lifecycle
+    (path_guiding_integrator.py:68-69, 77-105, 566-586)."""
+
+    def __init__(self):
+        self.prev = OracleTree()
+        self.current = OracleTree()
+        self.iteration = 0
+
+    def setup(self, bbox_min, bbox_max, sdTreeMaxDepth=10, quadTreeMaxDepth=30, isStoreNEERadiance=True):
+        self.current.setup(bbox_min, bbox_max, sdTreeMaxDepth, quadTreeMaxDepth, isStoreNEERadiance)
+        self.prev.copy_from(self.current)
+
+    def refine_and_prepare(self, iteration=None):
+        it = self.iteration if iteration is None else iteration
+        lib().pgo_refine_and_prepare(self.current._h, self.prev._h, it)
