@@ -1,0 +1,226 @@
+/*
+ * pgsd.h -- C ABI of libpgsd.so, the MI355X-native SD-tree ("spatial-directional tree")
+ * path-guiding library.  This is the drop-in boundary for the hot path of
+ * takkasila/practical_path_guiding_lab: everything the reference's Python integrator does
+ * with its two KDTree objects (src/path_guiding_integrator.py -> src/kdtree.py ->
+ * src/quadtree.py) is reachable through these entry points.  Citations below are
+ * file:line in that repository.
+ *
+ * Conventions
+ *  - Plain C, no exceptions cross the boundary.  Every call returns PG_OK (0) or a negative
+ *    pg_status; pg_last_error() returns a human-readable message for the last failure.
+ *  - All bulk pointers are DEVICE pointers owned by the caller unless a parameter is named
+ *    `h_*` (host).  The library owns the trees.  `stream` is a hipStream_t (NULL = default
+ *    stream); calls are asynchronous on it unless stated otherwise.
+ *  - Vector arrays are planar SoA: a Vector3f[n] is 3*n floats, plane-major
+ *    (x[0..n) y[0..n) z[0..n)); a Vector2f[n] likewise with 2 planes.  This is how Dr.Jit
+ *    stores mi.Vector3f and gives coalesced per-lane loads.
+ *  - Masks are one byte per lane (0 = inactive); a NULL mask means "all active".
+ *  - Arithmetic contract: DESIGN.md section 4 (fp32, no contraction; fixed-point accumulation).
+ */
+#ifndef PGSD_H
+#define PGSD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGSD_ABI_VERSION 1
+
+typedef struct pg_context pg_context;
+
+typedef enum pg_status {
+	PG_OK = 0,
+	PG_ERR_INVALID = -1,    /* bad argument / state                                   */
+	PG_ERR_HIP = -2,        /* a HIP runtime call failed (message has the HIP error)   */
+	PG_ERR_NOMEM = -3,      /* allocation failed                                       */
+	PG_ERR_FORMAT = -4,     /* imported tree violates the layout the kernels rely on   */
+	PG_ERR_NO_DEVICE = -5   /* no usable gfx950 device                                 */
+} pg_status;
+
+/* Fixed-point accumulation contract: weights are truncated to multiples of
+ * 2^-PG_FRAC_BITS after clamping |w| to 2^PG_W_CLAMP_LOG2; each accumulator is three signed
+ * 64-bit limbs of 32 payload bits (value = l0 + l1*2^32 + l2*2^64). */
+#define PG_FRAC_BITS 40
+#define PG_W_CLAMP_LOG2 48
+#define PG_ACC_LIMBS 3
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Creates a context bound to HIP device `device_ordinal`.  Fails with PG_ERR_NO_DEVICE when
+ * no GPU is visible: there is no CPU fallback. */
+int pg_create(pg_context **out, int device_ordinal);
+int pg_destroy(pg_context *ctx);
+/* ctx may be NULL: returns the message of the last failed pg_create on this thread. */
+const char *pg_last_error(const pg_context *ctx);
+int pg_abi_version(void);
+
+/* PathGuidingIntegrator.setup (path_guiding_integrator.py:77-105): both SD-trees become a
+ * single-leaf KD tree over [bbox_min,bbox_max] owning a single-leaf quadtree
+ * (kdtree.py:117-138, quadtree.py:350-362).  num_rays / max_depth size the dense record
+ * buffer of pg_process_records (path_guiding_integrator.py:93). */
+int pg_setup(pg_context *ctx, const float h_bbox_min[3], const float h_bbox_max[3],
+             uint64_t num_rays, int32_t max_depth, int32_t kd_max_depth, int32_t quad_max_depth,
+             int32_t store_nee, float bsdf_sampling_fraction);
+
+/* PathGuidingIntegrator.setIteration (path_guiding_integrator.py:121-123). */
+int pg_set_iteration(pg_context *ctx, int32_t iteration, int32_t is_final);
+
+/* ---- queries on sdTree_prev ----------------------------------------------------------- */
+
+/* KDTree.getLeafNodeIndex (kdtree.py:435-470): node index in the reference's numbering. */
+int pg_get_leaf_node_index(pg_context *ctx, uint64_t n, const float *p, const uint8_t *active,
+                           uint32_t *node_out, void *stream);
+
+/* KDTree.sample (kdtree.py:473-486): direction sampled from the quadtree of the leaf that
+ * contains p, and its pdf.  rng_state/rng_inc are per-lane PCG32 streams, advanced in place
+ * by 3 draws per visited quadtree node (quadtree.py:956, 980).  Inactive lanes return
+ * dir (0,0,-1), pdf 1 and leave their stream untouched. */
+int pg_sample(pg_context *ctx, uint64_t n, const float *p, uint64_t *rng_state,
+              const uint64_t *rng_inc, const uint8_t *active, float *dir_out, float *pdf_out,
+              void *stream);
+
+/* KDTree.pdf (kdtree.py:489-496). */
+int pg_pdf(pg_context *ctx, uint64_t n, const float *p, const float *dir, const uint8_t *active,
+           float *pdf_out, void *stream);
+
+/* The three SD-tree calls of one bounce (path_guiding_integrator.py:244, 301, 307) with a
+ * single KD descent:
+ *   pdf_nee_out[i] = sdTree_prev.pdf(p, dir_nee)             if nee_active[i]   (else 1)
+ *   select[i] == 2 : (dir_io, pdf_out) = sdTree_prev.sample(p, rng)   ("sdtree-mis" lanes)
+ *   select[i] == 1 : pdf_out = sdTree_prev.pdf(p, dir_io)             ("bsdf-mis" lanes)
+ *   select[i] == 0 : pdf_out = 1, dir_io untouched, stream untouched
+ * dir_io holds the BSDF-sampled world direction on entry. */
+int pg_guide_bounce(pg_context *ctx, uint64_t n, const float *p, const float *dir_nee,
+                    const uint8_t *nee_active, const uint8_t *select, float *dir_io,
+                    uint64_t *rng_state, const uint64_t *rng_inc, float *pdf_nee_out,
+                    float *pdf_out, void *stream);
+
+/* Mitsuba `independent` sampler seeding for lanes lane0..lane0+n (PCG32 + TEA). */
+int pg_rng_seed(pg_context *ctx, uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *rng_state,
+                uint64_t *rng_inc, void *stream);
+
+/* ---- recording into sdTree_current ---------------------------------------------------- */
+
+/* Compact record stream = what KDTree.addDataPropagate consumes (kdtree.py:180-225,
+ * quadtree.py:389-464) after scatterDataIntoSDTree's gathers
+ * (path_guiding_integrator.py:485-497).  radiance_nee_lum = mi.luminance(radiance_nee). */
+typedef struct pg_records {
+	const float *position;         /* Vector3f[m] planar */
+	const float *direction;        /* Vector2f[m] canonical, planar */
+	const float *radiance;         /* Float[m] */
+	const float *wo_pdf;           /* Float[m] */
+	const float *direction_nee;    /* Vector2f[m] canonical, planar (ignored if !store_nee) */
+	const float *radiance_nee_lum; /* Float[m]                       (ignored if !store_nee) */
+} pg_records;
+
+/* KDTree.addDataPropagate: adds the m records to sdTree_current.  If d_count is non-NULL it
+ * points to a device uint32 holding the number of valid records (<= m), e.g. the counter
+ * written by pg_process_records; otherwise all m are used. */
+int pg_splat(pg_context *ctx, uint64_t m, const pg_records *rec, const uint32_t *d_count,
+             void *stream);
+
+/* Dense per-pass record buffer, slot = ray*max_depth + depth
+ * (path_guiding_integrator.py:318-346). */
+typedef struct pg_dense_records {
+	const uint8_t *active;
+	const float *position;            /* Vector3f[S] */
+	const float *direction;           /* Vector2f[S] canonical */
+	const float *bsdf;                /* Color3f[S]  bsdf_weight */
+	const float *throughput_bsdf;     /* Color3f[S]  */
+	const float *throughput_radiance; /* Color3f[S]  */
+	const float *radiance_nee;        /* Color3f[S]  */
+	const float *direction_nee;       /* Vector2f[S] canonical */
+	const float *wo_pdf;              /* Float[S] */
+} pg_dense_records;
+
+typedef struct pg_records_out {
+	float *position, *direction, *radiance, *wo_pdf, *direction_nee, *radiance_nee_lum;
+} pg_records_out;
+
+/* processPathData + scatterDataIntoSDTree's filter (path_guiding_integrator.py:434-497):
+ * writes the surviving records (any order) with plane stride S = num_rays*max_depth and their
+ * number to *d_count (device uint32, zeroed by the call). */
+int pg_process_records(pg_context *ctx, uint64_t num_rays, int32_t max_depth, const float *l_final,
+                       const pg_dense_records *rec, const pg_records_out *out, uint32_t *d_count,
+                       void *stream);
+
+/* Same, fused with pg_splat: no intermediate stream (path_guiding_integrator.py:388-395). */
+int pg_process_and_splat(pg_context *ctx, uint64_t num_rays, int32_t max_depth,
+                         const float *l_final, const pg_dense_records *rec, void *stream);
+
+/* ---- per-iteration refinement --------------------------------------------------------- */
+
+/* refineAndPrepareSDTreeForNextIteration (path_guiding_integrator.py:566-586) with the
+ * iteration number given to pg_set_iteration: KD split, quadtree threshold/merge/split,
+ * canonical re-layout, prev <- current, reset.  Synchronises `stream`. */
+int pg_refine_and_swap(pg_context *ctx, void *stream);
+
+/* Views of sdTree_current's integer accumulators for the multi-GPU exchange: one contiguous
+ * device buffer of `count` int64 that is element-wise summable across ranks (topology is
+ * frozen during an iteration, so the buffers are index-aligned).  Sum it with an RCCL
+ * all-reduce (ncclInt64, ncclSum) before pg_refine_and_swap. */
+int pg_accumulators(pg_context *ctx, int64_t **d_buffer, uint64_t *count);
+
+/* ---- import / export in the reference's schema (kdtree.py:539-602) -------------------- */
+
+typedef struct pg_tree_sizes {
+	uint64_t n_kd, n_quad, n_roots;
+} pg_tree_sizes;
+
+/* HOST arrays in the reference's column layout: bbox columns are row-major [n][3] / [n][2]
+ * exactly as `.numpy()` yields them. */
+typedef struct pg_tree_columns {
+	double kd_max_leaf_size;
+	int32_t kd_max_depth, quad_max_depth, quad_store_nee;
+	float *kd_bbox_min, *kd_bbox_max;
+	uint32_t *kd_depth;
+	float *kd_vert_count;
+	uint8_t *kd_is_leaf;
+	uint32_t *kd_quad_root_index, *kd_child_left, *kd_child_right;
+	uint32_t *quad_root_node_index;
+	float *quad_bbox_min, *quad_bbox_max;
+	uint32_t *quad_depth;
+	float *quad_irradiance;
+	uint8_t *quad_is_leaf;
+	float *quad_threshold;
+	uint32_t *quad_child[4];
+} pg_tree_columns;
+
+/* Sizes of sdTree_prev in canonical layout. Synchronous. */
+int pg_export_sizes(pg_context *ctx, pg_tree_sizes *sizes);
+/* KDTree.saveToFile's columns for sdTree_prev (path_guiding_integrator.py:589-594). */
+int pg_export(pg_context *ctx, const pg_tree_sizes *sizes, pg_tree_columns *h_out);
+/* loadSDTreeFromFile (path_guiding_integrator.py:597-608): prev <- file, current <- reset copy. */
+int pg_import(pg_context *ctx, const pg_tree_sizes *sizes, const pg_tree_columns *h_in);
+/* Exact accumulators of sdTree_current resolved per canonical node (tests, diagnostics):
+ * kd_count[n_kd] (records through each KD node), quad_acc_lo/hi[n_quad] (128-bit sums). */
+int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t *h_kd_count,
+                           uint64_t *h_quad_acc_lo, int64_t *h_quad_acc_hi);
+
+/* ---- statistics for the roofline model ------------------------------------ */
+typedef struct pg_stats {
+	uint64_t n_kd_nodes, n_kd_leaves, n_quad_records, n_quad_nodes, n_trees;
+	double mean_kd_leaf_depth;   /* over KD leaves                           */
+	double mean_quad_leaf_depth; /* over quadtree leaves of all trees        */
+	uint32_t max_kd_depth, max_quad_depth;
+	uint64_t bytes_kd, bytes_quad_records, bytes_accumulators;
+} pg_stats;
+int pg_get_stats(pg_context *ctx, pg_stats *out);
+
+/* Measured mean descent depths of the last pg_guide_bounce / pg_splat launch (device counters;
+ * enabled by pg_enable_depth_counters(ctx, 1); off by default because they add atomics). */
+typedef struct pg_depth_counters {
+	uint64_t kd_levels, kd_queries;     /* sum of KD leaf depths, number of descents  */
+	uint64_t quad_levels, quad_queries; /* sum of quadtree leaf depths, descents      */
+} pg_depth_counters;
+int pg_enable_depth_counters(pg_context *ctx, int32_t on);
+int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGSD_H */

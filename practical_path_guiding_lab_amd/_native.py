@@ -1,0 +1,141 @@
+"""ctypes binding of libpgsd.so (include/pgsd.h).
+
+The library is the product: if it is missing, cannot be loaded, or finds no gfx950 device, this
+module raises.  There is deliberately no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpgsd.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+PG_OK = 0
+PG_ACC_LIMBS = 3
+PG_FRAC_BITS = 40
+
+
+class PgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpgsd error {code}: {msg}")
+        self.code = code
+
+
+class pg_records(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "position", "direction", "radiance", "wo_pdf", "direction_nee", "radiance_nee_lum")]
+
+
+class pg_dense_records(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "active", "position", "direction", "bsdf", "throughput_bsdf", "throughput_radiance",
+        "radiance_nee", "direction_nee", "wo_pdf")]
+
+
+class pg_records_out(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "position", "direction", "radiance", "wo_pdf", "direction_nee", "radiance_nee_lum")]
+
+
+class pg_tree_sizes(C.Structure):
+    _fields_ = [("n_kd", C.c_uint64), ("n_quad", C.c_uint64), ("n_roots", C.c_uint64)]
+
+
+class pg_tree_columns(C.Structure):
+    _fields_ = [
+        ("kd_max_leaf_size", C.c_double),
+        ("kd_max_depth", C.c_int32), ("quad_max_depth", C.c_int32), ("quad_store_nee", C.c_int32),
+        ("kd_bbox_min", C.c_void_p), ("kd_bbox_max", C.c_void_p), ("kd_depth", C.c_void_p),
+        ("kd_vert_count", C.c_void_p), ("kd_is_leaf", C.c_void_p), ("kd_quad_root_index", C.c_void_p),
+        ("kd_child_left", C.c_void_p), ("kd_child_right", C.c_void_p),
+        ("quad_root_node_index", C.c_void_p), ("quad_bbox_min", C.c_void_p), ("quad_bbox_max", C.c_void_p),
+        ("quad_depth", C.c_void_p), ("quad_irradiance", C.c_void_p), ("quad_is_leaf", C.c_void_p),
+        ("quad_threshold", C.c_void_p), ("quad_child", C.c_void_p * 4),
+    ]
+
+
+class pg_stats(C.Structure):
+    _fields_ = [
+        ("n_kd_nodes", C.c_uint64), ("n_kd_leaves", C.c_uint64), ("n_quad_records", C.c_uint64),
+        ("n_quad_nodes", C.c_uint64), ("n_trees", C.c_uint64),
+        ("mean_kd_leaf_depth", C.c_double), ("mean_quad_leaf_depth", C.c_double),
+        ("max_kd_depth", C.c_uint32), ("max_quad_depth", C.c_uint32),
+        ("bytes_kd", C.c_uint64), ("bytes_quad_records", C.c_uint64), ("bytes_accumulators", C.c_uint64),
+    ]
+
+
+class pg_depth_counters(C.Structure):
+    _fields_ = [("kd_levels", C.c_uint64), ("kd_queries", C.c_uint64),
+                ("quad_levels", C.c_uint64), ("quad_queries", C.c_uint64)]
+
+
+# every symbol include/pgsd.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "pg_create", "pg_destroy", "pg_last_error", "pg_abi_version", "pg_setup", "pg_set_iteration",
+    "pg_get_leaf_node_index", "pg_sample", "pg_pdf", "pg_guide_bounce", "pg_rng_seed", "pg_splat",
+    "pg_process_records", "pg_process_and_splat", "pg_refine_and_swap", "pg_accumulators",
+    "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
+    "pg_enable_depth_counters", "pg_read_depth_counters",
+)
+
+
+def build(force: bool = False) -> str:
+    """Compile libpgsd.so in-tree with hipcc --offload-arch=gfx950 (works without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). This package has no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    V, U64, I32, U32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
+    L.pg_last_error.restype = C.c_char_p
+    L.pg_last_error.argtypes = [V]
+    L.pg_abi_version.restype = C.c_int
+    L.pg_create.argtypes = [C.POINTER(V), C.c_int]
+    L.pg_destroy.argtypes = [V]
+    L.pg_setup.argtypes = [V, V, V, U64, I32, I32, I32, I32, C.c_float]
+    L.pg_set_iteration.argtypes = [V, I32, I32]
+    L.pg_get_leaf_node_index.argtypes = [V, U64, V, V, V, V]
+    L.pg_sample.argtypes = [V, U64, V, V, V, V, V, V, V]
+    L.pg_pdf.argtypes = [V, U64, V, V, V, V, V]
+    L.pg_guide_bounce.argtypes = [V, U64, V, V, V, V, V, V, V, V, V, V]
+    L.pg_rng_seed.argtypes = [V, U64, U32, U32, V, V, V]
+    L.pg_splat.argtypes = [V, U64, C.POINTER(pg_records), V, V]
+    L.pg_process_records.argtypes = [V, U64, I32, V, C.POINTER(pg_dense_records), C.POINTER(pg_records_out), V, V]
+    L.pg_process_and_splat.argtypes = [V, U64, I32, V, C.POINTER(pg_dense_records), V]
+    L.pg_refine_and_swap.argtypes = [V, V]
+    L.pg_accumulators.argtypes = [V, C.POINTER(V), C.POINTER(U64)]
+    L.pg_export_sizes.argtypes = [V, C.POINTER(pg_tree_sizes)]
+    L.pg_export.argtypes = [V, C.POINTER(pg_tree_sizes), C.POINTER(pg_tree_columns)]
+    L.pg_import.argtypes = [V, C.POINTER(pg_tree_sizes), C.POINTER(pg_tree_columns)]
+    L.pg_export_accumulators.argtypes = [V, C.POINTER(pg_tree_sizes), V, V, V]
+    L.pg_get_stats.argtypes = [V, C.POINTER(pg_stats)]
+    L.pg_enable_depth_counters.argtypes = [V, I32]
+    L.pg_read_depth_counters.argtypes = [V, C.POINTER(pg_depth_counters), I32]
+    for name in EXPORTS:
+        if name not in ("pg_last_error", "pg_abi_version"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(ctx, rc: int):
+    if rc != PG_OK:
+        msg = lib().pg_last_error(ctx)
+        raise PgError(rc, msg.decode() if msg else "")

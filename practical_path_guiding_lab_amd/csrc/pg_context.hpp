@@ -1,0 +1,120 @@
+// pg_context.hpp -- host-side state of one pg_context (library-owned device memory).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pgsd.h"
+#include "pg_kernels.hpp"
+#include "pg_tree.hpp"
+
+namespace pg {
+
+// Growable device array.  ensure() discards contents when it has to reallocate.
+template <class T> struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	~DevBuf() { release(); }
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	void release()
+	{
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+	hipError_t ensure(size_t n, double slack = 1.0)
+	{
+		if (n <= cap) return hipSuccess;
+		release();
+		size_t want = (size_t)((double)n * slack);
+		if (want < n) want = n;
+		if (want < 16) want = 16;
+		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+		if (e != hipSuccess) { p = nullptr; return e; }
+		cap = want;
+		return hipSuccess;
+	}
+	void swap(DevBuf &o)
+	{
+		T *tp = p; p = o.p; o.p = tp;
+		size_t tc = cap; cap = o.cap; o.cap = tc;
+	}
+};
+
+// One SD-tree topology + sampling values (sdTree_prev) + integer accumulators (sdTree_current).
+// The two reference objects always share their topology (prev <- copy of current after every
+// refine, path_guiding_integrator.py:582), so it is stored once.
+struct Forest {
+	// KD tree, reference node numbering
+	DevBuf<KdNode> kd;
+	DevBuf<float> kd_bmin, kd_bmax;  // [n_kd][3], kept for refine/export only
+	DevBuf<float> kd_vcount;         // fp32 vertCount column of sdTree_prev (export only)
+	uint32_t n_kd = 0;
+	// quadtree forest
+	DevBuf<QuadRec> rec;
+	uint32_t n_rec = 0;
+	std::vector<uint32_t> level_off; // level l records are [level_off[l], level_off[l+1])
+	DevBuf<TreeHead> head;
+	DevBuf<float> tree_thr;          // refinementThreshold of each tree (export only)
+	uint32_t n_trees = 0;
+	// accumulators of the running iteration: [rec_acc | root_acc | leaf_count]
+	DevBuf<long long> acc;
+	uint64_t acc_count() const { return (uint64_t)n_rec * 4 * 3 + (uint64_t)n_trees * 3 + n_trees; }
+	AccumView accum_view()
+	{
+		AccumView a;
+		a.rec_acc = acc.p;
+		a.root_acc = acc.p + (uint64_t)n_rec * 12;
+		a.leaf_count = reinterpret_cast<unsigned long long *>(acc.p + (uint64_t)n_rec * 12 + (uint64_t)n_trees * 3);
+		return a;
+	}
+};
+
+} // namespace pg
+
+struct pg_context {
+	int device = 0;
+	std::string err;
+	bool configured = false;
+	float bmin[3] = {0, 0, 0}, bmax[3] = {1, 1, 1};
+	uint64_t num_rays = 0;
+	int32_t max_depth = 0, kd_max_depth = 10, quad_max_depth = 30, store_nee = 1;
+	float bsdf_fraction = 0.5f;
+	int32_t iteration = 0, is_final = 0;
+	double kd_max_leaf_size = 1.0;
+	pg::Forest f;
+	pg::DepthCounters *dc = nullptr; // device
+	bool dc_on = false;
+
+	pg::TreeView view() const
+	{
+		pg::TreeView t;
+		t.kd = f.kd.p;
+		t.rec = f.rec.p;
+		t.head = f.head.p;
+		for (int a = 0; a < 3; ++a) { t.bmin[a] = bmin[a]; t.bmax[a] = bmax[a]; }
+		t.n_kd = f.n_kd;
+		t.n_rec = f.n_rec;
+		t.n_trees = f.n_trees;
+		return t;
+	}
+};
+
+namespace pg {
+// pg_refine.hip
+int refine_and_swap(pg_context *ctx, hipStream_t s);
+// helpers shared by pg_context.hip / pg_refine.hip
+int fail(pg_context *ctx, int code, const std::string &msg);
+int hip_fail(pg_context *ctx, hipError_t e, const char *what);
+} // namespace pg
+
+#define PG_HIP(ctx, call)                                                      \
+	do {                                                                       \
+		hipError_t e__ = (call);                                               \
+		if (e__ != hipSuccess) return pg::hip_fail((ctx), e__, #call);        \
+	} while (0)

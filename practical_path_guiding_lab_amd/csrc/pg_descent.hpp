@@ -1,0 +1,212 @@
+// pg_descent.hpp -- per-lane SD-tree descents (device functions shared by the query and
+// splat kernels).  Each function states the reference lines whose result it reproduces.
+#pragma once
+
+#include "pg_math.hpp"
+#include "pg_tree.hpp"
+
+namespace pg {
+
+__device__ __forceinline__ KdNode load_kd(const KdNode *kd, uint32_t i)
+{
+	const uint4 v = *reinterpret_cast<const uint4 *>(kd + i);
+	KdNode n;
+	n.child = v.x;
+	n.split = __uint_as_float(v.y);
+	n.axis_depth = v.z;
+	n.tree = v.w;
+	return n;
+}
+
+__device__ __forceinline__ bool inside_root(const TreeView &t, float x, float y, float z)
+{
+	// mi.BoundingBox3f.contains, inclusive; NaN fails (kdtree.py:446-447)
+	return x >= t.bmin[0] && x <= t.bmax[0] && y >= t.bmin[1] && y <= t.bmax[1] &&
+	       z >= t.bmin[2] && z <= t.bmax[2];
+}
+
+// KDTree.getLeafNodeIndex (kdtree.py:435-470).  Inside a node, "left.contains then
+// right.contains, right overwrites" is p[axis] >= mid ? right : left because the children
+// share the parent's other four planes and meet at mid (kdtree.py:282-297).
+// Returns the reference node index; `leaf` receives the node's packed record.
+__device__ __forceinline__ uint32_t kd_descend(const KdNode *kd, float x, float y, float z,
+                                               bool search, KdNode &leaf, uint32_t &levels)
+{
+	uint32_t node = 0;
+	KdNode nd = load_kd(kd, 0);
+	levels = 0;
+	if (search) {
+		for (int it = 0; it < kMaxLevels && nd.child != 0; ++it) {
+			const uint32_t axis = nd.axis_depth & 3u;
+			const float v = axis == 0 ? x : (axis == 1 ? y : z);
+			node = nd.child + (v >= nd.split ? 1u : 0u);
+			nd = load_kd(kd, node);
+			++levels;
+		}
+	}
+	leaf = nd;
+	return node;
+}
+
+struct QuadLoad {
+	float i0, i1, i2, i3;
+	uint32_t c0, c1, c2, c3;
+};
+
+__device__ __forceinline__ QuadLoad load_rec(const QuadRec *rec, uint32_t r)
+{
+	const uint4 a = reinterpret_cast<const uint4 *>(rec + r)[0];
+	const uint4 b = reinterpret_cast<const uint4 *>(rec + r)[1];
+	QuadLoad q;
+	q.i0 = __uint_as_float(a.x); q.i1 = __uint_as_float(a.y);
+	q.i2 = __uint_as_float(a.z); q.i3 = __uint_as_float(a.w);
+	q.c0 = b.x; q.c1 = b.y; q.c2 = b.z; q.c3 = b.w;
+	return q;
+}
+
+__device__ __forceinline__ float sel4f(int k, float a, float b, float c, float d)
+{
+	return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
+}
+__device__ __forceinline__ uint32_t sel4u(int k, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+	return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
+}
+
+// Which child quadrants of the cell [lo, lo+2h]^2 contain (cx,cy), inclusive on every edge
+// (quadtree.py:153-175, 1043-1053).  `first` = lowest-numbered containing child (the energy
+// pick, quadtree.py:1063-1075), `last` = highest-numbered (the descent, quadtree.py:424-438,
+// 1095-1098).  Both are -1 when the point is outside the cell.
+__device__ __forceinline__ void quadrant(float cx, float cy, float mx, float my, int &first, int &last)
+{
+	const bool xge = cx >= mx, xle = cx <= mx, yge = cy >= my, yle = cy <= my;
+	const bool t0 = xge && yge, t1 = xle && yge, t2 = xle && yle, t3 = xge && yle;
+	first = t0 ? 0 : (t1 ? 1 : (t2 ? 2 : (t3 ? 3 : -1)));
+	last = t3 ? 3 : (t2 ? 2 : (t1 ? 1 : (t0 ? 0 : -1)));
+}
+
+// QuadTree.pdfQuadTree (quadtree.py:1001-1101) for canonical position (cx,cy) in [0,1]^2.
+__device__ __forceinline__ float quad_pdf(const QuadRec *rec, TreeHead head, float cx, float cy,
+                                          uint32_t &levels)
+{
+	float pdf = 1.0f;
+	levels = 0;
+	if (head.root_rec == kNoRecord) return pdf * kInvFourPiF;
+	uint32_t r = head.root_rec;
+	float node_irr = head.root_irr;
+	float lox = 0.0f, loy = 0.0f, h = 0.5f;
+	for (int it = 0; it < kMaxLevels; ++it) {
+		const QuadLoad q = load_rec(rec, r);
+		const float mx = lox + h, my = loy + h;
+		int first, last;
+		quadrant(cx, cy, mx, my, first, last);
+		const float child_irr = first < 0 ? 0.0f : sel4f(first, q.i0, q.i1, q.i2, q.i3);
+		pdf = pdf * ((4.0f * child_irr) / node_irr);
+		if (pdf != pdf) return 0.0f;          // quadtree.py:1090-1092
+		if (last < 0) return pdf;             // outside every child: the reference would spin
+		++levels;
+		node_irr = sel4f(last, q.i0, q.i1, q.i2, q.i3);
+		const uint32_t c = sel4u(last, q.c0, q.c1, q.c2, q.c3);
+		if (last == 0 || last == 3) lox = mx;
+		if (last == 0 || last == 1) loy = my;
+		h *= 0.5f;
+		if (c == 0) return pdf * kInvFourPiF; // child is a leaf (quadtree.py:1025-1030)
+		r = c;
+	}
+	return pdf;
+}
+
+// QuadTree.sampleQuadTree + the pdfQuadTree call of KDTree.sample (kdtree.py:483-484,
+// quadtree.py:931-998).  Three uniforms are drawn per visited node, the leaf included
+// (quadtree.py:956, 980).  The pdf along the sampled path is accumulated on the way down;
+// it equals pdfQuadTree(dir) whenever the round trip dir -> canonical lands strictly inside
+// the sampled leaf cell, otherwise the literal second descent is taken.
+__device__ __forceinline__ void quad_sample(const QuadRec *rec, TreeHead head, Pcg32 &rng,
+                                            float &dx, float &dy, float &dz, float &pdf_out,
+                                            uint32_t &levels)
+{
+	float px = 0.0f, py = 0.0f;
+	float lox = 0.0f, loy = 0.0f, size = 1.0f;
+	float pdf = 1.0f, node_irr = head.root_irr;
+	bool dead = false, reached_leaf = false;
+	uint32_t r = head.root_rec;
+	levels = 0;
+	for (int it = 0; it < kMaxLevels + 1; ++it) {
+		const float u = rng.next_f32();
+		const float v = rng.next_f32();
+		const float xi = rng.next_f32();
+		if (r == kNoRecord) { // leaf: uniform point in the cell (quadtree.py:956)
+			const float ux = u * size, uy = v * size;
+			px = lox + ux;
+			py = loy + uy;
+			reached_leaf = true;
+			break;
+		}
+		const QuadLoad q = load_rec(rec, r);
+		const float c1 = q.i0;
+		const float c2 = q.i1 + c1;
+		const float c3 = q.i2 + c2;
+		const float c4 = q.i3 + c3;
+		const float s = xi * c4;
+		int k = -1;
+		if (s < c1) k = 0;
+		if (c1 <= s && s < c2) k = 1;
+		if (c2 <= s && s < c3) k = 2;
+		if (c3 <= s) k = 3;
+		if (k < 0) break; // NaN energies: the reference would never terminate
+		++levels;
+		const float child_irr = sel4f(k, q.i0, q.i1, q.i2, q.i3);
+		if (!dead) {
+			pdf = pdf * ((4.0f * child_irr) / node_irr);
+			if (pdf != pdf) { pdf = 0.0f; dead = true; }
+		}
+		node_irr = child_irr;
+		const float half = size * 0.5f;
+		if (k == 0 || k == 3) lox = lox + half;
+		if (k == 0 || k == 1) loy = loy + half;
+		size = half;
+		const uint32_t c = sel4u(k, q.c0, q.c1, q.c2, q.c3);
+		r = c == 0 ? kNoRecord : c;
+	}
+	canonical_to_dir(px, py, dx, dy, dz);
+	float qx, qy;
+	dir_to_canonical(dx, dy, dz, qx, qy);
+	const bool strictly_inside = reached_leaf && qx > lox && qx < lox + size && qy > loy && qy < loy + size;
+	if (strictly_inside) {
+		pdf_out = dead ? 0.0f : pdf * kInvFourPiF;
+	} else {
+		uint32_t lv;
+		pdf_out = quad_pdf(rec, head, qx, qy, lv);
+	}
+}
+
+// One addIrradiancePropagate call (quadtree.py:398-441): returns the accumulator slot of the
+// leaf that (cx,cy) falls into -- rec*4+child for a leaf below a record, or ~tree when the
+// root itself is the leaf -- or false when the root cell does not contain the point.
+__device__ __forceinline__ bool quad_find_leaf_slot(const QuadRec *rec, TreeHead head, float cx,
+                                                    float cy, uint32_t &slot, bool &is_root,
+                                                    uint32_t &levels)
+{
+	levels = 0;
+	if (!(cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f)) return false; // quadtree.py:404-405
+	is_root = head.root_rec == kNoRecord;
+	if (is_root) return true;
+	uint32_t r = head.root_rec;
+	float lox = 0.0f, loy = 0.0f, h = 0.5f;
+	for (int it = 0; it < kMaxLevels; ++it) {
+		const uint4 ch = reinterpret_cast<const uint4 *>(rec + r)[1];
+		const float mx = lox + h, my = loy + h;
+		int first, last;
+		quadrant(cx, cy, mx, my, first, last);
+		++levels;
+		const uint32_t c = sel4u(last, ch.x, ch.y, ch.z, ch.w);
+		if (c == 0) { slot = r * 4u + (uint32_t)last; return true; }
+		if (last == 0 || last == 3) lox = mx;
+		if (last == 0 || last == 1) loy = my;
+		h *= 0.5f;
+		r = c;
+	}
+	return false;
+}
+
+} // namespace pg

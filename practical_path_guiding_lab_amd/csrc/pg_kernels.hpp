@@ -1,0 +1,41 @@
+// pg_kernels.hpp -- host-callable launchers of the HIP kernels (definitions in pg_kernels_*.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pgsd.h"
+#include "pg_tree.hpp"
+
+namespace pg {
+
+struct DepthCounters { // device-resident, optional
+	unsigned long long kd_levels, kd_queries, quad_levels, quad_queries;
+};
+
+// ---- queries (pg_kernels_query.hip) ----
+void launch_leaf_index(const TreeView &t, uint64_t n, const float *p, const uint8_t *active,
+                       uint32_t *node_out, hipStream_t s);
+void launch_sample(const TreeView &t, uint64_t n, const float *p, uint64_t *rng_state,
+                   const uint64_t *rng_inc, const uint8_t *active, float *dir_out, float *pdf_out,
+                   DepthCounters *dc, hipStream_t s);
+void launch_pdf(const TreeView &t, uint64_t n, const float *p, const float *dir,
+                const uint8_t *active, float *pdf_out, DepthCounters *dc, hipStream_t s);
+void launch_guide_bounce(const TreeView &t, uint64_t n, const float *p, const float *dir_nee,
+                         const uint8_t *nee_active, const uint8_t *select, float *dir_io,
+                         uint64_t *rng_state, const uint64_t *rng_inc, float *pdf_nee_out,
+                         float *pdf_out, DepthCounters *dc, hipStream_t s);
+void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state, uint64_t *inc,
+                     hipStream_t s);
+
+// ---- recording (pg_kernels_splat.hip) ----
+void launch_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t m,
+                  const pg_records &rec, const uint32_t *d_count, DepthCounters *dc, hipStream_t s);
+void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l_final,
+                            const pg_dense_records &rec, const pg_records_out &out,
+                            uint32_t *d_count, hipStream_t s);
+void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee,
+                              uint64_t num_rays, int32_t max_depth, const float *l_final,
+                              const pg_dense_records &rec, DepthCounters *dc, hipStream_t s);
+
+} // namespace pg

@@ -1,0 +1,218 @@
+// pg_kernels_splat.hip -- recording into sdTree_current.
+//
+// The reference adds fp32 values with one float atomic per node on the root->leaf path
+// (kdtree.py:199, quadtree.py:93): D_kd + 2*D_quad atomics per record, all records hitting the
+// same root words.  Here a record touches only its KD leaf counter (one u64 atomic, which the
+// compiler folds per wave for equal addresses) and its two quadtree leaf accumulators
+// (<= 2 non-zero 32-bit-payload limbs each, fire-and-forget int64 atomics).  Integer sums are
+// order independent, so inner-node totals are formed once at refine time by a bottom-up pass
+// and the multi-GPU exchange is an exact int64 all-reduce.
+#include "pg_descent.hpp"
+#include "pg_kernels.hpp"
+
+namespace pg {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ TreeHead load_head_s(const TreeHead *h, uint32_t t)
+{
+	const uint2 v = *reinterpret_cast<const uint2 *>(h + t);
+	TreeHead r;
+	r.root_rec = v.x;
+	r.root_irr = __uint_as_float(v.y);
+	return r;
+}
+
+__device__ __forceinline__ void add_limbs(long long *base, const Limbs &q)
+{
+	if (q.l0) atomicAdd(reinterpret_cast<unsigned long long *>(base + 0), (unsigned long long)q.l0);
+	if (q.l1) atomicAdd(reinterpret_cast<unsigned long long *>(base + 1), (unsigned long long)q.l1);
+	if (q.l2) atomicAdd(reinterpret_cast<unsigned long long *>(base + 2), (unsigned long long)q.l2);
+}
+
+// quadtree.py:398-441 for one (direction, weight) pair
+__device__ __forceinline__ uint32_t splat_dir(const TreeView &t, const AccumView &a, TreeHead head,
+                                              uint32_t tree, float cx, float cy, float w)
+{
+	uint32_t slot = 0, lv = 0;
+	bool is_root = false;
+	if (!quad_find_leaf_slot(t.rec, head, cx, cy, slot, is_root, lv)) return 0;
+	const Limbs q = quantize_weight(w);
+	if (!q.zero()) add_limbs(is_root ? a.root_acc + 3ull * tree : a.rec_acc + 3ull * slot, q);
+	return lv;
+}
+
+// KDTree.addDataPropagate (kdtree.py:180-225) + QuadTree.addDataPropagate (quadtree.py:389-464)
+__device__ __forceinline__ void splat_record(const TreeView &t, const AccumView &a, int store_nee,
+                                             float x, float y, float z, float dx, float dy, float radiance,
+                                             float wo_pdf, float nx, float ny, float nee_lum,
+                                             unsigned &kd_lv, unsigned &q_lv, unsigned &q_q)
+{
+	const bool inside = inside_root(t, x, y, z);
+	KdNode leaf;
+	uint32_t lv;
+	kd_descend(t.kd, x, y, z, inside, leaf, lv);
+	kd_lv = lv;
+	const uint32_t tree = leaf.tree; // outside the bbox: node 0's (stale) tree (kdtree.py:224)
+	if (inside) atomicAdd(a.leaf_count + tree, 1ull);
+	const TreeHead head = load_head_s(t.head, tree);
+	const float w = wo_pdf > 0.0f ? radiance / wo_pdf : 0.0f; // quadtree.py:451
+	q_lv += splat_dir(t, a, head, tree, dx, dy, w);
+	++q_q;
+	if (store_nee) {
+		const float wn = wo_pdf > 0.0f ? nee_lum / wo_pdf : 0.0f; // quadtree.py:462
+		q_lv += splat_dir(t, a, head, tree, nx, ny, wn);
+		++q_q;
+	}
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_s(unsigned long long v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+__device__ __forceinline__ void count_depths_s(DepthCounters *dc, unsigned kd_lv, unsigned kd_q,
+                                               unsigned q_lv, unsigned q_q)
+{
+	if (dc == nullptr) return;
+	const unsigned long long a = wave_sum_s(kd_lv), b = wave_sum_s(kd_q), c = wave_sum_s(q_lv), d = wave_sum_s(q_q);
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(&dc->kd_levels, a);
+		atomicAdd(&dc->kd_queries, b);
+		atomicAdd(&dc->quad_levels, c);
+		atomicAdd(&dc->quad_queries, d);
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void k_splat(TreeView t, AccumView a, int store_nee, uint64_t m,
+                                                  const float *__restrict__ pos, const float *__restrict__ dir,
+                                                  const float *__restrict__ radiance,
+                                                  const float *__restrict__ wo_pdf,
+                                                  const float *__restrict__ dir_nee,
+                                                  const float *__restrict__ nee_lum,
+                                                  const uint32_t *__restrict__ d_count, DepthCounters *dc)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	const uint64_t valid = d_count ? (uint64_t)*d_count : m; // plane stride stays m
+	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
+	if (i < valid && i < m) {
+		const float nx = store_nee ? dir_nee[i] : 0.0f, ny = store_nee ? dir_nee[m + i] : 0.0f;
+		const float nl = store_nee ? nee_lum[i] : 0.0f;
+		splat_record(t, a, store_nee, pos[i], pos[m + i], pos[2 * m + i], dir[i], dir[m + i], radiance[i],
+		             wo_pdf[i], nx, ny, nl, kd_lv, q_lv, q_q);
+		did = 1;
+	}
+	count_depths_s(dc, kd_lv, did, q_lv, q_q);
+}
+
+// processPathData + scatterDataIntoSDTree's filter for dense slot g
+// (path_guiding_integrator.py:434-478).  Returns keep; outputs the tree's inputs.
+__device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t num_rays, int32_t max_depth,
+                                             const float *__restrict__ l_final, const pg_dense_records &r,
+                                             float &radiance, float &nee_lum, float &wp)
+{
+	const uint64_t ray = g / (uint64_t)max_depth;
+	float in[3], nee[3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		float out = (l_final[ch * num_rays + ray] - r.throughput_radiance[ch * S + g]) / r.throughput_bsdf[ch * S + g];
+		if (out != out) out = 0.0f;                         // :444
+		float v = out / r.bsdf[ch * S + g];
+		if (v != v) v = 0.0f;                               // :449
+		in[ch] = v;
+		float e = r.radiance_nee[ch * S + g];
+		if (e != e) e = 0.0f;                               // :467
+		nee[ch] = e;
+	}
+	radiance = luminance(in[0], in[1], in[2]);            // :452
+	if (radiance != radiance) radiance = 0.0f;            // :466
+	nee_lum = luminance(nee[0], nee[1], nee[2]);
+	wp = r.wo_pdf[g];
+	const bool both_zero = (radiance == 0.0f) && (nee_lum == 0.0f); // :470-472
+	return r.active[g] != 0 && !both_zero && !(wp == 0.0f) && !(wp != wp); // :475-478
+}
+
+// Stream compaction with one atomic per wave: ballot -> popcount -> lane-prefix via mbcnt.
+__global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, int32_t max_depth,
+                                                            const float *__restrict__ l_final,
+                                                            pg_dense_records r, pg_records_out o,
+                                                            uint32_t *__restrict__ d_count)
+{
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
+	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp);
+	const unsigned long long mask = __ballot(keep);
+	const unsigned lane = threadIdx.x & 63;
+	unsigned base = 0;
+	if (lane == 0 && mask) base = atomicAdd(d_count, (uint32_t)__popcll(mask));
+	base = __shfl(base, 0, 64);
+	if (keep) {
+		const uint64_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+		o.position[k] = r.position[g];
+		o.position[S + k] = r.position[S + g];
+		o.position[2 * S + k] = r.position[2 * S + g];
+		o.direction[k] = r.direction[g];
+		o.direction[S + k] = r.direction[S + g];
+		o.direction_nee[k] = r.direction_nee[g];
+		o.direction_nee[S + k] = r.direction_nee[S + g];
+		o.radiance[k] = radiance;
+		o.wo_pdf[k] = wp;
+		o.radiance_nee_lum[k] = nee_lum;
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumView a, int store_nee,
+                                                              uint64_t num_rays, int32_t max_depth,
+                                                              const float *__restrict__ l_final,
+                                                              pg_dense_records r, DepthCounters *dc)
+{
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
+	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
+	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp);
+	if (keep) {
+		splat_record(t, a, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
+		             r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum,
+		             kd_lv, q_lv, q_q);
+		did = 1;
+	}
+	count_depths_s(dc, kd_lv, did, q_lv, q_q);
+}
+
+static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+void launch_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t m, const pg_records &rec,
+                  const uint32_t *d_count, DepthCounters *dc, hipStream_t s)
+{
+	if (m == 0) return;
+	hipLaunchKernelGGL(k_splat, grid_for(m), dim3(kBlock), 0, s, t, a, store_nee, m, rec.position,
+	                   rec.direction, rec.radiance, rec.wo_pdf, rec.direction_nee, rec.radiance_nee_lum,
+	                   d_count, dc);
+}
+
+void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l_final,
+                            const pg_dense_records &rec, const pg_records_out &out, uint32_t *d_count,
+                            hipStream_t s)
+{
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	(void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), s);
+	if (S == 0) return;
+	hipLaunchKernelGGL(k_process_records, grid_for(S), dim3(kBlock), 0, s, num_rays, max_depth, l_final, rec,
+	                   out, d_count);
+}
+
+void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,
+                              int32_t max_depth, const float *l_final, const pg_dense_records &rec,
+                              DepthCounters *dc, hipStream_t s)
+{
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	if (S == 0) return;
+	hipLaunchKernelGGL(k_process_and_splat, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
+	                   max_depth, l_final, rec, dc);
+}
+
+} // namespace pg

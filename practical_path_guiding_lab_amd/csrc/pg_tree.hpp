@@ -1,0 +1,66 @@
+// pg_tree.hpp -- device-resident layout of the SD-tree.
+//
+// The reference keeps one Dr.Jit column per field (45 B per KD node, 45 B per quadtree node,
+// explicit bounding boxes everywhere: kdtree.py:16-35, quadtree.py:12-37).  The descent
+// kernels need far less, so the hot data is packed for one aligned vector load per level:
+//
+//   KdNode   16 B  one per KD node, indexed by the REFERENCE'S node numbering
+//                  (children of a split are adjacent: kdtree.py:243-245)
+//   QuadRec  32 B  one per NON-LEAF quadtree node; it carries the four children's energies
+//                  and, per child, the index of the child's own record (0 = child is a leaf).
+//                  Leaves own no record: bounding boxes are implicit (midpoint splits,
+//                  quadtree.py:151) and a leaf is known from its parent.
+//   TreeHead  8 B  one per quadtree (= per KD leaf): root record + root energy.
+//
+// Records are stored level-major over the whole forest, each level in the order induced by
+// the previous one (SURVEY Appendix A8 restricted to non-leaf nodes), so export to the
+// reference's canonical arena is a pure expansion and a bottom-up pass is one contiguous
+// range per level.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pg {
+
+constexpr uint32_t kNoRecord = 0xffffffffu; // TreeHead.root_rec: the root itself is a leaf
+constexpr int kMaxLevels = 32;              // hard bound on any descent loop
+
+struct alignas(16) KdNode {
+	uint32_t child; // index of the left child (right = child+1); 0 = leaf
+	float split;    // fp32 midpoint of the node's bbox on `axis` (kdtree.py:270)
+	uint32_t axis_depth; // axis (= depth % 3) in bits 0-1, depth in bits 2..
+	uint32_t tree;  // quadTreeRootIndex (kdtree.py:23); for inner nodes the stale parent value
+};
+
+struct alignas(16) QuadRec {
+	float irr[4];      // irradiance of child 1..4 (quadrants of quadtree.py:153-175)
+	uint32_t child[4]; // record index of child 1..4, 0 = leaf
+};
+
+struct alignas(8) TreeHead {
+	uint32_t root_rec; // kNoRecord when the root is a leaf
+	float root_irr;
+};
+
+// Read-only view handed to the query kernels (sdTree_prev).
+struct TreeView {
+	const KdNode *kd;
+	const QuadRec *rec;
+	const TreeHead *head;
+	float bmin[3], bmax[3]; // root bounding box (kdtree.py:138)
+	uint32_t n_kd, n_rec, n_trees;
+};
+
+// Accumulation view (sdTree_current: same topology, integer accumulators).
+// acc layout: one contiguous int64 buffer [ rec_acc | root_acc | leaf_count ]
+//   rec_acc   : n_rec*4 slots * 3 limbs   (slot = rec*4 + child)
+//   root_acc  : n_trees * 3 limbs         (used directly when the root is a leaf)
+//   leaf_count: n_trees                   (records that reached the KD leaf owning the tree)
+struct AccumView {
+	long long *rec_acc;
+	long long *root_acc;
+	unsigned long long *leaf_count;
+};
+
+} // namespace pg

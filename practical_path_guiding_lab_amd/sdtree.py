@@ -1,0 +1,337 @@
+"""Host-side handle of the device-resident SD-tree pair (sdTree_prev / sdTree_current).
+
+Mirrors the method surface the reference integrator uses on its two `KDTree` objects
+(takkasila/practical_path_guiding_lab src/kdtree.py; call sites in
+src/path_guiding_integrator.py:100-105, 244, 301, 307, 500, 559-563, 575-586, 594, 602-608),
+on top of the C ABI of libpgsd.so.  Arrays are torch CUDA tensors in planar layout:
+a Vector3f[N] is a float32 tensor of shape (3, N) -- the layout Dr.Jit uses for mi.Vector3f.
+
+PyTorch is used only as the owner of caller-side device buffers and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: torch.Tensor, shape) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+        raise ValueError(f"expected contiguous CUDA float32 tensor of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t
+
+
+def _mask(active: Optional[torch.Tensor], n: int):
+    if active is None:
+        return None, None
+    if active.dtype == torch.bool:
+        active = active.to(torch.uint8)
+    if active.dtype != torch.uint8 or not active.is_cuda or tuple(active.shape) != (n,):
+        raise ValueError("mask must be a CUDA bool/uint8 tensor of shape (N,)")
+    active = active.contiguous()
+    return active, active.data_ptr()
+
+
+class PCG32Sampler:
+    """Per-lane PCG32 streams laid out like Mitsuba's `independent` sampler (state/inc arrays)."""
+
+    def __init__(self, tree: "SDTree", n: int, seed: int = 0, lane0: int = 0):
+        self.n = n
+        self.state = torch.empty(n, dtype=torch.int64, device=tree.device)
+        self.inc = torch.empty(n, dtype=torch.int64, device=tree.device)
+        tree._seed(self, seed, lane0)
+
+
+class SDTree:
+    """Both reference trees behind one context: queries read sdTree_prev, recording writes
+    sdTree_current; `refineAndPrepare` is path_guiding_integrator.py:566-586."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SDTree needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+        self._lib = N.lib()
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        N.check(None, self._lib.pg_create(C.byref(h), device))
+        self._h = h
+        self.store_nee = True
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.pg_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        N.check(self._h, rc)
+
+    # ---- lifecycle -----------------------------------------------------------------------
+    def setup(self, bbox_min, bbox_max, numRays=0, max_depth=0, sdTreeMaxDepth=10, quadTreeMaxDepth=30,
+              isStoreNEERadiance=True, bsdfSamplingFraction=0.5):
+        bmin = (C.c_float * 3)(*[float(v) for v in bbox_min])
+        bmax = (C.c_float * 3)(*[float(v) for v in bbox_max])
+        self.store_nee = bool(isStoreNEERadiance)
+        self._ck(self._lib.pg_setup(self._h, bmin, bmax, int(numRays), int(max_depth), int(sdTreeMaxDepth),
+                                    int(quadTreeMaxDepth), int(self.store_nee), float(bsdfSamplingFraction)))
+
+    def setIteration(self, iteration: int, isFinalIter: bool = False):
+        self._ck(self._lib.pg_set_iteration(self._h, int(iteration), int(bool(isFinalIter))))
+
+    def _seed(self, sampler: PCG32Sampler, seed: int, lane0: int):
+        self._ck(self._lib.pg_rng_seed(self._h, sampler.n, seed & 0xFFFFFFFF, lane0 & 0xFFFFFFFF,
+                                       sampler.state.data_ptr(), sampler.inc.data_ptr(), _stream_ptr()))
+
+    # ---- queries (kdtree.py:435-496) ------------------------------------------------------
+    def getLeafNodeIndex(self, position: torch.Tensor, active: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = position.shape[1]
+        _f32(position, (3, n))
+        m, mp = _mask(active, n)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._ck(self._lib.pg_get_leaf_node_index(self._h, n, position.data_ptr(), mp, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def sample(self, position: torch.Tensor, sampler: PCG32Sampler, active: Optional[torch.Tensor] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = position.shape[1]
+        _f32(position, (3, n))
+        m, mp = _mask(active, n)
+        d = torch.empty((3, n), dtype=torch.float32, device=self.device)
+        pdf = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._ck(self._lib.pg_sample(self._h, n, position.data_ptr(), sampler.state.data_ptr(), sampler.inc.data_ptr(),
+                                     mp, d.data_ptr(), pdf.data_ptr(), _stream_ptr()))
+        return d, pdf
+
+    def pdf(self, position: torch.Tensor, direction: torch.Tensor, active: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = position.shape[1]
+        _f32(position, (3, n))
+        _f32(direction, (3, n))
+        m, mp = _mask(active, n)
+        pdf = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._ck(self._lib.pg_pdf(self._h, n, position.data_ptr(), direction.data_ptr(), mp, pdf.data_ptr(), _stream_ptr()))
+        return pdf
+
+    def guideBounce(self, position, dir_nee, nee_active, select, dir_io, sampler: PCG32Sampler,
+                    pdf_nee_out=None, pdf_out=None):
+        """The three SD-tree calls of one bounce with one KD descent (pg_guide_bounce)."""
+        n = position.shape[1]
+        _f32(position, (3, n)); _f32(dir_nee, (3, n)); _f32(dir_io, (3, n))
+        na, nap = _mask(nee_active, n)
+        sl, slp = _mask(select, n)
+        if pdf_nee_out is None:
+            pdf_nee_out = torch.empty(n, dtype=torch.float32, device=self.device)
+        if pdf_out is None:
+            pdf_out = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._ck(self._lib.pg_guide_bounce(self._h, n, position.data_ptr(), dir_nee.data_ptr(), nap, slp,
+                                           dir_io.data_ptr(), sampler.state.data_ptr(), sampler.inc.data_ptr(),
+                                           pdf_nee_out.data_ptr(), pdf_out.data_ptr(), _stream_ptr()))
+        return pdf_nee_out, pdf_out
+
+    # ---- recording (kdtree.py:180-225) ----------------------------------------------------
+    def addDataPropagate(self, rec: Dict[str, torch.Tensor], count: Optional[torch.Tensor] = None):
+        """rec: position (3,M), direction (2,M), radiance (M,), woPdf (M,), direction_nee (2,M),
+        radiance_nee_lum (M,) -- the stream scatterDataIntoSDTree hands to the tree."""
+        m = rec["position"].shape[1]
+        r = N.pg_records()
+        r.position = _f32(rec["position"], (3, m)).data_ptr()
+        r.direction = _f32(rec["direction"], (2, m)).data_ptr()
+        r.radiance = _f32(rec["radiance"], (m,)).data_ptr()
+        r.wo_pdf = _f32(rec["woPdf"], (m,)).data_ptr()
+        if self.store_nee:
+            r.direction_nee = _f32(rec["direction_nee"], (2, m)).data_ptr()
+            r.radiance_nee_lum = _f32(rec["radiance_nee_lum"], (m,)).data_ptr()
+        cp = None
+        if count is not None:
+            if count.dtype != torch.int32 or not count.is_cuda:
+                raise ValueError("count must be a CUDA int32 tensor")
+            cp = count.data_ptr()
+        self._ck(self._lib.pg_splat(self._h, m, C.byref(r), cp, _stream_ptr()))
+
+    def _dense(self, rec: Dict[str, torch.Tensor], S: int) -> N.pg_dense_records:
+        d = N.pg_dense_records()
+        act = rec["active"]
+        if act.dtype == torch.bool:
+            act = act.to(torch.uint8)
+        rec["_active_u8"] = act.contiguous()
+        d.active = rec["_active_u8"].data_ptr()
+        d.position = _f32(rec["position"], (3, S)).data_ptr()
+        d.direction = _f32(rec["direction"], (2, S)).data_ptr()
+        d.bsdf = _f32(rec["bsdf"], (3, S)).data_ptr()
+        d.throughput_bsdf = _f32(rec["throughputBsdf"], (3, S)).data_ptr()
+        d.throughput_radiance = _f32(rec["throughputRadiance"], (3, S)).data_ptr()
+        d.radiance_nee = _f32(rec["radiance_nee"], (3, S)).data_ptr()
+        d.direction_nee = _f32(rec["direction_nee"], (2, S)).data_ptr()
+        d.wo_pdf = _f32(rec["woPdf"], (S,)).data_ptr()
+        return d
+
+    def processRecords(self, num_rays: int, max_depth: int, Lfinal: torch.Tensor, rec: Dict[str, torch.Tensor]):
+        """processPathData + the filter of scatterDataIntoSDTree (path_guiding_integrator.py:434-497)."""
+        S = num_rays * max_depth
+        _f32(Lfinal, (3, num_rays))
+        d = self._dense(rec, S)
+        out = {
+            "position": torch.empty((3, S), dtype=torch.float32, device=self.device),
+            "direction": torch.empty((2, S), dtype=torch.float32, device=self.device),
+            "radiance": torch.empty(S, dtype=torch.float32, device=self.device),
+            "woPdf": torch.empty(S, dtype=torch.float32, device=self.device),
+            "direction_nee": torch.empty((2, S), dtype=torch.float32, device=self.device),
+            "radiance_nee_lum": torch.empty(S, dtype=torch.float32, device=self.device),
+        }
+        o = N.pg_records_out()
+        o.position = out["position"].data_ptr(); o.direction = out["direction"].data_ptr()
+        o.radiance = out["radiance"].data_ptr(); o.wo_pdf = out["woPdf"].data_ptr()
+        o.direction_nee = out["direction_nee"].data_ptr(); o.radiance_nee_lum = out["radiance_nee_lum"].data_ptr()
+        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ck(self._lib.pg_process_records(self._h, num_rays, max_depth, Lfinal.data_ptr(), C.byref(d), C.byref(o),
+                                              count.data_ptr(), _stream_ptr()))
+        return out, count
+
+    def processAndSplat(self, num_rays: int, max_depth: int, Lfinal: torch.Tensor, rec: Dict[str, torch.Tensor]):
+        S = num_rays * max_depth
+        _f32(Lfinal, (3, num_rays))
+        d = self._dense(rec, S)
+        self._ck(self._lib.pg_process_and_splat(self._h, num_rays, max_depth, Lfinal.data_ptr(), C.byref(d), _stream_ptr()))
+
+    # ---- refinement ---------------------------------------------------------------------
+    def refineAndPrepare(self):
+        self._ck(self._lib.pg_refine_and_swap(self._h, _stream_ptr()))
+
+    def accumulators(self) -> torch.Tensor:
+        """int64 view of sdTree_current's accumulators for torch.distributed.all_reduce (RCCL)."""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._ck(self._lib.pg_accumulators(self._h, C.byref(p), C.byref(n)))
+        return _wrap_device_i64(p.value, n.value, self.device)
+
+    # ---- import / export in the reference's npz schema (kdtree.py:539-602) -----------------
+    def sizes(self) -> N.pg_tree_sizes:
+        s = N.pg_tree_sizes()
+        self._ck(self._lib.pg_export_sizes(self._h, C.byref(s)))
+        return s
+
+    def export(self) -> Dict[str, np.ndarray]:
+        s = self.sizes()
+        nk, nq, nr = s.n_kd, s.n_quad, s.n_roots
+        a = {
+            "kdtree_bbox_min": np.empty((nk, 3), np.float32), "kdtree_bbox_max": np.empty((nk, 3), np.float32),
+            "kdtree_depth": np.empty(nk, np.uint32), "kdtree_vertCount": np.empty(nk, np.float32),
+            "kdtree_isLeaf": np.empty(nk, np.uint8), "kdtree_quadTreeRootIndex": np.empty(nk, np.uint32),
+            "kdtree_child_left_index": np.empty(nk, np.uint32), "kdtree_child_right_index": np.empty(nk, np.uint32),
+            "quadtree_rootNodeIndex": np.empty(nr, np.uint32),
+            "quadtree_bbox_min": np.empty((nq, 2), np.float32), "quadtree_bbox_max": np.empty((nq, 2), np.float32),
+            "quadtree_depth": np.empty(nq, np.uint32), "quadtree_irradiance": np.empty(nq, np.float32),
+            "quadtree_isLeaf": np.empty(nq, np.uint8), "quadtree_refinementThreshold": np.empty(nq, np.float32),
+        }
+        for k in (1, 2, 3, 4):
+            a["quadtree_child_%d_index" % k] = np.empty(nq, np.uint32)
+        c = _columns(a)
+        self._ck(self._lib.pg_export(self._h, C.byref(s), C.byref(c)))
+        a["kdtree_isLeaf"] = a["kdtree_isLeaf"].astype(bool)
+        a["quadtree_isLeaf"] = a["quadtree_isLeaf"].astype(bool)
+        a["kdtree_maxLeafSize"] = np.float64(c.kd_max_leaf_size)
+        a["kdtree_maxDepth"] = np.int64(c.kd_max_depth)
+        a["quadtree_maxDepth"] = np.int64(c.quad_max_depth)
+        a["quadtree_isStoreNEERadiance"] = np.bool_(c.quad_store_nee)
+        return a
+
+    def load(self, d: Dict[str, np.ndarray]):
+        a = {
+            "kdtree_bbox_min": np.ascontiguousarray(d["kdtree_bbox_min"], np.float32),
+            "kdtree_bbox_max": np.ascontiguousarray(d["kdtree_bbox_max"], np.float32),
+            "kdtree_depth": np.ascontiguousarray(d["kdtree_depth"], np.uint32),
+            "kdtree_vertCount": np.ascontiguousarray(d["kdtree_vertCount"], np.float32),
+            "kdtree_isLeaf": np.ascontiguousarray(d["kdtree_isLeaf"], np.uint8),
+            "kdtree_quadTreeRootIndex": np.ascontiguousarray(d["kdtree_quadTreeRootIndex"], np.uint32),
+            "kdtree_child_left_index": np.ascontiguousarray(d["kdtree_child_left_index"], np.uint32),
+            "kdtree_child_right_index": np.ascontiguousarray(d["kdtree_child_right_index"], np.uint32),
+            "quadtree_rootNodeIndex": np.ascontiguousarray(d["quadtree_rootNodeIndex"], np.uint32),
+            "quadtree_bbox_min": np.ascontiguousarray(d["quadtree_bbox_min"], np.float32),
+            "quadtree_bbox_max": np.ascontiguousarray(d["quadtree_bbox_max"], np.float32),
+            "quadtree_depth": np.ascontiguousarray(d["quadtree_depth"], np.uint32),
+            "quadtree_irradiance": np.ascontiguousarray(d["quadtree_irradiance"], np.float32),
+            "quadtree_isLeaf": np.ascontiguousarray(d["quadtree_isLeaf"], np.uint8),
+            "quadtree_refinementThreshold": np.ascontiguousarray(d["quadtree_refinementThreshold"], np.float32),
+        }
+        for k in (1, 2, 3, 4):
+            a["quadtree_child_%d_index" % k] = np.ascontiguousarray(d["quadtree_child_%d_index" % k], np.uint32)
+        c = _columns(a)
+        c.kd_max_leaf_size = float(d["kdtree_maxLeafSize"])
+        c.kd_max_depth = int(d["kdtree_maxDepth"])
+        c.quad_max_depth = int(d["quadtree_maxDepth"])
+        c.quad_store_nee = int(bool(d["quadtree_isStoreNEERadiance"]))
+        s = N.pg_tree_sizes(a["kdtree_depth"].shape[0], a["quadtree_depth"].shape[0], a["quadtree_rootNodeIndex"].shape[0])
+        self._ck(self._lib.pg_import(self._h, C.byref(s), C.byref(c)))
+        self.store_nee = bool(c.quad_store_nee)
+
+    def saveToFile(self, fileName: str):  # kdtree.py:539-602
+        np.savez_compressed(fileName, **self.export())
+
+    def loadFromFile(self, fileName: str):  # path_guiding_integrator.py:597-608
+        self.load(dict(np.load(fileName)))
+
+    def exportAccumulators(self):
+        s = self.sizes()
+        kd = np.empty(s.n_kd, np.uint64)
+        lo = np.empty(s.n_quad, np.uint64)
+        hi = np.empty(s.n_quad, np.int64)
+        self._ck(self._lib.pg_export_accumulators(self._h, C.byref(s), kd.ctypes.data, lo.ctypes.data, hi.ctypes.data))
+        return kd, lo, hi
+
+    def stats(self) -> N.pg_stats:
+        st = N.pg_stats()
+        self._ck(self._lib.pg_get_stats(self._h, C.byref(st)))
+        return st
+
+    def enableDepthCounters(self, on: bool = True):
+        self._ck(self._lib.pg_enable_depth_counters(self._h, int(on)))
+
+    def readDepthCounters(self, reset: bool = True) -> N.pg_depth_counters:
+        dc = N.pg_depth_counters()
+        self._ck(self._lib.pg_read_depth_counters(self._h, C.byref(dc), int(reset)))
+        return dc
+
+
+def _columns(a: Dict[str, np.ndarray]) -> N.pg_tree_columns:
+    c = N.pg_tree_columns()
+    c.kd_bbox_min = a["kdtree_bbox_min"].ctypes.data
+    c.kd_bbox_max = a["kdtree_bbox_max"].ctypes.data
+    c.kd_depth = a["kdtree_depth"].ctypes.data
+    c.kd_vert_count = a["kdtree_vertCount"].ctypes.data
+    c.kd_is_leaf = a["kdtree_isLeaf"].ctypes.data
+    c.kd_quad_root_index = a["kdtree_quadTreeRootIndex"].ctypes.data
+    c.kd_child_left = a["kdtree_child_left_index"].ctypes.data
+    c.kd_child_right = a["kdtree_child_right_index"].ctypes.data
+    c.quad_root_node_index = a["quadtree_rootNodeIndex"].ctypes.data
+    c.quad_bbox_min = a["quadtree_bbox_min"].ctypes.data
+    c.quad_bbox_max = a["quadtree_bbox_max"].ctypes.data
+    c.quad_depth = a["quadtree_depth"].ctypes.data
+    c.quad_irradiance = a["quadtree_irradiance"].ctypes.data
+    c.quad_is_leaf = a["quadtree_isLeaf"].ctypes.data
+    c.quad_threshold = a["quadtree_refinementThreshold"].ctypes.data
+    for k in range(4):
+        c.quad_child[k] = a["quadtree_child_%d_index" % (k + 1)].ctypes.data
+    return c
+
+
+class _DevMem:
+    """Minimal __cuda_array_interface__ carrier so torch can alias library-owned device memory."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {
+            "shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2, "strides": None,
+        }
+
+
+def _wrap_device_i64(ptr: int, n: int, device) -> torch.Tensor:
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=device)
+    return torch.as_tensor(_DevMem(ptr, n), device=device)

@@ -1,0 +1,304 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical seeded inputs.
+Bit-exact: node indices, sampled directions, pdfs, RNG states, integer accumulators, and the
+canonical topology after refinement.  Runs on the MI355X box only (-m gpu)."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import pg_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+BB0, BB1 = [0.0] * 3, [100.0] * 3
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def gpu_tree_from(oracle_tree):
+    from practical_path_guiding_lab_amd.sdtree import SDTree
+
+    t = SDTree()
+    t.load(oracle_tree.export())
+    return t
+
+
+def assert_same_tree(a: dict, b: dict):
+    assert set(a) == set(b)
+    for k in sorted(a):
+        av, bv = np.asarray(a[k]), np.asarray(b[k])
+        assert av.shape == bv.shape, (k, av.shape, bv.shape)
+        if av.dtype.kind == "f":
+            np.testing.assert_array_equal(av.view(np.uint32 if av.dtype == np.float32 else np.uint64),
+                                          bv.astype(av.dtype).view(np.uint32 if av.dtype == np.float32 else np.uint64),
+                                          err_msg=k)
+        else:
+            np.testing.assert_array_equal(av.astype(np.int64), bv.astype(np.int64), err_msg=k)
+
+
+@pytest.fixture(scope="module")
+def balanced():
+    return synth.build_balanced(6, 4)
+
+
+@pytest.fixture(scope="module")
+def skewed():
+    return synth.build_skewed(1 << 15, 5)
+
+
+def test_import_export_roundtrip(balanced, skewed):
+    for tree in (balanced, skewed.prev):
+        g = gpu_tree_from(tree)
+        assert_same_tree(tree.export(), g.export())
+
+
+def test_setup_state_matches_oracle():
+    from practical_path_guiding_lab_amd.sdtree import SDTree
+
+    g = SDTree()
+    g.setup(BB0, BB1, 0, 0, 20, 20, True, 0.5)
+    o = po.OracleTree()
+    o.setup(BB0, BB1, 20, 20, True)
+    e = o.export()
+    e["kdtree_maxLeafSize"] = np.float64(1.0)
+    assert_same_tree(e, g.export())
+
+
+def queries(n, seed):
+    p = synth.positions_uniform(n, seed, BB0, BB1)
+    # sprinkle special positions: outside, on the bbox faces, on split planes, NaN
+    p[:, 0] = [-1.0, 50.0, 50.0]
+    p[:, 1] = [0.0, 0.0, 0.0]
+    p[:, 2] = [100.0, 100.0, 100.0]
+    p[:, 3] = [50.0, 50.0, 50.0]
+    p[:, 4] = [25.0, 75.0, 12.5]
+    p[:, 5] = [np.nan, 1.0, 1.0]
+    p[:, 6] = [100.00001, 1.0, 1.0]
+    return p
+
+
+@pytest.mark.parametrize("which", ["balanced", "skewed"])
+def test_leaf_index_sample_pdf_parity(torch_mod, balanced, skewed, which):
+    torch = torch_mod
+    from practical_path_guiding_lab_amd.sdtree import PCG32Sampler
+
+    tree = balanced if which == "balanced" else skewed.prev
+    g = gpu_tree_from(tree)
+    n = 200_003
+    p = queries(n, 5)
+    act = (synth.uniform(n, 6)[0] < 0.8).astype(np.uint8)
+    dp, dact = dev(torch, p), dev(torch, act)
+    # leaf index
+    np.testing.assert_array_equal(g.getLeafNodeIndex(dp).cpu().numpy().astype(np.uint32), tree.get_leaf_node_index(p))
+    np.testing.assert_array_equal(g.getLeafNodeIndex(dp, dact).cpu().numpy().astype(np.uint32),
+                                  tree.get_leaf_node_index(p, act))
+    # sample
+    smp = PCG32Sampler(g, n, seed=11)
+    st, inc = po.rng_seed(n, 11)
+    np.testing.assert_array_equal(smp.state.cpu().numpy().view(np.uint64), st)
+    np.testing.assert_array_equal(smp.inc.cpu().numpy().view(np.uint64), inc)
+    d_g, pdf_g = g.sample(dp, smp, dact)
+    d_o, pdf_o = tree.sample(p, st, inc, act)
+    np.testing.assert_array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+    np.testing.assert_array_equal(pdf_g.cpu().numpy().view(np.uint32), pdf_o.view(np.uint32))
+    np.testing.assert_array_equal(smp.state.cpu().numpy().view(np.uint64), st)
+    # pdf of arbitrary directions (incl. axis-aligned and non-finite ones)
+    d = synth.directions_uniform(n, 8)
+    d[:, 0] = [0, 0, 1]; d[:, 1] = [0, 0, -1]; d[:, 2] = [-1, 0, 0]; d[:, 3] = [0, -1, 0]
+    d[:, 4] = [np.nan, 0, 0]; d[:, 5] = [1, 0, 0]; d[:, 6] = [-1, -0.0, 0]
+    pdf_g = g.pdf(dp, dev(torch, d), dact).cpu().numpy()
+    pdf_o = tree.pdf(p, d, act)
+    np.testing.assert_array_equal(pdf_g.view(np.uint32), pdf_o.view(np.uint32))
+
+
+def test_guide_bounce_equals_three_reference_calls(torch_mod, skewed):
+    torch = torch_mod
+    from practical_path_guiding_lab_amd.sdtree import PCG32Sampler
+
+    tree = skewed.prev
+    g = gpu_tree_from(tree)
+    n = 100_001
+    p = queries(n, 15)
+    d_nee = synth.directions_uniform(n, 16)
+    d_bsdf = synth.directions_uniform(n, 17)
+    u = synth.uniform(n, 18, 2)
+    nee = (u[0] < 0.9).astype(np.uint8)
+    sel = np.where(u[1] < 0.1, 0, np.where(u[1] < 0.55, 1, 2)).astype(np.uint8)
+    smp = PCG32Sampler(g, n, seed=3)
+    st, inc = po.rng_seed(n, 3)
+    dio = dev(torch, d_bsdf)
+    pn_g, po_g = g.guideBounce(dev(torch, p), dev(torch, d_nee), dev(torch, nee), dev(torch, sel), dio, smp)
+    # oracle: path_guiding_integrator.py:244, 301, 307
+    pn_o = tree.pdf(p, d_nee, nee)
+    ds_o, ps_o = tree.sample(p, st, inc, (sel == 2).astype(np.uint8))
+    pb_o = tree.pdf(p, d_bsdf, (sel == 1).astype(np.uint8))
+    exp_pdf = np.where(sel == 2, ps_o, np.where(sel == 1, pb_o, np.float32(1))).astype(np.float32)
+    exp_dir = np.where(sel == 2, ds_o, d_bsdf).astype(np.float32)
+    np.testing.assert_array_equal(pn_g.cpu().numpy().view(np.uint32), pn_o.view(np.uint32))
+    np.testing.assert_array_equal(po_g.cpu().numpy().view(np.uint32), exp_pdf.view(np.uint32))
+    np.testing.assert_array_equal(dio.cpu().numpy().view(np.uint32), exp_dir.view(np.uint32))
+    np.testing.assert_array_equal(smp.state.cpu().numpy().view(np.uint64), st)
+
+
+def special_records(m, seed):
+    rec = synth.records(m, seed, BB0, BB1)
+    # edge cases the reference handles in-band
+    rec["position"][:, 0] = [-5.0, 1.0, 1.0]        # outside the bbox: no count, tree 0 still gets energy
+    rec["woPdf"][1] = 0.0                            # zero weight
+    rec["woPdf"][2] = -1.0
+    rec["radiance"][3] = np.inf                      # clamped to 2^48
+    rec["radiance"][4] = np.nan                      # adds nothing
+    rec["direction"][:, 5] = [0.5, 0.5]              # cell corners / edges (tie rules)
+    rec["direction"][:, 6] = [0.25, 0.5]
+    rec["direction"][:, 7] = [1.0, 1.0]
+    rec["direction"][:, 8] = [0.0, 0.0]
+    rec["direction"][:, 9] = [1.5, 0.5]              # outside the root square: skipped
+    rec["direction_nee"][:, 10] = [np.nan, 0.5]
+    rec["radiance"][11] = 1e-13                      # below 2^-40: truncates to zero
+    rec["radiance"][12] = -3.0                       # negative weights are legal
+    return rec
+
+
+def gpu_splat(torch, g, rec):
+    g.addDataPropagate({k: dev(torch, v) for k, v in rec.items()})
+
+
+def check_accumulators(g, o):
+    kd, lo, hi = g.exportAccumulators()
+    np.testing.assert_array_equal(kd, o.kd_column("count"))
+    np.testing.assert_array_equal(lo, o.quad_column("acc_lo"))
+    np.testing.assert_array_equal(hi, o.quad_column("acc_hi"))
+
+
+@pytest.mark.parametrize("nee", [True, False])
+def test_splat_accumulators_bit_exact(torch_mod, nee):
+    torch = torch_mod
+    pair = synth.build_skewed(1 << 14, 4)
+    o = pair.current  # reset copy of the refined tree
+    e = pair.prev.export()
+    e["quadtree_isStoreNEERadiance"] = np.bool_(nee)
+    o.load(e)
+    o.reset()
+    g = gpu_tree_from(o)
+    for k in range(3):  # accumulate over several passes like main.py:208-218
+        rec = special_records(150_001 + k, 40 + k)
+        synth.splat(o, rec)
+        gpu_splat(torch, g, rec)
+    check_accumulators(g, o)
+
+
+def test_splat_into_single_leaf_tree(torch_mod):
+    torch = torch_mod
+    from practical_path_guiding_lab_amd.sdtree import SDTree
+
+    g = SDTree()
+    g.setup(BB0, BB1, 0, 0, 20, 20, True, 0.5)
+    o = po.OracleTree()
+    o.setup(BB0, BB1, 20, 20, True)
+    rec = special_records(70_000, 2)
+    synth.splat(o, rec)
+    gpu_splat(torch, g, rec)
+    check_accumulators(g, o)
+
+
+def test_empty_and_ragged_batches(torch_mod, balanced):
+    torch = torch_mod
+    from practical_path_guiding_lab_amd.sdtree import PCG32Sampler
+
+    g = gpu_tree_from(balanced)
+    z3 = torch.empty((3, 0), dtype=torch.float32, device="cuda")
+    assert g.getLeafNodeIndex(z3).shape == (0,)
+    smp = PCG32Sampler(g, 0)
+    d, pdf = g.sample(z3, smp)
+    assert d.shape == (3, 0) and pdf.shape == (0,)
+    assert g.pdf(z3, z3).shape == (0,)
+    for n in (1, 63, 64, 65, 257):
+        p = synth.positions_uniform(n, n, BB0, BB1)
+        np.testing.assert_array_equal(g.getLeafNodeIndex(dev(torch, p)).cpu().numpy().astype(np.uint32),
+                                      balanced.get_leaf_node_index(p))
+    with pytest.raises(ValueError):
+        g.pdf(torch.zeros((3, 4), device="cuda"), torch.zeros((3, 5), device="cuda"))
+
+
+def dense_records(num_rays, max_depth, seed):
+    S = num_rays * max_depth
+    u = synth.uniform(S, seed, 16)
+    depth_of = np.tile(np.arange(max_depth), num_rays)
+    path_len = np.repeat((synth.uniform(num_rays, seed + 1)[0] * (max_depth + 1)).astype(np.int32), max_depth)
+    active = (depth_of < path_len).astype(np.uint8)
+    rec = {
+        "active": active,
+        "position": synth.positions_clustered(S, seed + 2, BB0, BB1),
+        "direction": synth.canonical_lobes(S, seed + 3),
+        "bsdf": (np.float32(0.05) + u[0:3]).astype(np.float32),
+        "throughputBsdf": (u[3:6] * u[6:9]).astype(np.float32),
+        "throughputRadiance": (u[9:12] * np.float32(0.5)).astype(np.float32),
+        "radiance_nee": np.where(u[12] < 0.3, np.float32(0), u[13:16]).astype(np.float32),
+        "direction_nee": synth.canonical_lobes(S, seed + 4),
+        "woPdf": np.where(u[15] < 0.05, np.float32(0), np.float32(0.05) + u[15]).astype(np.float32),
+    }
+    # inactive slots are all-zero as dr.zeros leaves them (path_guiding_integrator.py:116)
+    for k, v in rec.items():
+        if k != "active":
+            v[..., active == 0] = 0
+    rec["throughputBsdf"][:, 5] = 0.0      # 0/0 -> NaN -> 0
+    rec["bsdf"][:, 7] = 0.0                # x/0 -> inf survives
+    rec["woPdf"][9] = np.nan
+    Lfinal = (synth.uniform(num_rays, seed + 5, 3) * np.float32(2.0)).astype(np.float32)
+    return Lfinal, rec
+
+
+def test_process_records_and_fused_splat(torch_mod, skewed):
+    torch = torch_mod
+    R, D = 20_011, 8
+    Lfinal, rec = dense_records(R, D, 77)
+    exp = po.process_records(R, D, Lfinal, rec)
+    o = skewed.current
+    g = gpu_tree_from(skewed.prev)
+    drec = {k: dev(torch, v) for k, v in rec.items()}
+    out, count = g.processRecords(R, D, dev(torch, Lfinal), drec)
+    m = int(count.item())
+    assert m == exp["radiance"].shape[0] and m > 0
+
+    def rows(d, m_):
+        cols = [d["position"][0][:m_], d["position"][1][:m_], d["position"][2][:m_], d["direction"][0][:m_],
+                d["direction"][1][:m_], d["radiance"][:m_], d["woPdf"][:m_], d["direction_nee"][0][:m_],
+                d["direction_nee"][1][:m_], d["radiance_nee_lum"][:m_]]
+        a = np.stack([np.asarray(c, np.float32).view(np.uint32) for c in cols], axis=1)
+        return a[np.lexsort(a.T[::-1])]
+
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    np.testing.assert_array_equal(rows(got, m), rows(exp, m))  # same multiset (order is free)
+    # splat of the compacted stream with the device-side count, and the fused kernel, both equal the oracle
+    o.reset()
+    synth.splat(o, exp)
+    g.addDataPropagate(out, count)
+    check_accumulators(g, o)
+    g2 = gpu_tree_from(skewed.prev)
+    g2.processAndSplat(R, D, dev(torch, Lfinal), drec)
+    check_accumulators(g2, o)
+    o.reset()
+
+
+def test_depth_counters_and_stats(torch_mod, balanced):
+    torch = torch_mod
+    g = gpu_tree_from(balanced)
+    st = g.stats()
+    assert st.n_kd_leaves == 64 and st.n_trees == 64 and st.n_kd_nodes == 127
+    assert st.mean_kd_leaf_depth == 6.0 and st.mean_quad_leaf_depth == 4.0
+    assert st.n_quad_records == 64 * (1 + 4 + 16 + 64)
+    g.enableDepthCounters(True)
+    n = 10_000
+    p = synth.positions_uniform(n, 1, BB0, BB1)
+    d = synth.directions_uniform(n, 2)
+    g.pdf(dev(torch, p), dev(torch, d))
+    dc = g.readDepthCounters()
+    assert dc.kd_queries == n and dc.kd_levels == 6 * n and dc.quad_levels == 4 * n
