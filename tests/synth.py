@@ -45,10 +45,12 @@ def canonical_uniform(n, seed):
     return uniform(n, seed, 2)
 
 
-def canonical_lobes(n, seed):
-    """Mixture of 4 tight lobes + uniform background in canonical [0,1)^2."""
+def canonical_lobes(n, seed, shift=0):
+    """Mixture of 4 tight lobes + uniform background in canonical [0,1)^2.  `shift` moves the
+    lobes (in sixteenths) so that successive iterations make earlier refinement obsolete (merges)."""
     u = uniform(n, seed, 5)
     centres = np.array([[0.125, 0.75], [0.625, 0.25], [0.375, 0.375], [0.875, 0.875]], np.float32)
+    centres = ((centres + np.float32(shift) * np.float32(0.0625)) % np.float32(1.0)).astype(np.float32)
     k = np.minimum((u[0] * np.float32(5)).astype(np.int32), 4)
     out = np.empty((2, n), np.float32)
     bg = k == 4
@@ -65,11 +67,11 @@ def directions_uniform(n, seed):
     return po.canonical_to_dir(canonical_uniform(n, seed))
 
 
-def records(m, seed, bbox_min, bbox_max, skew=True):
+def records(m, seed, bbox_min, bbox_max, skew=True, shift=0):
     """A record stream shaped like scatterDataIntoSDTree's output (path_guiding_integrator.py:485-497)."""
     pos = positions_clustered(m, seed, bbox_min, bbox_max) if skew else positions_uniform(m, seed, bbox_min, bbox_max)
-    d = canonical_lobes(m, seed + 1) if skew else canonical_uniform(m, seed + 1)
-    dn = canonical_lobes(m, seed + 2) if skew else canonical_uniform(m, seed + 2)
+    d = canonical_lobes(m, seed + 1, shift) if skew else canonical_uniform(m, seed + 1)
+    dn = canonical_lobes(m, seed + 2, shift) if skew else canonical_uniform(m, seed + 2)
     u = uniform(m, seed + 3, 4)
     # heavy-tailed positive radiance: 2^(8u-4) * u'  (exact: ldexp + multiply)
     e = np.floor(u[0] * np.float32(8)).astype(np.int32) - 4
