@@ -102,6 +102,13 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). This package has no fallback path.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64; importing torch first makes
+    # libpgsd.so bind to that copy instead of loading /opt/rocm's next to it (two runtimes in one
+    # process cannot both open the device: the second one sees no GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     V, U64, I32, U32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
     L.pg_last_error.restype = C.c_char_p

@@ -100,7 +100,8 @@ int pg_create(pg_context **out, int device_ordinal)
 	if (e != hipSuccess || count <= 0) {
 		(void)hipGetLastError();
 		return fail(nullptr, PG_ERR_NO_DEVICE,
-		            "pg_create: no HIP device visible (this library has no CPU fallback)");
+		            std::string("pg_create: no HIP device visible (this library has no CPU fallback): ") +
+		                (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
 	}
 	if (device_ordinal < 0 || device_ordinal >= count)
 		return fail(nullptr, PG_ERR_INVALID, "pg_create: device ordinal out of range");

@@ -1,0 +1,175 @@
+"""Host-side mirror of the reference's Mitsuba plugin class
+(takkasila/practical_path_guiding_lab src/path_guiding_integrator.py:27-628): same method names,
+argument meaning and error behaviour, with the two KDTree objects replaced by one device-resident
+SDTree (libpgsd.so).  Mitsuba is not required: `sample()` drives any scene object that implements
+the small wavefront protocol of `practical_path_guiding_lab_amd.render` instead of mi.Scene.
+
+Only what the drivers call is mirrored: setup, setIteration, resetVarianceCounter,
+sample, computeVariance, computeMSE, refineAndPrepareSDTreeForNextIteration, saveSDTreeToFile,
+loadSDTreeFromFile, saveSDTreeOBJ, aov_names, to_string, and the `max_depth` attribute.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .sdtree import SDTree
+
+epsilon = 0.00001  # path_guiding_integrator.py:14
+
+_LUM = (0.212671, 0.715160, 0.072169)
+
+
+def luminance(c: torch.Tensor) -> torch.Tensor:
+    """mi.luminance for planar (3, N) colours."""
+    return c[0] * _LUM[0] + c[1] * _LUM[1] + c[2] * _LUM[2]
+
+
+class PathGuidingIntegrator:
+    def __init__(self, props: Optional[dict] = None, device: int = 0):
+        props = props or {}
+        # path_guiding_integrator.py:32-41
+        self.max_depth = props.get("max_depth", 30)
+        if self.max_depth < 0 and self.max_depth != -1:
+            raise Exception('"max_depth" must be set to -1 (infinite) or a value >= 0')
+        self.rr_depth = props.get("rr_depth", 8)
+        if self.rr_depth < 0:
+            raise Exception('"rr_depth" must be set to >= 0')
+        self.numRays = 0
+        self.array_size = 0
+        self.isStoreNEERadiance = False
+        self.bsdfSamplingFraction = 0.5
+        self.iteration = 0
+        self.isFinalIter = False
+        self.sdTree = SDTree(device)  # sdTree_prev (values) + sdTree_current (accumulators)
+        self.device = self.sdTree.device
+        self.sumL = None
+        self.sumL2 = None
+        self._bbox = None
+
+    # ---- path_guiding_integrator.py:77-105 ---------------------------------------------------
+    def setup(self, numRays: int, bbox_min, bbox_max, sdTreeMaxDepth: int = 10, quadTreeMaxDepth: int = 30,
+              isStoreNEERadiance: bool = True, bsdfSamplingFraction: float = 0.5) -> None:
+        self.numRays = int(numRays)
+        self.array_size = self.numRays * self.max_depth
+        self.isStoreNEERadiance = bool(isStoreNEERadiance)
+        self.bsdfSamplingFraction = float(bsdfSamplingFraction)
+        self._bbox = (tuple(float(v) for v in bbox_min), tuple(float(v) for v in bbox_max))
+        self.sdTree.setup(bbox_min, bbox_max, self.numRays, self.max_depth, sdTreeMaxDepth, quadTreeMaxDepth,
+                          isStoreNEERadiance, bsdfSamplingFraction)
+        self.resetVarianceCounter()
+
+    def resetVarianceCounter(self) -> None:  # :108-110
+        self.sumL = torch.zeros((3, max(self.numRays, 1)), dtype=torch.float32, device=self.device)
+        self.sumL2 = torch.zeros_like(self.sumL)
+
+    def setIteration(self, iteration: int, isFinalIter: bool) -> None:  # :121-123
+        self.iteration = int(iteration)
+        self.isFinalIter = bool(isFinalIter)
+        self.sdTree.setIteration(self.iteration, self.isFinalIter)
+
+    # ---- the render hook (:126-431) ------------------------------------------------------------
+    def sample(self, scene, sampler, ray=None, medium=None, active=True, aovs=None):
+        """One pass over all pixels.  `scene` must implement the wavefront protocol of
+        practical_path_guiding_lab_amd.render (trace_pass); returns (L (3,N), valid (N,), [1])."""
+        if not hasattr(scene, "trace_pass"):
+            raise TypeError("scene must provide trace_pass(integrator, sampler): see practical_path_guiding_lab_amd.render")
+        L, valid, spp_per_pass = scene.trace_pass(self, sampler)
+        self.accumulate(L, spp_per_pass)
+        return L, valid, [1]
+
+    def accumulate(self, L: torch.Tensor, spp_per_pass: int = 1) -> None:
+        """sumL / sumL2 bookkeeping (:400-429): lanes of one pixel are adjacent when spp_per_pass > 1."""
+        if spp_per_pass == 1:
+            self.sumL += L
+            self.sumL2 += L * L
+        else:
+            Lr = L.reshape(3, -1, spp_per_pass)
+            self.sumL += Lr.sum(dim=2)
+            self.sumL2 += (Lr * Lr).sum(dim=2)
+
+    # ---- metrics (:503-550) ---------------------------------------------------------------------
+    def computeMSE(self, spp: float, groundTruth: torch.Tensor) -> float:
+        L = self.sumL / spp
+        mse = (L - groundTruth) ** 2
+        mse = torch.clamp(luminance(mse), max=10000.0)
+        return float(mse.mean().item())
+
+    def computeVariance(self, spp: float, groundTruth: Optional[torch.Tensor] = None) -> float:
+        if groundTruth is not None:
+            variance = (self.sumL2 / spp) - (groundTruth * groundTruth)
+            variance = torch.clamp(luminance(variance), max=10000.0)
+            return float(variance.mean().item()) / spp
+        L = self.sumL / spp
+        L2 = self.sumL2 / spp
+        variance = torch.clamp(luminance(L2 - L * L), max=10000.0)
+        v = float(variance.mean().item())
+        if spp > 1:
+            v /= spp - 1
+        return v
+
+    # ---- refinement (:553-586) ------------------------------------------------------------------
+    def refineAndPrepareSDTreeForNextIteration(self, all_reduce=None) -> None:
+        """all_reduce: optional callable(int64 tensor) -> None summing the accumulators over ranks
+        (torch.distributed.all_reduce on the RCCL group) before the deterministic refine."""
+        if all_reduce is not None:
+            all_reduce(self.sdTree.accumulators())
+        self.sdTree.refineAndPrepare()
+
+    # ---- files (:589-615) -----------------------------------------------------------------------
+    def saveSDTreeToFile(self, fileName: str) -> None:
+        self.sdTree.saveToFile(fileName)
+
+    def loadSDTreeFromFile(self, fileName: str) -> None:
+        self.sdTree.loadFromFile(fileName)
+        self.isStoreNEERadiance = self.sdTree.store_nee
+
+    def saveSDTreeOBJ(self, fileName: str) -> None:
+        write_kd_obj(self.sdTree.export(), fileName)
+
+    def aov_names(self):  # :618-620
+        return ["depth.Y"]
+
+    def to_string(self):  # :623-624
+        return "path_guiding_integrator"
+
+
+def write_kd_obj(tree: dict, fileName: str) -> None:
+    """KDTree.saveOBJ (kdtree.py:605-663): one wireframe box per KD node."""
+    bmin, bmax = tree["kdtree_bbox_min"], tree["kdtree_bbox_max"]
+    sceneName = fileName.split("/")[-1].split(".")[0]
+    vertCount = 1
+    with open(fileName, "w") as f:
+        f.write("# OBJ file of KDTree Bounding Boxes\n")
+        f.write(f"o {sceneName}\n")
+        for i in range(bmin.shape[0]):
+            a, b = bmin[i], bmax[i]
+            f.write(f"v {a[0]} {a[1]} {a[2]}\n")
+            f.write(f"v {b[0]} {a[1]} {a[2]}\n")
+            f.write(f"v {b[0]} {a[1]} {b[2]}\n")
+            f.write(f"v {a[0]} {a[1]} {b[2]}\n")
+            f.write(f"l {vertCount + 0} {vertCount + 1} {vertCount + 2} {vertCount + 3} {vertCount + 0}\n")
+            f.write(f"v {a[0]} {b[1]} {a[2]}\n")
+            f.write(f"v {b[0]} {b[1]} {a[2]}\n")
+            f.write(f"v {b[0]} {b[1]} {b[2]}\n")
+            f.write(f"v {a[0]} {b[1]} {b[2]}\n")
+            f.write(f"l {vertCount + 4} {vertCount + 5} {vertCount + 6} {vertCount + 7} {vertCount + 4}\n")
+            f.write(f"l {vertCount + 0} {vertCount + 4}\n")
+            f.write(f"l {vertCount + 1} {vertCount + 5}\n")
+            f.write(f"l {vertCount + 2} {vertCount + 6}\n")
+            f.write(f"l {vertCount + 3} {vertCount + 7}\n")
+            vertCount += 8
+
+
+def register_with_mitsuba() -> bool:
+    """mi.register_integrator('path_guiding_integrator', ...) (path_guiding_integrator.py:628) when
+    Mitsuba 3 is importable; the wavefront protocol still has to be provided by the scene."""
+    try:
+        import mitsuba as mi  # type: ignore
+    except ImportError:
+        return False
+    mi.register_integrator("path_guiding_integrator",
+                           lambda props: PathGuidingIntegrator({k: props[k] for k in props.keys()}))
+    return True

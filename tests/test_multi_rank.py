@@ -1,0 +1,148 @@
+"""N>1 path under world_size 2.
+
+CPU (gloo): the exchange step -- per-rank accumulators in the device's limb format, summed with
+practical_path_guiding_lab_amd.parallel.all_reduce_accumulators, resolve to exactly the
+accumulators of a single process that saw all records (integer sums are order- and
+partition-independent).  The per-rank accumulators come from the oracle (no GPU here).
+
+GPU (-m gpu): two ranks sharing cuda:0 over gloo run the real product path (splat shard ->
+all-reduce -> refine) and must end with the single-rank tree, bit for bit.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from oracle import pg_oracle as po
+
+BB0, BB1 = [0.0] * 3, [100.0] * 3
+M = 60_000
+
+
+def _limbs(lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    """128-bit two's complement (lo, hi) -> three int64 limbs with value l0 + l1*2^32 + l2*2^64."""
+    l0 = (lo & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    l1 = (lo >> np.uint64(32)).astype(np.int64)
+    return np.stack([l0, l1, hi.astype(np.int64)], axis=1)
+
+
+def _resolve(limbs: np.ndarray):
+    return [int(a) + (int(b) << 32) + (int(c) << 64) for a, b, c in limbs]
+
+
+def _base_tree():
+    pair = synth.build_skewed(1 << 13, 3)
+    return pair.prev.export()
+
+
+def _rank_records(rank, world):
+    from practical_path_guiding_lab_amd.parallel import shard
+
+    rec = synth.records(M, 4242, BB0, BB1)
+    s, c = shard(M, rank, world)
+    return {k: np.ascontiguousarray(v[..., s:s + c]) for k, v in rec.items()}
+
+
+def _worker_cpu(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators, max_over_ranks
+
+    t = po.OracleTree()
+    t.load(_base_tree())
+    t.reset()
+    synth.splat(t, _rank_records(rank, world))
+    limbs = _limbs(t.quad_column("acc_lo"), t.quad_column("acc_hi"))
+    cnt = t.kd_column("count").astype(np.int64)
+    buf = torch.from_numpy(np.concatenate([limbs.reshape(-1), cnt]))
+    all_reduce_accumulators(buf)
+    assert max_over_ranks(float(rank)) == float(world - 1)
+    if rank == 0:
+        np.save(out, buf.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_covers_everything():
+    from practical_path_guiding_lab_amd.parallel import shard
+
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            parts = [shard(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+            for (s0, c0), (s1, _) in zip(parts, parts[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    with pytest.raises(ValueError):
+        shard(10, 2, 2)
+
+
+def test_two_rank_allreduce_equals_single_process(tmp_path):
+    world, out = 2, str(tmp_path / "sum.npy")
+    mp.spawn(_worker_cpu, args=(world, 29611, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = po.OracleTree()
+    ref.load(_base_tree())
+    ref.reset()
+    synth.splat(ref, synth.records(M, 4242, BB0, BB1))
+    nq = ref.quad_size
+    exp = [(int(h) << 64) + int(l) for l, h in zip(ref.quad_column("acc_lo"), ref.quad_column("acc_hi"))]
+    # two's complement of negative totals: compare modulo 2^128 like the hardware does
+    got_v = [v % (1 << 128) for v in _resolve(got[: nq * 3].reshape(nq, 3))]
+    assert got_v == [v % (1 << 128) for v in exp]
+    np.testing.assert_array_equal(got[nq * 3:], ref.kd_column("count").astype(np.int64))
+
+
+def test_single_rank_is_a_noop():
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators
+
+    a = torch.arange(10, dtype=torch.int64)
+    assert all_reduce_accumulators(a) is a
+    with pytest.raises(TypeError):
+        all_reduce_accumulators(torch.zeros(3, dtype=torch.int32))
+
+
+# ---------------------------------------------------------------------------------------------
+def _worker_gpu(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators
+    from practical_path_guiding_lab_amd.sdtree import SDTree
+
+    g = SDTree(0)
+    g.load(_base_tree())
+    g.setIteration(3, False)
+    rec = _rank_records(rank, world)
+    g.addDataPropagate({k: torch.from_numpy(v).cuda() for k, v in rec.items()})
+    all_reduce_accumulators(g.accumulators())
+    g.refineAndPrepare()
+    e = g.export()
+    np.savez(out % rank, **e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_gpu_match_single_rank_and_oracle(tmp_path):
+    world = 2
+    out = str(tmp_path / "tree%d.npz")
+    mp.spawn(_worker_gpu, args=(world, 29612, out), nprocs=world, join=True)
+    o = po.OracleSDTreePair()
+    o.current.load(_base_tree())
+    o.current.reset()
+    synth.splat(o.current, synth.records(M, 4242, BB0, BB1))
+    o.refine_and_prepare(3)
+    exp = o.prev.export()
+    for r in range(world):
+        got = dict(np.load(out % r))
+        assert set(got) == set(exp)
+        for k in exp:
+            np.testing.assert_array_equal(np.asarray(got[k]).astype(np.float64), np.asarray(exp[k]).astype(np.float64), err_msg=k)
