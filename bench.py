@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- guided-pass throughput of the SD-tree hot path on MI355X.
 
-step      = one 1-spp guided pass of the hot path over `--rays` camera paths (BASELINE.json
-            configs[1] geometry: cornell-box 512x512 rays/pass, max_depth 8): per bounce one
+step      = one guided pass of the hot path over pixels x spp_per_pass camera paths (BASELINE.json
+            configs[1] geometry: cornell-box 512x512, max_depth 8; 8 spp per pass): per bounce one
             pg_guide_bounce launch, then one pg_process_and_splat over the dense record buffer.
             Inputs are synthetic (seeded) and resident in HBM before the timed region.
 value     = camera paths (samples) completed per second over all ranks, in Msamples/s.
@@ -30,16 +30,24 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=512 * 512, help="camera paths per pass and per GPU")
+    ap.add_argument("--pixels", type=int, default=512 * 512, help="pixels per GPU (cornell-box 512x512)")
+    ap.add_argument("--spp-per-pass", type=int, default=8,
+                    help="samples per pixel traced by one pass (one wavefront launch per bounce)")
     ap.add_argument("--depth", type=int, default=8, help="max_depth (record slots per path)")
     ap.add_argument("--train-iters", type=int, default=6, help="refine iterations used to grow the tree")
-    ap.add_argument("--cpu-passes", type=int, default=3, help="oracle passes timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-passes", type=int, default=1, help="oracle passes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
+    ap.add_argument("--no-compaction", action="store_true", help="mask dead lanes instead of compacting them")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    # The reference renders 1 spp per pass while training (main.py:192) because each pass keeps a
+    # dense numRays*max_depth record buffer in a 2017-size GPU.  With 288 GB per MI355X one pass
+    # traces spp_per_pass samples of every pixel: same samples, same tree (integer accumulation is
+    # order independent), 8x larger wavefronts.
+    args.rays = args.pixels * args.spp_per_pass
     import torch
     import torch.distributed as dist
 
@@ -62,6 +70,7 @@ def main():
     tree = SDTree(device=local_rank)
     tree.setup(W.CORNELL_BBOX_MIN, W.CORNELL_BBOX_MAX, args.rays, args.depth, 20, 20, True, 0.5)  # main.py:56-64
     wl = W.SyntheticPassWorkload(tree, args.rays, args.depth, seed=1, rank=rank)
+    wl.compaction = not args.no_compaction
 
     def all_reduce(acc):
         if world > 1 and acc.numel():
@@ -70,7 +79,7 @@ def main():
     # grow the tree with the library itself: every rank splats its own shard of records, the
     # accumulators are summed, every rank runs the same deterministic refine
     t_train = time.perf_counter()
-    wl.train(args.train_iters, records_per_pass=3 * args.rays, all_reduce=all_reduce if world > 1 else None)
+    wl.train(args.train_iters, records_per_pass=3 * args.pixels, all_reduce=all_reduce if world > 1 else None)
     torch.cuda.synchronize()
     t_train = time.perf_counter() - t_train
     stats = tree.stats()
@@ -91,6 +100,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         for b in range(D):
+            wl.run_compact(b)
             if use_ev:
                 ev[k][b][0].record()
             wl.run_bounce(b)
@@ -98,7 +108,7 @@ def main():
                 ev[k][b][1].record()
         if use_ev:
             ev[k][D][0].record()
-        tree.processAndSplat(wl.n, D, wl.Lfinal, wl.dense)
+        wl.run_splat()
         if use_ev:
             ev[k][D][1].record()
     torch.cuda.synchronize()
@@ -168,9 +178,10 @@ def main():
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2-synthetic: cornell-box 512x512 rays/pass, max_depth 8, SD-tree ops only "
-                               "(guide_bounce x max_depth + process_and_splat); no ray casting/BSDF",
-                   "rays_per_gpu": args.rays, "max_depth": D, "train_iters": args.train_iters,
+        "config": {"workload": "C2-synthetic: cornell-box 512x512 pixels x spp_per_pass paths/pass, max_depth 8, SD-tree ops only "
+                               "(lane compaction + guide_bounce per bounce, then process_and_splat); no ray casting/BSDF",
+                   "pixels_per_gpu": args.pixels, "spp_per_pass": args.spp_per_pass, "paths_per_pass_per_gpu": args.rays,
+                   "max_depth": D, "train_iters": args.train_iters,
                    "kd_nodes": stats.n_kd_nodes, "kd_leaves": stats.n_kd_leaves, "quad_records": stats.n_quad_records,
                    "mean_kd_leaf_depth": round(stats.mean_kd_leaf_depth, 3),
                    "mean_quad_leaf_depth": round(stats.mean_quad_leaf_depth, 3),

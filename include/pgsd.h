@@ -93,11 +93,26 @@ int pg_pdf(pg_context *ctx, uint64_t n, const float *p, const float *dir, const 
  *   select[i] == 2 : (dir_io, pdf_out) = sdTree_prev.sample(p, rng)   ("sdtree-mis" lanes)
  *   select[i] == 1 : pdf_out = sdTree_prev.pdf(p, dir_io)             ("bsdf-mis" lanes)
  *   select[i] == 0 : pdf_out = 1, dir_io untouched, stream untouched
- * dir_io holds the BSDF-sampled world direction on entry. */
+ * dir_io holds the BSDF-sampled world direction on entry.
+ * lane_index / d_lane_count (both NULL, or both set): the compacted list of live ray slots and
+ * its two counters as written by pg_compact_lanes; only those slots are processed (and written),
+ * and the launch costs waves in proportion to the counters, which are read on the device (no
+ * host round trip between bounces). */
 int pg_guide_bounce(pg_context *ctx, uint64_t n, const float *p, const float *dir_nee,
                     const uint8_t *nee_active, const uint8_t *select, float *dir_io,
                     uint64_t *rng_state, const uint64_t *rng_inc, float *pdf_nee_out,
-                    float *pdf_out, void *stream);
+                    float *pdf_out, const uint32_t *lane_index, const uint32_t *d_lane_count,
+                    void *stream);
+
+/* Active-ray stream compaction between bounces of the wavefront loop (the reference masks dead
+ * lanes instead, path_guiding_integrator.py:179, 380).  A lane is live when select[i] != 0 or
+ * nee_active[i] != 0 (nee_active may be NULL).  idx_out (uint32[n]) receives the lanes with
+ * select == 2 packed from the front, idx_out[0 .. d_count[0]), and the other live lanes packed
+ * from the back, idx_out[n-1], idx_out[n-2], ... (d_count[1] of them), so that waves of the
+ * bounce kernel do not mix the sampling and the pdf-only code paths.  Order inside each class
+ * is unspecified.  d_count is a device uint32[2], zeroed by the call; masks 16-byte aligned. */
+int pg_compact_lanes(pg_context *ctx, uint64_t n, const uint8_t *select, const uint8_t *nee_active,
+                     uint32_t *idx_out, uint32_t *d_count, void *stream);
 
 /* Mitsuba `independent` sampler seeding for lanes lane0..lane0+n (PCG32 + TEA). */
 int pg_rng_seed(pg_context *ctx, uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *rng_state,

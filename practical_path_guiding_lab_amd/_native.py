@@ -75,7 +75,7 @@ class pg_depth_counters(C.Structure):
 # every symbol include/pgsd.h declares (checked by tests/test_abi.py)
 EXPORTS = (
     "pg_create", "pg_destroy", "pg_last_error", "pg_abi_version", "pg_setup", "pg_set_iteration",
-    "pg_get_leaf_node_index", "pg_sample", "pg_pdf", "pg_guide_bounce", "pg_rng_seed", "pg_splat",
+    "pg_get_leaf_node_index", "pg_sample", "pg_pdf", "pg_guide_bounce", "pg_compact_lanes", "pg_rng_seed", "pg_splat",
     "pg_process_records", "pg_process_and_splat", "pg_refine_and_swap", "pg_accumulators",
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters",
@@ -121,7 +121,8 @@ def lib() -> C.CDLL:
     L.pg_get_leaf_node_index.argtypes = [V, U64, V, V, V, V]
     L.pg_sample.argtypes = [V, U64, V, V, V, V, V, V, V]
     L.pg_pdf.argtypes = [V, U64, V, V, V, V, V]
-    L.pg_guide_bounce.argtypes = [V, U64, V, V, V, V, V, V, V, V, V, V]
+    L.pg_guide_bounce.argtypes = [V, U64, V, V, V, V, V, V, V, V, V, V, V, V]
+    L.pg_compact_lanes.argtypes = [V, U64, V, V, V, V, V]
     L.pg_rng_seed.argtypes = [V, U64, U32, U32, V, V, V]
     L.pg_splat.argtypes = [V, U64, C.POINTER(pg_records), V, V]
     L.pg_process_records.argtypes = [V, U64, I32, V, C.POINTER(pg_dense_records), C.POINTER(pg_records_out), V, V]

@@ -221,13 +221,32 @@ int pg_pdf(pg_context *ctx, uint64_t n, const float *p, const float *dir, const 
 
 int pg_guide_bounce(pg_context *ctx, uint64_t n, const float *p, const float *dir_nee,
                     const uint8_t *nee_active, const uint8_t *select, float *dir_io, uint64_t *rng_state,
-                    const uint64_t *rng_inc, float *pdf_nee_out, float *pdf_out, void *stream)
+                    const uint64_t *rng_inc, float *pdf_nee_out, float *pdf_out, const uint32_t *lane_index,
+                    const uint32_t *d_lane_count, void *stream)
 {
 	PG_READY(ctx);
 	if (n && (!p || !dir_nee || !dir_io || !rng_state || !rng_inc || !pdf_nee_out || !pdf_out))
 		return fail(ctx, PG_ERR_INVALID, "pg_guide_bounce: NULL pointer");
+	if ((lane_index == nullptr) != (d_lane_count == nullptr))
+		return fail(ctx, PG_ERR_INVALID, "pg_guide_bounce: lane_index and d_lane_count go together");
+	if (n > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_guide_bounce: more than 2^32 lanes");
 	launch_guide_bounce(ctx->view(), n, p, dir_nee, nee_active, select, dir_io, rng_state, rng_inc,
-	                    pdf_nee_out, pdf_out, ctx->dc_on ? ctx->dc : nullptr, (hipStream_t)stream);
+	                    pdf_nee_out, pdf_out, lane_index, d_lane_count, ctx->dc_on ? ctx->dc : nullptr,
+	                    (hipStream_t)stream);
+	PG_LAUNCHED(ctx);
+	return PG_OK;
+}
+
+int pg_compact_lanes(pg_context *ctx, uint64_t n, const uint8_t *select, const uint8_t *nee_active,
+                     uint32_t *idx_out, uint32_t *d_count, void *stream)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	if (!d_count || (n && (!select || !idx_out))) return fail(ctx, PG_ERR_INVALID, "pg_compact_lanes: NULL pointer");
+	if (n > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_compact_lanes: more than 2^32 lanes");
+	if (((uintptr_t)select & 15u) || ((uintptr_t)nee_active & 15u))
+		return fail(ctx, PG_ERR_INVALID, "pg_compact_lanes: masks must be 16-byte aligned");
+	launch_compact_lanes(n, select, nee_active, idx_out, d_count, (hipStream_t)stream);
 	PG_LAUNCHED(ctx);
 	return PG_OK;
 }

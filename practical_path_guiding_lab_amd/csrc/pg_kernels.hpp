@@ -24,7 +24,10 @@ void launch_pdf(const TreeView &t, uint64_t n, const float *p, const float *dir,
 void launch_guide_bounce(const TreeView &t, uint64_t n, const float *p, const float *dir_nee,
                          const uint8_t *nee_active, const uint8_t *select, float *dir_io,
                          uint64_t *rng_state, const uint64_t *rng_inc, float *pdf_nee_out,
-                         float *pdf_out, DepthCounters *dc, hipStream_t s);
+                         float *pdf_out, const uint32_t *lane_index, const uint32_t *d_lane_count,
+                         DepthCounters *dc, hipStream_t s);
+void launch_compact_lanes(uint64_t n, const uint8_t *select, const uint8_t *nee_active, uint32_t *idx_out,
+                          uint32_t *d_count, hipStream_t s);
 void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state, uint64_t *inc,
                      hipStream_t s);
 

@@ -106,6 +106,10 @@ __global__ __launch_bounds__(kBlock) void k_pdf(TreeView t, uint64_t n, const fl
 
 // One KD descent shared by the NEE pdf and the sample-or-pdf of the continuation direction
 // (path_guiding_integrator.py:244, 301, 307 all pass the same si.p).
+//
+// lane_index/d_lane_count (optional): a compacted list of live ray slots produced by
+// k_compact_lanes.  Thread i then serves ray lane_index[i]; threads past *d_lane_count retire at
+// once, so a late bounce with few live rays costs few waves without a host round trip.
 __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n, const float *__restrict__ p,
                                                          const float *__restrict__ dir_nee,
                                                          const uint8_t *__restrict__ nee_active,
@@ -114,18 +118,29 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
                                                          uint64_t *__restrict__ rng_state,
                                                          const uint64_t *__restrict__ rng_inc,
                                                          float *__restrict__ pdf_nee_out,
-                                                         float *__restrict__ pdf_out, DepthCounters *dc)
+                                                         float *__restrict__ pdf_out,
+                                                         const uint32_t *__restrict__ lane_index,
+                                                         const uint32_t *__restrict__ d_lane_count,
+                                                         DepthCounters *dc)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	// compacted list: [0, front) from the start of lane_index (sample lanes), the next `back`
+	// entries from its end, walking down (pdf-only lanes): waves are homogeneous in `select`
+	const uint64_t front = lane_index ? (uint64_t)d_lane_count[0] : n;
+	const uint64_t live = lane_index ? front + (uint64_t)d_lane_count[1] : n;
+	if ((uint64_t)blockIdx.x * kBlock >= live) return; // whole workgroup idle (uniform)
+	stage_kd_top(s_kd, t.kd, t.n_kd);
 	unsigned kd_lv = 0, kd_q = 0, q_lv = 0, q_q = 0;
-	if (i < n) {
+	if (tid < live && tid < n) {
+		const uint64_t i = lane_index ? (uint64_t)lane_index[tid < front ? tid : n - 1 - (tid - front)] : tid;
 		const bool nee = nee_active ? nee_active[i] != 0 : true;
 		const int sel = select ? (int)select[i] : 2;
 		float pdf_nee = 1.0f, pdf = 1.0f;
 		if (nee || sel != 0) {
 			const float x = p[i], y = p[n + i], z = p[2 * n + i];
 			KdNode leaf;
-			kd_descend(t.kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
+			kd_descend_lds(t.kd, s_kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			kd_q = 1;
 			const TreeHead head = load_head(t.head, leaf.tree);
 			if (nee) {
@@ -160,6 +175,81 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 		pdf_out[i] = pdf;
 	}
 	count_depths(dc, kd_lv, kd_q, q_lv, q_q);
+}
+
+// Active-ray stream compaction, partitioned by what the lane will do: lanes that sample the tree
+// (select == 2) are packed from the front of idx_out, the other live lanes (select == 1, or only
+// an NEE pdf) from its back, so the bounce kernel's waves do not mix the two code paths.
+// One workgroup owns kCompactTile consecutive lanes (16 per thread, one 16-B load of each mask):
+// thread-local counts -> wave prefix (shuffles) -> workgroup prefix (LDS) -> ONE atomic pair per
+// workgroup.  A single counter word takes ~11 ns per atomic (MI355X_MICROARCH.md, "dequeue"), so
+// one atomic per wave would cost 45 us at 2^18 lanes; per 4096 lanes it is < 1 us.
+constexpr int kCompactItems = 16;
+constexpr int kCompactTile = kBlock * kCompactItems;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+	const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(v, o, 64);
+		if ((int)lane >= o) v += t;
+	}
+	return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact_lanes(uint64_t n, const uint8_t *__restrict__ select,
+                                                          const uint8_t *__restrict__ nee_active,
+                                                          uint32_t *__restrict__ idx_out,
+                                                          uint32_t *__restrict__ d_count /*[2]*/)
+{
+	__shared__ uint32_t s_wave[2][kBlock / 64];
+	__shared__ uint32_t s_base[2];
+	const uint64_t base = (uint64_t)blockIdx.x * kCompactTile + (uint64_t)threadIdx.x * kCompactItems;
+	alignas(16) uint8_t sel[kCompactItems];
+	alignas(16) uint8_t nee[kCompactItems];
+	if (base + kCompactItems <= n) {
+		*reinterpret_cast<uint4 *>(sel) = *reinterpret_cast<const uint4 *>(select + base);
+		if (nee_active) *reinterpret_cast<uint4 *>(nee) = *reinterpret_cast<const uint4 *>(nee_active + base);
+	} else {
+#pragma unroll
+		for (int k = 0; k < kCompactItems; ++k) {
+			sel[k] = base + k < n ? select[base + k] : 0;
+			nee[k] = (nee_active && base + k < n) ? nee_active[base + k] : 0;
+		}
+	}
+	uint32_t front_bits = 0, back_bits = 0;
+#pragma unroll
+	for (int k = 0; k < kCompactItems; ++k) {
+		const bool f = sel[k] == 2;
+		const bool b = !f && (sel[k] != 0 || (nee_active && nee[k] != 0));
+		front_bits |= (uint32_t)f << k;
+		back_bits |= (uint32_t)b << k;
+	}
+	const uint32_t nf = __popc(front_bits), nb = __popc(back_bits);
+	const uint32_t inf = wave_inclusive_scan(nf), inb = wave_inclusive_scan(nb);
+	const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	if (lane == 63) { s_wave[0][wid] = inf; s_wave[1][wid] = inb; }
+	__syncthreads();
+	uint32_t off_f = inf - nf, off_b = inb - nb, tot_f = 0, tot_b = 0;
+#pragma unroll
+	for (unsigned w = 0; w < kBlock / 64; ++w) {
+		if (w < wid) { off_f += s_wave[0][w]; off_b += s_wave[1][w]; }
+		tot_f += s_wave[0][w];
+		tot_b += s_wave[1][w];
+	}
+	if (threadIdx.x == 0) {
+		s_base[0] = tot_f ? atomicAdd(&d_count[0], tot_f) : 0;
+		s_base[1] = tot_b ? atomicAdd(&d_count[1], tot_b) : 0;
+	}
+	__syncthreads();
+	uint32_t wf = s_base[0] + off_f;
+	uint32_t wb = (uint32_t)(n - 1) - (s_base[1] + off_b);
+#pragma unroll
+	for (int k = 0; k < kCompactItems; ++k) {
+		if ((front_bits >> k) & 1u) idx_out[wf++] = (uint32_t)(base + k);
+		if ((back_bits >> k) & 1u) idx_out[wb--] = (uint32_t)(base + k);
+	}
 }
 
 __global__ __launch_bounds__(kBlock) void k_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0,
@@ -200,11 +290,21 @@ void launch_pdf(const TreeView &t, uint64_t n, const float *p, const float *dir,
 void launch_guide_bounce(const TreeView &t, uint64_t n, const float *p, const float *dir_nee,
                          const uint8_t *nee_active, const uint8_t *select, float *dir_io,
                          uint64_t *rng_state, const uint64_t *rng_inc, float *pdf_nee_out,
-                         float *pdf_out, DepthCounters *dc, hipStream_t s)
+                         float *pdf_out, const uint32_t *lane_index, const uint32_t *d_lane_count,
+                         DepthCounters *dc, hipStream_t s)
 {
 	if (n == 0) return;
 	hipLaunchKernelGGL(k_guide_bounce, grid_for(n), dim3(kBlock), 0, s, t, n, p, dir_nee, nee_active,
-	                   select, dir_io, rng_state, rng_inc, pdf_nee_out, pdf_out, dc);
+	                   select, dir_io, rng_state, rng_inc, pdf_nee_out, pdf_out, lane_index, d_lane_count, dc);
+}
+
+void launch_compact_lanes(uint64_t n, const uint8_t *select, const uint8_t *nee_active, uint32_t *idx_out,
+                          uint32_t *d_count, hipStream_t s)
+{
+	(void)hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), s);
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_compact_lanes, dim3((unsigned)((n + kCompactTile - 1) / kCompactTile)), dim3(kBlock), 0, s, n,
+	                   select, nee_active, idx_out, d_count);
 }
 
 void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state, uint64_t *inc,

@@ -154,6 +154,8 @@ struct Pcg32 {
 	{
 		return __uint_as_float((next_u32() >> 9) | 0x3f800000u) - 1.0f;
 	}
+	// a draw whose value is not needed: only the LCG step, no output permutation
+	__device__ __forceinline__ void skip() { state = state * 0x5851f42d4c957f2dULL + inc; }
 };
 
 __device__ __forceinline__ uint64_t tea64(uint32_t v0, uint32_t v1)

@@ -121,8 +121,18 @@ class SDTree:
         return pdf
 
     def guideBounce(self, position, dir_nee, nee_active, select, dir_io, sampler: PCG32Sampler,
-                    pdf_nee_out=None, pdf_out=None):
-        """The three SD-tree calls of one bounce with one KD descent (pg_guide_bounce)."""
+                    pdf_nee_out=None, pdf_out=None, lane_index=None, lane_count=None):
+        """The three SD-tree calls of one bounce with one KD descent (pg_guide_bounce).
+        lane_index/lane_count: compacted live-ray list from compactLanes (optional)."""
+        self.prepareGuideBounce(position, dir_nee, nee_active, select, dir_io, sampler, pdf_nee_out, pdf_out,
+                                lane_index, lane_count)()
+        return self._last_bounce_out
+
+    def prepareGuideBounce(self, position, dir_nee, nee_active, select, dir_io, sampler: PCG32Sampler,
+                           pdf_nee_out=None, pdf_out=None, lane_index=None, lane_count=None):
+        """Validates once and returns a zero-argument callable that launches pg_guide_bounce on the
+        current stream with the argument list already marshalled (a wavefront loop re-launches the
+        same buffers every bounce of every pass; per-call checks would dominate a 30 us kernel)."""
         n = position.shape[1]
         _f32(position, (3, n)); _f32(dir_nee, (3, n)); _f32(dir_io, (3, n))
         na, nap = _mask(nee_active, n)
@@ -131,10 +141,49 @@ class SDTree:
             pdf_nee_out = torch.empty(n, dtype=torch.float32, device=self.device)
         if pdf_out is None:
             pdf_out = torch.empty(n, dtype=torch.float32, device=self.device)
-        self._ck(self._lib.pg_guide_bounce(self._h, n, position.data_ptr(), dir_nee.data_ptr(), nap, slp,
-                                           dir_io.data_ptr(), sampler.state.data_ptr(), sampler.inc.data_ptr(),
-                                           pdf_nee_out.data_ptr(), pdf_out.data_ptr(), _stream_ptr()))
-        return pdf_nee_out, pdf_out
+        lip = lcp = None
+        if (lane_index is None) != (lane_count is None):
+            raise ValueError("lane_index and lane_count go together")
+        if lane_index is not None:
+            if (lane_index.dtype != torch.int32 or lane_count.dtype != torch.int32 or lane_index.numel() < n
+                    or lane_count.numel() < 2):
+                raise ValueError("lane_index must be int32[n], lane_count int32[2] (from compactLanes)")
+            lip, lcp = lane_index.data_ptr(), lane_count.data_ptr()
+        keep = (position, dir_nee, na, sl, dir_io, sampler, pdf_nee_out, pdf_out, lane_index, lane_count)
+        self._last_bounce_out = (pdf_nee_out, pdf_out)
+        fn, h = self._lib.pg_guide_bounce, self._h
+        args = (h, n, position.data_ptr(), dir_nee.data_ptr(), nap, slp, dir_io.data_ptr(), sampler.state.data_ptr(),
+                sampler.inc.data_ptr(), pdf_nee_out.data_ptr(), pdf_out.data_ptr(), lip, lcp)
+        ck = self._ck
+
+        def launch(_keep=keep):
+            ck(fn(*args, torch.cuda.current_stream().cuda_stream))
+        return launch
+
+    def compactLanes(self, select: torch.Tensor, nee_active: Optional[torch.Tensor] = None,
+                     idx_out: Optional[torch.Tensor] = None, count_out: Optional[torch.Tensor] = None):
+        """Active-ray stream compaction (pg_compact_lanes): returns (idx int32[n], counts int32[2]);
+        idx[:counts[0]] are the select==2 lanes, idx[n-counts[1]:] (reversed) the other live lanes."""
+        self.prepareCompactLanes(select, nee_active, idx_out, count_out)()
+        return self._last_compact_out
+
+    def prepareCompactLanes(self, select: torch.Tensor, nee_active=None, idx_out=None, count_out=None):
+        n = select.shape[0]
+        s, sp = _mask(select, n)
+        ne, nep = _mask(nee_active, n)
+        if idx_out is None:
+            idx_out = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        if count_out is None:
+            count_out = torch.zeros(2, dtype=torch.int32, device=self.device)
+        if count_out.numel() < 2 or count_out.dtype != torch.int32:
+            raise ValueError("count_out must be int32[2]")
+        self._last_compact_out = (idx_out, count_out)
+        fn, h, ck = self._lib.pg_compact_lanes, self._h, self._ck
+        args = (h, n, sp, nep, idx_out.data_ptr(), count_out.data_ptr())
+
+        def launch(_keep=(s, ne, idx_out, count_out)):
+            ck(fn(*args, torch.cuda.current_stream().cuda_stream))
+        return launch
 
     # ---- recording (kdtree.py:180-225) ----------------------------------------------------
     def addDataPropagate(self, rec: Dict[str, torch.Tensor], count: Optional[torch.Tensor] = None):
@@ -196,10 +245,18 @@ class SDTree:
         return out, count
 
     def processAndSplat(self, num_rays: int, max_depth: int, Lfinal: torch.Tensor, rec: Dict[str, torch.Tensor]):
+        self.prepareProcessAndSplat(num_rays, max_depth, Lfinal, rec)()
+
+    def prepareProcessAndSplat(self, num_rays: int, max_depth: int, Lfinal: torch.Tensor, rec: Dict[str, torch.Tensor]):
         S = num_rays * max_depth
         _f32(Lfinal, (3, num_rays))
         d = self._dense(rec, S)
-        self._ck(self._lib.pg_process_and_splat(self._h, num_rays, max_depth, Lfinal.data_ptr(), C.byref(d), _stream_ptr()))
+        fn, h, ck = self._lib.pg_process_and_splat, self._h, self._ck
+        args = (h, num_rays, max_depth, Lfinal.data_ptr(), C.byref(d))
+
+        def launch(_keep=(Lfinal, rec, d)):
+            ck(fn(*args, torch.cuda.current_stream().cuda_stream))
+        return launch
 
     # ---- refinement ---------------------------------------------------------------------
     def refineAndPrepare(self):

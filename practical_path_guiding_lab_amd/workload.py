@@ -146,18 +146,41 @@ class SyntheticPassWorkload:
         for k, v in self.dense.items():
             if k != "active":
                 v.mul_(active.to(v.dtype))  # dr.zeros leaves unwritten slots at 0 (:116)
+        # pre-marshalled launches: per bounce one stream compaction of the live lanes (what a wavefront
+        # renderer does between bounces) and one guide_bounce over the compacted list
+        self.lane_idx = torch.empty(n, dtype=torch.int32, device=self.dev)
+        self.lane_cnt = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        self._compact, self._bounce = [], []
+        for bb in self.bounce:
+            # dir_io holds the BSDF-sampled direction on entry; sel==2 lanes overwrite it with the
+            # guided direction and never read it, so the buffer needs no reset between passes
+            bb["dir_io"] = bb["d_bsdf"].clone()
+            use_compaction = self.compaction
+            self._compact.append(self.tree.prepareCompactLanes(bb["sel"], bb["nee"], self.lane_idx, self.lane_cnt)
+                                 if use_compaction else None)
+            self._bounce.append(self.tree.prepareGuideBounce(
+                bb["p"], bb["d_nee"], bb["nee"], bb["sel"], bb["dir_io"], self.sampler, bb["pdf_nee"], bb["pdf"],
+                self.lane_idx if use_compaction else None, self.lane_cnt if use_compaction else None))
+        self._splat = self.tree.prepareProcessAndSplat(self.n, self.depth, self.Lfinal, self.dense)
         torch.cuda.synchronize()
 
+    compaction = True
+
+    def run_compact(self, b: int):
+        if self._compact[b] is not None:
+            self._compact[b]()
+
     def run_bounce(self, b: int):
-        bb = self.bounce[b]
-        bb["dir_io"].copy_(bb["d_bsdf"])
-        self.tree.guideBounce(bb["p"], bb["d_nee"], bb["nee"], bb["sel"], bb["dir_io"], self.sampler,
-                              bb["pdf_nee"], bb["pdf"])
+        self._bounce[b]()
+
+    def run_splat(self):
+        self._splat()
 
     def run_pass(self):
         for b in range(self.depth):
+            self.run_compact(b)
             self.run_bounce(b)
-        self.tree.processAndSplat(self.n, self.depth, self.Lfinal, self.dense)
+        self.run_splat()
 
     # ---- byte model ---------------------------------------------------------------
     def measure_depths(self) -> Dict[str, float]:
@@ -167,10 +190,11 @@ class SyntheticPassWorkload:
         t.readDepthCounters(reset=True)
         out = {"bounce": [], "splat": None}
         for b in range(self.depth):
+            self.run_compact(b)
             self.run_bounce(b)
             dc = t.readDepthCounters(reset=True)
             out["bounce"].append((dc.kd_levels, dc.kd_queries, dc.quad_levels, dc.quad_queries))
-        t.processAndSplat(self.n, self.depth, self.Lfinal, self.dense)
+        self.run_splat()
         dc = t.readDepthCounters(reset=True)
         out["splat"] = (dc.kd_levels, dc.kd_queries, dc.quad_levels, dc.quad_queries)
         t.enableDepthCounters(False)
