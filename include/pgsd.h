@@ -216,6 +216,39 @@ int pg_import(pg_context *ctx, const pg_tree_sizes *sizes, const pg_tree_columns
 int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t *h_kd_count,
                            uint64_t *h_quad_acc_lo, int64_t *h_quad_acc_hi);
 
+/* ---- renderer substrate: PathGuidingIntegrator.sample() on device ----- */
+
+/* Scene subset of the reference's scenes/cornell-box/scene.xml: parallelograms ("rectangle" and
+ * the six faces of "cube" shapes) with twosided diffuse BSDFs, one one-sided area emitter, a
+ * perspective sensor.  h_quads is a HOST array of n_quads*24 floats:
+ *   0-2 origin  3-5 edge1  6-8 edge2  9-11 unit normal (= normalised e1 x e2)
+ *   12 1/|e1|^2  13 1/|e2|^2  14 area  15 emitter flag  16-18 diffuse reflectance
+ *   19-21 emitted radiance  22-23 unused
+ * (practical_path_guiding_lab_amd/scene.py builds it from Mitsuba XML). */
+typedef struct pg_camera {
+	float origin[3];
+	float axis_x[3], axis_y[3], axis_z[3]; /* columns of the sensor's to_world rotation */
+	float tan_half_fov_x;
+	int32_t width, height;
+} pg_camera;
+int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const pg_camera *cam);
+
+typedef struct pg_pass_params {
+	uint32_t seed;    /* sampler seed of the pass (main.py:218: initial_seed + cumm_spp) */
+	int32_t spp;      /* samples per pixel traced by this pass; lane = pixel*spp + s (:414-417) */
+	int32_t rr_depth; /* Russian roulette from this depth on (:39, 375) */
+} pg_pass_params;
+
+/* One call of PathGuidingIntegrator.sample() for all width*height*spp lanes
+ * (path_guiding_integrator.py:126-431): camera rays, max_depth bounces with NEE + one-sample MIS
+ * between BSDF and sdTree_prev sampling (guiding active when iteration > 1), record store, then
+ * processPathData + scatterDataIntoSDTree into sdTree_current unless the iteration is final.
+ * max_depth, iteration, is_final, store_nee and the sampling fraction come from pg_setup /
+ * pg_set_iteration.  L_out: Color3f[lanes] planar (device); valid_out: uint8[lanes] or NULL;
+ * sumL/sumL2: Color3f[width*height] planar accumulators (:400-429) or both NULL. */
+int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uint8_t *valid_out,
+                   float *sumL, float *sumL2, void *stream);
+
 /* ---- statistics for the roofline model ------------------------------------ */
 typedef struct pg_stats {
 	uint64_t n_kd_nodes, n_kd_leaves, n_quad_records, n_quad_nodes, n_trees;

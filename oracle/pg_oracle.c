@@ -1086,3 +1086,21 @@ void pgo_atan2_v(size_t n, const float *y, const float *x, float *out)
 {
 	for (size_t i = 0; i < n; ++i) out[i] = pgo_atan2(y[i], x[i]);
 }
+
+/* ---- scalar entry points for the oracle's integrator loop (pg_oracle_render.c) ---- */
+uint32_t pgo_i_quadtree_of(const pgo_tree *t, const float p[3], int active)
+{
+	/* kdtree.py:481-482: masked gather of quadTreeRootIndex at the leaf */
+	uint32_t leaf = kd_leaf_index(&t->kd, p, active);
+	return active ? t->kd.qroot[leaf] : 0;
+}
+void pgo_i_sample(const pgo_tree *t, uint32_t root, uint64_t *state, uint64_t inc, int active, float dir[3])
+{
+	pgo_pcg32 r = { *state, inc };
+	qt_sample_one(&t->qt, root, &r, active, dir);
+	*state = r.state;
+}
+float pgo_i_pdf(const pgo_tree *t, uint32_t root, const float dir[3], int active)
+{
+	return qt_pdf_one(&t->qt, root, dir, active);
+}

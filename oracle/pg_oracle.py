@@ -22,7 +22,7 @@ W_CLAMP_LOG2 = 48
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (needs only oracle/*.c, no reference files)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pg_oracle.c", "pg_oracle.h", "pgo_math.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pg_oracle.c", "pg_oracle.h", "pgo_math.h", "pg_oracle_render.c", "pg_oracle_render.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s)
     )
@@ -438,3 +438,37 @@ class OracleSDTreePair:
     def refine_and_prepare(self, iteration=None):
         it = self.iteration if iteration is None else iteration
         lib().pgo_refine_and_prepare(self.current._h, self.prev._h, it)
+
+
+# ---- integrator loop over the quad substrate (pg_oracle_render.c) -------------------------------
+class _Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("axis_x", C.c_float * 3), ("axis_y", C.c_float * 3),
+                ("axis_z", C.c_float * 3), ("tan_half_fov_x", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class _RenderParams(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("iteration", C.c_int32), ("is_final", C.c_int32),
+                ("store_nee", C.c_int32), ("bsdf_sampling_fraction", C.c_float), ("seed", C.c_uint32), ("spp", C.c_int32)]
+
+
+def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, iteration, is_final, seed, spp=1,
+                store_nee=True, bsdf_sampling_fraction=0.5, sumL=None, sumL2=None):
+    """One pass of PathGuidingIntegrator.sample() (path_guiding_integrator.py:126-431) on the CPU.
+    cam: object with origin/axis_x/axis_y/axis_z/tan_half_fov_x/width/height.  Returns (L (3,N), valid (N,))."""
+    L = lib()
+    L.pgo_render_pass.argtypes = [_P, _P, _SZ, _P, C.POINTER(_Camera), C.POINTER(_RenderParams), _P, _P, _P, _P]
+    L.pgo_render_pass.restype = None
+    quads = np.ascontiguousarray(quads, np.float32)
+    c = _Camera()
+    for k in ("origin", "axis_x", "axis_y", "axis_z"):
+        setattr(c, k, (C.c_float * 3)(*[float(v) for v in getattr(cam, k)]))
+    c.tan_half_fov_x = float(cam.tan_half_fov_x)
+    c.width, c.height = int(cam.width), int(cam.height)
+    p = _RenderParams(int(max_depth), int(rr_depth), int(iteration), int(bool(is_final)), int(bool(store_nee)),
+                      float(bsdf_sampling_fraction), int(seed) & 0xFFFFFFFF, int(spp))
+    n = c.width * c.height * int(spp)
+    Lout = np.zeros((3, n), np.float32)
+    valid = np.zeros(n, np.uint8)
+    L.pgo_render_pass(pair.prev._h, pair.current._h, quads.shape[0], _ptr(quads), C.byref(c), C.byref(p),
+                      _ptr(Lout), _ptr(valid), _ptr(sumL), _ptr(sumL2))
+    return Lout, valid

@@ -1,0 +1,363 @@
+/*
+ * pg_oracle_render.c -- TEST INFRASTRUCTURE.  Scalar restatement of the reference's integrator
+ * loop, PathGuidingIntegrator.sample() (src/path_guiding_integrator.py:126-431), one lane at a
+ * time, on top of the oracle's SD-tree (pg_oracle.c) and a minimal quad/diffuse/area-light
+ * substrate that replaces the Mitsuba calls (see pg_oracle_render.h for the unpinned-parity note).
+ */
+#include "pg_oracle_render.h"
+
+#include <stdlib.h>
+
+#include "pgo_math.h"
+
+/* scalar hooks exported by pg_oracle.c */
+uint32_t pgo_i_quadtree_of(const pgo_tree *t, const float p[3], int active);
+void pgo_i_sample(const pgo_tree *t, uint32_t root, uint64_t *state, uint64_t inc, int active, float dir[3]);
+float pgo_i_pdf(const pgo_tree *t, uint32_t root, const float dir[3], int active);
+
+typedef struct { float x, y, z; } v3;
+
+#define INV_PI_F 0.31830988618379067154f
+#define RAY_EPS_F 1e-4f
+#define SHADOW_EPS_F 1e-3f
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+static inline v3 vdiv(v3 a, v3 b) { return V(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 ld3(const float *p) { return V(p[0], p[1], p[2]); }
+static inline float max3(v3 a) { float m = a.x > a.y ? a.x : a.y; return m > a.z ? m : a.z; }
+
+/* path_guiding_integrator.py:16-24 */
+static inline float mis_weight(float a, float b)
+{
+	float a2 = a * a;
+	float r = a > 0.0f ? a2 / (b * b + a2) : 0.0f;
+	if (r != r) r = 0.0f;
+	return r;
+}
+
+/* Mitsuba coordinate_system(n) (Duff et al. 2017) */
+static inline void frame_from_normal(v3 n, v3 *s, v3 *t)
+{
+	float sign = n.z >= 0.0f ? 1.0f : -1.0f; /* copysign(1, n.z) up to -0 */
+	if (pgo_f2u(n.z) >> 31) sign = -1.0f;
+	float a = -1.0f / (sign + n.z);
+	float b = (n.x * n.y) * a;
+	*s = V(1.0f + (sign * (n.x * n.x)) * a, sign * b, -sign * n.x);
+	*t = V(b, sign + (n.y * n.y) * a, -n.y);
+}
+
+typedef struct { v3 s, t, n; } frame;
+static inline v3 to_local(const frame *f, v3 v) { return V(dot3(v, f->s), dot3(v, f->t), dot3(v, f->n)); }
+static inline v3 to_world(const frame *f, v3 v)
+{
+	return vadd(vadd(vscale(f->s, v.x), vscale(f->t, v.y)), vscale(f->n, v.z));
+}
+
+/* closest hit over all quads: 0 < t < tmax */
+static int intersect(size_t nq, const float *quads, v3 o, v3 d, float tmax, float *t_out)
+{
+	int best = -1;
+	float bt = tmax;
+	for (size_t q = 0; q < nq; ++q) {
+		const float *Q = quads + q * PGO_QUAD_STRIDE;
+		v3 n = ld3(Q + 9);
+		float denom = dot3(n, d);
+		if (denom == 0.0f) continue;
+		float t = dot3(n, vsub(ld3(Q), o)) / denom;
+		if (!(t > 0.0f && t < bt)) continue;
+		v3 w = vsub(vadd(o, vscale(d, t)), ld3(Q));
+		float u = dot3(w, ld3(Q + 3)) * Q[12];
+		float v = dot3(w, ld3(Q + 6)) * Q[13];
+		if (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) { bt = t; best = (int)q; }
+	}
+	*t_out = bt;
+	return best;
+}
+
+/* Mitsuba warp::square_to_cosine_hemisphere (concentric disk + z = safe_sqrt(1 - r^2)) */
+static inline v3 square_to_cosine_hemisphere(float u, float v)
+{
+	float x = 2.0f * u - 1.0f, y = 2.0f * v - 1.0f;
+	int is_zero = (x == 0.0f) && (y == 0.0f);
+	int q13 = fabsf(x) < fabsf(y);
+	float r = q13 ? y : x, rp = q13 ? x : y;
+	float phi = (0.25f * 3.14159265358979323846f) * (rp / r);
+	if (q13) phi = (0.5f * 3.14159265358979323846f) - phi;
+	if (is_zero) phi = 0.0f;
+	float s, c;
+	pgo_sincos(phi, &s, &c);
+	float px = r * c, py = r * s;
+	float zz = 1.0f - (px * px + py * py);
+	float z = zz > 0.0f ? sqrtf(zz) : 0.0f;
+	if (z == 0.0f) z = 1e-10f;
+	return V(px, py, z);
+}
+
+/* twosided(diffuse).eval_pdf: value includes cos(theta_o) */
+static inline void bsdf_eval_pdf(v3 refl, v3 wi, v3 wo, int active, v3 *value, float *pdf)
+{
+	*value = V(0, 0, 0);
+	*pdf = 0.0f;
+	if (!active) return;
+	if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
+	*value = vscale(vscale(refl, INV_PI_F), wo.z);
+	*pdf = INV_PI_F * wo.z;
+}
+
+/* twosided(diffuse).sample: returns wo (local), pdf, weight = value/pdf */
+static inline void bsdf_sample(v3 refl, v3 wi, float u, float v, int active, v3 *wo, float *pdf, v3 *weight,
+                               float *eta)
+{
+	*wo = V(0, 0, 0); *pdf = 0.0f; *weight = V(0, 0, 0); *eta = 0.0f;
+	if (!active) return;
+	int flip = wi.z < 0.0f;
+	float cos_i = flip ? -wi.z : wi.z;
+	if (!(cos_i > 0.0f)) return;
+	v3 w = square_to_cosine_hemisphere(u, v);
+	float p = INV_PI_F * w.z;
+	*eta = 1.0f;
+	*pdf = p;
+	if (p > 0.0f) *weight = refl;
+	if (flip) w.z = -w.z;
+	*wo = w;
+}
+
+void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const float *quads,
+                     const pgo_camera *cam, const pgo_render_params *prm, float *L_out, uint8_t *valid_out,
+                     float *sumL, float *sumL2)
+{
+	const int W = cam->width, H = cam->height, spp = prm->spp, D = prm->max_depth;
+	const size_t npix = (size_t)W * H, N = npix * (size_t)spp, S = N * (size_t)(D > 0 ? D : 1);
+	const float f = prm->bsdf_sampling_fraction;
+	const int guided = prm->iteration > 1; /* :223, 250, 283 */
+	const int record = !prm->is_final;
+	/* dense record buffer, slot = ray*max_depth + depth (:318), zero-filled every pass (:155) */
+	uint8_t *r_act = NULL;
+	float *r_pos = NULL, *r_dir = NULL, *r_bsdf = NULL, *r_tb = NULL, *r_tr = NULL, *r_nee = NULL, *r_dnee = NULL, *r_wp = NULL;
+	if (record) {
+		r_act = calloc(S, 1);
+		r_pos = calloc(3 * S, 4); r_dir = calloc(2 * S, 4); r_bsdf = calloc(3 * S, 4); r_tb = calloc(3 * S, 4);
+		r_tr = calloc(3 * S, 4); r_nee = calloc(3 * S, 4); r_dnee = calloc(2 * S, 4); r_wp = calloc(S, 4);
+	}
+	const float aspect_tan_y = cam->tan_half_fov_x / ((float)W / (float)H);
+	for (size_t lane = 0; lane < N; ++lane) {
+		pgo_pcg32 rng;
+		pgo_pcg32_seed(&rng, prm->seed, (uint32_t)lane);
+		const size_t pixel = lane / (size_t)spp;
+		const float px = (float)(pixel % (size_t)W), py = (float)(pixel / (size_t)W);
+		/* camera ray: position sample next_2d */
+		float jx = pgo_pcg32_next_f32(&rng), jy = pgo_pcg32_next_f32(&rng);
+		float cx = (1.0f - 2.0f * ((px + jx) / (float)W)) * cam->tan_half_fov_x;
+		float cy = (1.0f - 2.0f * ((py + jy) / (float)H)) * aspect_tan_y;
+		float len = sqrtf((cx * cx + cy * cy) + 1.0f);
+		v3 dc = V(cx / len, cy / len, 1.0f / len);
+		v3 ray_o = ld3(cam->origin);
+		v3 ray_d = vadd(vadd(vscale(ld3(cam->axis_x), dc.x), vscale(ld3(cam->axis_y), dc.y)), vscale(ld3(cam->axis_z), dc.z));
+		v3 thr = V(1, 1, 1), L = V(0, 0, 0);
+		uint32_t depth = 0;
+		float ior = 1.0f;
+		int active = 1;
+		v3 prev_p = V(0, 0, 0);
+		float prev_bsdf_pdf = 1.0f;
+		int prev_delta = 1;
+		for (int it = 0; it < D && active; ++it) {
+			/* ---- :185 ray_intersect ---- */
+			float t_hit;
+			int q = intersect(nq, quads, ray_o, ray_d, INFINITY, &t_hit);
+			int valid = q >= 0;
+			const float *Q = valid ? quads + (size_t)q * PGO_QUAD_STRIDE : quads;
+			v3 p = valid ? vadd(ray_o, vscale(ray_d, t_hit)) : V(0, 0, 0);
+			v3 n = valid ? ld3(Q + 9) : V(0, 0, 1);
+			frame fr;
+			fr.n = n;
+			frame_from_normal(n, &fr.s, &fr.t);
+			v3 wi = to_local(&fr, V(-ray_d.x, -ray_d.y, -ray_d.z));
+			v3 refl = valid ? ld3(Q + 16) : V(0, 0, 0);
+			int is_em = valid && Q[15] != 0.0f;
+			/* ---- :189-200 direct emission ---- */
+			v3 em_radiance = (is_em && wi.z > 0.0f) ? ld3(Q + 19) : V(0, 0, 0);
+			float emitter_pdf = 0.0f;
+			if (is_em && !prev_delta) {
+				v3 dd = vsub(p, prev_p);
+				float d2 = dot3(dd, dd), dist = sqrtf(d2);
+				v3 dn = vdivs(dd, dist);
+				float dp = dot3(dn, n);
+				if (dp < 0.0f) emitter_pdf = d2 / (fabsf(dp) * Q[14]);
+			}
+			float mis = mis_weight(prev_bsdf_pdf, emitter_pdf);
+			v3 Le = vmul(vscale(thr, mis), em_radiance);
+			/* ---- :207-220 emitter sampling ---- */
+			int active_next = (depth + 1 < (uint32_t)D) && valid;
+			int active_em = active_next; /* diffuse: BSDFFlags.Smooth */
+			float e1 = pgo_pcg32_next_f32(&rng), e2 = pgo_pcg32_next_f32(&rng); /* :214 next_2d, unmasked */
+			v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
+			float ds_pdf = 0.0f;
+			if (active_em) {
+				/* single area emitter: the first quad with the emitter flag */
+				size_t le = 0;
+				while (le < nq && quads[le * PGO_QUAD_STRIDE + 15] == 0.0f) ++le;
+				if (le < nq) {
+					const float *E = quads + le * PGO_QUAD_STRIDE;
+					v3 pl = vadd(vadd(ld3(E), vscale(ld3(E + 3), e1)), vscale(ld3(E + 6), e2));
+					v3 dir0 = vsub(pl, p);
+					/* si.spawn_ray_to(pl): offset origin, then aim at the light point */
+					float mag = (1.0f + max3(V(fabsf(p.x), fabsf(p.y), fabsf(p.z)))) * RAY_EPS_F;
+					if (dot3(n, dir0) < 0.0f) mag = -mag;
+					v3 so = vadd(p, vscale(n, mag));
+					v3 dd = vsub(pl, p);
+					float d2 = dot3(dd, dd), dist = sqrtf(d2);
+					ds_d = vdivs(dd, dist);
+					float dp = dot3(ds_d, ld3(E + 9));
+					float pdf = dp < 0.0f ? d2 / (fabsf(dp) * E[14]) : 0.0f;
+					if (!(pdf == pdf) || pdf == INFINITY) pdf = 0.0f;
+					ds_pdf = pdf;
+					if (pdf > 0.0f) {
+						v3 sd = vsub(pl, so);
+						float sdist = sqrtf(dot3(sd, sd));
+						v3 sdn = vdivs(sd, sdist);
+						float th;
+						int occ = intersect(nq, quads, so, sdn, sdist * (1.0f - SHADOW_EPS_F), &th) >= 0;
+						if (!occ) em_weight = vdivs(ld3(E + 19), pdf);
+					}
+				}
+			}
+			active_em = active_em && (ds_pdf != 0.0f); /* :216 */
+			v3 wo_em = to_local(&fr, ds_d);
+			v3 bsdf_value_em;
+			float bsdf_pdf_em;
+			bsdf_eval_pdf(refl, wi, wo_em, active_em, &bsdf_value_em, &bsdf_pdf_em);
+			/* ---- :223-256 NEE MIS against the mixture pdf ---- */
+			int active_sd_em = active_em && guided;
+			float pdf_diffuse = 1.0f; /* :222-241, SURVEY A12 */
+			float pp[3] = { p.x, p.y, p.z };
+			uint32_t tree = 0;
+			int tree_known = 0;
+			float sdtree_pdf_em = 1.0f;
+			if (active_sd_em) {
+				tree = pgo_i_quadtree_of(prev, pp, 1);
+				tree_known = 1;
+				float dv[3] = { ds_d.x, ds_d.y, ds_d.z };
+				sdtree_pdf_em = pgo_i_pdf(prev, tree, dv, 1);
+			}
+			float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
+			if (!guided) surface_pdf_em = bsdf_pdf_em;
+			float mis_em = mis_weight(ds_pdf, surface_pdf_em);
+			v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em), em_weight);
+			L = vadd(L, vadd(Le, Lr_dir)); /* :261 */
+			/* ---- :272-311 next direction ---- */
+			float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
+			if (active_next) { s1 = pgo_pcg32_next_f32(&rng); s2x = pgo_pcg32_next_f32(&rng); s2y = pgo_pcg32_next_f32(&rng); }
+			(void)s1;
+			v3 wo_local, bsdf_weight;
+			float bsdf_pdf, eta;
+			bsdf_sample(refl, wi, s2x, s2y, active_next, &wo_local, &bsdf_pdf, &bsdf_weight, &eta);
+			v3 bsdf_value = vscale(bsdf_weight, bsdf_pdf);
+			float woPdf = bsdf_pdf;
+			v3 wo_world = to_world(&fr, wo_local);
+			int delta = 0;
+			int do_mis = active_next && !delta && guided;
+			int pick_tree = 0;
+			if (active_next) pick_tree = pgo_pcg32_next_f32(&rng) > f; /* :286 */
+			int smp_tree = pick_tree && do_mis;
+			int bsdf_mis = do_mis && !smp_tree;
+			float sdtree_pdf = 1.0f;
+			if (smp_tree) { /* :301-304 */
+				if (!tree_known) { tree = pgo_i_quadtree_of(prev, pp, 1); tree_known = 1; }
+				float dv[3];
+				pgo_i_sample(prev, tree, &rng.state, rng.inc, 1, dv);
+				sdtree_pdf = pgo_i_pdf(prev, tree, dv, 1);
+				wo_world = V(dv[0], dv[1], dv[2]);
+				wo_local = to_local(&fr, wo_world);
+				bsdf_eval_pdf(refl, wi, wo_local, 1, &bsdf_value, &bsdf_pdf);
+			}
+			if (bsdf_mis) { /* :307 */
+				if (!tree_known) { tree = pgo_i_quadtree_of(prev, pp, 1); tree_known = 1; }
+				float dv[3] = { wo_world.x, wo_world.y, wo_world.z };
+				sdtree_pdf = pgo_i_pdf(prev, tree, dv, 1);
+			}
+			if (do_mis) { /* :310-311 */
+				woPdf = f * bsdf_pdf + (1.0f - f) * sdtree_pdf;
+				bsdf_weight = vdivs(bsdf_value, woPdf);
+			}
+			/* ---- :318-346 record ---- */
+			if (record && active && valid) {
+				size_t g = lane * (size_t)D + depth;
+				float c[2];
+				r_act[g] = 1;
+				r_pos[g] = p.x; r_pos[S + g] = p.y; r_pos[2 * S + g] = p.z;
+				pgo_dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, c);
+				r_dir[g] = c[0]; r_dir[S + g] = c[1];
+				r_bsdf[g] = bsdf_weight.x; r_bsdf[S + g] = bsdf_weight.y; r_bsdf[2 * S + g] = bsdf_weight.z;
+				r_tb[g] = thr.x; r_tb[S + g] = thr.y; r_tb[2 * S + g] = thr.z;
+				r_tr[g] = L.x; r_tr[S + g] = L.y; r_tr[2 * S + g] = L.z;
+				if (prm->store_nee) {
+					v3 rn = vdiv(Lr_dir, thr);
+					r_nee[g] = rn.x; r_nee[S + g] = rn.y; r_nee[2 * S + g] = rn.z;
+					pgo_dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, c);
+					r_dnee[g] = c[0]; r_dnee[S + g] = c[1];
+				}
+				r_wp[g] = woPdf;
+			}
+			/* ---- :352-381 advance ---- */
+			{
+				float mag = (1.0f + max3(V(fabsf(p.x), fabsf(p.y), fabsf(p.z)))) * RAY_EPS_F;
+				if (dot3(n, wo_world) < 0.0f) mag = -mag;
+				ray_o = vadd(p, vscale(n, mag));
+				ray_d = wo_world;
+			}
+			ior = ior * eta;
+			thr = vmul(thr, bsdf_weight);
+			prev_p = p;
+			prev_bsdf_pdf = woPdf;
+			prev_delta = delta;
+			float tmax = max3(thr);
+			active_next = active_next && (tmax != 0.0f);
+			float rr_prob = tmax * (ior * ior);
+			if (!(rr_prob < 0.95f)) rr_prob = 0.95f; /* dr.minimum(x, 0.95): NaN -> 0.95 */
+			int rr_active = depth >= (uint32_t)prm->rr_depth;
+			float rr = pgo_pcg32_next_f32(&rng); /* :377, unmasked */
+			int rr_continue = rr < rr_prob;
+			active_next = active_next && (!rr_active || rr_continue);
+			active = active_next;
+			if (valid) depth += 1;
+		}
+		L_out[lane] = L.x; L_out[N + lane] = L.y; L_out[2 * N + lane] = L.z;
+		valid_out[lane] = depth != 0;
+	}
+	/* ---- :388-395 ---- */
+	if (record) {
+		float *o_pos = malloc(3 * S * 4), *o_dir = malloc(2 * S * 4), *o_rad = malloc(S * 4), *o_wp = malloc(S * 4);
+		float *o_dnee = malloc(2 * S * 4), *o_nl = malloc(S * 4);
+		size_t kept = pgo_process_records(N, (size_t)D, L_out, r_act, r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee,
+		                                  r_wp, o_pos, o_dir, o_rad, o_wp, o_dnee, o_nl);
+		if (kept) {
+			/* planes have stride S: repack to stride `kept` */
+			float *c_pos = malloc(3 * kept * 4), *c_dir = malloc(2 * kept * 4), *c_dnee = malloc(2 * kept * 4);
+			for (int a = 0; a < 3; ++a) memcpy(c_pos + a * kept, o_pos + a * S, kept * 4);
+			for (int a = 0; a < 2; ++a) { memcpy(c_dir + a * kept, o_dir + a * S, kept * 4); memcpy(c_dnee + a * kept, o_dnee + a * S, kept * 4); }
+			pgo_add_data_propagate(current, kept, c_pos, c_dir, o_rad, o_wp, c_dnee, o_nl);
+			free(c_pos); free(c_dir); free(c_dnee);
+		}
+		free(o_pos); free(o_dir); free(o_rad); free(o_wp); free(o_dnee); free(o_nl);
+		free(r_act); free(r_pos); free(r_dir); free(r_bsdf); free(r_tb); free(r_tr); free(r_nee); free(r_dnee); free(r_wp);
+	}
+	/* ---- :400-429 per-pixel sums, samples of a pixel in lane order ---- */
+	if (sumL && sumL2) {
+		for (size_t pix = 0; pix < npix; ++pix)
+			for (int s = 0; s < spp; ++s) {
+				size_t lane = pix * (size_t)spp + (size_t)s;
+				for (int ch = 0; ch < 3; ++ch) {
+					float v = L_out[(size_t)ch * N + lane];
+					sumL[(size_t)ch * npix + pix] += v;
+					sumL2[(size_t)ch * npix + pix] += v * v;
+				}
+			}
+	}
+}

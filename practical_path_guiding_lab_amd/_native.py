@@ -67,6 +67,15 @@ class pg_stats(C.Structure):
     ]
 
 
+class pg_camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("axis_x", C.c_float * 3), ("axis_y", C.c_float * 3),
+                ("axis_z", C.c_float * 3), ("tan_half_fov_x", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class pg_pass_params(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32)]
+
+
 class pg_depth_counters(C.Structure):
     _fields_ = [("kd_levels", C.c_uint64), ("kd_queries", C.c_uint64),
                 ("quad_levels", C.c_uint64), ("quad_queries", C.c_uint64)]
@@ -78,7 +87,7 @@ EXPORTS = (
     "pg_get_leaf_node_index", "pg_sample", "pg_pdf", "pg_guide_bounce", "pg_compact_lanes", "pg_rng_seed", "pg_splat",
     "pg_process_records", "pg_process_and_splat", "pg_refine_and_swap", "pg_accumulators",
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
-    "pg_enable_depth_counters", "pg_read_depth_counters",
+    "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
 )
 
 
@@ -136,6 +145,8 @@ def lib() -> C.CDLL:
     L.pg_get_stats.argtypes = [V, C.POINTER(pg_stats)]
     L.pg_enable_depth_counters.argtypes = [V, I32]
     L.pg_read_depth_counters.argtypes = [V, C.POINTER(pg_depth_counters), I32]
+    L.pg_scene_set.argtypes = [V, U64, V, C.POINTER(pg_camera)]
+    L.pg_render_pass.argtypes = [V, C.POINTER(pg_pass_params), V, V, V, V, V]
     for name in EXPORTS:
         if name not in ("pg_last_error", "pg_abi_version"):
             getattr(L, name).restype = C.c_int

@@ -128,6 +128,7 @@ int pg_destroy(pg_context *ctx)
 	if (!ctx) return PG_OK;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->dc) (void)hipFree(ctx->dc);
+	destroy_render_state(ctx);
 	delete ctx;
 	return PG_OK;
 }

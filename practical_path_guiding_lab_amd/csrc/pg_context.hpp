@@ -77,7 +77,10 @@ struct Forest {
 
 } // namespace pg
 
+struct pg_render_state; // pg_render.hip
+
 struct pg_context {
+	pg_render_state *render = nullptr;
 	int device = 0;
 	std::string err;
 	bool configured = false;
@@ -108,6 +111,8 @@ struct pg_context {
 namespace pg {
 // pg_refine.hip
 int refine_and_swap(pg_context *ctx, hipStream_t s);
+// pg_render.hip
+void destroy_render_state(pg_context *ctx);
 // helpers shared by pg_context.hip / pg_refine.hip
 int fail(pg_context *ctx, int code, const std::string &msg);
 int hip_fail(pg_context *ctx, hipError_t e, const char *what);

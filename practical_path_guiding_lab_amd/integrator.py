@@ -76,8 +76,8 @@ class PathGuidingIntegrator:
         practical_path_guiding_lab_amd.render (trace_pass); returns (L (3,N), valid (N,), [1])."""
         if not hasattr(scene, "trace_pass"):
             raise TypeError("scene must provide trace_pass(integrator, sampler): see practical_path_guiding_lab_amd.render")
-        L, valid, spp_per_pass = scene.trace_pass(self, sampler)
-        self.accumulate(L, spp_per_pass)
+        # the pass also adds its samples to sumL / sumL2 on the device (:400-429)
+        L, valid, _ = scene.trace_pass(self, sampler, accumulate=True)
         return L, valid, [1]
 
     def accumulate(self, L: torch.Tensor, spp_per_pass: int = 1) -> None:

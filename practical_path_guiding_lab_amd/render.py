@@ -1,0 +1,95 @@
+"""Renderer-side host glue: the objects a `main.py`-style driver needs around
+PathGuidingIntegrator when Mitsuba 3 is not there -- a scene that can trace one pass on the device
+(pg_render_pass), a sampler carrying seed and sample count, and `render()` in the role of
+`mi.render(scene, spp=..., seed=...)` (main.py:218).
+
+The per-pixel estimate returned by `render()` is the box-filtered mean of the pass's samples; the
+reference's metric (computeMSE / computeVariance, path_guiding_integrator.py:503-550) is defined
+on the raw per-pixel sums sumL / sumL2, which are accumulated on the device exactly as :400-429.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .scene import Scene
+
+
+class IndependentSampler:
+    """What the driver uses of mi.Sampler: `sample_count()` and a seed (PCG32 streams are derived
+    per lane on the device: pcg32_seed(seed, lane))."""
+
+    def __init__(self, sample_count: int = 1, seed: int = 0):
+        self._spp = int(sample_count)
+        self._seed = int(seed)
+
+    def sample_count(self) -> int:
+        return self._spp
+
+    def set_sample_count(self, spp: int) -> None:
+        self._spp = int(spp)
+
+    def seed(self, seed: int) -> None:
+        self._seed = int(seed)
+
+    @property
+    def seed_value(self) -> int:
+        return self._seed
+
+
+class WavefrontScene:
+    """Device-resident scene (quads + camera) implementing the `trace_pass` protocol of
+    PathGuidingIntegrator.sample()."""
+
+    def __init__(self, scene: Scene):
+        self.scene = scene
+        self._uploaded_to = None
+
+    # what main.py reads from mi.Scene (main.py:48-53)
+    def bbox(self) -> Tuple[np.ndarray, np.ndarray]:
+        return self.scene.bbox_min, self.scene.bbox_max
+
+    @property
+    def film_size(self) -> Tuple[int, int]:
+        return self.scene.camera.width, self.scene.camera.height
+
+    def _upload(self, tree) -> None:
+        if self._uploaded_to is tree:
+            return
+        cam = self.scene.camera
+        c = N.pg_camera()
+        for k in ("origin", "axis_x", "axis_y", "axis_z"):
+            setattr(c, k, (C.c_float * 3)(*[float(v) for v in getattr(cam, k)]))
+        c.tan_half_fov_x = float(cam.tan_half_fov_x)
+        c.width, c.height = int(cam.width), int(cam.height)
+        q = np.ascontiguousarray(self.scene.quads, np.float32)
+        N.check(tree._h, tree._lib.pg_scene_set(tree._h, q.shape[0], q.ctypes.data, C.byref(c)))
+        self._uploaded_to = tree
+
+    def trace_pass(self, integrator, sampler: IndependentSampler, accumulate: bool = True):
+        """One device pass; returns (L (3,N) float32 cuda, valid (N,) uint8 cuda, spp)."""
+        tree = integrator.sdTree
+        self._upload(tree)
+        cam = self.scene.camera
+        spp = sampler.sample_count()
+        n = cam.width * cam.height * spp
+        L = torch.empty((3, n), dtype=torch.float32, device=tree.device)
+        valid = torch.empty(n, dtype=torch.uint8, device=tree.device)
+        p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth))
+        sl = integrator.sumL.data_ptr() if accumulate else None
+        sl2 = integrator.sumL2.data_ptr() if accumulate else None
+        N.check(tree._h, tree._lib.pg_render_pass(tree._h, C.byref(p), L.data_ptr(), valid.data_ptr(), sl, sl2,
+                                                  torch.cuda.current_stream().cuda_stream))
+        return L, valid, spp
+
+
+def render(scene: WavefrontScene, integrator, spp: int, seed: int) -> torch.Tensor:
+    """mi.render(scene, spp=spp, seed=seed) (main.py:218): one pass, returns the (H, W, 3) estimate."""
+    sampler = IndependentSampler(spp, seed)
+    L, _, _ = integrator.sample(scene, sampler)
+    w, h = scene.film_size
+    return L.reshape(3, h, w, spp).mean(dim=3).permute(1, 2, 0).contiguous()

@@ -1,0 +1,193 @@
+"""Scene description for the renderer substrate: quads (rectangles and cube faces) with twosided
+diffuse BSDFs, one-sided area emitters and a perspective camera -- the subset of Mitsuba 3 scene
+XML that scenes/cornell-box/scene.xml of the reference uses.
+
+`load_xml(path)` parses that subset from a Mitsuba 3 XML file (e.g. the reference's own scene
+files, when they are available); `cornell_box()` builds the same scene from its numeric
+parameters so that tests and the benchmark do not need the file.
+
+This module is plain data preparation (numpy); it is shared by the product and by the tests
+that feed the same arrays to the CPU oracle.
+"""
+from __future__ import annotations
+
+import math
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+QUAD_STRIDE = 24  # floats per quad, layout documented in include/pgsd.h (pg_scene_desc)
+
+
+@dataclass
+class Camera:
+    origin: np.ndarray
+    axis_x: np.ndarray
+    axis_y: np.ndarray
+    axis_z: np.ndarray
+    tan_half_fov_x: np.float32
+    width: int
+    height: int
+
+
+@dataclass
+class Scene:
+    quads: np.ndarray                 # (Q, 24) float32
+    camera: Camera
+    max_depth: int = 30
+    rr_depth: int = 8
+    bbox_min: np.ndarray = field(default_factory=lambda: np.zeros(3, np.float32))
+    bbox_max: np.ndarray = field(default_factory=lambda: np.ones(3, np.float32))
+    names: List[str] = field(default_factory=list)
+
+
+def _f32(v):
+    return np.asarray(v, dtype=np.float32)
+
+
+def _quad(o, e1, e2, refl, radiance=None) -> np.ndarray:
+    """All derived quantities are computed here once, in fp32, and handed to every consumer."""
+    o, e1, e2 = _f32(o), _f32(e1), _f32(e2)
+    n = np.cross(e1, e2).astype(np.float32)
+    ln = np.float32(np.sqrt(np.float32(np.dot(n, n))))
+    q = np.zeros(QUAD_STRIDE, np.float32)
+    q[0:3], q[3:6], q[6:9] = o, e1, e2
+    q[9:12] = (n / ln).astype(np.float32)
+    q[12] = np.float32(1.0) / np.float32(np.dot(e1, e1))
+    q[13] = np.float32(1.0) / np.float32(np.dot(e2, e2))
+    q[14] = ln  # |e1 x e2| = area of the parallelogram
+    q[15] = 1.0 if radiance is not None else 0.0
+    q[16:19] = _f32(refl)
+    if radiance is not None:
+        q[19:22] = _f32(radiance)
+    return q
+
+
+def _xf(m: np.ndarray, p, w=1.0) -> np.ndarray:
+    v = m @ np.array([p[0], p[1], p[2], w], np.float64)
+    return v[:3]
+
+
+def rectangle(to_world: np.ndarray, refl, radiance=None) -> List[np.ndarray]:
+    """Mitsuba `rectangle`: [-1,1]^2 in the xy-plane, normal +z, transformed by to_world."""
+    o = _xf(to_world, (-1, -1, 0))
+    e1 = _xf(to_world, (2, 0, 0), 0.0)
+    e2 = _xf(to_world, (0, 2, 0), 0.0)
+    if np.linalg.det(to_world[:3, :3]) < 0:  # keep e1 x e2 on the side of Mitsuba's transformed normal
+        o, e1, e2 = o + e1, -e1, e2
+    return [_quad(o, e1, e2, refl, radiance)]
+
+
+def cube(to_world: np.ndarray, refl) -> List[np.ndarray]:
+    """Mitsuba `cube`: [-1,1]^3, six outward-facing faces."""
+    faces = [  # (origin, e1, e2) with e1 x e2 pointing outwards
+        ((-1, -1, 1), (2, 0, 0), (0, 2, 0)),    # +z
+        ((1, -1, -1), (-2, 0, 0), (0, 2, 0)),   # -z
+        ((1, -1, 1), (0, 0, -2), (0, 2, 0)),    # +x
+        ((-1, -1, -1), (0, 0, 2), (0, 2, 0)),   # -x
+        ((-1, 1, 1), (2, 0, 0), (0, 0, -2)),    # +y
+        ((-1, -1, -1), (2, 0, 0), (0, 0, 2)),   # -y
+    ]
+    out = []
+    mirrored = np.linalg.det(to_world[:3, :3]) < 0
+    for o, a, b in faces:
+        wo, wa, wb = _xf(to_world, o), _xf(to_world, a, 0.0), _xf(to_world, b, 0.0)
+        if mirrored:
+            wo, wa = wo + wa, -wa
+        out.append(_quad(wo, wa, wb, refl))
+    return out
+
+
+def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names) -> Scene:
+    q = np.stack(quads).astype(np.float32)
+    corners = np.concatenate([q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]])
+    return Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
+
+
+def make_camera(to_world: np.ndarray, fov_deg: float, width: int, height: int) -> Camera:
+    m = np.asarray(to_world, np.float64)
+    return Camera(_f32(m[:3, 3]), _f32(m[:3, 0]), _f32(m[:3, 1]), _f32(m[:3, 2]),
+                  np.float32(math.tan(math.radians(fov_deg) / 2.0)), int(width), int(height))
+
+
+def _mat(values: str) -> np.ndarray:
+    return np.array([float(v) for v in values.replace(",", " ").split()], np.float64).reshape(4, 4)
+
+
+def cornell_box(width: int = 512, height: int = 512, max_depth: int = 8, rr_depth: int = 8) -> Scene:
+    """The cornell-box of the reference (scenes/cornell-box/scene.xml: fov 19.5, camera at
+    (0,1,6.8) looking down -z, five walls, two boxes, one ceiling light of radiance (17,12,4))."""
+    white, red, green = (0.725, 0.71, 0.68), (0.63, 0.065, 0.05), (0.14, 0.45, 0.091)
+    shapes = [
+        ("Floor", "rectangle", "-4.37114e-008 1 4.37114e-008 0 0 -8.74228e-008 2 0 1 4.37114e-008 1.91069e-015 0 0 0 0 1", white, None),
+        ("Ceiling", "rectangle", "-1 7.64274e-015 -1.74846e-007 0 8.74228e-008 8.74228e-008 -2 2 0 -1 -4.37114e-008 0 0 0 0 1", white, None),
+        ("BackWall", "rectangle", "1.91069e-015 1 1.31134e-007 0 1 3.82137e-015 -8.74228e-008 1 -4.37114e-008 1.31134e-007 -2 -1 0 0 0 1", white, None),
+        ("RightWall", "rectangle", "4.37114e-008 -1.74846e-007 2 1 1 3.82137e-015 -8.74228e-008 1 3.82137e-015 1 2.18557e-007 0 0 0 0 1", green, None),
+        ("LeftWall", "rectangle", "-4.37114e-008 8.74228e-008 -2 -1 1 3.82137e-015 -8.74228e-008 1 0 -1 -4.37114e-008 0 0 0 0 1", red, None),
+        ("ShortBox", "cube", "0.0851643 0.289542 1.31134e-008 0.328631 3.72265e-009 1.26563e-008 -0.3 0.3 -0.284951 0.0865363 5.73206e-016 0.374592 0 0 0 1", white, None),
+        ("TallBox", "cube", "0.286776 0.098229 -2.29282e-015 -0.335439 -4.36233e-009 1.23382e-008 -0.6 0.6 -0.0997984 0.282266 2.62268e-008 -0.291415 0 0 0 1", white, None),
+        ("Light", "rectangle", "0.235 -1.66103e-008 -7.80685e-009 -0.005 -2.05444e-008 3.90343e-009 -0.0893 1.98 2.05444e-008 0.19 8.30516e-009 -0.03 0 0 0 1", (0, 0, 0), (17, 12, 4)),
+    ]
+    quads, names = [], []
+    for name, kind, m, refl, rad in shapes:
+        qs = rectangle(_mat(m), refl, rad) if kind == "rectangle" else cube(_mat(m), refl)
+        quads += qs
+        names += [name] * len(qs)
+    cam = make_camera(_mat("-1 0 0 0 0 1 0 1 0 0 -1 6.8 0 0 0 1"), 19.5, width, height)
+    return _finish(quads, cam, max_depth, rr_depth, names)
+
+
+def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None) -> Scene:
+    """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world matrix, film size),
+    twosided/diffuse bsdfs with rgb reflectance (by id), rectangle/cube shapes with a to_world
+    matrix, optional area emitter.  Anything else raises ValueError."""
+    root = ET.parse(path).getroot()
+    defaults: Dict[str, str] = {d.get("name"): d.get("value") for d in root.findall("default")}
+
+    def val(s: str) -> str:
+        return defaults[s[1:]] if s.startswith("$") else s
+
+    def rgb(node) -> Tuple[float, float, float]:
+        v = [float(x) for x in node.get("value").replace(",", " ").split()]
+        return tuple(v * 3) if len(v) == 1 else tuple(v)
+
+    def diffuse(node):
+        if node.get("type") == "twosided":
+            return diffuse(node.find("bsdf"))
+        if node.get("type") != "diffuse":
+            raise ValueError(f"unsupported bsdf type {node.get('type')}")
+        r = node.find("rgb")
+        return rgb(r) if r is not None else (0.5, 0.5, 0.5)
+
+    bsdfs = {b.get("id"): diffuse(b) for b in root.findall("bsdf")}
+    integ = root.find("integrator")
+    props = {i.get("name"): int(val(i.get("value"))) for i in integ.findall("integer")} if integ is not None else {}
+    sensor = root.find("sensor")
+    if sensor is None or sensor.get("type") != "perspective":
+        raise ValueError("need a perspective sensor")
+    fov = float(val(sensor.find("float[@name='fov']").get("value")))
+    film = sensor.find("film")
+    fw = int(val(film.find("integer[@name='width']").get("value")))
+    fh = int(val(film.find("integer[@name='height']").get("value")))
+    cam = make_camera(_mat(sensor.find("transform/matrix").get("value")), fov, width or fw, height or fh)
+    quads, names = [], []
+    for sh in root.findall("shape"):
+        kind = sh.get("type")
+        m = _mat(sh.find("transform/matrix").get("value"))
+        ref = sh.find("ref")
+        refl = bsdfs[ref.get("id")] if ref is not None else diffuse(sh.find("bsdf"))
+        em = sh.find("emitter")
+        rad = rgb(em.find("rgb")) if em is not None else None
+        if kind == "rectangle":
+            qs = rectangle(m, refl, rad)
+        elif kind == "cube":
+            if rad is not None:
+                raise ValueError("emitting cubes are not supported")
+            qs = cube(m, refl)
+        else:
+            raise ValueError(f"unsupported shape type {kind}")
+        quads += qs
+        names += [sh.get("id", kind)] * len(qs)
+    return _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names)
