@@ -285,6 +285,11 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 			if (do_mis) { /* :310-311 */
 				woPdf = f * bsdf_pdf + (1.0f - f) * sdtree_pdf;
 				bsdf_weight = vdivs(bsdf_value, woPdf);
+				/* DELIBERATE DEVIATION: a direction sampled from a zero-energy quadtree
+				 * (pdf 0, quadtree.py:1086-1092) below the surface has bsdf_pdf = 0 too, and the
+				 * reference then divides 0/0 -- its throughput turns NaN and poisons the pixel
+				 * (about 1e-7 of the paths on cornell-box).  Such a path carries no energy: stop it. */
+				if (!(woPdf > 0.0f)) bsdf_weight = V(0, 0, 0);
 			}
 			/* ---- :318-346 record ---- */
 			if (record && active && valid) {

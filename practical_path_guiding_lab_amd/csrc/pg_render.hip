@@ -147,6 +147,7 @@ struct RenderArgs {
 	int spp, max_depth, rr_depth, guided, record, store_nee;
 	float frac;
 	uint32_t seed;
+	DepthCounters *dc;
 	// per-lane state (planar)
 	float *ray_o, *ray_d, *thr, *L, *prev_p, *prev_pdf, *ior;
 	uint32_t *depth;
@@ -272,9 +273,11 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	bool tree_known = false;
 	float sdtree_pdf_em = 1.0f;
 	uint32_t lv;
+	unsigned c_kd = 0, c_kdq = 0, c_q = 0, c_qq = 0; // descent statistics for the byte model
 	if (active_sd_em) {
 		KdNode leaf;
 		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		c_kd += lv; ++c_kdq;
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		float cx, cy;
 		dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, cx, cy);
 		sdtree_pdf_em = quad_pdf(a.tree.rec, head, cx, cy, lv);
+		c_q += lv; ++c_qq;
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
 	if (!a.guided) surface_pdf_em = bsdf_pdf_em;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	if ((smp_tree || bsdf_mis) && !tree_known) {
 		KdNode leaf;
 		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		c_kd += lv; ++c_kdq;
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	if (smp_tree) { // :301-304
 		float dx, dy, dz;
 		quad_sample(a.tree.rec, head, rng, dx, dy, dz, sdtree_pdf, lv);
+		c_q += lv; ++c_qq;
 		wo_world = V(dx, dy, dz);
 		wo_local = to_local(fr, wo_world);
 		bsdf_eval_pdf(refl, wi, wo_local, true, bsdf_value, bsdf_pdf);
@@ -321,10 +327,20 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		float cx, cy;
 		dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, cx, cy);
 		sdtree_pdf = quad_pdf(a.tree.rec, head, cx, cy, lv);
+		c_q += lv; ++c_qq;
+	}
+	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
+		atomicAdd(&a.dc->kd_levels, (unsigned long long)c_kd);
+		atomicAdd(&a.dc->kd_queries, (unsigned long long)c_kdq);
+		atomicAdd(&a.dc->quad_levels, (unsigned long long)c_q);
+		atomicAdd(&a.dc->quad_queries, (unsigned long long)c_qq);
 	}
 	if (do_mis) { // :310-311
 		woPdf = f * bsdf_pdf + (1.0f - f) * sdtree_pdf;
 		bsdf_weight = vdivs(bsdf_value, woPdf);
+		// deliberate deviation: 0/0 when a zero-energy tree proposes a direction below
+		// the surface; the reference's throughput turns NaN there, here the path simply ends
+		if (!(woPdf > 0.0f)) bsdf_weight = V(0, 0, 0);
 	}
 	// ---- :318-346 record ----
 	if (a.record && valid) {
@@ -496,6 +512,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.store_nee = ctx->store_nee;
 	a.frac = ctx->bsdf_fraction;
 	a.seed = prm->seed;
+	a.dc = ctx->dc_on ? ctx->dc : nullptr;
 	a.ray_o = r->ray_o.p; a.ray_d = r->ray_d.p; a.thr = r->thr.p; a.L = L_out; a.prev_p = r->prev_p.p;
 	a.prev_pdf = r->prev_pdf.p; a.ior = r->ior.p; a.depth = r->depth.p; a.active = r->active.p;
 	a.prev_delta = r->prev_delta.p; a.rng_state = r->rng_state.p; a.rng_inc = r->rng_inc.p;

@@ -1,0 +1,195 @@
+"""The guided-render driver: the schedule, stopping policy, image blending and logging of the
+reference's main.py (takkasila/practical_path_guiding_lab main.py:92-430) around
+PathGuidingIntegrator, without Mitsuba.
+
+Differences that are deliberate and visible in the arguments:
+  * `training_spp_per_pass` (main.py:192 hard-codes 1): a pass may trace several samples per pixel
+    while training -- the SD-tree result does not depend on how an iteration's samples are split
+    into passes (integer accumulation), and bigger wavefronts keep an MI355X busy;
+  * the per-pass variance/MSE log of main.py:245-265 is optional (`record_in_iteration`), because
+    every entry costs a device->host sync;
+  * images are written as PNG (sRGB) + .npy (linear) instead of PNG + EXR.
+"""
+from __future__ import annotations
+
+import csv
+import math
+import os
+import time
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .integrator import PathGuidingIntegrator
+from .render import WavefrontScene, render
+
+
+class PerformanceData:
+    """common.py:66-97: rows of time, spp, cumm_spp, iteration, variance, mse."""
+
+    FIELDS = ["time", "spp", "cumm_spp", "iteration", "variance", "mse"]
+
+    def __init__(self):
+        self.rows: List[List[float]] = []
+
+    def append(self, time=0, spp=0, cumm_spp=0, iteration=0, variance=0, mse=0):
+        self.rows.append([time, spp, cumm_spp, iteration, variance, mse])
+
+    def saveToFile(self, fileName: str):
+        with open(fileName, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(self.FIELDS)
+            w.writerows(self.rows)
+
+
+def possible_cumm_spp(budget_spp: int) -> List[int]:
+    """main.py:105-117."""
+    cumm, k, out = 0, 0, []
+    while cumm < budget_spp:
+        cumm += 2 ** (k + 2)
+        out.append(cumm)
+        k += 1
+    return out
+
+
+def save_image(path_noext: str, image: torch.Tensor):
+    from PIL import Image
+
+    img = image.detach().cpu().numpy().astype(np.float32)
+    np.save(path_noext + ".npy", img)
+    srgb = np.where(img <= 0.0031308, 12.92 * img, 1.055 * np.power(np.clip(img, 0.0031308, None), 1 / 2.4) - 0.055)
+    Image.fromarray((np.clip(srgb, 0, 1) * 255 + 0.5).astype(np.uint8)).save(path_noext + ".png")
+
+
+def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, budget_spp: int,
+                      initial_seed: int = 0, ground_truth: Optional[torch.Tensor] = None,
+                      sdTreeMaxDepth: int = 20, quadTreeMaxDepth: int = 20, isStoreNEERadiance: bool = True,
+                      bsdfSamplingFraction: float = 0.5, batch_spp: int = 4, training_spp_per_pass: int = 1,
+                      stable_variance_spp_threshold: int = 256, train_stop_cumm_spp: int = 1000,
+                      record_in_iteration: bool = False, out_dir: Optional[str] = None,
+                      all_reduce: Optional[Callable[[torch.Tensor], None]] = None,
+                      log: Callable[[str], None] = print) -> Dict:
+    """Runs the whole training + rendering schedule; returns the final image, logs and timings."""
+    w, h = scene.film_size
+    bmin, bmax = scene.bbox()
+    eps = np.float32(1e-4)  # main.py:55-59
+    integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
+                     quadTreeMaxDepth=quadTreeMaxDepth, isStoreNEERadiance=isStoreNEERadiance,
+                     bsdfSamplingFraction=bsdfSamplingFraction)
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    rec = {k: PerformanceData() for k in ("variance_inIter", "variance_groundTruth_inIter", "mse_groundTruth_inIter",
+                                          "variance_endIter", "variance_groundTruth_endIter", "mse_groundTruth_endIter",
+                                          "variance_estimated_final")}
+    possible = possible_cumm_spp(budget_spp)
+    cumm_spp = cumm_spp_prev = image_spp = 0
+    remaining = budget_spp
+    is_final, is_train, is_clear = False, True, True
+    k = 0
+    variance_prev = 0.0
+    cumm_time = 0.0
+    image = prev_iter_image = None
+    guided_samples, guided_time = 0, 0.0
+    per_iter = []
+    while remaining > 0:
+        torch.cuda.synchronize()
+        t_iter = time.perf_counter()
+        if is_clear:
+            integrator.resetVarianceCounter()
+            image_spp = 0
+        if not is_final:
+            iter_spp = 2 ** (k + 2)
+            if iter_spp == remaining:
+                is_final = True
+        else:
+            iter_spp = remaining
+        integrator.setIteration(k, is_final)
+        spp_per_pass = batch_spp if is_final else training_spp_per_pass
+        n_pass = math.ceil(iter_spp / spp_per_pass)
+        done = 0
+        curr_iter_image = None
+        curr_iter_acc = None
+        log(f"Iteration {k}: SPP {iter_spp}, cumm_SPP {cumm_spp}, remaining {budget_spp - cumm_spp}, final {is_final}")
+        for p in range(n_pass):
+            cur = min(spp_per_pass, iter_spp - done)
+            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp)  # main.py:218
+            wimg = img * float(cur / iter_spp)
+            curr_iter_image = wimg if curr_iter_image is None else curr_iter_image + wimg
+            if is_final:
+                curr_iter_acc = img * cur if curr_iter_acc is None else curr_iter_acc + img * cur
+            image_spp += cur
+            done += cur
+            cumm_spp += cur
+            if record_in_iteration:
+                el = time.perf_counter() - t_iter + cumm_time
+                rec["variance_inIter"].append(el, image_spp, cumm_spp, k, variance=integrator.computeVariance(image_spp))
+                if ground_truth is not None:
+                    rec["variance_groundTruth_inIter"].append(el, image_spp, cumm_spp, k,
+                                                              variance=integrator.computeVariance(image_spp, ground_truth))
+                    rec["mse_groundTruth_inIter"].append(el, image_spp, cumm_spp, k,
+                                                         mse=integrator.computeMSE(image_spp, ground_truth))
+            if is_final and cumm_spp in possible and prev_iter_image is not None and out_dir:
+                cur_cnt = cumm_spp - cumm_spp_prev
+                blend = (curr_iter_acc / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
+                save_image(os.path.join(out_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), blend)
+        torch.cuda.synchronize()
+        t_render = time.perf_counter() - t_iter
+        if k >= 2 or is_final and not is_train:
+            guided_samples += w * h * iter_spp
+            guided_time += t_render
+        if is_final and not is_train and prev_iter_image is not None:
+            image = (curr_iter_image * iter_spp + prev_iter_image * (image_spp - iter_spp)) / image_spp  # main.py:287-288
+        else:
+            image = curr_iter_image
+        variance = integrator.computeVariance(image_spp)
+        variance_gt = integrator.computeVariance(image_spp, ground_truth) if ground_truth is not None else 0.0
+        mse_gt = integrator.computeMSE(image_spp, ground_truth) if ground_truth is not None else 0.0
+        el = time.perf_counter() - t_iter + cumm_time
+        rec["variance_endIter"].append(el, image_spp, cumm_spp, k, variance=variance)
+        rec["variance_groundTruth_endIter"].append(el, image_spp, cumm_spp, k, variance=variance_gt)
+        rec["mse_groundTruth_endIter"].append(el, image_spp, cumm_spp, k, mse=mse_gt)
+        budget_upto_prev = budget_spp - cumm_spp_prev
+        variance_current = (variance * image_spp) / budget_upto_prev  # main.py:324-325
+        rec["variance_estimated_final"].append(el, image_spp, cumm_spp, k, variance=variance_current)
+        log(f"  variance {variance:.6g}  variance_gt {variance_gt:.6g}  mse_gt {mse_gt:.6g}  est.final {variance_current:.6g}  "
+            f"render {t_render * 1e3:.1f} ms")
+        # main.py:334-377
+        next_spp = 2 ** (k + 3)
+        remaining = budget_spp - cumm_spp
+        stop = (cumm_spp > stable_variance_spp_threshold and variance_current > variance_prev) or cumm_spp >= train_stop_cumm_spp
+        was_training = is_train
+        if next_spp < remaining:
+            if stop:
+                is_final, is_train, is_clear = True, False, False
+        elif next_spp == remaining:
+            is_final = True
+            if stop:
+                is_train, is_clear = False, False
+        else:
+            is_final, is_train, is_clear = True, False, False
+        t_ref = 0.0
+        if is_train and remaining > 0:
+            t0 = time.perf_counter()
+            integrator.refineAndPrepareSDTreeForNextIteration(all_reduce)  # main.py:383
+            torch.cuda.synchronize()
+            t_ref = time.perf_counter() - t0
+        elif was_training and not is_train:
+            log("  -- stop training SDTree --")
+        prev_iter_image = image
+        torch.cuda.synchronize()
+        cumm_time += time.perf_counter() - t_iter
+        per_iter.append({"iteration": k, "spp": iter_spp, "render_s": t_render, "refine_s": t_ref})
+        if out_dir:
+            save_image(os.path.join(out_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), image)
+            integrator.saveSDTreeToFile(os.path.join(out_dir, f"sdtree_iter-{k}.npz"))
+            integrator.saveSDTreeOBJ(os.path.join(out_dir, f"kdtree_iter-{k}.obj"))
+        variance_prev = variance_current
+        k += 1
+        cumm_spp_prev = cumm_spp
+    if out_dir:
+        for name, r in rec.items():
+            if r.rows:
+                r.saveToFile(os.path.join(out_dir, name + ".csv"))
+    return {"image": image, "records": rec, "iterations": per_iter, "cumm_spp": cumm_spp, "time_s": cumm_time,
+            "guided_samples": guided_samples, "guided_time_s": guided_time}
