@@ -237,6 +237,12 @@ typedef struct pg_pass_params {
 	uint32_t seed;    /* sampler seed of the pass (main.py:218: initial_seed + cumm_spp) */
 	int32_t spp;      /* samples per pixel traced by this pass; lane = pixel*spp + s (:414-417) */
 	int32_t rr_depth; /* Russian roulette from this depth on (:39, 375) */
+	int32_t reserved;
+	/* image tile traced by this call (multi-GPU sharding): pixels [pixel_begin, pixel_begin +
+	 * pixel_count) in row-major film order; pixel_count 0 = up to the end of the film.  Sampler
+	 * streams are keyed by the global lane id, so the union of tiles equals the full-frame pass.
+	 * L_out / valid_out hold only the tile's lanes; sumL / sumL2 are full-film arrays. */
+	uint64_t pixel_begin, pixel_count;
 } pg_pass_params;
 
 /* One call of PathGuidingIntegrator.sample() for all width*height*spp lanes
@@ -248,6 +254,15 @@ typedef struct pg_pass_params {
  * sumL/sumL2: Color3f[width*height] planar accumulators (:400-429) or both NULL. */
 int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uint8_t *valid_out,
                    float *sumL, float *sumL2, void *stream);
+
+/* Per-kernel device time of pg_render_pass, measured with HIP events recorded on the launch
+ * stream around each kernel (off by default).  pg_read_kernel_timing synchronises. */
+typedef struct pg_kernel_timing {
+	double bounce_ms, splat_ms, generate_ms, finish_ms;
+	uint64_t bounce_launches, splat_launches, passes;
+} pg_kernel_timing;
+int pg_enable_kernel_timing(pg_context *ctx, int32_t on);
+int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset);
 
 /* ---- statistics for the roofline model ------------------------------------ */
 typedef struct pg_stats {

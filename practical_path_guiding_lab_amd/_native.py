@@ -73,7 +73,14 @@ class pg_camera(C.Structure):
 
 
 class pg_pass_params(C.Structure):
-    _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32)]
+    _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32), ("reserved", C.c_int32),
+                ("pixel_begin", C.c_uint64), ("pixel_count", C.c_uint64)]
+
+
+class pg_kernel_timing(C.Structure):
+    _fields_ = [("bounce_ms", C.c_double), ("splat_ms", C.c_double), ("generate_ms", C.c_double),
+                ("finish_ms", C.c_double), ("bounce_launches", C.c_uint64), ("splat_launches", C.c_uint64),
+                ("passes", C.c_uint64)]
 
 
 class pg_depth_counters(C.Structure):
@@ -88,6 +95,7 @@ EXPORTS = (
     "pg_process_records", "pg_process_and_splat", "pg_refine_and_swap", "pg_accumulators",
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
+    "pg_enable_kernel_timing", "pg_read_kernel_timing",
 )
 
 
@@ -147,6 +155,8 @@ def lib() -> C.CDLL:
     L.pg_read_depth_counters.argtypes = [V, C.POINTER(pg_depth_counters), I32]
     L.pg_scene_set.argtypes = [V, U64, V, C.POINTER(pg_camera)]
     L.pg_render_pass.argtypes = [V, C.POINTER(pg_pass_params), V, V, V, V, V]
+    L.pg_enable_kernel_timing.argtypes = [V, I32]
+    L.pg_read_kernel_timing.argtypes = [V, C.POINTER(pg_kernel_timing), I32]
     for name in EXPORTS:
         if name not in ("pg_last_error", "pg_abi_version"):
             getattr(L, name).restype = C.c_int

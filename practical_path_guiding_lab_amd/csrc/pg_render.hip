@@ -143,7 +143,8 @@ struct RenderArgs {
 	const float *quads;
 	int n_quads, emitter_quad;
 	pg_camera cam;
-	uint64_t n_lanes, n_pixels;
+	uint64_t n_lanes, n_pixels;      // of this pass (tile)
+	uint64_t pixel_begin, film_pixels; // first pixel of the tile, pixels of the whole film
 	int spp, max_depth, rr_depth, guided, record, store_nee;
 	float frac;
 	uint32_t seed;
@@ -163,8 +164,10 @@ __global__ __launch_bounds__(kRBlock) void k_generate(RenderArgs a)
 	const uint64_t lane = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	if (lane >= a.n_lanes) return;
 	const uint64_t N = a.n_lanes;
-	Pcg32 rng = pcg32_seed(a.seed, (uint32_t)lane);
-	const uint64_t pixel = lane / (uint64_t)a.spp;
+	// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
+	// the full-frame pass would, whatever the number of ranks
+	Pcg32 rng = pcg32_seed(a.seed, (uint32_t)(a.pixel_begin * (uint64_t)a.spp + lane));
+	const uint64_t pixel = a.pixel_begin + lane / (uint64_t)a.spp;
 	const int W = a.cam.width, H = a.cam.height;
 	const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
 	const float jx = rng.next_f32(), jy = rng.next_f32();
@@ -403,15 +406,16 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 {
 	const uint64_t pix = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	if (pix >= a.n_pixels) return;
-	const uint64_t N = a.n_lanes, P = a.n_pixels;
+	const uint64_t N = a.n_lanes, P = a.film_pixels;
+	const uint64_t gpix = a.pixel_begin + pix; // the sums are full-film arrays
 	for (int s = 0; s < a.spp; ++s) {
 		const uint64_t lane = pix * (uint64_t)a.spp + (uint64_t)s;
 		if (valid_out) valid_out[lane] = a.depth[lane] != 0;
 		if (sumL && sumL2)
 			for (int c = 0; c < 3; ++c) {
 				const float v = a.L[c * N + lane];
-				sumL[c * P + pix] = sumL[c * P + pix] + v;
-				sumL2[c * P + pix] = sumL2[c * P + pix] + v * v;
+				sumL[c * P + gpix] = sumL[c * P + gpix] + v;
+				sumL2[c * P + gpix] = sumL2[c * P + gpix] + v * v;
 			}
 	}
 }
@@ -432,7 +436,33 @@ struct pg_render_state {
 	DevBuf<uint64_t> rng_state, rng_inc;
 	DevBuf<uint8_t> r_act;
 	DevBuf<float> r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee, r_wp;
+	// optional per-kernel timing: (kind, start, stop) event triples still to be read
+	bool timing_on = false;
+	struct Ev { int kind; hipEvent_t a, b; };
+	std::vector<Ev> events;
+	pg_kernel_timing acc = {0, 0, 0, 0, 0, 0, 0};
 };
+
+namespace {
+struct Timed { // records an event pair around a launch when timing is enabled
+	pg_render_state *r;
+	hipStream_t s;
+	int kind;
+	hipEvent_t a = nullptr, b = nullptr;
+	Timed(pg_render_state *r_, hipStream_t s_, int kind_) : r(r_), s(s_), kind(kind_)
+	{
+		if (!r->timing_on) return;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+		(void)hipEventRecord(a, s);
+	}
+	~Timed()
+	{
+		if (!a) return;
+		(void)hipEventRecord(b, s);
+		r->events.push_back({kind, a, b});
+	}
+};
+} // namespace
 
 static pg_render_state *rstate(pg_context *ctx)
 {
@@ -479,7 +509,11 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	hipStream_t s = (hipStream_t)stream;
 	pg_render_state *r = ctx->render;
-	const uint64_t P = (uint64_t)r->cam.width * (uint64_t)r->cam.height;
+	const uint64_t film = (uint64_t)r->cam.width * (uint64_t)r->cam.height;
+	if (prm->pixel_begin > film || prm->pixel_count > film - prm->pixel_begin)
+		return fail(ctx, PG_ERR_INVALID, "pg_render_pass: pixel range outside the film");
+	const uint64_t P = prm->pixel_count ? prm->pixel_count : film - prm->pixel_begin; // 0 = to the end
+	if (P == 0) return PG_OK;
 	const uint64_t N = P * (uint64_t)prm->spp;
 	const int D = ctx->max_depth;
 	const uint64_t S = N * (uint64_t)D;
@@ -504,6 +538,8 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.cam = r->cam;
 	a.n_lanes = N;
 	a.n_pixels = P;
+	a.pixel_begin = prm->pixel_begin;
+	a.film_pixels = film;
 	a.spp = prm->spp;
 	a.max_depth = D;
 	a.rr_depth = prm->rr_depth;
@@ -519,23 +555,63 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.r_act = r->r_act.p; a.r_pos = r->r_pos.p; a.r_dir = r->r_dir.p; a.r_bsdf = r->r_bsdf.p; a.r_tb = r->r_tb.p;
 	a.r_tr = r->r_tr.p; a.r_nee = r->r_nee.p; a.r_dnee = r->r_dnee.p; a.r_wp = r->r_wp.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
-	hipLaunchKernelGGL(k_generate, grid, dim3(kRBlock), 0, s, a);
-	for (int it = 0; it < D; ++it) hipLaunchKernelGGL(k_bounce, grid, dim3(kRBlock), 0, s, a);
+	{
+		Timed t(r, s, 0);
+		hipLaunchKernelGGL(k_generate, grid, dim3(kRBlock), 0, s, a);
+	}
+	for (int it = 0; it < D; ++it) {
+		Timed t(r, s, 1);
+		hipLaunchKernelGGL(k_bounce, grid, dim3(kRBlock), 0, s, a);
+	}
 	PG_HIP(ctx, hipGetLastError());
 	if (record) {
 		pg_dense_records d;
 		d.active = r->r_act.p; d.position = r->r_pos.p; d.direction = r->r_dir.p; d.bsdf = r->r_bsdf.p;
 		d.throughput_bsdf = r->r_tb.p; d.throughput_radiance = r->r_tr.p; d.radiance_nee = r->r_nee.p;
 		d.direction_nee = r->r_dnee.p; d.wo_pdf = r->r_wp.p;
+		Timed t(r, s, 2);
 		launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d,
 		                         ctx->dc_on ? ctx->dc : nullptr, s);
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (valid_out || sumL) {
+		Timed t(r, s, 3);
 		hipLaunchKernelGGL(k_finish, dim3((unsigned)((P + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, s, a, valid_out,
 		                   sumL, sumL2);
 		PG_HIP(ctx, hipGetLastError());
 	}
+	if (r->timing_on) ++r->acc.passes;
+	return PG_OK;
+}
+
+int pg_enable_kernel_timing(pg_context *ctx, int32_t on)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	rstate(ctx)->timing_on = on != 0;
+	return PG_OK;
+}
+
+int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
+{
+	if (!ctx || !out) return PG_ERR_INVALID;
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	pg_render_state *r = rstate(ctx);
+	for (auto &e : r->events) {
+		float ms = 0.0f;
+		PG_HIP(ctx, hipEventSynchronize(e.b));
+		PG_HIP(ctx, hipEventElapsedTime(&ms, e.a, e.b));
+		switch (e.kind) {
+		case 0: r->acc.generate_ms += ms; break;
+		case 1: r->acc.bounce_ms += ms; ++r->acc.bounce_launches; break;
+		case 2: r->acc.splat_ms += ms; ++r->acc.splat_launches; break;
+		default: r->acc.finish_ms += ms; break;
+		}
+		(void)hipEventDestroy(e.a);
+		(void)hipEventDestroy(e.b);
+	}
+	r->events.clear();
+	*out = r->acc;
+	if (reset) r->acc = pg_kernel_timing{0, 0, 0, 0, 0, 0, 0};
 	return PG_OK;
 }
 

@@ -70,16 +70,22 @@ class WavefrontScene:
         N.check(tree._h, tree._lib.pg_scene_set(tree._h, q.shape[0], q.ctypes.data, C.byref(c)))
         self._uploaded_to = tree
 
+    # image tile of this rank (multi-GPU): (first pixel, pixel count) in row-major order; None = whole film
+    pixel_range = None
+
     def trace_pass(self, integrator, sampler: IndependentSampler, accumulate: bool = True):
-        """One device pass; returns (L (3,N) float32 cuda, valid (N,) uint8 cuda, spp)."""
+        """One device pass over this rank's tile; returns (L (3,N) float32 cuda, valid (N,) uint8 cuda, spp)."""
         tree = integrator.sdTree
         self._upload(tree)
         cam = self.scene.camera
         spp = sampler.sample_count()
-        n = cam.width * cam.height * spp
+        begin, count = self.pixel_range if self.pixel_range is not None else (0, cam.width * cam.height)
+        n = count * spp
         L = torch.empty((3, n), dtype=torch.float32, device=tree.device)
         valid = torch.empty(n, dtype=torch.uint8, device=tree.device)
-        p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth))
+        if n == 0:
+            return L, valid, spp
+        p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth), 0, begin, count)
         sl = integrator.sumL.data_ptr() if accumulate else None
         sl2 = integrator.sumL2.data_ptr() if accumulate else None
         N.check(tree._h, tree._lib.pg_render_pass(tree._h, C.byref(p), L.data_ptr(), valid.data_ptr(), sl, sl2,

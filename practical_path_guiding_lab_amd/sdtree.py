@@ -348,6 +348,14 @@ class SDTree:
         self._ck(self._lib.pg_get_stats(self._h, C.byref(st)))
         return st
 
+    def enableKernelTiming(self, on: bool = True):
+        self._ck(self._lib.pg_enable_kernel_timing(self._h, int(on)))
+
+    def readKernelTiming(self, reset: bool = True) -> N.pg_kernel_timing:
+        kt = N.pg_kernel_timing()
+        self._ck(self._lib.pg_read_kernel_timing(self._h, C.byref(kt), int(reset)))
+        return kt
+
     def enableDepthCounters(self, on: bool = True):
         self._ck(self._lib.pg_enable_depth_counters(self._h, int(on)))
 
