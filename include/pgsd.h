@@ -258,7 +258,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 /* Per-kernel device time of pg_render_pass, measured with HIP events recorded on the launch
  * stream around each kernel (off by default).  pg_read_kernel_timing synchronises. */
 typedef struct pg_kernel_timing {
-	double bounce_ms, splat_ms, generate_ms, finish_ms;
+	double bounce_ms, splat_ms, generate_ms, finish_ms, compact_ms;
 	uint64_t bounce_launches, splat_launches, passes;
 } pg_kernel_timing;
 int pg_enable_kernel_timing(pg_context *ctx, int32_t on);

@@ -79,7 +79,8 @@ class pg_pass_params(C.Structure):
 
 class pg_kernel_timing(C.Structure):
     _fields_ = [("bounce_ms", C.c_double), ("splat_ms", C.c_double), ("generate_ms", C.c_double),
-                ("finish_ms", C.c_double), ("bounce_launches", C.c_uint64), ("splat_launches", C.c_uint64),
+                ("finish_ms", C.c_double), ("compact_ms", C.c_double), ("bounce_launches", C.c_uint64),
+                ("splat_launches", C.c_uint64),
                 ("passes", C.c_uint64)]
 
 

@@ -111,9 +111,11 @@ __global__ __launch_bounds__(kBlock) void k_splat(TreeView t, AccumView a, int s
 // (path_guiding_integrator.py:434-478).  Returns keep; outputs the tree's inputs.
 __device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t num_rays, int32_t max_depth,
                                              const float *__restrict__ l_final, const pg_dense_records &r,
-                                             float &radiance, float &nee_lum, float &wp)
+                                             float &radiance, float &nee_lum, float &wp, int depth_major = 0)
 {
-	const uint64_t ray = g / (uint64_t)max_depth;
+	// slot = ray*max_depth + depth as the reference lays it out (:318), or depth*num_rays + ray for the
+	// library's own renderer (coalesced record stores from the bounce kernels)
+	const uint64_t ray = depth_major ? g % num_rays : g / (uint64_t)max_depth;
 	float in[3], nee[3];
 #pragma unroll
 	for (int ch = 0; ch < 3; ++ch) {
@@ -167,13 +169,13 @@ __global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, i
 __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumView a, int store_nee,
                                                               uint64_t num_rays, int32_t max_depth,
                                                               const float *__restrict__ l_final,
-                                                              pg_dense_records r, DepthCounters *dc)
+                                                              pg_dense_records r, DepthCounters *dc, int depth_major)
 {
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
 	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
-	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp);
+	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp, depth_major);
 	if (keep) {
 		splat_record(t, a, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
 		             r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum,
@@ -207,12 +209,12 @@ void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l
 
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,
                               int32_t max_depth, const float *l_final, const pg_dense_records &rec,
-                              DepthCounters *dc, hipStream_t s)
+                              DepthCounters *dc, hipStream_t s, int depth_major)
 {
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	if (S == 0) return;
 	hipLaunchKernelGGL(k_process_and_splat, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
-	                   max_depth, l_final, rec, dc);
+	                   max_depth, l_final, rec, dc, depth_major);
 }
 
 } // namespace pg

@@ -149,6 +149,8 @@ struct RenderArgs {
 	float frac;
 	uint32_t seed;
 	DepthCounters *dc;
+	const uint32_t *order;       // compacted live-ray list (NULL for the first bounce)
+	const uint32_t *order_count; // [2], as written by k_compact_lanes
 	// per-lane state (planar)
 	float *ray_o, *ray_d, *thr, *L, *prev_p, *prev_pdf, *ior;
 	uint32_t *depth;
@@ -193,11 +195,20 @@ __global__ __launch_bounds__(kRBlock) void k_generate(RenderArgs a)
 __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
-	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
-	const uint64_t lane = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	if (lane >= a.n_lanes) return;
-	if (!a.active[lane]) return;
+	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t N = a.n_lanes;
+	// live-ray list from the stream compaction that ran after the previous bounce (none before the
+	// first): thread t serves ray slot order[N-1-t]; workgroups past the live count retire at once
+	const uint64_t live = a.order ? (uint64_t)a.order_count[0] + (uint64_t)a.order_count[1] : N;
+	if ((uint64_t)blockIdx.x * kRBlock >= live) return;
+	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	if (tid >= live || tid >= N) return;
+	uint64_t lane = tid;
+	if (a.order) {
+		const uint64_t front = a.order_count[0];
+		lane = a.order[tid < front ? tid : N - 1 - (tid - front)];
+	}
+	if (!a.active[lane]) return;
 	const int D = a.max_depth;
 	const float f = a.frac;
 	const float *quads = a.quads;
@@ -348,7 +359,9 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	// ---- :318-346 record ----
 	if (a.record && valid) {
 		const uint64_t S = N * (uint64_t)D;
-		const uint64_t g = lane * (uint64_t)D + depth;
+		// the reference's slot is ray*max_depth + depth (:318), a stride-max_depth scatter; the library's
+		// own buffer is depth-major so that a wavefront's stores coalesce (pg_process_and_splat is told)
+		const uint64_t g = (uint64_t)depth * N + lane;
 		float c0, c1;
 		a.r_act[g] = 1;
 		a.r_pos[g] = p.x; a.r_pos[S + g] = p.y; a.r_pos[2 * S + g] = p.z;
@@ -434,13 +447,14 @@ struct pg_render_state {
 	DevBuf<uint32_t> depth;
 	DevBuf<uint8_t> active, prev_delta;
 	DevBuf<uint64_t> rng_state, rng_inc;
+	DevBuf<uint32_t> order, order_count;
 	DevBuf<uint8_t> r_act;
 	DevBuf<float> r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee, r_wp;
 	// optional per-kernel timing: (kind, start, stop) event triples still to be read
 	bool timing_on = false;
 	struct Ev { int kind; hipEvent_t a, b; };
 	std::vector<Ev> events;
-	pg_kernel_timing acc = {0, 0, 0, 0, 0, 0, 0};
+	pg_kernel_timing acc = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -523,6 +537,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N)); PG_HIP(ctx, r->ior.ensure(N));
 	PG_HIP(ctx, r->depth.ensure(N)); PG_HIP(ctx, r->active.ensure(N)); PG_HIP(ctx, r->prev_delta.ensure(N));
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
+	PG_HIP(ctx, r->order.ensure(N)); PG_HIP(ctx, r->order_count.ensure(2));
 	if (record) {
 		PG_HIP(ctx, r->r_act.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
 		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
@@ -559,9 +574,18 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		Timed t(r, s, 0);
 		hipLaunchKernelGGL(k_generate, grid, dim3(kRBlock), 0, s, a);
 	}
+	a.order = nullptr;
+	a.order_count = r->order_count.p;
 	for (int it = 0; it < D; ++it) {
-		Timed t(r, s, 1);
-		hipLaunchKernelGGL(k_bounce, grid, dim3(kRBlock), 0, s, a);
+		{
+			Timed t(r, s, 1);
+			hipLaunchKernelGGL(k_bounce, grid, dim3(kRBlock), 0, s, a);
+		}
+		if (it + 1 < D) { // active-ray stream compaction for the next bounce
+			Timed t(r, s, 4);
+			launch_compact_lanes(N, r->active.p, nullptr, r->order.p, r->order_count.p, s);
+			a.order = r->order.p;
+		}
 	}
 	PG_HIP(ctx, hipGetLastError());
 	if (record) {
@@ -570,8 +594,9 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		d.throughput_bsdf = r->r_tb.p; d.throughput_radiance = r->r_tr.p; d.radiance_nee = r->r_nee.p;
 		d.direction_nee = r->r_dnee.p; d.wo_pdf = r->r_wp.p;
 		Timed t(r, s, 2);
-		launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d,
-		                         ctx->dc_on ? ctx->dc : nullptr, s);
+		// the depth counters of an instrumented pass describe the bounce kernels only
+		launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d, nullptr, s,
+		                         /*depth_major=*/1);
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (valid_out || sumL) {
@@ -604,6 +629,7 @@ int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
 		case 0: r->acc.generate_ms += ms; break;
 		case 1: r->acc.bounce_ms += ms; ++r->acc.bounce_launches; break;
 		case 2: r->acc.splat_ms += ms; ++r->acc.splat_launches; break;
+		case 4: r->acc.compact_ms += ms; break;
 		default: r->acc.finish_ms += ms; break;
 		}
 		(void)hipEventDestroy(e.a);
@@ -611,7 +637,7 @@ int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
 	}
 	r->events.clear();
 	*out = r->acc;
-	if (reset) r->acc = pg_kernel_timing{0, 0, 0, 0, 0, 0, 0};
+	if (reset) r->acc = pg_kernel_timing{0, 0, 0, 0, 0, 0, 0, 0};
 	return PG_OK;
 }
 
