@@ -47,6 +47,9 @@ typedef enum pg_status {
 #define PG_FRAC_BITS 40
 #define PG_W_CLAMP_LOG2 48
 #define PG_ACC_LIMBS 3
+/* An accumulator occupies PG_ACC_WORDS int64 in one 32-byte sector: the three limbs and a record
+ * counter (records inside the KD bbox whose path direction ended in this quadtree leaf). */
+#define PG_ACC_WORDS 4
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 

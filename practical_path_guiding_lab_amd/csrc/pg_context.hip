@@ -476,34 +476,45 @@ int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t
 	PG_HIP(ctx, download(rec, f.rec, f.n_rec));
 	PG_HIP(ctx, download(head, f.head, f.n_trees));
 	const long long *rec_acc = acc.data();
-	const long long *root_acc = acc.data() + (size_t)f.n_rec * 12;
+	const long long *root_acc = acc.data() + (size_t)f.n_rec * 4 * kAccWords;
 	const unsigned long long *leaf_count =
-	    reinterpret_cast<const unsigned long long *>(acc.data() + (size_t)f.n_rec * 12 + (size_t)f.n_trees * 3);
-	// KD: leaves take their tree's counter, inner nodes the sum of their children (children have
-	// larger indices than their parent: kdtree.py:243-245)
-	for (int64_t i = (int64_t)f.n_kd - 1; i >= 0; --i)
-		kd_count[i] = kd[i].child == 0 ? leaf_count[kd[i].tree] : kd_count[kd[i].child] + kd_count[kd[i].child + 1];
-	// quadtree: per-record totals bottom-up (child records have larger indices than the parent)
+	    reinterpret_cast<const unsigned long long *>(root_acc + (size_t)f.n_trees * kAccWords);
+	// quadtree: per-record totals bottom-up (child records have larger indices than the parent);
+	// word 3 of every accumulator counts the records whose path direction ended there
 	std::vector<I128> tot(f.n_rec);
+	std::vector<uint64_t> cnt_tot(f.n_rec);
 	std::vector<I128> slot((size_t)f.n_rec * 4);
 	for (int64_t r = (int64_t)f.n_rec - 1; r >= 0; --r) {
 		I128 s = {0, 0};
+		uint64_t c = 0;
 		for (int j = 0; j < 4; ++j) {
 			I128 v;
-			if (rec[r].child[j]) v = tot[rec[r].child[j]];
-			else { const long long *l = rec_acc + ((size_t)r * 4 + j) * 3; v = limbs_resolve(l[0], l[1], l[2]); }
+			if (rec[r].child[j]) { v = tot[rec[r].child[j]]; c += cnt_tot[rec[r].child[j]]; }
+			else {
+				const long long *l = rec_acc + ((size_t)r * 4 + j) * kAccWords;
+				v = limbs_resolve(l[0], l[1], l[2]);
+				c += (uint64_t)l[3];
+			}
 			slot[(size_t)r * 4 + j] = v;
 			s = i128_add(s, v);
 		}
 		tot[r] = s;
+		cnt_tot[r] = c;
 	}
+	std::vector<uint64_t> tree_count(f.n_trees);
 	for (uint32_t t = 0; t < f.n_trees; ++t) {
 		I128 v;
-		if (head[t].root_rec == kNoRecord) v = limbs_resolve(root_acc[3 * t], root_acc[3 * t + 1], root_acc[3 * t + 2]);
-		else v = tot[head[t].root_rec];
+		const long long *ra = root_acc + (size_t)t * kAccWords;
+		if (head[t].root_rec == kNoRecord) { v = limbs_resolve(ra[0], ra[1], ra[2]); tree_count[t] = (uint64_t)ra[3]; }
+		else { v = tot[head[t].root_rec]; tree_count[t] = cnt_tot[head[t].root_rec]; }
+		tree_count[t] += leaf_count[t];
 		acc_lo[t] = v.lo;
 		acc_hi[t] = v.hi;
 	}
+	// KD: leaves take their tree's count, inner nodes the sum of their children (children have
+	// larger indices than their parent: kdtree.py:243-245)
+	for (int64_t i = (int64_t)f.n_kd - 1; i >= 0; --i)
+		kd_count[i] = kd[i].child == 0 ? tree_count[kd[i].tree] : kd_count[kd[i].child] + kd_count[kd[i].child + 1];
 	const size_t L = f.level_off.size() - 1;
 	for (size_t l = 0; l < L; ++l)
 		for (uint32_t r = f.level_off[l]; r < f.level_off[l + 1]; ++r)

@@ -64,13 +64,16 @@ struct Forest {
 	uint32_t n_trees = 0;
 	// accumulators of the running iteration: [rec_acc | root_acc | leaf_count]
 	DevBuf<long long> acc;
-	uint64_t acc_count() const { return (uint64_t)n_rec * 4 * 3 + (uint64_t)n_trees * 3 + n_trees; }
+	uint64_t acc_count() const
+	{
+		return (uint64_t)n_rec * 4 * kAccWords + (uint64_t)n_trees * kAccWords + n_trees;
+	}
 	AccumView accum_view()
 	{
 		AccumView a;
 		a.rec_acc = acc.p;
-		a.root_acc = acc.p + (uint64_t)n_rec * 12;
-		a.leaf_count = reinterpret_cast<unsigned long long *>(acc.p + (uint64_t)n_rec * 12 + (uint64_t)n_trees * 3);
+		a.root_acc = acc.p + (uint64_t)n_rec * 4 * kAccWords;
+		a.leaf_count = reinterpret_cast<unsigned long long *>(a.root_acc + (uint64_t)n_trees * kAccWords);
 		return a;
 	}
 };

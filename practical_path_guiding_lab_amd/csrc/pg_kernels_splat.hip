@@ -2,11 +2,15 @@
 //
 // The reference adds fp32 values with one float atomic per node on the root->leaf path
 // (kdtree.py:199, quadtree.py:93): D_kd + 2*D_quad atomics per record, all records hitting the
-// same root words.  Here a record touches only its KD leaf counter (one u64 atomic, which the
-// compiler folds per wave for equal addresses) and its two quadtree leaf accumulators
-// (<= 2 non-zero 32-bit-payload limbs each, fire-and-forget int64 atomics).  Integer sums are
-// order independent, so inner-node totals are formed once at refine time by a bottom-up pass
-// and the multi-GPU exchange is an exact int64 all-reduce.
+// same root words.  Here a record touches only the accumulators of the two quadtree leaves its
+// directions fall into: integer sums are order independent, so inner-node totals (and the KD
+// counts, carried in word 3 of the path direction's accumulator) are formed once at refine time
+// by a bottom-up pass, and the multi-GPU exchange is an exact int64 all-reduce.
+//
+// Scattered global atomics are the bound of this kernel (about 24 G sector-updates/s on MI355X,
+// tools/atomic_probe.hip), and the hardware charges one update per 32-byte sector touched by a
+// wave-instruction, not per lane.  A record's four words therefore go out from four ADJACENT lanes
+// of one instruction (transposed through LDS): one update per direction instead of up to four.
 #include "pg_descent.hpp"
 #include "pg_kernels.hpp"
 
@@ -23,46 +27,75 @@ __device__ __forceinline__ TreeHead load_head_s(const TreeHead *h, uint32_t t)
 	return r;
 }
 
-__device__ __forceinline__ void add_limbs(long long *base, const Limbs &q)
-{
-	if (q.l0) atomicAdd(reinterpret_cast<unsigned long long *>(base + 0), (unsigned long long)q.l0);
-	if (q.l1) atomicAdd(reinterpret_cast<unsigned long long *>(base + 1), (unsigned long long)q.l1);
-	if (q.l2) atomicAdd(reinterpret_cast<unsigned long long *>(base + 2), (unsigned long long)q.l2);
-}
+struct SlotAdd { // what one (direction, weight) pair adds, and where
+	long long *ptr; // accumulator base (kAccWords words), nullptr = nothing to add
+	long long w0, w1, w2, w3;
+};
 
-// quadtree.py:398-441 for one (direction, weight) pair
-__device__ __forceinline__ uint32_t splat_dir(const TreeView &t, const AccumView &a, TreeHead head,
-                                              uint32_t tree, float cx, float cy, float w)
+// quadtree.py:398-441 for one (direction, weight) pair; `count` goes to word 3
+__device__ __forceinline__ SlotAdd plan_dir(const TreeView &t, const AccumView &a, TreeHead head, uint32_t tree,
+                                            float cx, float cy, float w, long long count, uint32_t &levels)
 {
-	uint32_t slot = 0, lv = 0;
+	SlotAdd s = {nullptr, 0, 0, 0, 0};
+	uint32_t slot = 0;
 	bool is_root = false;
-	if (!quad_find_leaf_slot(t.rec, head, cx, cy, slot, is_root, lv)) return 0;
+	if (!quad_find_leaf_slot(t.rec, head, cx, cy, slot, is_root, levels)) return s;
 	const Limbs q = quantize_weight(w);
-	if (!q.zero()) add_limbs(is_root ? a.root_acc + 3ull * tree : a.rec_acc + 3ull * slot, q);
-	return lv;
+	s.ptr = is_root ? a.root_acc + (size_t)kAccWords * tree : a.rec_acc + (size_t)kAccWords * slot;
+	s.w0 = q.l0; s.w1 = q.l1; s.w2 = q.l2; s.w3 = count;
+	return s;
 }
 
-// KDTree.addDataPropagate (kdtree.py:180-225) + QuadTree.addDataPropagate (quadtree.py:389-464)
-__device__ __forceinline__ void splat_record(const TreeView &t, const AccumView &a, int store_nee,
-                                             float x, float y, float z, float dx, float dy, float radiance,
-                                             float wo_pdf, float nx, float ny, float nee_lum,
-                                             unsigned &kd_lv, unsigned &q_lv, unsigned &q_q)
+// KDTree.addDataPropagate (kdtree.py:180-225) + QuadTree.addDataPropagate (quadtree.py:389-464):
+// finds where the record's two contributions go; the adds themselves are issued by coop_add
+__device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &a, const uint4 *s_kd, int store_nee,
+                                            float x, float y, float z, float dx, float dy, float radiance,
+                                            float wo_pdf, float nx, float ny, float nee_lum, SlotAdd &path,
+                                            SlotAdd &nee, unsigned &kd_lv, unsigned &q_lv, unsigned &q_q)
 {
 	const bool inside = inside_root(t, x, y, z);
 	KdNode leaf;
 	uint32_t lv;
-	kd_descend(t.kd, x, y, z, inside, leaf, lv);
+	kd_descend_lds(t.kd, s_kd, x, y, z, inside, leaf, lv);
 	kd_lv = lv;
 	const uint32_t tree = leaf.tree; // outside the bbox: node 0's (stale) tree (kdtree.py:224)
-	if (inside) atomicAdd(a.leaf_count + tree, 1ull);
 	const TreeHead head = load_head_s(t.head, tree);
 	const float w = wo_pdf > 0.0f ? radiance / wo_pdf : 0.0f; // quadtree.py:451
-	q_lv += splat_dir(t, a, head, tree, dx, dy, w);
+	path = plan_dir(t, a, head, tree, dx, dy, w, inside ? 1 : 0, lv);
+	q_lv += lv;
 	++q_q;
+	// a counted record whose direction reaches no leaf (outside the unit square): fallback counter
+	if (inside && path.ptr == nullptr) atomicAdd(a.leaf_count + tree, 1ull);
+	nee.ptr = nullptr;
+	nee.w0 = nee.w1 = nee.w2 = nee.w3 = 0;
 	if (store_nee) {
 		const float wn = wo_pdf > 0.0f ? nee_lum / wo_pdf : 0.0f; // quadtree.py:462
-		q_lv += splat_dir(t, a, head, tree, nx, ny, wn);
+		nee = plan_dir(t, a, head, tree, nx, ny, wn, 0, lv);
+		q_lv += lv;
 		++q_q;
+	}
+}
+
+// Every thread of the workgroup calls this (convergent).  Lane L of a wave issues word (L & 3) of
+// the record held by lane r*16 + (L >> 2) in round r: the four words of one accumulator leave in
+// one wave-instruction from four adjacent lanes.
+__device__ __forceinline__ void coop_add(const SlotAdd &s, long long *s_val, unsigned long long *s_ptr)
+{
+	const unsigned t = threadIdx.x;
+	__syncthreads(); // the previous call's readers are done
+	s_val[4 * t + 0] = s.w0;
+	s_val[4 * t + 1] = s.w1;
+	s_val[4 * t + 2] = s.w2;
+	s_val[4 * t + 3] = s.w3;
+	s_ptr[t] = reinterpret_cast<unsigned long long>(s.ptr);
+	__syncthreads();
+	const unsigned lane = t & 63u, wbase = t & ~63u, word = lane & 3u;
+#pragma unroll
+	for (unsigned r = 0; r < 4; ++r) {
+		const unsigned src = wbase + r * 16u + (lane >> 2);
+		const long long v = s_val[4 * src + word];
+		long long *p = reinterpret_cast<long long *>(s_ptr[src]);
+		if (p != nullptr && v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(p + word), (unsigned long long)v);
 	}
 }
 
@@ -94,16 +127,23 @@ __global__ __launch_bounds__(kBlock) void k_splat(TreeView t, AccumView a, int s
                                                   const float *__restrict__ nee_lum,
                                                   const uint32_t *__restrict__ d_count, DepthCounters *dc)
 {
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	__shared__ long long s_val[kBlock * 4];
+	__shared__ unsigned long long s_ptr[kBlock];
+	stage_kd_top(s_kd, t.kd, t.n_kd);
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	const uint64_t valid = d_count ? (uint64_t)*d_count : m; // plane stride stays m
 	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
+	SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
 	if (i < valid && i < m) {
 		const float nx = store_nee ? dir_nee[i] : 0.0f, ny = store_nee ? dir_nee[m + i] : 0.0f;
 		const float nl = store_nee ? nee_lum[i] : 0.0f;
-		splat_record(t, a, store_nee, pos[i], pos[m + i], pos[2 * m + i], dir[i], dir[m + i], radiance[i],
-		             wo_pdf[i], nx, ny, nl, kd_lv, q_lv, q_q);
+		plan_record(t, a, s_kd, store_nee, pos[i], pos[m + i], pos[2 * m + i], dir[i], dir[m + i], radiance[i],
+		            wo_pdf[i], nx, ny, nl, path, nee, kd_lv, q_lv, q_q);
 		did = 1;
 	}
+	coop_add(path, s_val, s_ptr);
+	if (store_nee) coop_add(nee, s_val, s_ptr);
 	count_depths_s(dc, kd_lv, did, q_lv, q_q);
 }
 
@@ -136,23 +176,34 @@ __device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t nu
 	return r.active[g] != 0 && !both_zero && !(wp == 0.0f) && !(wp != wp); // :475-478
 }
 
-// Stream compaction with one atomic per wave: ballot -> popcount -> lane-prefix via mbcnt.
+// Stream compaction: thread-local keep flag -> workgroup prefix -> ONE atomic per workgroup
+// (a single counter word serialises at ~11 ns per atomic: one per wave would dominate the kernel).
 __global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, int32_t max_depth,
                                                             const float *__restrict__ l_final,
                                                             pg_dense_records r, pg_records_out o,
                                                             uint32_t *__restrict__ d_count)
 {
+	__shared__ uint32_t s_wave[kBlock / 64];
+	__shared__ uint32_t s_base;
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
 	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp);
 	const unsigned long long mask = __ballot(keep);
-	const unsigned lane = threadIdx.x & 63;
-	unsigned base = 0;
-	if (lane == 0 && mask) base = atomicAdd(d_count, (uint32_t)__popcll(mask));
-	base = __shfl(base, 0, 64);
+	const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	if (lane == 0) s_wave[wid] = (uint32_t)__popcll(mask);
+	__syncthreads();
+	uint32_t off = 0, tot = 0;
+#pragma unroll
+	for (unsigned w = 0; w < kBlock / 64; ++w) {
+		if (w < wid) off += s_wave[w];
+		tot += s_wave[w];
+	}
+	if (threadIdx.x == 0) s_base = tot ? atomicAdd(d_count, tot) : 0;
+	__syncthreads();
 	if (keep) {
-		const uint64_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+		const uint64_t k = (uint64_t)s_base + off +
+		                   __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 		o.position[k] = r.position[g];
 		o.position[S + k] = r.position[S + g];
 		o.position[2 * S + k] = r.position[2 * S + g];
@@ -171,17 +222,24 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
                                                               const float *__restrict__ l_final,
                                                               pg_dense_records r, DepthCounters *dc, int depth_major)
 {
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	__shared__ long long s_val[kBlock * 4];
+	__shared__ unsigned long long s_ptr[kBlock];
+	stage_kd_top(s_kd, t.kd, t.n_kd);
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
 	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
+	SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
 	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp, depth_major);
 	if (keep) {
-		splat_record(t, a, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
-		             r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum,
-		             kd_lv, q_lv, q_q);
+		plan_record(t, a, s_kd, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
+		            r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum, path, nee,
+		            kd_lv, q_lv, q_q);
 		did = 1;
 	}
+	coop_add(path, s_val, s_ptr);
+	if (store_nee) coop_add(nee, s_val, s_ptr);
 	count_depths_s(dc, kd_lv, did, q_lv, q_q);
 }
 

@@ -115,41 +115,52 @@ __global__ __launch_bounds__(kBlk) void k_scan_apply(const uint32_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlk) void k_resolve_level(const QuadRec *__restrict__ rec,
                                                         const long long *__restrict__ rec_acc,
-                                                        I128 *__restrict__ tot, float *__restrict__ slot_irr,
-                                                        uint32_t begin, uint32_t end)
+                                                        I128 *__restrict__ tot,
+                                                        unsigned long long *__restrict__ cnt_tot,
+                                                        float *__restrict__ slot_irr, uint32_t begin, uint32_t end)
 {
 	const uint32_t r = begin + blockIdx.x * kBlk + threadIdx.x;
 	if (r >= end) return;
 	const uint4 ch = reinterpret_cast<const uint4 *>(rec + r)[1];
 	const uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
 	I128 s = {0, 0};
+	unsigned long long n = 0;
 	float irr[4];
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		I128 v;
-		if (c[j]) v = tot[c[j]]; // child records live on the next level: already resolved
-		else {
-			const long long *l = rec_acc + ((size_t)r * 4 + j) * 3;
+		if (c[j]) { // child records live on the next level: already resolved
+			v = tot[c[j]];
+			n += cnt_tot[c[j]];
+		} else {
+			const long long *l = rec_acc + ((size_t)r * 4 + j) * kAccWords;
 			v = limbs_resolve(l[0], l[1], l[2]);
+			n += (unsigned long long)l[3];
 		}
 		irr[j] = i128_to_f32(v);
 		s = i128_add(s, v);
 	}
 	tot[r] = s;
+	cnt_tot[r] = n;
 	reinterpret_cast<float4 *>(slot_irr)[r] = make_float4(irr[0], irr[1], irr[2], irr[3]);
 }
 
+// per tree: root irradiance and the number of records its KD leaf received (= vertCount, kdtree.py:199)
 __global__ __launch_bounds__(kBlk) void k_resolve_roots(const TreeHead *__restrict__ head,
                                                         const long long *__restrict__ root_acc,
                                                         const I128 *__restrict__ tot,
-                                                        float *__restrict__ root_irr, uint32_t n_trees)
+                                                        const unsigned long long *__restrict__ cnt_tot,
+                                                        const unsigned long long *__restrict__ fallback_count,
+                                                        float *__restrict__ root_irr,
+                                                        unsigned long long *__restrict__ tree_count, uint32_t n_trees)
 {
 	const uint32_t t = blockIdx.x * kBlk + threadIdx.x;
 	if (t >= n_trees) return;
 	const uint32_t rr = head[t].root_rec;
-	const I128 v = rr == kNoRecord ? limbs_resolve(root_acc[3 * (size_t)t], root_acc[3 * (size_t)t + 1], root_acc[3 * (size_t)t + 2])
-	                               : tot[rr];
+	const long long *ra = root_acc + (size_t)t * kAccWords;
+	const I128 v = rr == kNoRecord ? limbs_resolve(ra[0], ra[1], ra[2]) : tot[rr];
 	root_irr[t] = i128_to_f32(v);
+	tree_count[t] = (rr == kNoRecord ? (unsigned long long)ra[3] : cnt_tot[rr]) + fallback_count[t];
 }
 
 // exact per-node record counts (what kdtree.py:199 accumulates on every visited node)
@@ -461,22 +472,24 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 	// ---- 1. resolve --------------------------------------------------------------------------
 	DevBuf<I128> tot;
 	DevBuf<float> slot_irr, root_irr;
-	DevBuf<unsigned long long> kd_cnt;
+	DevBuf<unsigned long long> kd_cnt, cnt_tot, tree_count;
 	PG_HIP(ctx, tot.ensure(f.n_rec));
+	PG_HIP(ctx, cnt_tot.ensure(f.n_rec));
 	PG_HIP(ctx, slot_irr.ensure((size_t)f.n_rec * 4));
 	PG_HIP(ctx, root_irr.ensure(f.n_trees));
+	PG_HIP(ctx, tree_count.ensure(f.n_trees));
 	for (int l = (int)L - 1; l >= 0; --l) {
 		const uint32_t b = f.level_off[l], e = f.level_off[l + 1];
 		if (e > b)
 			hipLaunchKernelGGL(k_resolve_level, grid_for(e - b), dim3(kBlk), 0, s, f.rec.p, av.rec_acc, tot.p,
-			                   slot_irr.p, b, e);
+			                   cnt_tot.p, slot_irr.p, b, e);
 	}
 	hipLaunchKernelGGL(k_resolve_roots, grid_for(f.n_trees), dim3(kBlk), 0, s, f.head.p, av.root_acc, tot.p,
-	                   root_irr.p, f.n_trees);
+	                   cnt_tot.p, av.leaf_count, root_irr.p, tree_count.p, f.n_trees);
 	PG_HIP(ctx, kd_cnt.ensure(f.n_kd));
-	hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, av.leaf_count, kd_cnt.p, 0, 1);
+	hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, tree_count.p, kd_cnt.p, 0, 1);
 	for (int d = ctx->kd_max_depth - 1; d >= 0; --d)
-		hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, av.leaf_count, kd_cnt.p, d, 0);
+		hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, tree_count.p, kd_cnt.p, d, 0);
 	hipLaunchKernelGGL(k_kd_vcount, grid_for(f.n_kd), dim3(kBlk), 0, s, kd_cnt.p, f.kd_vcount.p, f.n_kd);
 	PG_HIP(ctx, hipGetLastError());
 

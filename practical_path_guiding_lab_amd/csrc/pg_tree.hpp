@@ -53,10 +53,18 @@ struct TreeView {
 };
 
 // Accumulation view (sdTree_current: same topology, integer accumulators).
+// One accumulator = kAccWords int64 words in one 32-byte sector: three limbs of the irradiance sum
+//  and the number of in-bbox records whose path direction ended in this leaf.
+// Keeping all four words in one sector matters: gfx950 services the atomics of one wave-instruction
+// per touched sector, not per lane (tools/atomic_probe.hip: two lanes adding to the two halves of a
+// 16-byte slot cost one atomic), so the splat kernels hand a record's words to adjacent lanes.
 // acc layout: one contiguous int64 buffer [ rec_acc | root_acc | leaf_count ]
-//   rec_acc   : n_rec*4 slots * 3 limbs   (slot = rec*4 + child)
-//   root_acc  : n_trees * 3 limbs         (used directly when the root is a leaf)
-//   leaf_count: n_trees                   (records that reached the KD leaf owning the tree)
+//   rec_acc   : n_rec*4 slots * 4 words   (slot = rec*4 + child)
+//   root_acc  : n_trees * 4 words         (used directly when the root is a leaf)
+//   leaf_count: n_trees                   (fallback counter: in-bbox records whose direction lies
+//                                          outside the unit square, which reach no quadtree leaf)
+// The KD vertCount of a leaf (kdtree.py:199) is the sum of word 3 over its tree plus the fallback.
+constexpr int kAccWords = 4;
 struct AccumView {
 	long long *rec_acc;
 	long long *root_acc;
