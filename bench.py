@@ -153,10 +153,11 @@ def run_render(args):
     # one instrumented pass for the byte model (depth counters add atomics: not timed)
     tree.enableDepthCounters(True)
     tree.readDepthCounters(reset=True)
+    rec_before = int(tree.exportAccumulators()[0][0])  # records counted at the KD root so far
     step()
     dc = tree.readDepthCounters(reset=True)
     tree.enableDepthCounters(False)
-    kd, lo, hi = (None, None, None)
+    records_per_pass = int(tree.exportAccumulators()[0][0]) - rec_before
 
     tree.enableKernelTiming(True)
     tree.readKernelTiming(reset=True)
@@ -188,27 +189,35 @@ def run_render(args):
     # bounce: 16 B per KD level + 20 B per quadtree level; splat: per record 16*D_kd + 4 + 48 + 12 per quadtree level
     # the splat's depths are not separated from the bounce's by the counters, so it is priced with the
     # tree's mean depths over the records actually kept (counted from sdTree_current's leaf counters)
-    bounce_bytes = 16.0 * dc.kd_levels + 20.0 * dc.quad_levels
+    paths_bytes = 16.0 * dc.kd_levels + 20.0 * dc.quad_levels          # all bounces of one pass
+    d_kd = dc.kd_levels / max(dc.kd_queries, 1)
+    d_q = dc.quad_levels / max(dc.quad_queries, 1)
+    splat_bytes = records_per_pass * (16.0 * d_kd + 4.0 + 48.0 + 12.0 * 2.0 * d_q)  # B_rec with the measured mean depths
     n_b, n_s = max(kt.bounce_launches, 1), max(kt.splat_launches, 1)
-    bounce_us = 1e3 * kt.bounce_ms / n_b
+    paths_us = 1e3 * kt.bounce_ms / n_b
     splat_us = 1e3 * kt.splat_ms / n_s
     passes = max(kt.passes, 1)
+    per_pass = n_b / passes  # bounce launches per pass (= max_depth)
     kern = {
-        "k_bounce": {"launches": int(kt.bounce_launches), "avg_us": round(bounce_us, 2),
-                     "alg_bytes_per_launch": round(bounce_bytes / args.depth),
-                     "alg_GBps": round(bounce_bytes / args.depth / (bounce_us * 1e-6) / 1e9, 2) if bounce_us else 0.0},
-        "k_process_and_splat": {"launches": int(kt.splat_launches), "avg_us": round(splat_us, 2)},
+        "k_bounce": {"launches": int(kt.bounce_launches), "avg_us": round(paths_us, 2),
+                     "alg_bytes_per_launch": round(paths_bytes / per_pass),
+                     "alg_GBps": round(paths_bytes / per_pass / (paths_us * 1e-6) / 1e9, 2) if paths_us else 0.0},
+        "k_process_and_splat": {"launches": int(kt.splat_launches), "avg_us": round(splat_us, 2),
+                                "records_per_launch": int(records_per_pass), "alg_bytes_per_launch": round(splat_bytes),
+                                "alg_GBps": round(splat_bytes / (splat_us * 1e-6) / 1e9, 2) if splat_us else 0.0},
         "k_generate": {"avg_us": round(1e3 * kt.generate_ms / passes, 2)},
         "k_finish": {"avg_us": round(1e3 * kt.finish_ms / passes, 2)},
         "k_compact_lanes": {"per_pass_us": round(1e3 * kt.compact_ms / passes, 2)},
     }
     dom = "k_bounce" if kt.bounce_ms >= kt.splat_ms else "k_process_and_splat"
     cfg_key = f"render res={args.res} depth={args.depth} spp={args.spp_per_pass}"
-    roof = {"bound": "hbm", "kernel": "k_bounce", "achieved": kern["k_bounce"]["alg_GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(kern["k_bounce"]["alg_GBps"] / HBM_PEAK_GBS, 5),
-            "traffic": traffic_for("k_bounce", cfg_key), "dominant_by_time": dom,
-            "note": "algorithmic bytes count only the SD-tree descents inside the fused bounce kernel "
-                    "(16 B/KD level, 20 B/quadtree level); ray casting and shading bytes are not credited"}
+    roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 5),
+            "traffic": traffic_for(dom, cfg_key),
+            "note": "k_bounce is one whole bounce of the wavefront (ray casting, NEE incl. shadow ray, shading, SD-tree "
+                    "queries, record store, state load/store); its algorithmic bytes count only the SD-tree descents "
+                    "(16 B/KD level, 20 B/quadtree level, SURVEY 8d). k_process_and_splat is bound by scattered "
+                    "atomics, not HBM (DESIGN.md 5)"}
     cpu = cpu_baseline_render(args, tree, sc) if (args.cpu_res > 0 and world == 1) else None
     out = {
         "metric": "Msamples/s guided, cornell-box 512x512 max_depth 8", "value": round(value, 3), "unit": "Msamples/s",

@@ -238,8 +238,29 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 		            kd_lv, q_lv, q_q);
 		did = 1;
 	}
-	coop_add(path, s_val, s_ptr);
-	if (store_nee) coop_add(nee, s_val, s_ptr);
+	if (t.n_rec == 0 && t.n_trees == 1) {
+		// First iteration: one KD leaf owning a single-leaf quadtree (kdtree.py:122, quadtree.py:355), so
+		// every record of the pass lands in the same accumulator.  One word takes ~11 ns per atomic;
+		// sum inside the workgroup and send four atomics per workgroup instead of two per record.
+		long long v[4] = {0, 0, 0, 0};
+		if (path.ptr) { v[0] += path.w0; v[1] += path.w1; v[2] += path.w2; v[3] += path.w3; }
+		if (nee.ptr) { v[0] += nee.w0; v[1] += nee.w1; v[2] += nee.w2; v[3] += nee.w3; }
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const unsigned long long sw = wave_sum_s((unsigned long long)v[k]);
+			if ((threadIdx.x & 63) == 0) s_val[(threadIdx.x >> 6) * 4 + k] = (long long)sw;
+		}
+		__syncthreads();
+		if (threadIdx.x < 4) {
+			unsigned long long tot = 0;
+			for (int w = 0; w < kBlock / 64; ++w) tot += (unsigned long long)s_val[w * 4 + threadIdx.x];
+			if (tot) atomicAdd(reinterpret_cast<unsigned long long *>(a.root_acc + threadIdx.x), tot);
+		}
+	} else {
+		coop_add(path, s_val, s_ptr);
+		if (store_nee) coop_add(nee, s_val, s_ptr);
+	}
 	count_depths_s(dc, kd_lv, did, q_lv, q_q);
 }
 

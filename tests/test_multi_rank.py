@@ -130,6 +130,81 @@ def _worker_gpu(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_render(rank, world, port, out, mode):
+    """mode 'tiles': ranks split the film rows; mode 'passes': ranks take alternate passes."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators, shard
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+    from practical_path_guiding_lab_amd.scene import cornell_box
+
+    sc = cornell_box(RES, RES, 6, 8)
+    g = PathGuidingIntegrator({"max_depth": 6, "rr_depth": 8})
+    g.setup(RES * RES, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
+    ws = WavefrontScene(sc)
+    if mode == "tiles":
+        ws.pixel_range = shard(RES * RES, rank, world)
+    Ls = []
+    cumm = 0
+    for k in range(3):
+        g.setIteration(k, False)
+        for p in range(2 ** (k + 2)):
+            if mode == "tiles" or p % world == rank:
+                L, _, _ = g.sample(ws, IndependentSampler(1, 77 + cumm + p))
+                if k == 2 and p < 2:
+                    Ls.append(L.cpu().numpy())
+        cumm += 2 ** (k + 2)
+        g.refineAndPrepareSDTreeForNextIteration(all_reduce_accumulators)
+    sums = g.sumL.cpu()
+    dist.all_reduce(sums)
+    np.savez(out % rank, sumL=sums.numpy(), L=np.stack(Ls) if Ls else np.zeros(0), **g.sdTree.export())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+RES = 24
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,port", [("tiles", 29613), ("passes", 29614)])
+def test_two_ranks_render_like_one(tmp_path, mode, port):
+    from practical_path_guiding_lab_amd.parallel import shard
+    from practical_path_guiding_lab_amd.scene import cornell_box
+
+    world = 2
+    out = str(tmp_path / "r%d.npz")
+    mp.spawn(_worker_render, args=(world, port, out, mode), nprocs=world, join=True)
+    sc = cornell_box(RES, RES, 6, 8)
+    o = po.OracleSDTreePair()
+    o.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
+    sumL = np.zeros((3, RES * RES), np.float32)
+    sumL2 = np.zeros_like(sumL)
+    cumm, keepL = 0, []
+    for k in range(3):
+        for p in range(2 ** (k + 2)):
+            L, _ = po.render_pass(o, sc.quads, sc.camera, 6, 8, k, False, 77 + cumm + p, 1, True, 0.5, sumL, sumL2)
+            if k == 2 and p < 2:
+                keepL.append(L)
+        cumm += 2 ** (k + 2)
+        o.refine_and_prepare(k)
+    exp = o.prev.export()
+    for r in range(world):
+        got = dict(np.load(out % r))
+        for key in exp:  # every rank ends with the single-process tree, bit for bit
+            np.testing.assert_array_equal(np.asarray(got[key]).astype(np.float64), np.asarray(exp[key]).astype(np.float64), err_msg=key)
+        if mode == "tiles":  # a tile's lanes are the corresponding slice of the full-frame pass
+            b, c = shard(RES * RES, r, world)
+            for i in range(2):
+                np.testing.assert_array_equal(got["L"][i].view(np.uint32), keepL[i][:, b:b + c].view(np.uint32))
+            # disjoint tiles: the summed per-pixel sums are exactly the full-frame sums
+            np.testing.assert_array_equal(got["sumL"].view(np.uint32), sumL.view(np.uint32))
+        else:  # passes interleaved over ranks: same samples, fp32 sums in a different order
+            np.testing.assert_allclose(got["sumL"], sumL, rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_gpu_match_single_rank_and_oracle(tmp_path):
     world = 2

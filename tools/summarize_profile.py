@@ -1,0 +1,81 @@
+"""Dev tool: condense a tools/profile_bench.sh output directory into profiles/<round>/.
+
+    python tools/summarize_profile.py gpurun_out/prof_r01b profiles/r01 "render res=512 depth=8 spp=8"
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+KERNELS = ("k_bounce", "k_process_and_splat", "k_compact_lanes", "k_generate", "k_finish")
+
+
+def short(name):
+    for k in KERNELS:
+        if k in name:
+            return k
+    return None
+
+
+stats = glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0]
+shutil.copy(stats, os.path.join(dst, "bench_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, "bench_under_rocprof.json"))
+
+# exact per-launch durations of the timed region from the trace (last 10 passes)
+trace = glob.glob(f"{src}/trace/*/*kernel_trace.csv")[0]
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    k = short(r["Kernel_Name"])
+    if k:
+        dur[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+trace_summary = {}
+for k, v in dur.items():
+    v.sort()
+    per_pass = {"k_bounce": 8, "k_compact_lanes": 7}.get(k, 1)
+    last = [d for _, d in v[-10 * per_pass:]]
+    trace_summary[k] = {"launches_in_timed_region": len(last), "avg_us": round(sum(last) / len(last) / 1e3, 2),
+                        "min_us": round(min(last) / 1e3, 2), "max_us": round(max(last) / 1e3, 2)}
+
+
+def agg(sub):
+    fs = glob.glob(f"{src}/{sub}/*/*counter_collection.csv")
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    if fs:
+        for r in csv.DictReader(open(fs[0])):
+            k = short(r["Kernel_Name"])
+            if k:
+                d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+f, w, l2, sq = agg("pmc_fetch"), agg("pmc_write"), agg("pmc_l2"), agg("pmc_sq")
+out = {"config": cfg,
+       "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu-res 0`; means per launch over "
+               "all launches of the run (training + timed). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
+               "(2*FETCH_SIZE + WRITE_SIZE)*1024 applies the gfx950 x2 FETCH correction of MI355X_MICROARCH.md section HBM "
+               "(calibrated for wide coalesced reads only: an upper bound here).",
+       "kernels": {}, "trace": trace_summary}
+for k in KERNELS:
+    if k not in f:
+        continue
+    m = lambda d, c: (sum(d[k][c]) / len(d[k][c])) if d[k][c] else None
+    fs, ws = m(f, "FETCH_SIZE"), m(w, "WRITE_SIZE")
+    e = {"launches": len(f[k]["FETCH_SIZE"]), "FETCH_SIZE_KiB": round(fs, 1), "WRITE_SIZE_KiB": round(ws, 1),
+         "hbm_bytes_per_launch_uncorrected": round((fs + ws) * 1024), "hbm_bytes_per_launch": round((2 * fs + ws) * 1024)}
+    for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"):
+        if l2[k][c]:
+            e[c] = round(m(l2, c))
+    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+              "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD"):
+        if sq[k][c]:
+            e[c] = round(m(sq, c))
+    out["kernels"][k] = e
+json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+json.dump({"config": cfg, "kernels": {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in out["kernels"].items()}},
+          open(os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
