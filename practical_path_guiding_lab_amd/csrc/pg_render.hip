@@ -8,8 +8,9 @@
 // One kernel per bounce over all ray slots (lanes whose path has ended retire at once); the
 // SD-tree queries are the same device functions the stand-alone query kernels use, so a bounce
 // costs one KD descent and at most two quadtree descents per live lane and no intermediate
-// wavefront buffers.  Path-vertex records go to the dense slot buffer (ray*max_depth + depth,
-// :318) that pg_process_and_splat consumes after the last bounce (:388-395).
+// wavefront buffers.  Live rays are re-compacted after every bounce (k_compact_lanes).  Path-vertex
+// records go to a dense slot buffer (the reference's :318, stored depth-major here so that a
+// wavefront's stores coalesce) that pg_process_and_splat consumes after the last bounce (:388-395).
 //
 // Arithmetic mirrors oracle/pg_oracle_render.c operation by operation (fp32, no contraction), so
 // radiance, records and therefore the refined trees are bit-identical to the CPU restatement.
