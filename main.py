@@ -24,13 +24,12 @@ def main():
     ap.add_argument("--training-spp-per-pass", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)               # main.py:66-67
     ap.add_argument("--out", default="debug/cornell-box")
-    ap.add_argument("--ground-truth", default=None, help=".npy (H,W,3) linear ground truth for MSE")
+    ap.add_argument("--ground-truth", default=None, help=".exr or .npy (H,W,3) linear ground truth for MSE, e.g. "
+                    "scenes/cornell-box/TungstenRender.exr or tests/golden/cornell_gt_256_f16.npy")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
     from practical_path_guiding_lab_amd import scene as S
-    from practical_path_guiding_lab_amd.driver import run_guided_render
+    from practical_path_guiding_lab_amd.driver import load_ground_truth, run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import WavefrontScene
 
@@ -38,10 +37,7 @@ def main():
     if args.max_depth is not None:
         sc.max_depth = args.max_depth
     integ = PathGuidingIntegrator({"max_depth": sc.max_depth, "rr_depth": sc.rr_depth})
-    gt = None
-    if args.ground_truth:
-        g = np.load(args.ground_truth).astype(np.float32)
-        gt = torch.from_numpy(np.ascontiguousarray(g.reshape(-1, 3).T)).cuda()
+    gt = load_ground_truth(args.ground_truth, sc.camera.width, sc.camera.height) if args.ground_truth else None
     res = run_guided_render(WavefrontScene(sc), integ, args.budget_spp, initial_seed=args.seed, ground_truth=gt,
                             batch_spp=args.batch_spp, training_spp_per_pass=args.training_spp_per_pass, out_dir=args.out)
     n = sc.camera.width * sc.camera.height * res["cumm_spp"]

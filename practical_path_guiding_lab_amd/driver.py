@@ -62,6 +62,28 @@ def save_image(path_noext: str, image: torch.Tensor):
     Image.fromarray((np.clip(srgb, 0, 1) * 255 + 0.5).astype(np.uint8)).save(path_noext + ".png")
 
 
+def load_ground_truth(path: str, width: int, height: int) -> torch.Tensor:
+    """main.py:36-41 (`mi.Bitmap(gt).convert(RGB, Float32)`): a ground-truth image as the (3, H*W)
+    device tensor computeMSE/computeVariance take. `.exr` (scanline, NONE/ZIP/PIZ) or `.npy`
+    (H, W, 3) linear radiance; an image that is an integer multiple of the film size is
+    box-downsampled to it (the reference renders at the ground truth's own resolution)."""
+    if path.lower().endswith(".exr"):
+        from . import exr
+        img = exr.read_rgb(path)
+    else:
+        img = np.load(path)
+    img = np.asarray(img, dtype=np.float32)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError(f"ground truth {path}: expected (H, W, 3), got {img.shape}")
+    gh, gw = img.shape[:2]
+    if (gh, gw) != (height, width):
+        if gh % height or gw % width or gh // height != gw // width:
+            raise ValueError(f"ground truth {path} is {gw}x{gh}; the film is {width}x{height}")
+        f = gh // height
+        img = img.reshape(height, f, width, f, 3).astype(np.float64).mean(axis=(1, 3)).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(img.reshape(-1, 3).T)).cuda()
+
+
 def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, budget_spp: int,
                       initial_seed: int = 0, ground_truth: Optional[torch.Tensor] = None,
                       sdTreeMaxDepth: int = 20, quadTreeMaxDepth: int = 20, isStoreNEERadiance: bool = True,
