@@ -158,6 +158,7 @@ def run_render(args):
     dc = tree.readDepthCounters(reset=True)
     tree.enableDepthCounters(False)
     records_per_pass = int(tree.exportAccumulators()[0][0]) - rec_before
+    live = tree.renderLiveCounts(args.depth)  # paths alive after each bounce of that pass
 
     tree.enableKernelTiming(True)
     tree.readKernelTiming(reset=True)
@@ -231,7 +232,7 @@ def run_render(args):
                    "paths_per_step": paths_per_step, "kd_nodes": stats.n_kd_nodes, "kd_leaves": stats.n_kd_leaves,
                    "quad_records": stats.n_quad_records, "mean_kd_leaf_depth": round(stats.mean_kd_leaf_depth, 3),
                    "mean_quad_leaf_depth": round(stats.mean_quad_leaf_depth, 3),
-                   "guided_tree_queries_per_pass": int(dc.quad_queries),
+                   "guided_tree_queries_per_pass": int(dc.quad_queries), "paths_alive_after_bounce": live,
                    "measured_D_kd": round(dc.kd_levels / max(dc.kd_queries, 1), 3),
                    "measured_D_quad": round(dc.quad_levels / max(dc.quad_queries, 1), 3)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kern,

@@ -267,6 +267,11 @@ typedef struct pg_kernel_timing {
 int pg_enable_kernel_timing(pg_context *ctx, int32_t on);
 int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset);
 
+/* Paths still alive after each bounce of the most recent pg_render_pass: out[b] for
+ * b < min(n, max_depth) (the loop condition `active` of path_guiding_integrator.py:179 counted
+ * per iteration).  Synchronises the device. */
+int pg_render_live_counts(pg_context *ctx, uint32_t *out, int32_t n);
+
 /* ---- statistics for the roofline model ------------------------------------ */
 typedef struct pg_stats {
 	uint64_t n_kd_nodes, n_kd_leaves, n_quad_records, n_quad_nodes, n_trees;

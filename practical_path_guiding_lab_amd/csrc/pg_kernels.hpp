@@ -40,6 +40,6 @@ void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee,
                               uint64_t num_rays, int32_t max_depth, const float *l_final,
                               const pg_dense_records &rec, DepthCounters *dc, hipStream_t s,
-                              int depth_major = 0);
+                              const uint32_t *ray_of = nullptr, const uint32_t *live_count = nullptr);
 
 } // namespace pg

@@ -149,13 +149,10 @@ __global__ __launch_bounds__(kBlock) void k_splat(TreeView t, AccumView a, int s
 
 // processPathData + scatterDataIntoSDTree's filter for dense slot g
 // (path_guiding_integrator.py:434-478).  Returns keep; outputs the tree's inputs.
-__device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t num_rays, int32_t max_depth,
+__device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t num_rays, uint64_t ray, bool active,
                                              const float *__restrict__ l_final, const pg_dense_records &r,
-                                             float &radiance, float &nee_lum, float &wp, int depth_major = 0)
+                                             float &radiance, float &nee_lum, float &wp)
 {
-	// slot = ray*max_depth + depth as the reference lays it out (:318), or depth*num_rays + ray for the
-	// library's own renderer (coalesced record stores from the bounce kernels)
-	const uint64_t ray = depth_major ? g % num_rays : g / (uint64_t)max_depth;
 	float in[3], nee[3];
 #pragma unroll
 	for (int ch = 0; ch < 3; ++ch) {
@@ -173,7 +170,7 @@ __device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t nu
 	nee_lum = luminance(nee[0], nee[1], nee[2]);
 	wp = r.wo_pdf[g];
 	const bool both_zero = (radiance == 0.0f) && (nee_lum == 0.0f); // :470-472
-	return r.active[g] != 0 && !both_zero && !(wp == 0.0f) && !(wp != wp); // :475-478
+	return active && !both_zero && !(wp == 0.0f) && !(wp != wp); // :475-478
 }
 
 // Stream compaction: thread-local keep flag -> workgroup prefix -> ONE atomic per workgroup
@@ -188,7 +185,9 @@ __global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, i
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
-	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp);
+	// slot = ray*max_depth + depth, as the reference lays the buffer out (:318)
+	const bool keep = g < S && process_slot(g, S, num_rays, g / (uint64_t)max_depth, r.active[g] != 0, l_final, r,
+	                                        radiance, nee_lum, wp);
 	const unsigned long long mask = __ballot(keep);
 	const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	if (lane == 0) s_wave[wid] = (uint32_t)__popcll(mask);
@@ -217,21 +216,50 @@ __global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, i
 	}
 }
 
+// kList = false: the reference's dense buffer, slot = ray*max_depth + depth (:318), every slot visited.
+// kList = true: the library's own renderer appends one record per live path and bounce (the order
+// the bounce kernels visit them in: coalesced stores, no empty tail), `ray_of[g]` names the path a
+// record belongs to (kNoRay = the path left the scene there) and the number of records is the sum
+// of the per-bounce live counts, known only on the device.
+constexpr uint32_t kNoRay = 0xffffffffu;
+
+template <bool kList>
 __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumView a, int store_nee,
                                                               uint64_t num_rays, int32_t max_depth,
                                                               const float *__restrict__ l_final,
-                                                              pg_dense_records r, DepthCounters *dc, int depth_major)
+                                                              pg_dense_records r, DepthCounters *dc,
+                                                              const uint32_t *__restrict__ ray_of,
+                                                              const uint32_t *__restrict__ live_count)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
 	__shared__ long long s_val[kBlock * 4];
 	__shared__ unsigned long long s_ptr[kBlock];
-	stage_kd_top(s_kd, t.kd, t.n_kd);
 	const uint64_t S = num_rays * (uint64_t)max_depth;
+	uint64_t total = S;
+	if (kList) {
+		total = num_rays; // the first bounce visits every path, bounce b+1 the survivors of bounce b
+		for (int b = 0; b + 1 < max_depth; ++b) total += live_count[b];
+		if ((uint64_t)blockIdx.x * kBlock >= total) return;
+	}
+	stage_kd_top(s_kd, t.kd, t.n_kd);
 	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
 	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
 	SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
-	const bool keep = g < S && process_slot(g, S, num_rays, max_depth, l_final, r, radiance, nee_lum, wp, depth_major);
+	bool keep = false;
+	if (g < total) {
+		uint64_t ray;
+		bool active;
+		if (kList) {
+			const uint32_t rr = ray_of[g];
+			active = rr != kNoRay;
+			ray = active ? rr : 0;
+		} else {
+			ray = g / (uint64_t)max_depth;
+			active = r.active[g] != 0;
+		}
+		keep = process_slot(g, S, num_rays, ray, active, l_final, r, radiance, nee_lum, wp);
+	}
 	if (keep) {
 		plan_record(t, a, s_kd, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
 		            r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum, path, nee,
@@ -288,12 +316,18 @@ void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l
 
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,
                               int32_t max_depth, const float *l_final, const pg_dense_records &rec,
-                              DepthCounters *dc, hipStream_t s, int depth_major)
+                              DepthCounters *dc, hipStream_t s, const uint32_t *ray_of,
+                              const uint32_t *live_count)
 {
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	if (S == 0) return;
-	hipLaunchKernelGGL(k_process_and_splat, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
-	                   max_depth, l_final, rec, dc, depth_major);
+	// the list variant is sized for the worst case too: workgroups past the device-side count retire at once
+	if (ray_of)
+		hipLaunchKernelGGL(k_process_and_splat<true>, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
+		                   max_depth, l_final, rec, dc, ray_of, live_count);
+	else
+		hipLaunchKernelGGL(k_process_and_splat<false>, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
+		                   max_depth, l_final, rec, dc, ray_of, live_count);
 }
 
 } // namespace pg

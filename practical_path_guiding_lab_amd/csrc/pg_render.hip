@@ -5,12 +5,13 @@
 // :219, 277, 352, sampler.next_1d/2d) implemented for the scene subset of scenes/cornell-box:
 // quads, twosided diffuse BSDFs, one-sided area emitters, perspective camera.
 //
-// One kernel per bounce over all ray slots (lanes whose path has ended retire at once); the
-// SD-tree queries are the same device functions the stand-alone query kernels use, so a bounce
-// costs one KD descent and at most two quadtree descents per live lane and no intermediate
-// wavefront buffers.  Live rays are re-compacted after every bounce (k_compact_lanes).  Path-vertex
-// records go to a dense slot buffer (the reference's :318, stored depth-major here so that a
-// wavefront's stores coalesce) that pg_process_and_splat consumes after the last bounce (:388-395).
+// One kernel per bounce over the live rays; the SD-tree queries are the same device functions the
+// stand-alone query kernels use, so a bounce costs one KD descent and at most two quadtree descents
+// per live lane and no intermediate wavefront buffers.  The first bounce generates its camera rays
+// itself, every bounce appends its survivors to the live-ray list of the next one (one atomic per
+// workgroup), and a path carries 57 B of state between bounces.  Path-vertex records go to a dense
+// slot buffer (the reference's :318, stored depth-major here so that a wavefront's stores coalesce)
+// that pg_process_and_splat consumes after the last bounce (:388-395).
 //
 // Arithmetic mirrors oracle/pg_oracle_render.c operation by operation (fp32, no contraction), so
 // radiance, records and therefore the refined trees are bit-identical to the CPU restatement.
@@ -81,7 +82,11 @@ __device__ __forceinline__ int intersect(int nq, const float *__restrict__ quads
 		const v3 n = ld3(Q + 9);
 		const float denom = dot3(n, d);
 		if (denom == 0.0f) continue;
-		const float t = dot3(n, vsub(ld3(Q), o)) / denom;
+		const float num = dot3(n, vsub(ld3(Q), o));
+		// IEEE division keeps the sign: when the signs differ t is not > 0 and the (correctly rounded,
+		// hence long) division can be skipped without changing any result
+		if ((__float_as_uint(num) ^ __float_as_uint(denom)) >> 31) continue;
+		const float t = num / denom;
 		if (!(t > 0.0f && t < bt)) continue;
 		const v3 w = vsub(vadd(o, vscale(d, t)), ld3(Q));
 		const float u = dot3(w, ld3(Q + 3)) * Q[12];
@@ -150,79 +155,71 @@ struct RenderArgs {
 	float frac;
 	uint32_t seed;
 	DepthCounters *dc;
-	const uint32_t *order;       // compacted live-ray list (NULL for the first bounce)
-	const uint32_t *order_count; // [2], as written by k_compact_lanes
-	// per-lane state (planar)
-	float *ray_o, *ray_d, *thr, *L, *prev_p, *prev_pdf, *ior;
-	uint32_t *depth;
-	uint8_t *active, *prev_delta;
+	int bounce, last;          // index of this launch = path depth of every live lane; last launch of the pass
+	const uint32_t *order_in;  // live-ray list written by the previous bounce (unused by the first)
+	uint32_t *order_out;       // live-ray list for the next bounce
+	uint32_t *live_count;      // [max_depth]: live_count[b] = lanes alive after bounce b (zeroed per pass)
+	// per-lane state (planar), 57 B in and out per live lane and bounce.  The ray origin is not
+	// state: it is the previous vertex pushed off its quad (:352 spawn_ray), recomputed from prev_p
+	// and the quad id; depth is the launch index; ior stays 1 (every BSDF of the substrate has eta 1)
+	float *ray_d, *thr, *L, *prev_p, *prev_pdf;
+	uint16_t *prev_quad;
+	uint8_t *hit0; // the first bounce hit something (the `valid` flag, :400)
 	uint64_t *rng_state, *rng_inc;
-	// dense records
-	uint8_t *r_act;
+	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth
+	uint32_t *ray_of;
 	float *r_pos, *r_dir, *r_bsdf, *r_tb, *r_tr, *r_nee, *r_dnee, *r_wp;
 };
 
-__global__ __launch_bounds__(kRBlock) void k_generate(RenderArgs a)
+// One loop iteration of :179-381 for one live lane; returns whether the path continues.
+// kFirst: the camera ray is generated here (mi.render's sensor.sample_ray_differential: one 2-D
+// jitter draw per sample, box reconstruction) instead of being read back from a generate kernel.
+template <bool kFirst>
+__device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_kd, const uint64_t lane,
+                                            const uint64_t rec_slot)
 {
-	const uint64_t lane = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	if (lane >= a.n_lanes) return;
 	const uint64_t N = a.n_lanes;
-	// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
-	// the full-frame pass would, whatever the number of ranks
-	Pcg32 rng = pcg32_seed(a.seed, (uint32_t)(a.pixel_begin * (uint64_t)a.spp + lane));
-	const uint64_t pixel = a.pixel_begin + lane / (uint64_t)a.spp;
-	const int W = a.cam.width, H = a.cam.height;
-	const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
-	const float jx = rng.next_f32(), jy = rng.next_f32();
-	const float tan_y = a.cam.tan_half_fov_x / ((float)W / (float)H);
-	const float cx = (1.0f - 2.0f * ((px + jx) / (float)W)) * a.cam.tan_half_fov_x;
-	const float cy = (1.0f - 2.0f * ((py + jy) / (float)H)) * tan_y;
-	const float len = __builtin_sqrtf((cx * cx + cy * cy) + 1.0f);
-	const v3 dc = V(cx / len, cy / len, 1.0f / len);
-	const v3 d = vadd(vadd(vscale(ld3(a.cam.axis_x), dc.x), vscale(ld3(a.cam.axis_y), dc.y)), vscale(ld3(a.cam.axis_z), dc.z));
-	a.ray_o[lane] = a.cam.origin[0]; a.ray_o[N + lane] = a.cam.origin[1]; a.ray_o[2 * N + lane] = a.cam.origin[2];
-	a.ray_d[lane] = d.x; a.ray_d[N + lane] = d.y; a.ray_d[2 * N + lane] = d.z;
-	for (int c = 0; c < 3; ++c) { a.thr[c * N + lane] = 1.0f; a.L[c * N + lane] = 0.0f; a.prev_p[c * N + lane] = 0.0f; }
-	a.prev_pdf[lane] = 1.0f;
-	a.ior[lane] = 1.0f;
-	a.depth[lane] = 0;
-	a.active[lane] = 1;
-	a.prev_delta[lane] = 1;
-	a.rng_state[lane] = rng.state;
-	a.rng_inc[lane] = rng.inc;
-}
-
-// one loop iteration of :179-381 for every live lane
-__global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
-{
-	__shared__ uint4 s_kd[kLdsKdNodes];
-	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	const uint64_t N = a.n_lanes;
-	// live-ray list from the stream compaction that ran after the previous bounce (none before the
-	// first): thread t serves ray slot order[N-1-t]; workgroups past the live count retire at once
-	const uint64_t live = a.order ? (uint64_t)a.order_count[0] + (uint64_t)a.order_count[1] : N;
-	if ((uint64_t)blockIdx.x * kRBlock >= live) return;
-	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
-	if (tid >= live || tid >= N) return;
-	uint64_t lane = tid;
-	if (a.order) {
-		const uint64_t front = a.order_count[0];
-		lane = a.order[tid < front ? tid : N - 1 - (tid - front)];
-	}
-	if (!a.active[lane]) return;
 	const int D = a.max_depth;
 	const float f = a.frac;
 	const float *quads = a.quads;
-	Pcg32 rng = {a.rng_state[lane], a.rng_inc[lane]};
-	v3 ray_o = V(a.ray_o[lane], a.ray_o[N + lane], a.ray_o[2 * N + lane]);
-	v3 ray_d = V(a.ray_d[lane], a.ray_d[N + lane], a.ray_d[2 * N + lane]);
-	v3 thr = V(a.thr[lane], a.thr[N + lane], a.thr[2 * N + lane]);
-	v3 L = V(a.L[lane], a.L[N + lane], a.L[2 * N + lane]);
-	const v3 prev_p = V(a.prev_p[lane], a.prev_p[N + lane], a.prev_p[2 * N + lane]);
-	const float prev_bsdf_pdf = a.prev_pdf[lane];
-	const bool prev_delta = a.prev_delta[lane] != 0;
-	uint32_t depth = a.depth[lane];
-	float ior = a.ior[lane];
+	const uint32_t depth = (uint32_t)a.bounce;
+	Pcg32 rng;
+	v3 ray_o, ray_d, thr, L, prev_p;
+	float prev_bsdf_pdf;
+	const bool prev_delta = kFirst;
+	if (kFirst) {
+		// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
+		// the full-frame pass would, whatever the number of ranks
+		rng = pcg32_seed(a.seed, (uint32_t)(a.pixel_begin * (uint64_t)a.spp + lane));
+		const uint64_t pixel = a.pixel_begin + lane / (uint64_t)a.spp;
+		const int W = a.cam.width, H = a.cam.height;
+		const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
+		const float jx = rng.next_f32(), jy = rng.next_f32();
+		const float tan_y = a.cam.tan_half_fov_x / ((float)W / (float)H);
+		const float cx = (1.0f - 2.0f * ((px + jx) / (float)W)) * a.cam.tan_half_fov_x;
+		const float cy = (1.0f - 2.0f * ((py + jy) / (float)H)) * tan_y;
+		const float len = __builtin_sqrtf((cx * cx + cy * cy) + 1.0f);
+		const v3 dc = V(cx / len, cy / len, 1.0f / len);
+		ray_d = vadd(vadd(vscale(ld3(a.cam.axis_x), dc.x), vscale(ld3(a.cam.axis_y), dc.y)), vscale(ld3(a.cam.axis_z), dc.z));
+		ray_o = ld3(a.cam.origin);
+		thr = V(1, 1, 1);
+		L = V(0, 0, 0);
+		prev_p = V(0, 0, 0);
+		prev_bsdf_pdf = 1.0f;
+	} else {
+		rng.state = a.rng_state[lane];
+		rng.inc = a.rng_inc[lane];
+		ray_d = V(a.ray_d[lane], a.ray_d[N + lane], a.ray_d[2 * N + lane]);
+		thr = V(a.thr[lane], a.thr[N + lane], a.thr[2 * N + lane]);
+		L = V(a.L[lane], a.L[N + lane], a.L[2 * N + lane]);
+		prev_p = V(a.prev_p[lane], a.prev_p[N + lane], a.prev_p[2 * N + lane]);
+		prev_bsdf_pdf = a.prev_pdf[lane];
+		// :352 spawn_ray of the previous vertex: the same three operations that produced the origin
+		const v3 pn = ld3(quads + (uint32_t)a.prev_quad[lane] * kQuadStride + 9);
+		float mag = (1.0f + max3(V(fabs_(prev_p.x), fabs_(prev_p.y), fabs_(prev_p.z)))) * kRayEps;
+		if (dot3(pn, ray_d) < 0.0f) mag = -mag;
+		ray_o = vadd(prev_p, vscale(pn, mag));
+	}
 
 	// ---- :185 ray_intersect ----
 	float t_hit;
@@ -289,6 +286,11 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	float sdtree_pdf_em = 1.0f;
 	uint32_t lv;
 	unsigned c_kd = 0, c_kdq = 0, c_q = 0, c_qq = 0; // descent statistics for the byte model
+	const bool do_record = a.record && valid;
+	// dirToCanonical of the emitter direction feeds the NEE pdf query (:244) and the record (:338):
+	// one evaluation serves both
+	float nee_cx = 0.0f, nee_cy = 0.0f;
+	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, nee_cx, nee_cy);
 	if (active_sd_em) {
 		KdNode leaf;
 		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
@@ -297,9 +299,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
 		tree_known = true;
-		float cx, cy;
-		dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, cx, cy);
-		sdtree_pdf_em = quad_pdf(a.tree.rec, head, cx, cy, lv);
+		sdtree_pdf_em = quad_pdf(a.tree.rec, head, nee_cx, nee_cy, lv);
 		c_q += lv; ++c_qq;
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
@@ -338,10 +338,11 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		wo_local = to_local(fr, wo_world);
 		bsdf_eval_pdf(refl, wi, wo_local, true, bsdf_value, bsdf_pdf);
 	}
+	// dirToCanonical of the continuation direction feeds the pdf query (:307) and the record (:327)
+	float wo_cx = 0.0f, wo_cy = 0.0f;
+	if (bsdf_mis || do_record) dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, wo_cx, wo_cy);
 	if (bsdf_mis) { // :307
-		float cx, cy;
-		dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, cx, cy);
-		sdtree_pdf = quad_pdf(a.tree.rec, head, cx, cy, lv);
+		sdtree_pdf = quad_pdf(a.tree.rec, head, wo_cx, wo_cy, lv);
 		c_q += lv; ++c_qq;
 	}
 	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
@@ -358,24 +359,24 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		if (!(woPdf > 0.0f)) bsdf_weight = V(0, 0, 0);
 	}
 	// ---- :318-346 record ----
-	if (a.record && valid) {
+	// The reference's slot is ray*max_depth + depth (:318), a stride-max_depth scatter into a buffer
+	// that is mostly empty at the deeper bounces.  The library's own buffer is a list instead: this
+	// launch's thread t owns entry rec_slot = (records of the earlier bounces) + t, so a wavefront's
+	// stores coalesce and the splat visits no empty tail; ray_of names the path (pg_process_and_splat
+	// looks its final radiance up, :440), kNoRay marks a path that left the scene here.
+	if (a.record) a.ray_of[rec_slot] = valid ? (uint32_t)lane : 0xffffffffu;
+	if (do_record) {
 		const uint64_t S = N * (uint64_t)D;
-		// the reference's slot is ray*max_depth + depth (:318), a stride-max_depth scatter; the library's
-		// own buffer is depth-major so that a wavefront's stores coalesce (pg_process_and_splat is told)
-		const uint64_t g = (uint64_t)depth * N + lane;
-		float c0, c1;
-		a.r_act[g] = 1;
+		const uint64_t g = rec_slot;
 		a.r_pos[g] = p.x; a.r_pos[S + g] = p.y; a.r_pos[2 * S + g] = p.z;
-		dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, c0, c1);
-		a.r_dir[g] = c0; a.r_dir[S + g] = c1;
+		a.r_dir[g] = wo_cx; a.r_dir[S + g] = wo_cy;
 		a.r_bsdf[g] = bsdf_weight.x; a.r_bsdf[S + g] = bsdf_weight.y; a.r_bsdf[2 * S + g] = bsdf_weight.z;
 		a.r_tb[g] = thr.x; a.r_tb[S + g] = thr.y; a.r_tb[2 * S + g] = thr.z;
 		a.r_tr[g] = L.x; a.r_tr[S + g] = L.y; a.r_tr[2 * S + g] = L.z;
 		if (a.store_nee) {
 			const v3 rn = vdiv(Lr_dir, thr);
 			a.r_nee[g] = rn.x; a.r_nee[S + g] = rn.y; a.r_nee[2 * S + g] = rn.z;
-			dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, c0, c1);
-			a.r_dnee[g] = c0; a.r_dnee[S + g] = c1;
+			a.r_dnee[g] = nee_cx; a.r_dnee[S + g] = nee_cy;
 		} else {
 			a.r_nee[g] = 0.0f; a.r_nee[S + g] = 0.0f; a.r_nee[2 * S + g] = 0.0f;
 			a.r_dnee[g] = 0.0f; a.r_dnee[S + g] = 0.0f;
@@ -383,35 +384,74 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		a.r_wp[g] = woPdf;
 	}
 	// ---- :352-381 advance ----
-	{
-		float mag = (1.0f + max3(V(fabs_(p.x), fabs_(p.y), fabs_(p.z)))) * kRayEps;
-		if (dot3(n, wo_world) < 0.0f) mag = -mag;
-		ray_o = vadd(p, vscale(n, mag));
-		ray_d = wo_world;
-	}
-	ior = ior * eta;
+	// ior: every BSDF of the substrate returns eta = 1 to a sampled direction, so :357's running
+	// product stays exactly 1 and the Russian-roulette probability is max(throughput) * 1 * 1
+	(void)eta;
 	thr = vmul(thr, bsdf_weight);
 	const float tmax = max3(thr);
 	active_next = active_next && (tmax != 0.0f);
-	float rr_prob = tmax * (ior * ior);
+	float rr_prob = tmax * (1.0f * 1.0f);
 	if (!(rr_prob < 0.95f)) rr_prob = 0.95f;
 	const bool rr_active = depth >= (uint32_t)a.rr_depth;
 	const float rr = rng.next_f32(); // :377, unmasked
 	const bool rr_continue = rr < rr_prob;
 	active_next = active_next && (!rr_active || rr_continue);
-	if (valid) depth += 1;
-	// store state
-	a.rng_state[lane] = rng.state;
-	a.ray_o[lane] = ray_o.x; a.ray_o[N + lane] = ray_o.y; a.ray_o[2 * N + lane] = ray_o.z;
-	a.ray_d[lane] = ray_d.x; a.ray_d[N + lane] = ray_d.y; a.ray_d[2 * N + lane] = ray_d.z;
-	a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
+	// ---- state for the next bounce; a path that ends here leaves only its radiance ----
 	a.L[lane] = L.x; a.L[N + lane] = L.y; a.L[2 * N + lane] = L.z;
-	a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
-	a.prev_pdf[lane] = woPdf;
-	a.prev_delta[lane] = 0;
-	a.ior[lane] = ior;
-	a.depth[lane] = depth;
-	a.active[lane] = active_next ? 1 : 0;
+	if (kFirst) a.hit0[lane] = valid ? 1 : 0;
+	if (active_next) {
+		a.rng_state[lane] = rng.state;
+		if (kFirst) a.rng_inc[lane] = rng.inc;
+		a.ray_d[lane] = wo_world.x; a.ray_d[N + lane] = wo_world.y; a.ray_d[2 * N + lane] = wo_world.z;
+		a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
+		a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
+		a.prev_pdf[lane] = woPdf;
+		a.prev_quad[lane] = (uint16_t)q;
+	}
+	return active_next;
+}
+
+// One bounce of the wavefront: thread t serves the t-th entry of the live-ray list the previous
+// bounce wrote, runs the loop body, and the survivors of a workgroup append themselves to the
+// next list with one atomic per workgroup (order inside a workgroup is kept, so neighbouring
+// pixels stay neighbours; the order of workgroups is free -- every lane's result depends on its
+// own state only).
+template <bool kFirst>
+__global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
+{
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	__shared__ uint32_t s_wave[kRBlock / 64];
+	__shared__ uint32_t s_base;
+	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
+	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
+	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	const bool alive = tid < live;
+	const uint64_t lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
+	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
+	uint64_t rec_base = 0;
+	if (!kFirst) {
+		rec_base = a.n_lanes;
+		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+	}
+	bool cont = false;
+	if (alive) cont = bounce_lane<kFirst>(a, s_kd, lane, rec_base + tid);
+	if (a.last) return; // nothing survives the last bounce
+	const unsigned long long ballot = __ballot(cont);
+	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	if (wl == 0) s_wave[wv] = (uint32_t)__popcll(ballot);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
+		s_base = tot ? atomicAdd(&a.live_count[a.bounce], tot) : 0u;
+	}
+	__syncthreads();
+	if (cont) {
+		uint32_t off = s_base + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
+		for (unsigned w = 0; w < wv; ++w) off += s_wave[w];
+		a.order_out[off] = (uint32_t)lane;
+	}
 }
 
 // :400-431: valid flag and per-pixel sums, samples of a pixel added in lane order
@@ -424,7 +464,7 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	const uint64_t gpix = a.pixel_begin + pix; // the sums are full-film arrays
 	for (int s = 0; s < a.spp; ++s) {
 		const uint64_t lane = pix * (uint64_t)a.spp + (uint64_t)s;
-		if (valid_out) valid_out[lane] = a.depth[lane] != 0;
+		if (valid_out) valid_out[lane] = a.hit0[lane];
 		if (sumL && sumL2)
 			for (int c = 0; c < 3; ++c) {
 				const float v = a.L[c * N + lane];
@@ -444,12 +484,12 @@ struct pg_render_state {
 	int n_quads = 0, emitter_quad = -1;
 	pg_camera cam;
 	bool have_scene = false;
-	DevBuf<float> ray_o, ray_d, thr, prev_p, prev_pdf, ior;
-	DevBuf<uint32_t> depth;
-	DevBuf<uint8_t> active, prev_delta;
+	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
+	DevBuf<uint16_t> prev_quad;
+	DevBuf<uint8_t> hit0;
 	DevBuf<uint64_t> rng_state, rng_inc;
-	DevBuf<uint32_t> order, order_count;
-	DevBuf<uint8_t> r_act;
+	DevBuf<uint32_t> order[2], live_count;
+	DevBuf<uint32_t> ray_of;
 	DevBuf<float> r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee, r_wp;
 	// optional per-kernel timing: (kind, start, stop) event triples still to be read
 	bool timing_on = false;
@@ -534,17 +574,16 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	const uint64_t S = N * (uint64_t)D;
 	if (S > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_render_pass: more than 2^32 record slots in one pass");
 	const bool record = !ctx->is_final;
-	PG_HIP(ctx, r->ray_o.ensure(3 * N)); PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
-	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N)); PG_HIP(ctx, r->ior.ensure(N));
-	PG_HIP(ctx, r->depth.ensure(N)); PG_HIP(ctx, r->active.ensure(N)); PG_HIP(ctx, r->prev_delta.ensure(N));
+	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
+	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
+	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
-	PG_HIP(ctx, r->order.ensure(N)); PG_HIP(ctx, r->order_count.ensure(2));
+	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D));
+	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, (size_t)D * sizeof(uint32_t), s));
 	if (record) {
-		PG_HIP(ctx, r->r_act.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
+		PG_HIP(ctx, r->ray_of.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
 		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
 		PG_HIP(ctx, r->r_nee.ensure(3 * S)); PG_HIP(ctx, r->r_dnee.ensure(2 * S)); PG_HIP(ctx, r->r_wp.ensure(S));
-		// only the `active` column has to be cleared: inactive slots are never read for anything else
-		PG_HIP(ctx, hipMemsetAsync(r->r_act.p, 0, S, s));
 	}
 	RenderArgs a;
 	a.tree = ctx->view();
@@ -565,39 +604,33 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.frac = ctx->bsdf_fraction;
 	a.seed = prm->seed;
 	a.dc = ctx->dc_on ? ctx->dc : nullptr;
-	a.ray_o = r->ray_o.p; a.ray_d = r->ray_d.p; a.thr = r->thr.p; a.L = L_out; a.prev_p = r->prev_p.p;
-	a.prev_pdf = r->prev_pdf.p; a.ior = r->ior.p; a.depth = r->depth.p; a.active = r->active.p;
-	a.prev_delta = r->prev_delta.p; a.rng_state = r->rng_state.p; a.rng_inc = r->rng_inc.p;
-	a.r_act = r->r_act.p; a.r_pos = r->r_pos.p; a.r_dir = r->r_dir.p; a.r_bsdf = r->r_bsdf.p; a.r_tb = r->r_tb.p;
+	a.ray_d = r->ray_d.p; a.thr = r->thr.p; a.L = L_out; a.prev_p = r->prev_p.p;
+	a.prev_pdf = r->prev_pdf.p; a.prev_quad = r->prev_quad.p; a.hit0 = r->hit0.p;
+	a.rng_state = r->rng_state.p; a.rng_inc = r->rng_inc.p; a.live_count = r->live_count.p;
+	a.ray_of = r->ray_of.p; a.r_pos = r->r_pos.p; a.r_dir = r->r_dir.p; a.r_bsdf = r->r_bsdf.p; a.r_tb = r->r_tb.p;
 	a.r_tr = r->r_tr.p; a.r_nee = r->r_nee.p; a.r_dnee = r->r_dnee.p; a.r_wp = r->r_wp.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
-	{
-		Timed t(r, s, 0);
-		hipLaunchKernelGGL(k_generate, grid, dim3(kRBlock), 0, s, a);
-	}
-	a.order = nullptr;
-	a.order_count = r->order_count.p;
 	for (int it = 0; it < D; ++it) {
-		{
-			Timed t(r, s, 1);
-			hipLaunchKernelGGL(k_bounce, grid, dim3(kRBlock), 0, s, a);
-		}
-		if (it + 1 < D) { // active-ray stream compaction for the next bounce
-			Timed t(r, s, 4);
-			launch_compact_lanes(N, r->active.p, nullptr, r->order.p, r->order_count.p, s);
-			a.order = r->order.p;
-		}
+		a.bounce = it;
+		a.last = it + 1 == D ? 1 : 0;
+		a.order_in = r->order[it & 1].p;
+		a.order_out = r->order[(it + 1) & 1].p;
+		Timed t(r, s, 1);
+		// every launch is sized for the whole wavefront: the live count is only known on the device,
+		// and workgroups past it retire on their first instruction
+		if (it == 0) hipLaunchKernelGGL(k_bounce<true>, grid, dim3(kRBlock), 0, s, a);
+		else hipLaunchKernelGGL(k_bounce<false>, grid, dim3(kRBlock), 0, s, a);
 	}
 	PG_HIP(ctx, hipGetLastError());
 	if (record) {
 		pg_dense_records d;
-		d.active = r->r_act.p; d.position = r->r_pos.p; d.direction = r->r_dir.p; d.bsdf = r->r_bsdf.p;
+		d.active = nullptr; d.position = r->r_pos.p; d.direction = r->r_dir.p; d.bsdf = r->r_bsdf.p;
 		d.throughput_bsdf = r->r_tb.p; d.throughput_radiance = r->r_tr.p; d.radiance_nee = r->r_nee.p;
 		d.direction_nee = r->r_dnee.p; d.wo_pdf = r->r_wp.p;
 		Timed t(r, s, 2);
 		// the depth counters of an instrumented pass describe the bounce kernels only
 		launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d, nullptr, s,
-		                         /*depth_major=*/1);
+		                         r->ray_of.p, r->live_count.p);
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (valid_out || sumL) {
@@ -607,6 +640,18 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (r->timing_on) ++r->acc.passes;
+	return PG_OK;
+}
+
+int pg_render_live_counts(pg_context *ctx, uint32_t *out, int32_t n)
+{
+	if (!ctx || !out || n < 0) return PG_ERR_INVALID;
+	if (!ctx->render || !ctx->render->live_count.p) return fail(ctx, PG_ERR_INVALID, "pg_render_live_counts: no pass rendered yet");
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	PG_HIP(ctx, hipDeviceSynchronize());
+	int m = n < ctx->max_depth ? n : ctx->max_depth;
+	if ((size_t)m > ctx->render->live_count.cap) m = (int)ctx->render->live_count.cap;
+	PG_HIP(ctx, hipMemcpy(out, ctx->render->live_count.p, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return PG_OK;
 }
 

@@ -356,6 +356,12 @@ class SDTree:
         self._ck(self._lib.pg_read_kernel_timing(self._h, C.byref(kt), int(reset)))
         return kt
 
+    def renderLiveCounts(self, max_depth: int):
+        """Paths alive after each bounce of the last rendered pass (pg_render_live_counts)."""
+        out = (C.c_uint32 * int(max_depth))()
+        self._ck(self._lib.pg_render_live_counts(self._h, out, int(max_depth)))
+        return [int(v) for v in out]
+
     def enableDepthCounters(self, on: bool = True):
         self._ck(self._lib.pg_enable_depth_counters(self._h, int(on)))
 
