@@ -69,6 +69,14 @@ def init_dist(args):
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    if world > 1 and ndev < world:
+        # rehearsal on a box with fewer GPUs than ranks (ranks share devices): RCCL refuses two ranks on
+        # one device, so the exchange goes through gloo; the numbers of such a run are not a result
+        local_rank = local_rank % ndev
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="gloo")
+        return world, rank, local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -94,9 +102,8 @@ def timed_steps(step, steps, warmup, world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from practical_path_guiding_lab_amd.parallel import max_over_ranks
+        elapsed = max_over_ranks(elapsed, device="cuda")
     return elapsed
 
 

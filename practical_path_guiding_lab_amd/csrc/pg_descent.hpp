@@ -265,4 +265,61 @@ __device__ __forceinline__ bool quad_find_leaf_slot(const QuadRec *rec, TreeHead
 	return false;
 }
 
+// The same walk for the two directions of one record (path direction and emitter direction fall
+// into the same quadtree, quadtree.py:443-464), advanced in lock step so that the two dependent
+// gather chains overlap instead of running one after the other.
+struct LeafCursor {
+	uint32_t r, slot, levels;
+	float lox, loy, h, cx, cy;
+	bool walking, found, is_root;
+};
+
+__device__ __forceinline__ LeafCursor leaf_cursor(TreeHead head, float cx, float cy, bool enable)
+{
+	LeafCursor c;
+	c.r = head.root_rec;
+	c.slot = 0;
+	c.levels = 0;
+	c.lox = 0.0f; c.loy = 0.0f; c.h = 0.5f;
+	c.cx = cx; c.cy = cy;
+	const bool inside = enable && cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f; // quadtree.py:404-405
+	c.is_root = head.root_rec == kNoRecord;
+	c.found = inside && c.is_root;
+	c.walking = inside && !c.is_root;
+	return c;
+}
+
+__device__ __forceinline__ void leaf_step(LeafCursor &c, uint4 ch)
+{
+	const float mx = c.lox + c.h, my = c.loy + c.h;
+	int first, last;
+	quadrant(c.cx, c.cy, mx, my, first, last);
+	++c.levels;
+	const uint32_t child = sel4u(last, ch.x, ch.y, ch.z, ch.w);
+	if (child == 0) {
+		c.slot = c.r * 4u + (uint32_t)last;
+		c.found = true;
+		c.walking = false;
+		return;
+	}
+	if (last == 0 || last == 3) c.lox = mx;
+	if (last == 0 || last == 1) c.loy = my;
+	c.h *= 0.5f;
+	c.r = child;
+}
+
+__device__ __forceinline__ void quad_find_leaf_slots2(const QuadRec *rec, LeafCursor &a, LeafCursor &b)
+{
+	for (int it = 0; it < kMaxLevels && (a.walking || b.walking); ++it) {
+		// a cursor that has stopped re-reads record 0 (it exists: the other one is inside a record)
+		const uint4 cha = reinterpret_cast<const uint4 *>(rec + (a.walking ? a.r : 0u))[1];
+		const uint4 chb = reinterpret_cast<const uint4 *>(rec + (b.walking ? b.r : 0u))[1];
+		if (a.walking) leaf_step(a, cha);
+		if (b.walking) leaf_step(b, chb);
+	}
+	// kMaxLevels records deep without reaching a leaf: not a tree this library builds
+	a.walking = false;
+	b.walking = false;
+}
+
 } // namespace pg

@@ -32,16 +32,14 @@ struct SlotAdd { // what one (direction, weight) pair adds, and where
 	long long w0, w1, w2, w3;
 };
 
-// quadtree.py:398-441 for one (direction, weight) pair; `count` goes to word 3
-__device__ __forceinline__ SlotAdd plan_dir(const TreeView &t, const AccumView &a, TreeHead head, uint32_t tree,
-                                            float cx, float cy, float w, long long count, uint32_t &levels)
+// quadtree.py:398-441 for one (direction, weight) pair whose leaf has been found; `count` goes to word 3
+__device__ __forceinline__ SlotAdd plan_dir(const AccumView &a, uint32_t tree, const LeafCursor &c, float w,
+                                            long long count)
 {
 	SlotAdd s = {nullptr, 0, 0, 0, 0};
-	uint32_t slot = 0;
-	bool is_root = false;
-	if (!quad_find_leaf_slot(t.rec, head, cx, cy, slot, is_root, levels)) return s;
+	if (!c.found) return s;
 	const Limbs q = quantize_weight(w);
-	s.ptr = is_root ? a.root_acc + (size_t)kAccWords * tree : a.rec_acc + (size_t)kAccWords * slot;
+	s.ptr = c.is_root ? a.root_acc + (size_t)kAccWords * tree : a.rec_acc + (size_t)kAccWords * c.slot;
 	s.w0 = q.l0; s.w1 = q.l1; s.w2 = q.l2; s.w3 = count;
 	return s;
 }
@@ -60,35 +58,44 @@ __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &
 	kd_lv = lv;
 	const uint32_t tree = leaf.tree; // outside the bbox: node 0's (stale) tree (kdtree.py:224)
 	const TreeHead head = load_head_s(t.head, tree);
-	const float w = wo_pdf > 0.0f ? radiance / wo_pdf : 0.0f; // quadtree.py:451
-	path = plan_dir(t, a, head, tree, dx, dy, w, inside ? 1 : 0, lv);
-	q_lv += lv;
+	const float w = wo_pdf > 0.0f ? radiance / wo_pdf : 0.0f;   // quadtree.py:451
+	const float wn = wo_pdf > 0.0f ? nee_lum / wo_pdf : 0.0f;   // quadtree.py:462
+	LeafCursor cp = leaf_cursor(head, dx, dy, true), cn = leaf_cursor(head, nx, ny, store_nee != 0);
+	quad_find_leaf_slots2(t.rec, cp, cn);
+	path = plan_dir(a, tree, cp, w, inside ? 1 : 0);
+	q_lv += cp.levels;
 	++q_q;
 	// a counted record whose direction reaches no leaf (outside the unit square): fallback counter
 	if (inside && path.ptr == nullptr) atomicAdd(a.leaf_count + tree, 1ull);
-	nee.ptr = nullptr;
-	nee.w0 = nee.w1 = nee.w2 = nee.w3 = 0;
+	nee = plan_dir(a, tree, cn, wn, 0);
 	if (store_nee) {
-		const float wn = wo_pdf > 0.0f ? nee_lum / wo_pdf : 0.0f; // quadtree.py:462
-		nee = plan_dir(t, a, head, tree, nx, ny, wn, 0, lv);
-		q_lv += lv;
+		q_lv += cn.levels;
 		++q_q;
 	}
 }
 
-// Every thread of the workgroup calls this (convergent).  Lane L of a wave issues word (L & 3) of
+// The exchange below stays inside one wave (each wave owns its 64 entries of s_val / s_ptr), and a
+// wave's LDS operations execute in order: ordering the compiler's view is all that is needed, no
+// workgroup barrier (which would make every wave wait for the slowest descent of the workgroup).
+__device__ __forceinline__ void wave_lds_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// Every thread of the wave calls this (convergent).  Lane L of a wave issues word (L & 3) of
 // the record held by lane r*16 + (L >> 2) in round r: the four words of one accumulator leave in
 // one wave-instruction from four adjacent lanes.
 __device__ __forceinline__ void coop_add(const SlotAdd &s, long long *s_val, unsigned long long *s_ptr)
 {
 	const unsigned t = threadIdx.x;
-	__syncthreads(); // the previous call's readers are done
+	wave_lds_sync(); // the previous call's reads are done
 	s_val[4 * t + 0] = s.w0;
 	s_val[4 * t + 1] = s.w1;
 	s_val[4 * t + 2] = s.w2;
 	s_val[4 * t + 3] = s.w3;
 	s_ptr[t] = reinterpret_cast<unsigned long long>(s.ptr);
-	__syncthreads();
+	wave_lds_sync();
 	const unsigned lane = t & 63u, wbase = t & ~63u, word = lane & 3u;
 #pragma unroll
 	for (unsigned r = 0; r < 4; ++r) {

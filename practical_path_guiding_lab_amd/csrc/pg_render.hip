@@ -416,8 +416,13 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 // next list with one atomic per workgroup (order inside a workgroup is kept, so neighbouring
 // pixels stay neighbours; the order of workgroups is free -- every lane's result depends on its
 // own state only).
+#ifdef PG_BOUNCE_WAVES // occupancy experiments: make EXTRA=-DPG_BOUNCE_WAVES=5
+#define PG_BOUNCE_ATTR __attribute__((amdgpu_waves_per_eu(PG_BOUNCE_WAVES, PG_BOUNCE_WAVES)))
+#else
+#define PG_BOUNCE_ATTR
+#endif
 template <bool kFirst>
-__global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
 	__shared__ uint32_t s_wave[kRBlock / 64];

@@ -9,7 +9,7 @@ R=$PWD
 D=$R/gpurun_out/$OUT
 mkdir -p $D
 cd /tmp
-FILTER="k_bounce|k_process_and_splat|k_compact_lanes|k_generate|k_finish"
+FILTER="k_bounce|k_process_and_splat|k_finish"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-res 0 > $D/bench_under_trace.json 2> $D/trace.err &&
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-res 0 > /dev/null 2> $D/pmc_fetch.err &&
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-res 0 > /dev/null 2> $D/pmc_write.err &&

@@ -12,7 +12,7 @@ import sys
 
 src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
-KERNELS = ("k_bounce", "k_process_and_splat", "k_compact_lanes", "k_generate", "k_finish")
+KERNELS = ("k_bounce", "k_process_and_splat", "k_finish")
 
 
 def short(name):
@@ -36,27 +36,37 @@ for r in csv.DictReader(open(trace)):
 trace_summary = {}
 for k, v in dur.items():
     v.sort()
-    per_pass = {"k_bounce": 8, "k_compact_lanes": 7}.get(k, 1)
+    per_pass = {"k_bounce": 8}.get(k, 1)
     last = [d for _, d in v[-10 * per_pass:]]
     trace_summary[k] = {"launches_in_timed_region": len(last), "avg_us": round(sum(last) / len(last) / 1e3, 2),
                         "min_us": round(min(last) / 1e3, 2), "max_us": round(max(last) / 1e3, 2)}
 
 
+PMC_STEPS = 3  # tools/profile_bench.sh runs the counter passes with --steps 3
+
+
 def agg(sub):
+    """Counter values of the launches of the TIMED region only (the last PMC_STEPS passes of the run:
+    nothing of these kernels runs after it), in dispatch order."""
     fs = glob.glob(f"{src}/{sub}/*/*counter_collection.csv")
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     if fs:
-        for r in csv.DictReader(open(fs[0])):
+        rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
             k = short(r["Kernel_Name"])
             if k:
                 d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k in d:
+            per_pass = {"k_bounce": 8}.get(k, 1)
+            for c in d[k]:
+                d[k][c] = d[k][c][-PMC_STEPS * per_pass:]
     return d
 
 
 f, w, l2, sq = agg("pmc_fetch"), agg("pmc_write"), agg("pmc_l2"), agg("pmc_sq")
 out = {"config": cfg,
        "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu-res 0`; means per launch over "
-               "all launches of the run (training + timed). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
+               "the launches of the timed region (the last 3 passes). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024 applies the gfx950 x2 FETCH correction of MI355X_MICROARCH.md section HBM "
                "(calibrated for wide coalesced reads only: an upper bound here).",
        "kernels": {}, "trace": trace_summary}
