@@ -213,9 +213,7 @@ def run_render(args):
         "k_process_and_splat": {"launches": int(kt.splat_launches), "avg_us": round(splat_us, 2),
                                 "records_per_launch": int(records_per_pass), "alg_bytes_per_launch": round(splat_bytes),
                                 "alg_GBps": round(splat_bytes / (splat_us * 1e-6) / 1e9, 2) if splat_us else 0.0},
-        "k_generate": {"avg_us": round(1e3 * kt.generate_ms / passes, 2)},
         "k_finish": {"avg_us": round(1e3 * kt.finish_ms / passes, 2)},
-        "k_compact_lanes": {"per_pass_us": round(1e3 * kt.compact_ms / passes, 2)},
     }
     dom = "k_bounce" if kt.bounce_ms >= kt.splat_ms else "k_process_and_splat"
     cfg_key = f"render res={args.res} depth={args.depth} spp={args.spp_per_pass}"
