@@ -258,6 +258,14 @@ typedef struct pg_pass_params {
 int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uint8_t *valid_out,
                    float *sumL, float *sumL2, void *stream);
 
+/* Film reconstruction of one full-frame pass with Mitsuba's `tent` reconstruction filter of radius
+ * one pixel -- the <rfilter type="tent"/> of the reference's scenes (scenes/cornell-box/scene.xml:27),
+ * i.e. the image mi.render returns at main.py:218.  `seed` and `spp` are those of the pass that
+ * produced L (Color3f[W*H*spp] planar, as pg_render_pass wrote it): a sample's film position is
+ * pixel + its first two sampler draws, which the kernel recomputes.  image_out: Color3f[W*H] planar,
+ * sum(w L) / sum(w) over the samples of the pixel's 3x3 neighbourhood, summed in a fixed order. */
+int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream);
+
 /* Per-kernel device time of pg_render_pass, measured with HIP events recorded on the launch
  * stream around each kernel (off by default).  pg_read_kernel_timing synchronises. */
 typedef struct pg_kernel_timing {

@@ -472,3 +472,15 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
     L.pgo_render_pass(pair.prev._h, pair.current._h, quads.shape[0], _ptr(quads), C.byref(c), C.byref(p),
                       _ptr(Lout), _ptr(valid), _ptr(sumL), _ptr(sumL2))
     return Lout, valid
+
+
+def film_tent(seed, spp, width, height, L):
+    """hdrfilm + tent rfilter reconstruction of one full-frame pass (pgo_film_tent); returns (3, H*W)."""
+    lb = lib()
+    lb.pgo_film_tent.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
+    lb.pgo_film_tent.restype = None
+    L = np.ascontiguousarray(L, np.float32)
+    assert L.shape == (3, width * height * spp)
+    out = np.zeros((3, width * height), np.float32)
+    lb.pgo_film_tent(int(seed) & 0xFFFFFFFF, int(spp), int(width), int(height), _ptr(L), _ptr(out))
+    return out

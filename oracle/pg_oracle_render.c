@@ -366,3 +366,39 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 			}
 	}
 }
+
+static float tent1(float d)
+{
+	float a = 1.0f - fabsf(d);
+	return a > 0.0f ? a : 0.0f;
+}
+
+/* hdrfilm with <rfilter type="tent"/>: gather form of ImageBlock::put -- pixel (x,y) collects the
+ * samples of its 3x3 neighbourhood (rows, then columns, then samples, in ascending order) */
+void pgo_film_tent(uint32_t seed, int32_t spp, int32_t width, int32_t height, const float *L, float *image_out)
+{
+	const size_t npix = (size_t)width * (size_t)height, N = npix * (size_t)spp;
+	for (int32_t y = 0; y < height; ++y)
+		for (int32_t x = 0; x < width; ++x) {
+			float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
+			const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+			for (int32_t ny = y - 1; ny <= y + 1; ++ny)
+				for (int32_t nx = x - 1; nx <= x + 1; ++nx) {
+					if (nx < 0 || ny < 0 || nx >= width || ny >= height) continue;
+					const size_t pix = (size_t)ny * (size_t)width + (size_t)nx;
+					for (int32_t s = 0; s < spp; ++s) {
+						const size_t lane = pix * (size_t)spp + (size_t)s;
+						pgo_pcg32 rng;
+						pgo_pcg32_seed(&rng, seed, (uint32_t)lane);
+						const float jx = pgo_pcg32_next_f32(&rng), jy = pgo_pcg32_next_f32(&rng);
+						const float w = tent1(cx - ((float)nx + jx)) * tent1(cy - ((float)ny + jy));
+						acc[0] = acc[0] + w * L[lane];
+						acc[1] = acc[1] + w * L[N + lane];
+						acc[2] = acc[2] + w * L[2 * N + lane];
+						wsum = wsum + w;
+					}
+				}
+			const size_t o = (size_t)y * (size_t)width + (size_t)x;
+			for (int ch = 0; ch < 3; ++ch) image_out[(size_t)ch * npix + o] = wsum > 0.0f ? acc[ch] / wsum : 0.0f;
+		}
+}

@@ -49,6 +49,14 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t n_quads, co
                      const pgo_camera *cam, const pgo_render_params *prm, float *L_out,
                      uint8_t *valid_out, float *sumL, float *sumL2);
 
+/* Film reconstruction of one full-frame pass with Mitsuba's `tent` reconstruction filter, radius one
+ * pixel (the <rfilter type="tent"/> of scenes/cornell-box/scene.xml:27): what mi.render returns at
+ * main.py:218.  Sample s of pixel (px,py) sits at (px + jx, py + jy), its first two sampler draws;
+ * pixel (x,y) receives weight tent(x + 0.5 - sx) * tent(y + 0.5 - sy), tent(d) = max(0, 1 - |d|),
+ * and the image is sum(w L) / sum(w).  L: Color3f[W*H*spp] planar; image_out: Color3f[W*H] planar.
+ * Third-party behaviour (hdrfilm + ImageBlock::put), unpinned like the rest of the substrate. */
+void pgo_film_tent(uint32_t seed, int32_t spp, int32_t width, int32_t height, const float *L, float *image_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -479,6 +479,45 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	}
 }
 
+__device__ __forceinline__ float tent1(float d)
+{
+	const float a = 1.0f - fabs_(d);
+	return a > 0.0f ? a : 0.0f;
+}
+
+// hdrfilm with <rfilter type="tent"/>: gather form of ImageBlock::put -- pixel (x,y) collects the
+// samples of its 3x3 neighbourhood (rows, then columns, then samples, ascending), so the sums have
+// one order and need no atomics.  The film position of a sample is recomputed from its stream.
+__global__ __launch_bounds__(kRBlock) void k_film_tent(uint32_t seed, int spp, int W, int H,
+                                                       const float *__restrict__ L, float *__restrict__ out)
+{
+	const uint64_t npix = (uint64_t)W * (uint64_t)H, N = npix * (uint64_t)spp;
+	const uint64_t o = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	if (o >= npix) return;
+	const int x = (int)(o % (uint64_t)W), y = (int)(o / (uint64_t)W);
+	const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+	float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;
+	for (int ny = y - 1; ny <= y + 1; ++ny)
+		for (int nx = x - 1; nx <= x + 1; ++nx) {
+			if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+			const uint64_t pix = (uint64_t)ny * (uint64_t)W + (uint64_t)nx;
+			for (int s = 0; s < spp; ++s) {
+				const uint64_t lane = pix * (uint64_t)spp + (uint64_t)s;
+				Pcg32 rng = pcg32_seed(seed, (uint32_t)lane);
+				const float jx = rng.next_f32(), jy = rng.next_f32();
+				const float w = tent1(cx - ((float)nx + jx)) * tent1(cy - ((float)ny + jy));
+				a0 = a0 + w * L[lane];
+				a1 = a1 + w * L[N + lane];
+				a2 = a2 + w * L[2 * N + lane];
+				wsum = wsum + w;
+			}
+		}
+	const bool ok = wsum > 0.0f;
+	out[o] = ok ? a0 / wsum : 0.0f;
+	out[npix + o] = ok ? a1 / wsum : 0.0f;
+	out[2 * npix + o] = ok ? a2 / wsum : 0.0f;
+}
+
 } // namespace pg
 
 using namespace pg;
@@ -645,6 +684,20 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (r->timing_on) ++r->acc.passes;
+	return PG_OK;
+}
+
+int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_film_tent: call pg_scene_set first");
+	if (!L || !image_out || spp <= 0) return fail(ctx, PG_ERR_INVALID, "pg_film_tent: NULL pointer or spp <= 0");
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	const pg_camera &cam = ctx->render->cam;
+	const uint64_t npix = (uint64_t)cam.width * (uint64_t)cam.height;
+	hipLaunchKernelGGL(k_film_tent, dim3((unsigned)((npix + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, (hipStream_t)stream,
+	                   seed, spp, cam.width, cam.height, L, image_out);
+	PG_HIP(ctx, hipGetLastError());
 	return PG_OK;
 }
 

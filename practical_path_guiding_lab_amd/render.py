@@ -94,8 +94,17 @@ class WavefrontScene:
 
 
 def render(scene: WavefrontScene, integrator, spp: int, seed: int) -> torch.Tensor:
-    """mi.render(scene, spp=spp, seed=seed) (main.py:218): one pass, returns the (H, W, 3) estimate."""
+    """mi.render(scene, spp=spp, seed=seed) (main.py:218): one pass, returns the (H, W, 3) image the
+    film develops: with the scene's `tent` reconstruction filter (pg_film_tent) or the per-pixel
+    mean (`box`).  The integrator's own sums (computeMSE/computeVariance) are raw per-pixel sums
+    either way, as in the reference (:400-429)."""
     sampler = IndependentSampler(spp, seed)
     L, _, _ = integrator.sample(scene, sampler)
     w, h = scene.film_size
+    if scene.scene.rfilter == "tent" and scene.pixel_range is None:
+        tree = integrator.sdTree
+        img = torch.empty((3, h * w), dtype=torch.float32, device=tree.device)
+        N.check(tree._h, tree._lib.pg_film_tent(tree._h, sampler.seed_value & 0xFFFFFFFF, spp, L.data_ptr(), img.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream))
+        return img.reshape(3, h, w).permute(1, 2, 0).contiguous()
     return L.reshape(3, h, w, spp).mean(dim=3).permute(1, 2, 0).contiguous()

@@ -41,6 +41,7 @@ class Scene:
     bbox_min: np.ndarray = field(default_factory=lambda: np.zeros(3, np.float32))
     bbox_max: np.ndarray = field(default_factory=lambda: np.ones(3, np.float32))
     names: List[str] = field(default_factory=list)
+    rfilter: str = "tent"             # film reconstruction filter: "tent" (radius 1 pixel, the reference's scenes) or "box"
 
 
 def _f32(v):
@@ -190,4 +191,9 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             raise ValueError(f"unsupported shape type {kind}")
         quads += qs
         names += [sh.get("id", kind)] * len(qs)
-    return _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names)
+    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names)
+    rf = film.find("rfilter")
+    sc.rfilter = rf.get("type") if rf is not None else "gaussian"  # hdrfilm's default
+    if sc.rfilter not in ("tent", "box"):
+        raise ValueError(f"unsupported rfilter type {sc.rfilter}")
+    return sc

@@ -93,6 +93,45 @@ def test_guided_render_converges_to_the_ground_truth():
     assert abs(img.mean() - float(gt.mean())) < 0.015 * float(gt.mean())
 
 
+def test_tent_film_matches_the_oracle_bit_for_bit():
+    """pg_film_tent (hdrfilm + <rfilter type="tent"/>, scenes/cornell-box/scene.xml:27) against
+    pgo_film_tent on a ragged film; render() develops the image through it."""
+    import ctypes as C
+    import torch
+    from practical_path_guiding_lab_amd import _native as N
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene, render
+    from practical_path_guiding_lab_amd.scene import cornell_box
+
+    w, h, spp, seed = 37, 23, 3, 4242
+    sc = cornell_box(w, h, 4, 8)
+    assert sc.rfilter == "tent"
+    g = PathGuidingIntegrator({"max_depth": 4})
+    g.setup(w * h, sc.bbox_min - 1e-4, sc.bbox_max + 1e-4, 20, 20, True, 0.5)
+    g.setIteration(0, True)
+    ws = WavefrontScene(sc)
+    L, _, _ = g.sample(ws, IndependentSampler(spp, seed))
+    img = torch.empty((3, w * h), dtype=torch.float32, device="cuda")
+    t = g.sdTree
+    N.check(t._h, t._lib.pg_film_tent(t._h, seed, spp, L.data_ptr(), img.data_ptr(), None))
+    exp = po.film_tent(seed, spp, w, h, L.cpu().numpy())
+    np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    # the same pass through render(): (H, W, 3)
+    g2 = PathGuidingIntegrator({"max_depth": 4})
+    g2.setup(w * h, sc.bbox_min - 1e-4, sc.bbox_max + 1e-4, 20, 20, True, 0.5)
+    g2.setIteration(0, True)
+    out = render(WavefrontScene(sc), g2, spp, seed).cpu().numpy()
+    np.testing.assert_array_equal(out.view(np.uint32), exp.reshape(3, h, w).transpose(1, 2, 0).view(np.uint32))
+    # a box film is the per-pixel mean
+    sc.rfilter = "box"
+    g3 = PathGuidingIntegrator({"max_depth": 4})
+    g3.setup(w * h, sc.bbox_min - 1e-4, sc.bbox_max + 1e-4, 20, 20, True, 0.5)
+    g3.setIteration(0, True)
+    box = render(WavefrontScene(sc), g3, spp, seed).cpu().numpy()
+    np.testing.assert_allclose(box, L.cpu().numpy().reshape(3, h, w, spp).mean(axis=3).transpose(1, 2, 0), rtol=1e-6)
+    assert abs(out.mean() - box.mean()) < 0.05 * box.mean()
+
+
 def test_render_returns_plausible_cornell_image():
     import torch
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator

@@ -16,7 +16,7 @@ XML = """<scene version="3.0.0">
     <float name="fov" value="40" />
     <transform name="to_world"><matrix value="-1 0 0 0 0 1 0 1 0 0 -1 6.8 0 0 0 1" /></transform>
     <sampler type="independent"><integer name="sample_count" value="$spp" /></sampler>
-    <film type="hdrfilm"><integer name="width" value="$resx" /><integer name="height" value="$resy" /></film>
+    <film type="hdrfilm"><integer name="width" value="$resx" /><integer name="height" value="$resy" /><rfilter type="box" /></film>
   </sensor>
   <bsdf type="twosided" id="Red"><bsdf type="diffuse"><rgb name="reflectance" value="0.63, 0.065, 0.05" /></bsdf></bsdf>
   <bsdf type="twosided" id="Black"><bsdf type="diffuse"><rgb name="reflectance" value="0, 0, 0" /></bsdf></bsdf>
@@ -32,7 +32,11 @@ def test_xml_subset_parser(tmp_path):
     p.write_text(XML)
     sc = S.load_xml(str(p))
     assert sc.quads.shape == (1 + 6 + 1, S.QUAD_STRIDE) and sc.max_depth == 5 and sc.rr_depth == 3
-    assert (sc.camera.width, sc.camera.height) == (32, 16)
+    assert (sc.camera.width, sc.camera.height) == (32, 16) and sc.rfilter == "box"
+    p2 = tmp_path / "gauss.xml"
+    p2.write_text(XML.replace('<rfilter type="box" />', ""))  # hdrfilm's default filter is a gaussian: not built
+    with pytest.raises(ValueError):
+        S.load_xml(str(p2))
     assert abs(float(sc.camera.tan_half_fov_x) - np.tan(np.radians(20.0))) < 1e-6
     np.testing.assert_allclose(sc.camera.origin, [0, 1, 6.8], rtol=1e-6)
     np.testing.assert_allclose(sc.camera.axis_z, [0, 0, -1])
@@ -199,6 +203,37 @@ def test_ground_truth_fixture_is_the_cornell_box():
     assert gt[128, 4, 0] > 3 * gt[128, 4, 1]        # red wall on the left
     assert gt[128, 251, 1] > 2 * gt[128, 251, 0]    # green wall on the right
     assert gt[19:23, 108:148].mean() > 5.0          # the light, seen foreshortened on the ceiling
+
+
+def test_oracle_tent_film_known_answers():
+    """pgo_film_tent: hdrfilm with the tent filter of scenes/cornell-box/scene.xml:27 (radius 1)."""
+    from oracle import pg_oracle as po
+
+    w, h, spp, seed = 5, 4, 2, 77
+    n = w * h * spp
+    # a constant image stays constant (the weights are normalised per pixel)
+    out = po.film_tent(seed, spp, w, h, np.full((3, n), 0.25, np.float32))
+    np.testing.assert_allclose(out, 0.25, rtol=2e-6)
+    # one bright sample: its energy goes to the pixels within one pixel of its film position, with
+    # weight tent(dx)*tent(dy) over the pixel's weight sum -- recomputed here from the sampler stream
+    st, inc = po.rng_seed(n, seed, 0)
+    jx = po.rng_next_f32(st, inc)
+    jy = po.rng_next_f32(st, inc)
+    lane = (2 * w + 3) * spp + 1  # pixel (3,2), sample 1
+    L = np.zeros((3, n), np.float32)
+    L[:, lane] = [8.0, 4.0, 2.0]
+    out = po.film_tent(seed, spp, w, h, L).reshape(3, h, w)
+    sx, sy = 3 + jx[lane], 2 + jy[lane]
+    pix = np.arange(n) // spp
+    px, py = (pix % w) + jx, (pix // w) + jy
+    for y in range(h):
+        for x in range(w):
+            wgt = np.maximum(0, 1 - np.abs(x + 0.5 - px)) * np.maximum(0, 1 - np.abs(y + 0.5 - py))
+            mine = max(0.0, 1 - abs(x + 0.5 - sx)) * max(0.0, 1 - abs(y + 0.5 - sy))
+            expect = 8.0 * mine / wgt.sum() if wgt.sum() > 0 else 0.0
+            assert abs(out[0, y, x] - expect) <= 1e-5 * max(expect, 1e-3), (x, y)
+    assert (out[0] > 0).sum() in (1, 2, 4) and out[0, 2, 3] > 0  # at most a 2x2 footprint, its own pixel included
+    np.testing.assert_allclose(out[1], out[0] * 0.5, rtol=1e-6)
 
 
 def test_oracle_render_converges_to_the_tungsten_ground_truth():
