@@ -266,6 +266,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
  * sum(w L) / sum(w) over the samples of the pixel's 3x3 neighbourhood, summed in a fixed order. */
 int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream);
 
+/* Element-wise evaluation of the library's own fp32 transcendental functions (fixed
+ * sequences of double operations, no vendor math library), so that a caller -- the parity tests --
+ * can compare them with another implementation of the same contract.
+ * which: 0 exp, 1 log, 2 erf, 3 erfinv, 4 sin, 5 cos.  x, out: float[n] device pointers. */
+int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, float *out, void *stream);
+
 /* Per-kernel device time of pg_render_pass, measured with HIP events recorded on the launch
  * stream around each kernel (off by default).  pg_read_kernel_timing synchronises. */
 typedef struct pg_kernel_timing {

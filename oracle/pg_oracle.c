@@ -1086,6 +1086,11 @@ void pgo_atan2_v(size_t n, const float *y, const float *x, float *out)
 {
 	for (size_t i = 0; i < n; ++i) out[i] = pgo_atan2(y[i], x[i]);
 }
+void pgo_math1_v(size_t n, int which, const float *x, float *out)
+{
+	for (size_t i = 0; i < n; ++i)
+		out[i] = which == 0 ? pgo_exp(x[i]) : (which == 1 ? pgo_log(x[i]) : (which == 2 ? pgo_erf(x[i]) : pgo_erfinv(x[i])));
+}
 
 /* ---- scalar entry points for the oracle's integrator loop (pg_oracle_render.c) ---- */
 uint32_t pgo_i_quadtree_of(const pgo_tree *t, const float p[3], int active)

@@ -123,6 +123,7 @@ void pgo_quantize_v(size_t n, const float *w, uint64_t *lo, int64_t *hi);
 void pgo_acc_to_float_v(size_t n, const uint64_t *lo, const int64_t *hi, float *out);
 void pgo_sincos_v(size_t n, const float *phi, float *s, float *c);
 void pgo_atan2_v(size_t n, const float *y, const float *x, float *out);
+void pgo_math1_v(size_t n, int which, const float *x, float *out); /* 0 exp, 1 log, 2 erf, 3 erfinv (pgo_math.h) */
 
 #ifdef __cplusplus
 }

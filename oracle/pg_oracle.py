@@ -183,6 +183,17 @@ def atan2(y, x):
     return out
 
 
+def math1(which, x):
+    """which: 'exp' | 'log' | 'erf' | 'erfinv' -- the deterministic fp32 functions of pgo_math.h."""
+    x = _f32(x)
+    out = np.empty_like(x)
+    L = lib()
+    L.pgo_math1_v.argtypes = [_SZ, C.c_int, _P, _P]
+    L.pgo_math1_v.restype = None
+    L.pgo_math1_v(x.shape[0], ("exp", "log", "erf", "erfinv").index(which), _ptr(x), _ptr(out))
+    return out
+
+
 def process_records(num_rays, max_depth, Lfinal, rec):
     """rec: dict of dense columns (planar): active, position(3,S), direction(2,S), bsdf(3,S),
     throughputBsdf(3,S), throughputRadiance(3,S), radiance_nee(3,S), direction_nee(2,S), woPdf(S)."""

@@ -154,6 +154,138 @@ static inline float pgo_luminance(float r, float g, float b)
 	return r * 0.212671f + g * 0.715160f + b * 0.072169f;
 }
 
+/* ---- exp / log / erf / erfinv of fp32 arguments for the rough-conductor BSDF ----
+ * Same contract as sincos/atan2 above: a fixed sequence of IEEE double operations (no fma, no
+ * libm), rounded once to fp32, written out identically in csrc/pg_math.hpp.  exp and log are
+ * accurate to the last fp32 bit or so; erf (Abramowitz & Stegun 7.1.26, |err| < 1.5e-7) and erfinv
+ * (M. Giles' single-precision polynomial, rel. err < 1.3e-7) are as good as the approximations
+ * Dr.Jit ships for the same functions. */
+static inline double pgo_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+static inline uint64_t pgo_d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+
+static inline double pgo_exp_d(double x) /* finite x in [-750, 700] */
+{
+	const double inv_ln2 = 1.44269504088896338700;
+	const double ln2_hi = 6.93147180369123816490e-01; /* low 20 bits zero: k*ln2_hi is exact */
+	const double ln2_lo = 1.90821492927058770002e-10;
+	double k = rint(x * inv_ln2);
+	double r = (x - k * ln2_hi) - k * ln2_lo; /* |r| <= 0.3466 */
+	double p = 1.0 / 6227020800.0;  /* 1/13! */
+	p = 1.0 / 479001600.0 + r * p;
+	p = 1.0 / 39916800.0 + r * p;
+	p = 1.0 / 3628800.0 + r * p;
+	p = 1.0 / 362880.0 + r * p;
+	p = 1.0 / 40320.0 + r * p;
+	p = 1.0 / 5040.0 + r * p;
+	p = 1.0 / 720.0 + r * p;
+	p = 1.0 / 120.0 + r * p;
+	p = 1.0 / 24.0 + r * p;
+	p = 1.0 / 6.0 + r * p;
+	p = 0.5 + r * p;
+	p = 1.0 + r * p;
+	p = 1.0 + r * p;
+	long kk = (long)k;
+	return p * pgo_u2d((uint64_t)(kk + 1023) << 52);
+}
+
+static inline float pgo_exp(float xf)
+{
+	if (xf != xf) return xf;
+	if (xf > 88.8f) return INFINITY;
+	if (xf < -87.4f) return 0.0f; /* results below the smallest normal fp32 are flushed: no denormal dependence */
+	float r = (float)pgo_exp_d((double)xf);
+	return r < 1.17549435e-38f ? 0.0f : r;
+}
+
+static inline double pgo_log_d(double x) /* finite x > 0, normal double */
+{
+	const double ln2_hi = 6.93147180369123816490e-01;
+	const double ln2_lo = 1.90821492927058770002e-10;
+	uint64_t u = pgo_d2u(x);
+	long e = (long)((u >> 52) & 0x7ff) - 1023;
+	double m = pgo_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1, 2) */
+	if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
+	double s = (m - 1.0) / (m + 1.0); /* |s| <= 0.1716 */
+	double z = s * s;
+	double p = 1.0 / 27.0;
+	p = 1.0 / 25.0 + z * p;
+	p = 1.0 / 23.0 + z * p;
+	p = 1.0 / 21.0 + z * p;
+	p = 1.0 / 19.0 + z * p;
+	p = 1.0 / 17.0 + z * p;
+	p = 1.0 / 15.0 + z * p;
+	p = 1.0 / 13.0 + z * p;
+	p = 1.0 / 11.0 + z * p;
+	p = 1.0 / 9.0 + z * p;
+	p = 1.0 / 7.0 + z * p;
+	p = 1.0 / 5.0 + z * p;
+	p = 1.0 / 3.0 + z * p;
+	p = 1.0 + z * p;
+	double ed = (double)e;
+	return ed * ln2_hi + (ed * ln2_lo + (2.0 * s) * p);
+}
+
+static inline float pgo_log(float xf)
+{
+	if (xf != xf || xf < 0.0f) return NAN;
+	if (xf == 0.0f) return -INFINITY;
+	if (xf == INFINITY) return INFINITY;
+	return (float)pgo_log_d((double)xf); /* fp32 denormals are normal doubles */
+}
+
+static inline float pgo_erf(float xf)
+{
+	if (xf != xf) return xf;
+	double a = fabs((double)xf);
+	double r;
+	if (a >= 4.0) r = 1.0;
+	else {
+		double t = 1.0 / (1.0 + 0.3275911 * a);
+		double poly = 1.061405429;
+		poly = -1.453152027 + t * poly;
+		poly = 1.421413741 + t * poly;
+		poly = -0.284496736 + t * poly;
+		poly = 0.254829592 + t * poly;
+		poly = t * poly;
+		r = 1.0 - poly * pgo_exp_d(-(a * a));
+	}
+	return (float)(signbit(xf) ? -r : r);
+}
+
+static inline float pgo_erfinv(float xf)
+{
+	if (xf != xf) return xf;
+	double x = (double)xf;
+	double q = (1.0 - x) * (1.0 + x);
+	if (!(q > 0.0)) return q == 0.0 ? (signbit(xf) ? -INFINITY : INFINITY) : NAN;
+	double w = -pgo_log_d(q);
+	double p;
+	if (w < 5.0) {
+		w = w - 2.5;
+		p = 2.81022636e-08;
+		p = 3.43273939e-07 + p * w;
+		p = -3.5233877e-06 + p * w;
+		p = -4.39150654e-06 + p * w;
+		p = 0.00021858087 + p * w;
+		p = -0.00125372503 + p * w;
+		p = -0.00417768164 + p * w;
+		p = 0.246640727 + p * w;
+		p = 1.50140941 + p * w;
+	} else {
+		w = sqrt(w) - 3.0;
+		p = -0.000200214257;
+		p = 0.000100950558 + p * w;
+		p = 0.00134934322 + p * w;
+		p = -0.00367342844 + p * w;
+		p = 0.00573950773 + p * w;
+		p = -0.0076224613 + p * w;
+		p = 0.00943887047 + p * w;
+		p = 1.00167406 + p * w;
+		p = 2.83297682 + p * w;
+	}
+	return (float)(p * x);
+}
+
 /* ---- PCG32 (O'Neill) + TEA seeding, as Mitsuba's `independent` sampler uses them ---- */
 typedef struct { uint64_t state, inc; } pgo_pcg32;
 

@@ -106,6 +106,132 @@ __device__ __forceinline__ bool finite_f32(float v)
 	return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u;
 }
 
+// ---------------------------------------------------------------------------------------
+// exp / log / erf / erfinv of fp32 arguments for the rough-conductor BSDF (pg_render.hip): the
+// same fixed sequences of double operations as oracle/pgo_math.h, rounded once to fp32.
+// erf: Abramowitz & Stegun 7.1.26; erfinv: M. Giles' single-precision polynomial.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double exp_d(double x) // finite x in [-750, 700]
+{
+	const double k = __builtin_rint(x * 1.44269504088896338700);
+	const double r = (x - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+	double p = 1.0 / 6227020800.0;
+	p = 1.0 / 479001600.0 + r * p;
+	p = 1.0 / 39916800.0 + r * p;
+	p = 1.0 / 3628800.0 + r * p;
+	p = 1.0 / 362880.0 + r * p;
+	p = 1.0 / 40320.0 + r * p;
+	p = 1.0 / 5040.0 + r * p;
+	p = 1.0 / 720.0 + r * p;
+	p = 1.0 / 120.0 + r * p;
+	p = 1.0 / 24.0 + r * p;
+	p = 1.0 / 6.0 + r * p;
+	p = 0.5 + r * p;
+	p = 1.0 + r * p;
+	p = 1.0 + r * p;
+	const long long kk = (long long)k;
+	return p * __longlong_as_double((kk + 1023) << 52);
+}
+
+__device__ __forceinline__ float exp_f32(float xf)
+{
+	if (xf != xf) return xf;
+	if (xf > 88.8f) return __builtin_huge_valf();
+	if (xf < -87.4f) return 0.0f;
+	const float r = (float)exp_d((double)xf);
+	return r < 1.17549435e-38f ? 0.0f : r;
+}
+
+__device__ __forceinline__ double log_d(double x) // finite normal x > 0
+{
+	const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+	long long e = (long long)((u >> 52) & 0x7ffull) - 1023;
+	double m = __longlong_as_double((long long)((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+	if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
+	const double s = (m - 1.0) / (m + 1.0);
+	const double z = s * s;
+	double p = 1.0 / 27.0;
+	p = 1.0 / 25.0 + z * p;
+	p = 1.0 / 23.0 + z * p;
+	p = 1.0 / 21.0 + z * p;
+	p = 1.0 / 19.0 + z * p;
+	p = 1.0 / 17.0 + z * p;
+	p = 1.0 / 15.0 + z * p;
+	p = 1.0 / 13.0 + z * p;
+	p = 1.0 / 11.0 + z * p;
+	p = 1.0 / 9.0 + z * p;
+	p = 1.0 / 7.0 + z * p;
+	p = 1.0 / 5.0 + z * p;
+	p = 1.0 / 3.0 + z * p;
+	p = 1.0 + z * p;
+	const double ed = (double)e;
+	return ed * 6.93147180369123816490e-01 + (ed * 1.90821492927058770002e-10 + (2.0 * s) * p);
+}
+
+__device__ __forceinline__ float log_f32(float xf)
+{
+	if (xf != xf || xf < 0.0f) return __builtin_nanf("");
+	if (xf == 0.0f) return -__builtin_huge_valf();
+	if (xf == __builtin_huge_valf()) return xf;
+	return (float)log_d((double)xf);
+}
+
+__device__ __forceinline__ float erf_f32(float xf)
+{
+	if (xf != xf) return xf;
+	const double a = __builtin_fabs((double)xf);
+	double r;
+	if (a >= 4.0) r = 1.0;
+	else {
+		const double t = 1.0 / (1.0 + 0.3275911 * a);
+		double poly = 1.061405429;
+		poly = -1.453152027 + t * poly;
+		poly = 1.421413741 + t * poly;
+		poly = -0.284496736 + t * poly;
+		poly = 0.254829592 + t * poly;
+		poly = t * poly;
+		r = 1.0 - poly * exp_d(-(a * a));
+	}
+	return (float)((__float_as_uint(xf) >> 31) ? -r : r);
+}
+
+__device__ __forceinline__ float erfinv_f32(float xf)
+{
+	if (xf != xf) return xf;
+	const double x = (double)xf;
+	const double q = (1.0 - x) * (1.0 + x);
+	if (!(q > 0.0)) {
+		if (q == 0.0) return (__float_as_uint(xf) >> 31) ? -__builtin_huge_valf() : __builtin_huge_valf();
+		return __builtin_nanf("");
+	}
+	double w = -log_d(q);
+	double p;
+	if (w < 5.0) {
+		w = w - 2.5;
+		p = 2.81022636e-08;
+		p = 3.43273939e-07 + p * w;
+		p = -3.5233877e-06 + p * w;
+		p = -4.39150654e-06 + p * w;
+		p = 0.00021858087 + p * w;
+		p = -0.00125372503 + p * w;
+		p = -0.00417768164 + p * w;
+		p = 0.246640727 + p * w;
+		p = 1.50140941 + p * w;
+	} else {
+		w = __builtin_sqrt(w) - 3.0;
+		p = -0.000200214257;
+		p = 0.000100950558 + p * w;
+		p = 0.00134934322 + p * w;
+		p = -0.00367342844 + p * w;
+		p = 0.00573950773 + p * w;
+		p = -0.0076224613 + p * w;
+		p = 0.00943887047 + p * w;
+		p = 1.00167406 + p * w;
+		p = 2.83297682 + p * w;
+	}
+	return (float)(p * x);
+}
+
 // common.py:100-129
 __device__ __forceinline__ void canonical_to_dir(float px, float py, float &dx, float &dy, float &dz)
 {

@@ -479,6 +479,25 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	}
 }
 
+// element-wise evaluation of the library's deterministic fp32 functions (pg_math_eval)
+__global__ __launch_bounds__(kRBlock) void k_math_eval(int which, uint64_t n, const float *__restrict__ x,
+                                                       float *__restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	if (i >= n) return;
+	const float v = x[i];
+	float r, c;
+	switch (which) {
+	case 0: r = exp_f32(v); break;
+	case 1: r = log_f32(v); break;
+	case 2: r = erf_f32(v); break;
+	case 3: r = erfinv_f32(v); break;
+	case 4: sincos_f32(v, r, c); break;
+	default: sincos_f32(v, c, r); break;
+	}
+	out[i] = r;
+}
+
 __device__ __forceinline__ float tent1(float d)
 {
 	const float a = 1.0f - fabs_(d);
@@ -697,6 +716,18 @@ int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, fl
 	const uint64_t npix = (uint64_t)cam.width * (uint64_t)cam.height;
 	hipLaunchKernelGGL(k_film_tent, dim3((unsigned)((npix + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, (hipStream_t)stream,
 	                   seed, spp, cam.width, cam.height, L, image_out);
+	PG_HIP(ctx, hipGetLastError());
+	return PG_OK;
+}
+
+int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, float *out, void *stream)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	if (which < 0 || which > 5 || (n && (!x || !out))) return fail(ctx, PG_ERR_INVALID, "pg_math_eval: bad arguments");
+	if (n == 0) return PG_OK;
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, (hipStream_t)stream,
+	                   which, n, x, out);
 	PG_HIP(ctx, hipGetLastError());
 	return PG_OK;
 }

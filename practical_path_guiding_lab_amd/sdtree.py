@@ -356,6 +356,14 @@ class SDTree:
         self._ck(self._lib.pg_read_kernel_timing(self._h, C.byref(kt), int(reset)))
         return kt
 
+    def evalMath(self, which: str, x: torch.Tensor) -> torch.Tensor:
+        """The library's deterministic fp32 exp/log/erf/erfinv/sin/cos, element-wise (pg_math_eval)."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty_like(x)
+        self._ck(self._lib.pg_math_eval(self._h, ("exp", "log", "erf", "erfinv", "sin", "cos").index(which), x.numel(),
+                                        x.data_ptr(), out.data_ptr(), _stream_ptr()))
+        return out
+
     def renderLiveCounts(self, max_depth: int):
         """Paths alive after each bounce of the last rendered pass (pg_render_live_counts)."""
         out = (C.c_uint32 * int(max_depth))()

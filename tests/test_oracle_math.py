@@ -54,6 +54,34 @@ def test_sincos_atan2_correctly_rounded(oracle):
     np.testing.assert_array_equal(oracle.atan2(yy, xx), np.arctan2(yy, xx).astype(np.float32))
 
 
+def test_exp_log_erf_erfinv_contract(oracle):
+    """pgo_math.h's exp/log (double series, rounded once: within half an ulp of the true value on
+    these samples) and erf/erfinv (A&S 7.1.26, Giles: ~1.5e-7) -- the functions the rough-conductor
+    BSDF of the substrate is built from."""
+    from scipy import special as sp
+
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-87, 88, 200000).astype(np.float32)
+    np.testing.assert_array_equal(oracle.math1("exp", x), np.exp(x.astype(np.float64)).astype(np.float32))
+    x = np.exp(rng.uniform(-87, 88, 200000)).astype(np.float32)
+    np.testing.assert_array_equal(oracle.math1("log", x), np.log(x.astype(np.float64)).astype(np.float32))
+    x = rng.uniform(-5, 5, 200000).astype(np.float32)
+    assert np.abs(oracle.math1("erf", x) - sp.erf(x.astype(np.float64))).max() < 2.5e-7
+    x = rng.uniform(-1, 1, 200000).astype(np.float32)
+    r = sp.erfinv(x.astype(np.float64))
+    assert (np.abs(oracle.math1("erfinv", x) - r) / np.maximum(np.abs(r), 1e-20)).max() < 3e-7
+    # special values
+    with np.errstate(all="ignore"):
+        e = oracle.math1("exp", [np.inf, -np.inf, 0.0, -100.0, 89.0, -87.5])
+        assert e[0] == np.inf and e[1] == 0 and e[2] == 1 and e[3] == 0 and e[4] == np.inf and e[5] == 0
+        l = oracle.math1("log", [0.0, -1.0, np.inf, 1.0, 1e-45])
+        assert l[0] == -np.inf and np.isnan(l[1]) and l[2] == np.inf and l[3] == 0
+        assert l[4] == np.float32(np.log(float(np.float32(1e-45))))
+        assert list(oracle.math1("erf", [np.inf, -np.inf, 10.0])) == [1.0, -1.0, 1.0]
+        v = oracle.math1("erfinv", [1.0, -1.0, 0.0, 2.0])
+        assert v[0] == np.inf and v[1] == -np.inf and v[2] == 0 and np.isnan(v[3])
+
+
 def _py_quantize(w: np.float32) -> int:
     if np.isnan(w):
         return 0
