@@ -462,14 +462,27 @@ class _RenderParams(C.Structure):
                 ("store_nee", C.c_int32), ("bsdf_sampling_fraction", C.c_float), ("seed", C.c_uint32), ("spp", C.c_int32)]
 
 
+class _Scene(C.Structure):
+    _fields_ = [("n_quads", C.c_size_t), ("quads", C.c_void_p), ("n_spheres", C.c_size_t), ("spheres", C.c_void_p),
+                ("n_materials", C.c_size_t), ("materials", C.c_void_p)]
+
+
 def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, iteration, is_final, seed, spp=1,
-                store_nee=True, bsdf_sampling_fraction=0.5, sumL=None, sumL2=None):
+                store_nee=True, bsdf_sampling_fraction=0.5, sumL=None, sumL2=None, spheres=None, materials=None):
     """One pass of PathGuidingIntegrator.sample() (path_guiding_integrator.py:126-431) on the CPU.
-    cam: object with origin/axis_x/axis_y/axis_z/tan_half_fov_x/width/height.  Returns (L (3,N), valid (N,))."""
+    cam: object with origin/axis_x/axis_y/axis_z/tan_half_fov_x/width/height.  Returns (L (3,N), valid (N,)).
+    spheres (S,12) / materials (M,12): the optional parts of pgo_scene (pg_oracle_render.h)."""
     L = lib()
-    L.pgo_render_pass.argtypes = [_P, _P, _SZ, _P, C.POINTER(_Camera), C.POINTER(_RenderParams), _P, _P, _P, _P]
-    L.pgo_render_pass.restype = None
-    quads = np.ascontiguousarray(quads, np.float32)
+    L.pgo_render_pass_scene.argtypes = [_P, _P, C.POINTER(_Scene), C.POINTER(_Camera), C.POINTER(_RenderParams), _P, _P, _P, _P]
+    L.pgo_render_pass_scene.restype = None
+    quads = np.ascontiguousarray(quads, np.float32).reshape(-1, 24)
+    spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros((0, 12)), np.float32).reshape(-1, 12)
+    mats = None if materials is None else np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
+    if mats is None and spheres.shape[0]:
+        raise ValueError("spheres need a material table")
+    sc = _Scene(quads.shape[0], quads.ctypes.data if quads.size else None, spheres.shape[0],
+                spheres.ctypes.data if spheres.size else None, 0 if mats is None else mats.shape[0],
+                None if mats is None else mats.ctypes.data)
     c = _Camera()
     for k in ("origin", "axis_x", "axis_y", "axis_z"):
         setattr(c, k, (C.c_float * 3)(*[float(v) for v in getattr(cam, k)]))
@@ -480,9 +493,31 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
     n = c.width * c.height * int(spp)
     Lout = np.zeros((3, n), np.float32)
     valid = np.zeros(n, np.uint8)
-    L.pgo_render_pass(pair.prev._h, pair.current._h, quads.shape[0], _ptr(quads), C.byref(c), C.byref(p),
-                      _ptr(Lout), _ptr(valid), _ptr(sumL), _ptr(sumL2))
+    L.pgo_render_pass_scene(pair.prev._h, pair.current._h, C.byref(sc), C.byref(c), C.byref(p),
+                            _ptr(Lout), _ptr(valid), _ptr(sumL), _ptr(sumL2))
     return Lout, valid
+
+
+def bsdf_eval_pdf(material, wi, wo):
+    """twosided BSDF of one material row (12 floats) in the local frame: (value (3,), pdf)."""
+    lb = lib()
+    lb.pgo_bsdf_eval_pdf.argtypes = [_P, _P, _P, _P, _P]
+    lb.pgo_bsdf_eval_pdf.restype = None
+    m, a, b = _f32(material), _f32(wi), _f32(wo)
+    val, pdf = np.zeros(3, np.float32), np.zeros(1, np.float32)
+    lb.pgo_bsdf_eval_pdf(_ptr(m), _ptr(a), _ptr(b), _ptr(val), _ptr(pdf))
+    return val, float(pdf[0])
+
+
+def bsdf_sample(material, wi, u1, u2):
+    """-> (wo (3,), pdf, weight (3,)) of pgo_bsdf_sample."""
+    lb = lib()
+    lb.pgo_bsdf_sample.argtypes = [_P, _P, C.c_float, C.c_float, _P, _P, _P]
+    lb.pgo_bsdf_sample.restype = None
+    m, a = _f32(material), _f32(wi)
+    wo, pdf, w = np.zeros(3, np.float32), np.zeros(1, np.float32), np.zeros(3, np.float32)
+    lb.pgo_bsdf_sample(_ptr(m), _ptr(a), float(u1), float(u2), _ptr(wo), _ptr(pdf), _ptr(w))
+    return wo, float(pdf[0]), w
 
 
 def film_tent(seed, spp, width, height, L):

@@ -59,9 +59,19 @@ static inline v3 to_world(const frame *f, v3 v)
 	return vadd(vadd(vscale(f->s, v.x), vscale(f->t, v.y)), vscale(f->n, v.z));
 }
 
-/* closest hit over all quads: 0 < t < tmax */
-static int intersect(size_t nq, const float *quads, v3 o, v3 d, float tmax, float *t_out)
+#define PI_F 3.14159265358979323846f
+#define INV_TWO_PI_F 0.15915494309189533577f
+#define INV_SQRT_PI_F 0.56418958354775628695f
+#define SPHERE_EPS_F 8.94069671630859375e-05f /* Mitsuba's math::RayEpsilon<float> = 1500 * 2^-24 */
+
+static inline float safe_sqrtf(float v) { return sqrtf(v > 0.0f ? v : 0.0f); }
+static inline v3 normalize3(v3 v) { return vdivs(v, sqrtf(dot3(v, v))); }
+
+/* closest hit over all shapes: 0 < t < tmax; returns the shape number (quads, then spheres) */
+static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 {
+	const size_t nq = sc->n_quads;
+	const float *quads = sc->quads;
 	int best = -1;
 	float bt = tmax;
 	for (size_t q = 0; q < nq; ++q) {
@@ -76,8 +86,171 @@ static int intersect(size_t nq, const float *quads, v3 o, v3 d, float tmax, floa
 		float v = dot3(w, ld3(Q + 6)) * Q[13];
 		if (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) { bt = t; best = (int)q; }
 	}
+	/* spheres: the quadratic in double precision, as Mitsuba's Sphere::ray_intersect_preliminary */
+	for (size_t s = 0; s < sc->n_spheres; ++s) {
+		const float *S = sc->spheres + s * PGO_SPHERE_STRIDE;
+		const double ox = (double)o.x - (double)S[0], oy = (double)o.y - (double)S[1], oz = (double)o.z - (double)S[2];
+		const double dx = (double)d.x, dy = (double)d.y, dz = (double)d.z, r = (double)S[3];
+		const double A = (dx * dx + dy * dy) + dz * dz;
+		const double B = 2.0 * ((ox * dx + oy * dy) + oz * dz);
+		const double C = ((ox * ox + oy * oy) + oz * oz) - r * r;
+		const double disc = B * B - (4.0 * A) * C;
+		if (!(disc >= 0.0) || A == 0.0) continue;
+		const double root = sqrt(disc);
+		const double temp = -0.5 * (B + (B < 0.0 ? -root : root)); /* the cancellation-free root first */
+		double x0 = temp / A, x1 = temp != 0.0 ? C / temp : x0;
+		if (x0 > x1) { double tt = x0; x0 = x1; x1 = tt; }
+		const float t = (float)(x0 > 0.0 ? x0 : x1);
+		if (t > 0.0f && t < bt) { bt = t; best = (int)(nq + s); }
+	}
 	*t_out = bt;
 	return best;
+}
+
+/* ---- surface description at a hit ---- */
+typedef struct { int type; v3 refl; float alpha; v3 eta, k; } material;
+typedef struct { v3 p, n; int is_em; v3 radiance; material m; } surface;
+
+static material load_material(const float *M)
+{
+	material m;
+	m.type = (int)M[0];
+	m.refl = ld3(M + 1);
+	m.alpha = M[4];
+	m.eta = ld3(M + 5);
+	m.k = ld3(M + 8);
+	return m;
+}
+
+static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
+{
+	surface s;
+	memset(&s, 0, sizeof s);
+	int mi;
+	if ((size_t)prim < sc->n_quads) {
+		const float *Q = sc->quads + (size_t)prim * PGO_QUAD_STRIDE;
+		s.p = vadd(o, vscale(d, t));
+		s.n = ld3(Q + 9);
+		s.is_em = Q[15] != 0.0f;
+		s.radiance = ld3(Q + 19);
+		if (!sc->materials) { s.m.type = 0; s.m.refl = ld3(Q + 16); return s; }
+		mi = (int)Q[22];
+	} else {
+		const float *S = sc->spheres + ((size_t)prim - sc->n_quads) * PGO_SPHERE_STRIDE;
+		const v3 c = ld3(S);
+		/* sphere.h: n = normalize(ray(t) - c), p = c + n r.  The normal is then taken again from the
+		 * re-projected point, so that it is a function of p alone (the device recomputes the ray
+		 * origin of the next bounce from the stored vertex) */
+		const v3 n0 = normalize3(vsub(vadd(o, vscale(d, t)), c));
+		s.p = vadd(c, vscale(n0, S[3]));
+		s.n = normalize3(vsub(s.p, c));
+		s.is_em = S[5] != 0.0f;
+		s.radiance = ld3(S + 6);
+		mi = (int)S[4];
+	}
+	s.m = load_material(sc->materials + (size_t)mi * PGO_MATERIAL_STRIDE);
+	return s;
+}
+
+/* scene.pdf_emitter_direction(prev, ds) for a hit on emitter shape `prim` at p (normal n) seen from
+ * ref: the solid-angle density emitter sampling has for that direction, times the 1/count of the
+ * uniform emitter choice */
+static float emitter_hit_pdf(const pgo_scene *sc, int prim, v3 ref, v3 p, v3 n, float inv_count)
+{
+	const v3 dd = vsub(p, ref);
+	const float d2 = dot3(dd, dd), dist = sqrtf(d2);
+	const v3 dn = vdivs(dd, dist);
+	const float dp = dot3(dn, n);
+	if (!(dp < 0.0f)) return 0.0f;
+	float pdf;
+	if ((size_t)prim < sc->n_quads) {
+		const float *Q = sc->quads + (size_t)prim * PGO_QUAD_STRIDE;
+		pdf = d2 / (fabsf(dp) * Q[14]);
+	} else { /* Sphere::pdf_direction */
+		const float *S = sc->spheres + ((size_t)prim - sc->n_quads) * PGO_SPHERE_STRIDE;
+		const v3 cv = vsub(ld3(S), ref);
+		const float sin_alpha = S[3] / sqrtf(dot3(cv, cv));
+		const float cos_alpha = safe_sqrtf(1.0f - sin_alpha * sin_alpha);
+		if (sin_alpha < 0.99999994f) pdf = INV_TWO_PI_F / (1.0f - cos_alpha);
+		else pdf = (d2 / fabsf(dp)) / ((4.0f * PI_F) * (S[3] * S[3]));
+	}
+	return pdf * inv_count;
+}
+
+/* scene.sample_emitter_direction(si, (e1, e2), test_visibility=True): uniform choice of one
+ * emitter (e1 is reused after the choice), then a point on it; returns ds.d, ds.pdf and
+ * radiance / pdf (zero when occluded, facing away, or from inside a sphere) */
+static void sample_emitter(const pgo_scene *sc, const int *em, int n_em, v3 p, v3 n, float e1, float e2, v3 *ds_d,
+                           float *ds_pdf, v3 *em_weight)
+{
+	*ds_d = V(0, 0, 0);
+	*ds_pdf = 0.0f;
+	*em_weight = V(0, 0, 0);
+	if (n_em <= 0) return;
+	const float count = (float)n_em, inv_count = 1.0f / count;
+	uint32_t idx = (uint32_t)(e1 * count);
+	if (idx > (uint32_t)(n_em - 1)) idx = (uint32_t)(n_em - 1);
+	e1 = e1 * count - (float)idx;
+	const int prim = em[idx];
+	v3 pl, ln, radiance;
+	float pdf_cone = 0.0f; /* spheres: density over directions, known before the geometry term */
+	int is_sphere = (size_t)prim >= sc->n_quads;
+	if (!is_sphere) {
+		const float *E = sc->quads + (size_t)prim * PGO_QUAD_STRIDE;
+		pl = vadd(vadd(ld3(E), vscale(ld3(E + 3), e1)), vscale(ld3(E + 6), e2));
+		ln = ld3(E + 9);
+		radiance = ld3(E + 19);
+	} else { /* Sphere::sample_direction, reference point outside */
+		const float *S = sc->spheres + ((size_t)prim - sc->n_quads) * PGO_SPHERE_STRIDE;
+		const v3 c = ld3(S);
+		const float r = S[3];
+		const v3 dc_v = vsub(c, p);
+		const float dc_2 = dot3(dc_v, dc_v);
+		const float radius_adj = r * (1.0f - SPHERE_EPS_F);
+		if (!(dc_2 > radius_adj * radius_adj)) return;
+		const float inv_dc = 1.0f / sqrtf(dc_2);
+		const float sin_max = r * inv_dc, sin_max2 = sin_max * sin_max, inv_sin_max = 1.0f / sin_max;
+		const float cos_max = safe_sqrtf(1.0f - sin_max2);
+		float sin_theta_2;
+		if (sin_max2 > 0.00068523f) { /* sin^2(1.5 deg) */
+			const float tt = 1.0f + (cos_max - 1.0f) * e1;
+			sin_theta_2 = 1.0f - tt * tt;
+		} else sin_theta_2 = sin_max2 * e1; /* small-angle Taylor expansion */
+		const float cos_theta = safe_sqrtf(1.0f - sin_theta_2);
+		const float cos_alpha = sin_theta_2 * inv_sin_max +
+		                        cos_theta * safe_sqrtf(1.0f - sin_theta_2 * (inv_sin_max * inv_sin_max));
+		const float sin_alpha = safe_sqrtf(1.0f - cos_alpha * cos_alpha);
+		float sin_phi, cos_phi;
+		pgo_sincos(e2 * (2.0f * PI_F), &sin_phi, &cos_phi);
+		frame fr;
+		fr.n = vscale(dc_v, -inv_dc);
+		frame_from_normal(fr.n, &fr.s, &fr.t);
+		const v3 dl = to_world(&fr, V(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha));
+		pl = vadd(c, vscale(dl, r));
+		ln = dl;
+		radiance = ld3(S + 6);
+		pdf_cone = INV_TWO_PI_F / (1.0f - cos_max);
+	}
+	const v3 dir0 = vsub(pl, p);
+	/* si.spawn_ray_to(pl): offset origin, then aim at the light point */
+	float mag = (1.0f + max3(V(fabsf(p.x), fabsf(p.y), fabsf(p.z)))) * RAY_EPS_F;
+	if (dot3(n, dir0) < 0.0f) mag = -mag;
+	const v3 so = vadd(p, vscale(n, mag));
+	const float d2 = dot3(dir0, dir0), dist = sqrtf(d2);
+	*ds_d = vdivs(dir0, dist);
+	const float dp = dot3(*ds_d, ln);
+	float pdf = 0.0f;
+	if (dp < 0.0f) pdf = is_sphere ? (dist == 0.0f ? 0.0f : pdf_cone) : d2 / (fabsf(dp) * sc->quads[(size_t)prim * PGO_QUAD_STRIDE + 14]);
+	if (!(pdf == pdf) || pdf == INFINITY) pdf = 0.0f;
+	*ds_pdf = pdf * inv_count;
+	if (pdf > 0.0f) {
+		const v3 sd = vsub(pl, so);
+		const float sdist = sqrtf(dot3(sd, sd));
+		const v3 sdn = vdivs(sd, sdist);
+		float th;
+		const int occ = intersect(sc, so, sdn, sdist * (1.0f - SHADOW_EPS_F), &th) >= 0;
+		if (!occ) *em_weight = vscale(vdivs(radiance, pdf), count);
+	}
 }
 
 /* Mitsuba warp::square_to_cosine_hemisphere (concentric disk + z = safe_sqrt(1 - r^2)) */
@@ -99,9 +272,133 @@ static inline v3 square_to_cosine_hemisphere(float u, float v)
 	return V(px, py, z);
 }
 
-/* twosided(diffuse).eval_pdf: value includes cos(theta_o) */
-static inline void bsdf_eval_pdf(v3 refl, v3 wi, v3 wo, int active, v3 *value, float *pdf)
+/* ---- roughconductor (Beckmann, isotropic, sample_visible) after Mitsuba 3's microfacet.h /
+ * roughconductor.cpp; every function below works in the local frame with cos(theta_i) > 0 ---- */
+static float rc_D(v3 m, float alpha) /* MicrofacetDistribution::eval */
 {
+	const float ct = m.z, ct2 = ct * ct;
+	const float ax = m.x / alpha, ay = m.y / alpha;
+	const float result = pgo_exp(-((ax * ax + ay * ay) / ct2)) / (((PI_F * alpha) * alpha) * (ct2 * ct2));
+	return result * ct > 1e-20f ? result : 0.0f; /* "prevent potential numerical issues in other stages" */
+}
+
+static float rc_G1(v3 v, v3 m, float alpha) /* smith_g1: rational approximation for Beckmann */
+{
+	const float ax = alpha * v.x, ay = alpha * v.y;
+	const float xy = ax * ax + ay * ay;
+	const float a = 1.0f / sqrtf(xy / (v.z * v.z));
+	const float a2 = a * a;
+	float result = a >= 1.6f ? 1.0f : (3.535f * a + 2.181f * a2) / ((1.0f + 2.276f * a) + 2.577f * a2);
+	if (xy == 0.0f) result = 1.0f;                 /* perpendicular incidence */
+	if (dot3(v, m) * v.z <= 0.0f) result = 0.0f;    /* the back of a microfacet is not seen from the front */
+	return result;
+}
+
+static float fresnel_conductor(float cos_i, float eta_r, float eta_i)
+{
+	const float c2 = cos_i * cos_i, s2 = 1.0f - c2, s4 = s2 * s2;
+	const float temp_1 = (eta_r * eta_r - eta_i * eta_i) - s2;
+	const float a2pb2 = safe_sqrtf(temp_1 * temp_1 + ((4.0f * eta_i) * eta_i) * (eta_r * eta_r));
+	const float a = safe_sqrtf(0.5f * (a2pb2 + temp_1));
+	const float term_1 = a2pb2 + c2, term_2 = (2.0f * cos_i) * a;
+	const float r_s = (term_1 - term_2) / (term_1 + term_2);
+	const float term_3 = a2pb2 * c2 + s4, term_4 = term_2 * s2;
+	const float r_p = r_s * ((term_3 - term_4) / (term_3 + term_4));
+	return 0.5f * (r_s + r_p);
+}
+
+static v3 rc_fresnel(const material *m, float cos_i)
+{
+	return V(fresnel_conductor(cos_i, m->eta.x, m->k.x), fresnel_conductor(cos_i, m->eta.y, m->k.y),
+	         fresnel_conductor(cos_i, m->eta.z, m->k.z));
+}
+
+/* sample_visible_11: slopes of the visible Beckmann normals for alpha = 1 (numerical inversion,
+ * three Newton steps in the erf domain) */
+static void rc_sample_visible_11(float cos_i, float u1, float u2, float *sx, float *sy)
+{
+	const float tan_i = safe_sqrtf(1.0f - cos_i * cos_i) / cos_i;
+	const float cot_i = 1.0f / tan_i;
+	const float maxval = pgo_erf(cot_i);
+	u1 = u1 < 1.0f - 1e-6f ? u1 : 1.0f - 1e-6f; u1 = u1 > 1e-6f ? u1 : 1e-6f;
+	u2 = u2 < 1.0f - 1e-6f ? u2 : 1.0f - 1e-6f; u2 = u2 > 1e-6f ? u2 : 1e-6f;
+	float x = maxval - (maxval + 1.0f) * pgo_erf(sqrtf(-pgo_log(u1)));
+	/* tan(theta) exp(-cot^2): 0 at normal incidence (inf * 0 otherwise) */
+	const float tail = tan_i == 0.0f ? 0.0f : (INV_SQRT_PI_F * tan_i) * pgo_exp(-(cot_i * cot_i));
+	u1 = u1 * ((1.0f + maxval) + tail);
+	for (int i = 0; i < 3; ++i) {
+		const float slope = pgo_erfinv(x);
+		const float value = ((1.0f + x) + (INV_SQRT_PI_F * tan_i) * pgo_exp(-(slope * slope))) - u1;
+		const float derivative = 1.0f - slope * tan_i;
+		x = x - value / derivative;
+	}
+	*sx = pgo_erfinv(x);
+	*sy = pgo_erfinv(2.0f * u2 - 1.0f);
+}
+
+/* MicrofacetDistribution::sample (visible normals): microfacet normal and its density */
+static v3 rc_sample_m(v3 wi, float alpha, float u1, float u2, float *pdf)
+{
+	const v3 wip = normalize3(V(alpha * wi.x, alpha * wi.y, wi.z));
+	const float s2 = wip.x * wip.x + wip.y * wip.y; /* Frame::sincos_phi */
+	float cos_phi = 1.0f, sin_phi = 0.0f;
+	if (fabsf(s2) > 4.0f * 5.9604644775390625e-08f) {
+		const float inv = 1.0f / sqrtf(s2);
+		cos_phi = wip.x * inv; sin_phi = wip.y * inv;
+		cos_phi = cos_phi < -1.0f ? -1.0f : (cos_phi > 1.0f ? 1.0f : cos_phi);
+		sin_phi = sin_phi < -1.0f ? -1.0f : (sin_phi > 1.0f ? 1.0f : sin_phi);
+	}
+	float sx, sy;
+	rc_sample_visible_11(wip.z, u1, u2, &sx, &sy);
+	const float rx = (cos_phi * sx - sin_phi * sy) * alpha;
+	const float ry = (sin_phi * sx + cos_phi * sy) * alpha;
+	const v3 m = normalize3(V(-rx, -ry, 1.0f));
+	*pdf = ((rc_D(m, alpha) * rc_G1(wi, m, alpha)) * fabsf(dot3(wi, m))) / wi.z;
+	return m;
+}
+
+static void rc_eval_pdf(const material *mt, v3 wi, v3 wo, v3 *value, float *pdf) /* wi.z > 0 */
+{
+	*value = V(0, 0, 0);
+	*pdf = 0.0f;
+	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
+	const v3 H = normalize3(vadd(wo, wi));
+	const float D = rc_D(H, mt->alpha);
+	if (D == 0.0f) return;
+	const float g_i = rc_G1(wi, H, mt->alpha);
+	const float res = (D * (g_i * rc_G1(wo, H, mt->alpha))) / (4.0f * wi.z);
+	const v3 F = rc_fresnel(mt, dot3(wi, H));
+	*value = vmul(F, vscale(mt->refl, res));
+	if (dot3(wi, H) > 0.0f && dot3(wo, H) > 0.0f) *pdf = (D * g_i) / (4.0f * wi.z);
+}
+
+static void rc_sample(const material *mt, v3 wi, float u1, float u2, v3 *wo, float *pdf, v3 *weight) /* wi.z > 0 */
+{
+	*wo = V(0, 0, 0); *pdf = 0.0f; *weight = V(0, 0, 0);
+	float pdf_m;
+	const v3 m = rc_sample_m(wi, mt->alpha, u1, u2, &pdf_m);
+	const float wim = dot3(wi, m);
+	const v3 o = vsub(vscale(m, 2.0f * wim), wi); /* reflect(wi, m) */
+	if (!(pdf_m != 0.0f && o.z > 0.0f)) return;
+	const float p = pdf_m / (4.0f * dot3(o, m));
+	const v3 F = rc_fresnel(mt, wim);
+	*wo = o;
+	*pdf = p;
+	*weight = vmul(F, vscale(mt->refl, rc_G1(o, m, mt->alpha)));
+}
+
+/* twosided(bsdf).eval_pdf: value includes cos(theta_o) */
+static inline void bsdf_eval_pdf(const material *mt, v3 wi, v3 wo, int active, v3 *value, float *pdf)
+{
+	if (mt->type == 1) {
+		*value = V(0, 0, 0);
+		*pdf = 0.0f;
+		if (!active) return;
+		if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+		rc_eval_pdf(mt, wi, wo, value, pdf);
+		return;
+	}
+	const v3 refl = mt->refl;
 	*value = V(0, 0, 0);
 	*pdf = 0.0f;
 	if (!active) return;
@@ -111,8 +408,8 @@ static inline void bsdf_eval_pdf(v3 refl, v3 wi, v3 wo, int active, v3 *value, f
 	*pdf = INV_PI_F * wo.z;
 }
 
-/* twosided(diffuse).sample: returns wo (local), pdf, weight = value/pdf */
-static inline void bsdf_sample(v3 refl, v3 wi, float u, float v, int active, v3 *wo, float *pdf, v3 *weight,
+/* twosided(bsdf).sample: returns wo (local), pdf, weight = value/pdf */
+static inline void bsdf_sample(const material *mt, v3 wi, float u, float v, int active, v3 *wo, float *pdf, v3 *weight,
                                float *eta)
 {
 	*wo = V(0, 0, 0); *pdf = 0.0f; *weight = V(0, 0, 0); *eta = 0.0f;
@@ -120,6 +417,15 @@ static inline void bsdf_sample(v3 refl, v3 wi, float u, float v, int active, v3 
 	int flip = wi.z < 0.0f;
 	float cos_i = flip ? -wi.z : wi.z;
 	if (!(cos_i > 0.0f)) return;
+	if (mt->type == 1) {
+		v3 o;
+		rc_sample(mt, V(wi.x, wi.y, cos_i), u, v, &o, pdf, weight);
+		*eta = 1.0f;
+		if (flip) o.z = -o.z;
+		*wo = o;
+		return;
+	}
+	const v3 refl = mt->refl;
 	v3 w = square_to_cosine_hemisphere(u, v);
 	float p = INV_PI_F * w.z;
 	*eta = 1.0f;
@@ -129,10 +435,44 @@ static inline void bsdf_sample(v3 refl, v3 wi, float u, float v, int active, v3 
 	*wo = w;
 }
 
+void pgo_bsdf_eval_pdf(const float *m, const float wi[3], const float wo[3], float value[3], float *pdf)
+{
+	const material mt = load_material(m);
+	v3 val;
+	bsdf_eval_pdf(&mt, ld3(wi), ld3(wo), 1, &val, pdf);
+	value[0] = val.x; value[1] = val.y; value[2] = val.z;
+}
+
+void pgo_bsdf_sample(const float *m, const float wi[3], float u1, float u2, float wo[3], float *pdf, float weight[3])
+{
+	const material mt = load_material(m);
+	v3 o, w;
+	float eta;
+	bsdf_sample(&mt, ld3(wi), u1, u2, 1, &o, pdf, &w, &eta);
+	wo[0] = o.x; wo[1] = o.y; wo[2] = o.z;
+	weight[0] = w.x; weight[1] = w.y; weight[2] = w.z;
+}
+
 void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const float *quads,
                      const pgo_camera *cam, const pgo_render_params *prm, float *L_out, uint8_t *valid_out,
                      float *sumL, float *sumL2)
 {
+	const pgo_scene sc = { nq, quads, 0, NULL, 0, NULL };
+	pgo_render_pass_scene(prev, current, &sc, cam, prm, L_out, valid_out, sumL, sumL2);
+}
+
+void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_scene *sc,
+                           const pgo_camera *cam, const pgo_render_params *prm, float *L_out, uint8_t *valid_out,
+                           float *sumL, float *sumL2)
+{
+	/* emitters: flagged quads, then flagged spheres */
+	int *em = malloc((sc->n_quads + sc->n_spheres + 1) * sizeof(int));
+	int n_em = 0;
+	for (size_t q = 0; q < sc->n_quads; ++q)
+		if (sc->quads[q * PGO_QUAD_STRIDE + 15] != 0.0f) em[n_em++] = (int)q;
+	for (size_t s = 0; s < sc->n_spheres; ++s)
+		if (sc->spheres[s * PGO_SPHERE_STRIDE + 5] != 0.0f) em[n_em++] = (int)(sc->n_quads + s);
+	const float inv_em_count = n_em > 0 ? 1.0f / (float)n_em : 0.0f;
 	const int W = cam->width, H = cam->height, spp = prm->spp, D = prm->max_depth;
 	const size_t npix = (size_t)W * H, N = npix * (size_t)spp, S = N * (size_t)(D > 0 ? D : 1);
 	const float f = prm->bsdf_sampling_fraction;
@@ -170,27 +510,23 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 		for (int it = 0; it < D && active; ++it) {
 			/* ---- :185 ray_intersect ---- */
 			float t_hit;
-			int q = intersect(nq, quads, ray_o, ray_d, INFINITY, &t_hit);
+			int q = intersect(sc, ray_o, ray_d, INFINITY, &t_hit);
 			int valid = q >= 0;
-			const float *Q = valid ? quads + (size_t)q * PGO_QUAD_STRIDE : quads;
-			v3 p = valid ? vadd(ray_o, vscale(ray_d, t_hit)) : V(0, 0, 0);
-			v3 n = valid ? ld3(Q + 9) : V(0, 0, 1);
+			surface sf;
+			memset(&sf, 0, sizeof sf);
+			sf.n = V(0, 0, 1);
+			if (valid) sf = surface_at(sc, q, ray_o, ray_d, t_hit);
+			const v3 p = sf.p, n = sf.n;
+			const material *mt = &sf.m;
 			frame fr;
 			fr.n = n;
 			frame_from_normal(n, &fr.s, &fr.t);
 			v3 wi = to_local(&fr, V(-ray_d.x, -ray_d.y, -ray_d.z));
-			v3 refl = valid ? ld3(Q + 16) : V(0, 0, 0);
-			int is_em = valid && Q[15] != 0.0f;
+			int is_em = valid && sf.is_em;
 			/* ---- :189-200 direct emission ---- */
-			v3 em_radiance = (is_em && wi.z > 0.0f) ? ld3(Q + 19) : V(0, 0, 0);
+			v3 em_radiance = (is_em && wi.z > 0.0f) ? sf.radiance : V(0, 0, 0);
 			float emitter_pdf = 0.0f;
-			if (is_em && !prev_delta) {
-				v3 dd = vsub(p, prev_p);
-				float d2 = dot3(dd, dd), dist = sqrtf(d2);
-				v3 dn = vdivs(dd, dist);
-				float dp = dot3(dn, n);
-				if (dp < 0.0f) emitter_pdf = d2 / (fabsf(dp) * Q[14]);
-			}
+			if (is_em && !prev_delta) emitter_pdf = emitter_hit_pdf(sc, q, prev_p, p, n, inv_em_count);
 			float mis = mis_weight(prev_bsdf_pdf, emitter_pdf);
 			v3 Le = vmul(vscale(thr, mis), em_radiance);
 			/* ---- :207-220 emitter sampling ---- */
@@ -199,40 +535,12 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 			float e1 = pgo_pcg32_next_f32(&rng), e2 = pgo_pcg32_next_f32(&rng); /* :214 next_2d, unmasked */
 			v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 			float ds_pdf = 0.0f;
-			if (active_em) {
-				/* single area emitter: the first quad with the emitter flag */
-				size_t le = 0;
-				while (le < nq && quads[le * PGO_QUAD_STRIDE + 15] == 0.0f) ++le;
-				if (le < nq) {
-					const float *E = quads + le * PGO_QUAD_STRIDE;
-					v3 pl = vadd(vadd(ld3(E), vscale(ld3(E + 3), e1)), vscale(ld3(E + 6), e2));
-					v3 dir0 = vsub(pl, p);
-					/* si.spawn_ray_to(pl): offset origin, then aim at the light point */
-					float mag = (1.0f + max3(V(fabsf(p.x), fabsf(p.y), fabsf(p.z)))) * RAY_EPS_F;
-					if (dot3(n, dir0) < 0.0f) mag = -mag;
-					v3 so = vadd(p, vscale(n, mag));
-					v3 dd = vsub(pl, p);
-					float d2 = dot3(dd, dd), dist = sqrtf(d2);
-					ds_d = vdivs(dd, dist);
-					float dp = dot3(ds_d, ld3(E + 9));
-					float pdf = dp < 0.0f ? d2 / (fabsf(dp) * E[14]) : 0.0f;
-					if (!(pdf == pdf) || pdf == INFINITY) pdf = 0.0f;
-					ds_pdf = pdf;
-					if (pdf > 0.0f) {
-						v3 sd = vsub(pl, so);
-						float sdist = sqrtf(dot3(sd, sd));
-						v3 sdn = vdivs(sd, sdist);
-						float th;
-						int occ = intersect(nq, quads, so, sdn, sdist * (1.0f - SHADOW_EPS_F), &th) >= 0;
-						if (!occ) em_weight = vdivs(ld3(E + 19), pdf);
-					}
-				}
-			}
+			if (active_em) sample_emitter(sc, em, n_em, p, n, e1, e2, &ds_d, &ds_pdf, &em_weight);
 			active_em = active_em && (ds_pdf != 0.0f); /* :216 */
 			v3 wo_em = to_local(&fr, ds_d);
 			v3 bsdf_value_em;
 			float bsdf_pdf_em;
-			bsdf_eval_pdf(refl, wi, wo_em, active_em, &bsdf_value_em, &bsdf_pdf_em);
+			bsdf_eval_pdf(mt, wi, wo_em, active_em, &bsdf_value_em, &bsdf_pdf_em);
 			/* ---- :223-256 NEE MIS against the mixture pdf ---- */
 			int active_sd_em = active_em && guided;
 			float pdf_diffuse = 1.0f; /* :222-241, SURVEY A12 */
@@ -257,7 +565,7 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 			(void)s1;
 			v3 wo_local, bsdf_weight;
 			float bsdf_pdf, eta;
-			bsdf_sample(refl, wi, s2x, s2y, active_next, &wo_local, &bsdf_pdf, &bsdf_weight, &eta);
+			bsdf_sample(mt, wi, s2x, s2y, active_next, &wo_local, &bsdf_pdf, &bsdf_weight, &eta);
 			v3 bsdf_value = vscale(bsdf_weight, bsdf_pdf);
 			float woPdf = bsdf_pdf;
 			v3 wo_world = to_world(&fr, wo_local);
@@ -275,7 +583,7 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 				sdtree_pdf = pgo_i_pdf(prev, tree, dv, 1);
 				wo_world = V(dv[0], dv[1], dv[2]);
 				wo_local = to_local(&fr, wo_world);
-				bsdf_eval_pdf(refl, wi, wo_local, 1, &bsdf_value, &bsdf_pdf);
+				bsdf_eval_pdf(mt, wi, wo_local, 1, &bsdf_value, &bsdf_pdf);
 			}
 			if (bsdf_mis) { /* :307 */
 				if (!tree_known) { tree = pgo_i_quadtree_of(prev, pp, 1); tree_known = 1; }
@@ -353,6 +661,7 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
 		free(o_pos); free(o_dir); free(o_rad); free(o_wp); free(o_dnee); free(o_nl);
 		free(r_act); free(r_pos); free(r_dir); free(r_bsdf); free(r_tb); free(r_tr); free(r_nee); free(r_dnee); free(r_wp);
 	}
+	free(em);
 	/* ---- :400-429 per-pixel sums, samples of a pixel in lane order ---- */
 	if (sumL && sumL2) {
 		for (size_t pix = 0; pix < npix; ++pix)

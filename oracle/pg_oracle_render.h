@@ -23,8 +23,26 @@ extern "C" {
 
 /* one parallelogram: 24 floats
  *  0-2 origin  3-5 edge1  6-8 edge2  9-11 unit normal  12 1/|e1|^2  13 1/|e2|^2  14 area
- *  15 emitter flag  16-18 diffuse reflectance  19-21 emitted radiance  22-23 pad            */
+ *  15 emitter flag  16-18 diffuse reflectance (used when the scene has no material table)
+ *  19-21 emitted radiance  22 material index  23 pad                                        */
 #define PGO_QUAD_STRIDE 24
+/* one sphere: 0-2 centre  3 radius  4 material index  5 emitter flag  6-8 emitted radiance  9-11 pad */
+#define PGO_SPHERE_STRIDE 12
+/* one material: 0 type (0 twosided diffuse, 1 twosided roughconductor/beckmann, sample_visible)
+ *  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta  8-10 k  11 pad                 */
+#define PGO_MATERIAL_STRIDE 12
+
+/* Shapes are numbered quads first, then spheres; emitters in that order too.  Sphere support
+ * follows Mitsuba 3's sphere.h as documented: double-precision quadratic, cone sampling of the
+ * visible cap from outside (no emitter sampling from inside), one-sided emission. */
+typedef struct pgo_scene {
+	size_t n_quads;
+	const float *quads;
+	size_t n_spheres;
+	const float *spheres;
+	size_t n_materials;
+	const float *materials; /* NULL: quad i is diffuse with quads[i][16..18] (and there are no spheres) */
+} pgo_scene;
 
 typedef struct pgo_camera {
 	float origin[3];
@@ -48,6 +66,15 @@ typedef struct pgo_render_params {
 void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t n_quads, const float *quads,
                      const pgo_camera *cam, const pgo_render_params *prm, float *L_out,
                      uint8_t *valid_out, float *sumL, float *sumL2);
+/* the same over quads + spheres + a material table */
+void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_scene *scene,
+                           const pgo_camera *cam, const pgo_render_params *prm, float *L_out,
+                           uint8_t *valid_out, float *sumL, float *sumL2);
+
+/* BSDF of material `m` (PGO_MATERIAL_STRIDE floats) in the local frame, for unit tests:
+ * eval_pdf -> value (incl. cos theta_o) and pdf; sample -> wo, pdf, weight = value/pdf. */
+void pgo_bsdf_eval_pdf(const float *m, const float wi[3], const float wo[3], float value[3], float *pdf);
+void pgo_bsdf_sample(const float *m, const float wi[3], float u1, float u2, float wo[3], float *pdf, float weight[3]);
 
 /* Film reconstruction of one full-frame pass with Mitsuba's `tent` reconstruction filter, radius one
  * pixel (the <rfilter type="tent"/> of scenes/cornell-box/scene.xml:27): what mi.render returns at
