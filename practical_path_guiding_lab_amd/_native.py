@@ -72,6 +72,11 @@ class pg_camera(C.Structure):
                 ("axis_z", C.c_float * 3), ("tan_half_fov_x", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class pg_scene_desc(C.Structure):
+    _fields_ = [("n_quads", C.c_uint64), ("quads", C.c_void_p), ("n_spheres", C.c_uint64), ("spheres", C.c_void_p),
+                ("n_materials", C.c_uint64), ("materials", C.c_void_p)]
+
+
 class pg_pass_params(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32), ("reserved", C.c_int32),
                 ("pixel_begin", C.c_uint64), ("pixel_count", C.c_uint64)]
@@ -97,7 +102,7 @@ EXPORTS = (
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
-    "pg_math_eval",
+    "pg_math_eval", "pg_scene_set_ex",
 )
 
 
@@ -162,6 +167,7 @@ def lib() -> C.CDLL:
     L.pg_render_live_counts.argtypes = [V, C.POINTER(C.c_uint32), I32]
     L.pg_film_tent.argtypes = [V, U32, I32, V, V, V]
     L.pg_math_eval.argtypes = [V, I32, U64, V, V, V]
+    L.pg_scene_set_ex.argtypes = [V, C.POINTER(pg_scene_desc), C.POINTER(pg_camera)]
     for name in EXPORTS:
         if name not in ("pg_last_error", "pg_abi_version"):
             getattr(L, name).restype = C.c_int

@@ -72,9 +72,29 @@ __device__ __forceinline__ v3 to_world(const Frame &f, v3 v)
 	return vadd(vadd(vscale(f.s, v.x), vscale(f.t, v.y)), vscale(f.n, v.z));
 }
 
-// closest hit over all quads, 0 < t < tmax (scene.ray_intersect / ray_test)
-__device__ __forceinline__ int intersect(int nq, const float *__restrict__ quads, v3 o, v3 d, float tmax, float &t_out)
+constexpr float kPiF = 3.14159265358979323846f;
+constexpr float kInvTwoPiF = 0.15915494309189533577f;
+constexpr float kInvSqrtPiF = 0.56418958354775628695f;
+constexpr float kSphereEps = 8.94069671630859375e-05f; // Mitsuba's math::RayEpsilon<float> = 1500 * 2^-24
+constexpr int kSphereStride = 12;                       // PG_SPHERE_STRIDE
+constexpr int kMaterialStride = 12;                     // PG_MATERIAL_STRIDE
+
+__device__ __forceinline__ float safe_sqrtf(float v) { return __builtin_sqrtf(v > 0.0f ? v : 0.0f); }
+__device__ __forceinline__ v3 normalize3(v3 v) { return vdivs(v, __builtin_sqrtf(dot3(v, v))); }
+
+// The shapes of a scene: quads, then spheres (shape number = quad index, or n_quads + sphere index)
+struct Shapes {
+	const float *quads, *spheres;
+	int n_quads, n_spheres;
+};
+
+// closest hit over all shapes, 0 < t < tmax (scene.ray_intersect / ray_test).  kGeneral = false is
+// the quad-only scene (cornell-box): the sphere loop and its double arithmetic are compiled out.
+template <bool kGeneral>
+__device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out)
 {
+	const int nq = sh.n_quads;
+	const float *__restrict__ quads = sh.quads;
 	int best = -1;
 	float bt = tmax;
 	for (int q = 0; q < nq; ++q) {
@@ -93,8 +113,106 @@ __device__ __forceinline__ int intersect(int nq, const float *__restrict__ quads
 		const float v = dot3(w, ld3(Q + 6)) * Q[13];
 		if (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) { bt = t; best = q; }
 	}
+	if (kGeneral) { // spheres: the quadratic in double precision, as Mitsuba's Sphere::ray_intersect_preliminary
+		for (int s = 0; s < sh.n_spheres; ++s) {
+			const float *S = sh.spheres + s * kSphereStride;
+			const double ox = (double)o.x - (double)S[0], oy = (double)o.y - (double)S[1], oz = (double)o.z - (double)S[2];
+			const double dx = (double)d.x, dy = (double)d.y, dz = (double)d.z, r = (double)S[3];
+			const double A = (dx * dx + dy * dy) + dz * dz;
+			const double B = 2.0 * ((ox * dx + oy * dy) + oz * dz);
+			const double C = ((ox * ox + oy * oy) + oz * oz) - r * r;
+			const double disc = B * B - (4.0 * A) * C;
+			if (!(disc >= 0.0) || A == 0.0) continue;
+			const double root = __builtin_sqrt(disc);
+			const double temp = -0.5 * (B + (B < 0.0 ? -root : root)); // the cancellation-free root first
+			double x0 = temp / A, x1 = temp != 0.0 ? C / temp : x0;
+			if (x0 > x1) { const double tt = x0; x0 = x1; x1 = tt; }
+			const float t = (float)(x0 > 0.0 ? x0 : x1);
+			if (t > 0.0f && t < bt) { bt = t; best = nq + s; }
+		}
+	}
 	t_out = bt;
 	return best;
+}
+
+// ---- surface description at a hit ----
+struct Material {
+	int type;        // 0 twosided diffuse, 1 twosided roughconductor (Beckmann, visible normals)
+	v3 refl;         // reflectance | specular_reflectance
+	const float *M;  // the material row: alpha, eta, k are read where the rough BSDF needs them
+};
+struct Surface {
+	v3 p, n, radiance;
+	bool is_em;
+	Material m;
+};
+
+template <bool kGeneral>
+__device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mats, int prim, v3 o, v3 d, float t)
+{
+	Surface s;
+	const float *M;
+	if (!kGeneral || prim < sh.n_quads) {
+		const float *Q = sh.quads + prim * kQuadStride;
+		s.p = vadd(o, vscale(d, t));
+		s.n = ld3(Q + 9);
+		s.is_em = Q[15] != 0.0f;
+		s.radiance = ld3(Q + 19);
+		if (!kGeneral) { // all-diffuse quad scene: the reflectance sits in the quad itself (pg_scene_set keeps it there)
+			s.m.type = 0;
+			s.m.refl = ld3(Q + 16);
+			s.m.M = nullptr;
+			return s;
+		}
+		M = mats + (int)Q[22] * kMaterialStride;
+	} else {
+		const float *S = sh.spheres + (prim - sh.n_quads) * kSphereStride;
+		const v3 c = ld3(S);
+		// sphere.h: n = normalize(ray(t) - c), p = c + n r; the normal is then taken again from the
+		// re-projected point so that it is a function of p alone (the next bounce recomputes it)
+		const v3 n0 = normalize3(vsub(vadd(o, vscale(d, t)), c));
+		s.p = vadd(c, vscale(n0, S[3]));
+		s.n = normalize3(vsub(s.p, c));
+		s.is_em = S[5] != 0.0f;
+		s.radiance = ld3(S + 6);
+		M = mats + (int)S[4] * kMaterialStride;
+	}
+	s.m.type = (int)M[0];
+	s.m.refl = ld3(M + 1);
+	s.m.M = M;
+	return s;
+}
+
+// normal of shape `prim` at the surface point p (quads: constant; spheres: as surface_at defines it)
+template <bool kGeneral>
+__device__ __forceinline__ v3 normal_at(const Shapes &sh, int prim, v3 p)
+{
+	if (!kGeneral || prim < sh.n_quads) return ld3(sh.quads + prim * kQuadStride + 9);
+	return normalize3(vsub(p, ld3(sh.spheres + (prim - sh.n_quads) * kSphereStride)));
+}
+
+// scene.pdf_emitter_direction(prev, ds) for a hit on emitter shape `prim` at p (normal n) seen from
+// `ref`, times the 1/count of the uniform emitter choice
+template <bool kGeneral>
+__device__ __forceinline__ float emitter_hit_pdf(const Shapes &sh, int prim, v3 ref, v3 p, v3 n, float inv_count)
+{
+	const v3 dd = vsub(p, ref);
+	const float d2 = dot3(dd, dd), dist = __builtin_sqrtf(d2);
+	const v3 dn = vdivs(dd, dist);
+	const float dp = dot3(dn, n);
+	if (!(dp < 0.0f)) return 0.0f;
+	float pdf;
+	if (!kGeneral || prim < sh.n_quads) {
+		pdf = d2 / (fabs_(dp) * sh.quads[prim * kQuadStride + 14]);
+	} else { // Sphere::pdf_direction
+		const float *S = sh.spheres + (prim - sh.n_quads) * kSphereStride;
+		const v3 cv = vsub(ld3(S), ref);
+		const float sin_alpha = S[3] / __builtin_sqrtf(dot3(cv, cv));
+		const float cos_alpha = safe_sqrtf(1.0f - sin_alpha * sin_alpha);
+		if (sin_alpha < 0.99999994f) pdf = kInvTwoPiF / (1.0f - cos_alpha);
+		else pdf = (d2 / fabs_(dp)) / ((4.0f * kPiF) * (S[3] * S[3]));
+	}
+	return pdf * inv_count;
 }
 
 // Mitsuba warp::square_to_cosine_hemisphere (concentric disk)
@@ -116,18 +234,144 @@ __device__ __forceinline__ v3 square_to_cosine_hemisphere(float u, float v)
 	return V(px, py, z);
 }
 
-__device__ __forceinline__ void bsdf_eval_pdf(v3 refl, v3 wi, v3 wo, bool active, v3 &value, float &pdf)
+// ---- roughconductor (Beckmann, isotropic, sample_visible) after Mitsuba 3's microfacet.h /
+// roughconductor.cpp; local frame, cos(theta_i) > 0.  Not inlined: the diffuse-only kernel never
+// references them, and the general kernel calls them from two places each.
+__device__ __noinline__ float rc_D(v3 m, float alpha) // MicrofacetDistribution::eval
+{
+	const float ct = m.z, ct2 = ct * ct;
+	const float ax = m.x / alpha, ay = m.y / alpha;
+	const float result = exp_f32(-((ax * ax + ay * ay) / ct2)) / (((kPiF * alpha) * alpha) * (ct2 * ct2));
+	return result * ct > 1e-20f ? result : 0.0f;
+}
+
+__device__ __forceinline__ float rc_G1(v3 v, v3 m, float alpha) // smith_g1, rational approximation
+{
+	const float ax = alpha * v.x, ay = alpha * v.y;
+	const float xy = ax * ax + ay * ay;
+	const float a = 1.0f / __builtin_sqrtf(xy / (v.z * v.z));
+	const float a2 = a * a;
+	float result = a >= 1.6f ? 1.0f : (3.535f * a + 2.181f * a2) / ((1.0f + 2.276f * a) + 2.577f * a2);
+	if (xy == 0.0f) result = 1.0f;
+	if (dot3(v, m) * v.z <= 0.0f) result = 0.0f;
+	return result;
+}
+
+__device__ __forceinline__ float fresnel_conductor(float cos_i, float eta_r, float eta_i)
+{
+	const float c2 = cos_i * cos_i, s2 = 1.0f - c2, s4 = s2 * s2;
+	const float temp_1 = (eta_r * eta_r - eta_i * eta_i) - s2;
+	const float a2pb2 = safe_sqrtf(temp_1 * temp_1 + ((4.0f * eta_i) * eta_i) * (eta_r * eta_r));
+	const float a = safe_sqrtf(0.5f * (a2pb2 + temp_1));
+	const float term_1 = a2pb2 + c2, term_2 = (2.0f * cos_i) * a;
+	const float r_s = (term_1 - term_2) / (term_1 + term_2);
+	const float term_3 = a2pb2 * c2 + s4, term_4 = term_2 * s2;
+	const float r_p = r_s * ((term_3 - term_4) / (term_3 + term_4));
+	return 0.5f * (r_s + r_p);
+}
+
+__device__ __forceinline__ v3 rc_fresnel(const float *M, float cos_i)
+{
+	return V(fresnel_conductor(cos_i, M[5], M[8]), fresnel_conductor(cos_i, M[6], M[9]), fresnel_conductor(cos_i, M[7], M[10]));
+}
+
+__device__ __noinline__ float erfinv_call(float x) { return erfinv_f32(x); }
+
+// sample_visible_11: slopes of the visible Beckmann normals for alpha = 1
+__device__ __noinline__ void rc_sample_visible_11(float cos_i, float u1, float u2, float &sx, float &sy)
+{
+	const float tan_i = safe_sqrtf(1.0f - cos_i * cos_i) / cos_i;
+	const float cot_i = 1.0f / tan_i;
+	const float maxval = erf_f32(cot_i);
+	u1 = u1 < 1.0f - 1e-6f ? u1 : 1.0f - 1e-6f; u1 = u1 > 1e-6f ? u1 : 1e-6f;
+	u2 = u2 < 1.0f - 1e-6f ? u2 : 1.0f - 1e-6f; u2 = u2 > 1e-6f ? u2 : 1e-6f;
+	float x = maxval - (maxval + 1.0f) * erf_f32(__builtin_sqrtf(-log_f32(u1)));
+	const float tail = tan_i == 0.0f ? 0.0f : (kInvSqrtPiF * tan_i) * exp_f32(-(cot_i * cot_i));
+	u1 = u1 * ((1.0f + maxval) + tail);
+	for (int i = 0; i < 3; ++i) {
+		const float slope = erfinv_call(x);
+		const float value = ((1.0f + x) + (kInvSqrtPiF * tan_i) * exp_f32(-(slope * slope))) - u1;
+		const float derivative = 1.0f - slope * tan_i;
+		x = x - value / derivative;
+	}
+	sx = erfinv_call(x);
+	sy = erfinv_call(2.0f * u2 - 1.0f);
+}
+
+// MicrofacetDistribution::sample (visible normals): microfacet normal and its density
+__device__ __forceinline__ v3 rc_sample_m(v3 wi, float alpha, float u1, float u2, float &pdf)
+{
+	const v3 wip = normalize3(V(alpha * wi.x, alpha * wi.y, wi.z));
+	const float s2 = wip.x * wip.x + wip.y * wip.y; // Frame::sincos_phi
+	float cos_phi = 1.0f, sin_phi = 0.0f;
+	if (fabs_(s2) > 4.0f * 5.9604644775390625e-08f) {
+		const float inv = 1.0f / __builtin_sqrtf(s2);
+		cos_phi = wip.x * inv; sin_phi = wip.y * inv;
+		cos_phi = cos_phi < -1.0f ? -1.0f : (cos_phi > 1.0f ? 1.0f : cos_phi);
+		sin_phi = sin_phi < -1.0f ? -1.0f : (sin_phi > 1.0f ? 1.0f : sin_phi);
+	}
+	float sx, sy;
+	rc_sample_visible_11(wip.z, u1, u2, sx, sy);
+	const float rx = (cos_phi * sx - sin_phi * sy) * alpha;
+	const float ry = (sin_phi * sx + cos_phi * sy) * alpha;
+	const v3 m = normalize3(V(-rx, -ry, 1.0f));
+	pdf = ((rc_D(m, alpha) * rc_G1(wi, m, alpha)) * fabs_(dot3(wi, m))) / wi.z;
+	return m;
+}
+
+__device__ __forceinline__ void rc_eval_pdf(const Material &mt, v3 wi, v3 wo, v3 &value, float &pdf) // wi.z > 0
+{
+	value = V(0, 0, 0);
+	pdf = 0.0f;
+	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
+	const float alpha = mt.M[4];
+	const v3 H = normalize3(vadd(wo, wi));
+	const float D = rc_D(H, alpha);
+	if (D == 0.0f) return;
+	const float g_i = rc_G1(wi, H, alpha);
+	const float res = (D * (g_i * rc_G1(wo, H, alpha))) / (4.0f * wi.z);
+	const v3 F = rc_fresnel(mt.M, dot3(wi, H));
+	value = vmul(F, vscale(mt.refl, res));
+	if (dot3(wi, H) > 0.0f && dot3(wo, H) > 0.0f) pdf = (D * g_i) / (4.0f * wi.z);
+}
+
+__device__ __forceinline__ void rc_sample(const Material &mt, v3 wi, float u1, float u2, v3 &wo, float &pdf, v3 &weight) // wi.z > 0
+{
+	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0);
+	const float alpha = mt.M[4];
+	float pdf_m;
+	const v3 m = rc_sample_m(wi, alpha, u1, u2, pdf_m);
+	const float wim = dot3(wi, m);
+	const v3 o = vsub(vscale(m, 2.0f * wim), wi); // reflect(wi, m)
+	if (!(pdf_m != 0.0f && o.z > 0.0f)) return;
+	const float p = pdf_m / (4.0f * dot3(o, m));
+	const v3 F = rc_fresnel(mt.M, wim);
+	wo = o;
+	pdf = p;
+	weight = vmul(F, vscale(mt.refl, rc_G1(o, m, alpha)));
+}
+
+// twosided(bsdf).eval_pdf: value includes cos(theta_o)
+template <bool kGeneral>
+__device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, bool active, v3 &value, float &pdf)
 {
 	value = V(0, 0, 0);
 	pdf = 0.0f;
 	if (!active) return;
 	if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+	if (kGeneral && mt.type == 1) {
+		rc_eval_pdf(mt, wi, wo, value, pdf);
+		return;
+	}
+	const v3 refl = mt.refl;
 	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
 	value = vscale(vscale(refl, kInvPiF), wo.z);
 	pdf = kInvPiF * wo.z;
 }
 
-__device__ __forceinline__ void bsdf_sample(v3 refl, v3 wi, float u, float v, bool active, v3 &wo, float &pdf,
+// twosided(bsdf).sample: wo (local), pdf, weight = value / pdf
+template <bool kGeneral>
+__device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u, float v, bool active, v3 &wo, float &pdf,
                                             v3 &weight, float &eta)
 {
 	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta = 0.0f;
@@ -135,6 +379,15 @@ __device__ __forceinline__ void bsdf_sample(v3 refl, v3 wi, float u, float v, bo
 	const bool flip = wi.z < 0.0f;
 	const float cos_i = flip ? -wi.z : wi.z;
 	if (!(cos_i > 0.0f)) return;
+	if (kGeneral && mt.type == 1) {
+		v3 o;
+		rc_sample(mt, V(wi.x, wi.y, cos_i), u, v, o, pdf, weight);
+		eta = 1.0f;
+		if (flip) o.z = -o.z;
+		wo = o;
+		return;
+	}
+	const v3 refl = mt.refl;
 	v3 w = square_to_cosine_hemisphere(u, v);
 	const float p = kInvPiF * w.z;
 	eta = 1.0f;
@@ -144,10 +397,88 @@ __device__ __forceinline__ void bsdf_sample(v3 refl, v3 wi, float u, float v, bo
 	wo = w;
 }
 
+// scene.sample_emitter_direction(si, (e1, e2), test_visibility=True): uniform choice of one emitter
+// (e1 is reused after the choice), then a point on it; returns ds.d, ds.pdf and radiance / pdf
+// (zero when occluded, facing away, or from inside a sphere)
+template <bool kGeneral>
+__device__ __forceinline__ void sample_emitter(const Shapes &sh, const int32_t *__restrict__ emitters, int n_em, v3 p,
+                                               v3 n, float e1, float e2, v3 &ds_d, float &ds_pdf, v3 &em_weight)
+{
+	ds_d = V(0, 0, 0);
+	ds_pdf = 0.0f;
+	em_weight = V(0, 0, 0);
+	if (n_em <= 0) return;
+	const float count = (float)n_em, inv_count = 1.0f / count;
+	uint32_t idx = (uint32_t)(e1 * count);
+	if (idx > (uint32_t)(n_em - 1)) idx = (uint32_t)(n_em - 1);
+	e1 = e1 * count - (float)idx;
+	const int prim = emitters[idx];
+	v3 pl, ln, radiance;
+	float pdf_cone = 0.0f, area = 1.0f;
+	const bool is_sphere = kGeneral && prim >= sh.n_quads;
+	if (!is_sphere) {
+		const float *E = sh.quads + prim * kQuadStride;
+		pl = vadd(vadd(ld3(E), vscale(ld3(E + 3), e1)), vscale(ld3(E + 6), e2));
+		ln = ld3(E + 9);
+		radiance = ld3(E + 19);
+		area = E[14];
+	} else { // Sphere::sample_direction, reference point outside
+		const float *S = sh.spheres + (prim - sh.n_quads) * kSphereStride;
+		const v3 c = ld3(S);
+		const float r = S[3];
+		const v3 dc_v = vsub(c, p);
+		const float dc_2 = dot3(dc_v, dc_v);
+		const float radius_adj = r * (1.0f - kSphereEps);
+		if (!(dc_2 > radius_adj * radius_adj)) return;
+		const float inv_dc = 1.0f / __builtin_sqrtf(dc_2);
+		const float sin_max = r * inv_dc, sin_max2 = sin_max * sin_max, inv_sin_max = 1.0f / sin_max;
+		const float cos_max = safe_sqrtf(1.0f - sin_max2);
+		float sin_theta_2;
+		if (sin_max2 > 0.00068523f) { // sin^2(1.5 deg)
+			const float tt = 1.0f + (cos_max - 1.0f) * e1;
+			sin_theta_2 = 1.0f - tt * tt;
+		} else sin_theta_2 = sin_max2 * e1; // small-angle Taylor expansion
+		const float cos_theta = safe_sqrtf(1.0f - sin_theta_2);
+		const float cos_alpha = sin_theta_2 * inv_sin_max +
+		                        cos_theta * safe_sqrtf(1.0f - sin_theta_2 * (inv_sin_max * inv_sin_max));
+		const float sin_alpha = safe_sqrtf(1.0f - cos_alpha * cos_alpha);
+		float sin_phi, cos_phi;
+		sincos_f32(e2 * (2.0f * kPiF), sin_phi, cos_phi);
+		const Frame fr = make_frame(vscale(dc_v, -inv_dc));
+		const v3 dl = to_world(fr, V(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha));
+		pl = vadd(c, vscale(dl, r));
+		ln = dl;
+		radiance = ld3(S + 6);
+		pdf_cone = kInvTwoPiF / (1.0f - cos_max);
+	}
+	const v3 dir0 = vsub(pl, p);
+	// si.spawn_ray_to(pl): offset origin, then aim at the light point
+	float mag = (1.0f + max3(V(fabs_(p.x), fabs_(p.y), fabs_(p.z)))) * kRayEps;
+	if (dot3(n, dir0) < 0.0f) mag = -mag;
+	const v3 so = vadd(p, vscale(n, mag));
+	const float d2 = dot3(dir0, dir0), dist = __builtin_sqrtf(d2);
+	ds_d = vdivs(dir0, dist);
+	const float dp = dot3(ds_d, ln);
+	float pdf = 0.0f;
+	if (dp < 0.0f) pdf = is_sphere ? (dist == 0.0f ? 0.0f : pdf_cone) : d2 / (fabs_(dp) * area);
+	if (!(pdf == pdf) || pdf == __builtin_huge_valf()) pdf = 0.0f;
+	ds_pdf = pdf * inv_count;
+	if (pdf > 0.0f) {
+		const v3 sd = vsub(pl, so);
+		const float sdist = __builtin_sqrtf(dot3(sd, sd));
+		const v3 sdn = vdivs(sd, sdist);
+		float th;
+		const bool occ = intersect<kGeneral>(sh, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
+		if (!occ) em_weight = vscale(vdivs(radiance, pdf), count);
+	}
+}
+
 struct RenderArgs {
 	TreeView tree;
-	const float *quads;
-	int n_quads, emitter_quad;
+	Shapes shapes;
+	const float *mats;          // material table (general scenes)
+	const int32_t *emitters;    // shape numbers of the emitters: flagged quads, then flagged spheres
+	int n_emitters;
 	pg_camera cam;
 	uint64_t n_lanes, n_pixels;      // of this pass (tile)
 	uint64_t pixel_begin, film_pixels; // first pixel of the tile, pixels of the whole film
@@ -174,14 +505,15 @@ struct RenderArgs {
 // One loop iteration of :179-381 for one live lane; returns whether the path continues.
 // kFirst: the camera ray is generated here (mi.render's sensor.sample_ray_differential: one 2-D
 // jitter draw per sample, box reconstruction) instead of being read back from a generate kernel.
-template <bool kFirst>
+// kGeneral: the scene has spheres or rough conductors; false compiles the all-diffuse quad scene only.
+template <bool kFirst, bool kGeneral>
 __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_kd, const uint64_t lane,
                                             const uint64_t rec_slot)
 {
 	const uint64_t N = a.n_lanes;
 	const int D = a.max_depth;
 	const float f = a.frac;
-	const float *quads = a.quads;
+	const Shapes &sh = a.shapes;
 	const uint32_t depth = (uint32_t)a.bounce;
 	Pcg32 rng;
 	v3 ray_o, ray_d, thr, L, prev_p;
@@ -215,7 +547,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		prev_p = V(a.prev_p[lane], a.prev_p[N + lane], a.prev_p[2 * N + lane]);
 		prev_bsdf_pdf = a.prev_pdf[lane];
 		// :352 spawn_ray of the previous vertex: the same three operations that produced the origin
-		const v3 pn = ld3(quads + (uint32_t)a.prev_quad[lane] * kQuadStride + 9);
+		const v3 pn = normal_at<kGeneral>(sh, (int)a.prev_quad[lane], prev_p);
 		float mag = (1.0f + max3(V(fabs_(prev_p.x), fabs_(prev_p.y), fabs_(prev_p.z)))) * kRayEps;
 		if (dot3(pn, ray_d) < 0.0f) mag = -mag;
 		ray_o = vadd(prev_p, vscale(pn, mag));
@@ -223,25 +555,22 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 
 	// ---- :185 ray_intersect ----
 	float t_hit;
-	const int q = intersect(a.n_quads, quads, ray_o, ray_d, __builtin_huge_valf(), t_hit);
+	const int q = intersect<kGeneral>(sh, ray_o, ray_d, __builtin_huge_valf(), t_hit);
 	const bool valid = q >= 0;
-	const float *Q = valid ? quads + q * kQuadStride : quads;
-	const v3 p = valid ? vadd(ray_o, vscale(ray_d, t_hit)) : V(0, 0, 0);
-	const v3 n = valid ? ld3(Q + 9) : V(0, 0, 1);
+	Surface sf;
+	sf.p = V(0, 0, 0); sf.n = V(0, 0, 1); sf.radiance = V(0, 0, 0); sf.is_em = false;
+	sf.m.type = 0; sf.m.refl = V(0, 0, 0); sf.m.M = nullptr;
+	if (valid) sf = surface_at<kGeneral>(sh, a.mats, q, ray_o, ray_d, t_hit);
+	const v3 p = sf.p, n = sf.n;
+	const Material &mt = sf.m;
 	const Frame fr = make_frame(n);
 	const v3 wi = to_local(fr, V(-ray_d.x, -ray_d.y, -ray_d.z));
-	const v3 refl = valid ? ld3(Q + 16) : V(0, 0, 0);
-	const bool is_em = valid && Q[15] != 0.0f;
+	const bool is_em = valid && sf.is_em;
+	const float inv_em_count = 1.0f / (float)a.n_emitters; // only used when an emitter was hit
 	// ---- :189-200 direct emission ----
-	const v3 em_radiance = (is_em && wi.z > 0.0f) ? ld3(Q + 19) : V(0, 0, 0);
+	const v3 em_radiance = (is_em && wi.z > 0.0f) ? sf.radiance : V(0, 0, 0);
 	float emitter_pdf = 0.0f;
-	if (is_em && !prev_delta) {
-		const v3 dd = vsub(p, prev_p);
-		const float d2 = dot3(dd, dd), dist = __builtin_sqrtf(d2);
-		const v3 dn = vdivs(dd, dist);
-		const float dp = dot3(dn, n);
-		if (dp < 0.0f) emitter_pdf = d2 / (fabs_(dp) * Q[14]);
-	}
+	if (is_em && !prev_delta) emitter_pdf = emitter_hit_pdf<kGeneral>(sh, q, prev_p, p, n, inv_em_count);
 	const float mis = mis_weight(prev_bsdf_pdf, emitter_pdf);
 	const v3 Le = vmul(vscale(thr, mis), em_radiance);
 	// ---- :207-220 emitter sampling ----
@@ -250,34 +579,12 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const float e1 = rng.next_f32(), e2 = rng.next_f32(); // :214, unmasked
 	v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 	float ds_pdf = 0.0f;
-	if (active_em && a.emitter_quad >= 0) {
-		const float *E = quads + a.emitter_quad * kQuadStride;
-		const v3 pl = vadd(vadd(ld3(E), vscale(ld3(E + 3), e1)), vscale(ld3(E + 6), e2));
-		const v3 dir0 = vsub(pl, p);
-		float mag = (1.0f + max3(V(fabs_(p.x), fabs_(p.y), fabs_(p.z)))) * kRayEps;
-		if (dot3(n, dir0) < 0.0f) mag = -mag;
-		const v3 so = vadd(p, vscale(n, mag));
-		const v3 dd = vsub(pl, p);
-		const float d2 = dot3(dd, dd), dist = __builtin_sqrtf(d2);
-		ds_d = vdivs(dd, dist);
-		const float dp = dot3(ds_d, ld3(E + 9));
-		float pdf = dp < 0.0f ? d2 / (fabs_(dp) * E[14]) : 0.0f;
-		if (!(pdf == pdf) || pdf == __builtin_huge_valf()) pdf = 0.0f;
-		ds_pdf = pdf;
-		if (pdf > 0.0f) {
-			const v3 sd = vsub(pl, so);
-			const float sdist = __builtin_sqrtf(dot3(sd, sd));
-			const v3 sdn = vdivs(sd, sdist);
-			float th;
-			const bool occ = intersect(a.n_quads, quads, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
-			if (!occ) em_weight = vdivs(ld3(E + 19), pdf);
-		}
-	}
+	if (active_em) sample_emitter<kGeneral>(sh, a.emitters, a.n_emitters, p, n, e1, e2, ds_d, ds_pdf, em_weight);
 	active_em = active_em && (ds_pdf != 0.0f); // :216
 	const v3 wo_em = to_local(fr, ds_d);
 	v3 bsdf_value_em;
 	float bsdf_pdf_em;
-	bsdf_eval_pdf(refl, wi, wo_em, active_em, bsdf_value_em, bsdf_pdf_em);
+	bsdf_eval_pdf<kGeneral>(mt, wi, wo_em, active_em, bsdf_value_em, bsdf_pdf_em);
 	// ---- :223-256 NEE MIS against the mixture pdf ----
 	const bool active_sd_em = active_em && a.guided;
 	const float pdf_diffuse = 1.0f; // :222-241
@@ -312,7 +619,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	if (active_next) { rng.skip(); s2x = rng.next_f32(); s2y = rng.next_f32(); } // next_1d (unused by diffuse), next_2d
 	v3 wo_local, bsdf_weight;
 	float bsdf_pdf, eta;
-	bsdf_sample(refl, wi, s2x, s2y, active_next, wo_local, bsdf_pdf, bsdf_weight, eta);
+	bsdf_sample<kGeneral>(mt, wi, s2x, s2y, active_next, wo_local, bsdf_pdf, bsdf_weight, eta);
 	v3 bsdf_value = vscale(bsdf_weight, bsdf_pdf);
 	float woPdf = bsdf_pdf;
 	v3 wo_world = to_world(fr, wo_local);
@@ -336,7 +643,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		c_q += lv; ++c_qq;
 		wo_world = V(dx, dy, dz);
 		wo_local = to_local(fr, wo_world);
-		bsdf_eval_pdf(refl, wi, wo_local, true, bsdf_value, bsdf_pdf);
+		bsdf_eval_pdf<kGeneral>(mt, wi, wo_local, true, bsdf_value, bsdf_pdf);
 	}
 	// dirToCanonical of the continuation direction feeds the pdf query (:307) and the record (:327)
 	float wo_cx = 0.0f, wo_cy = 0.0f;
@@ -421,7 +728,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 #else
 #define PG_BOUNCE_ATTR
 #endif
-template <bool kFirst>
+template <bool kFirst, bool kGeneral>
 __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
@@ -440,7 +747,7 @@ __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
 	}
 	bool cont = false;
-	if (alive) cont = bounce_lane<kFirst>(a, s_kd, lane, rec_base + tid);
+	if (alive) cont = bounce_lane<kFirst, kGeneral>(a, s_kd, lane, rec_base + tid);
 	if (a.last) return; // nothing survives the last bounce
 	const unsigned long long ballot = __ballot(cont);
 	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -543,8 +850,10 @@ using namespace pg;
 
 // library-owned renderer state
 struct pg_render_state {
-	DevBuf<float> quads;
-	int n_quads = 0, emitter_quad = -1;
+	DevBuf<float> quads, spheres, mats;
+	DevBuf<int32_t> emitters;
+	int n_quads = 0, n_spheres = 0, n_emitters = 0;
+	bool general = false; // spheres or rough conductors present: the general kernels are launched
 	pg_camera cam;
 	bool have_scene = false;
 	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
@@ -598,18 +907,77 @@ extern "C" {
 
 int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const pg_camera *cam)
 {
+	pg_scene_desc d;
+	d.n_quads = n_quads; d.quads = h_quads;
+	d.n_spheres = 0; d.spheres = nullptr;
+	d.n_materials = 0; d.materials = nullptr;
+	return pg_scene_set_ex(ctx, &d, cam);
+}
+
+int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *cam)
+{
 	if (!ctx) return PG_ERR_INVALID;
-	if (!h_quads || !cam || n_quads == 0 || n_quads > 4096)
-		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: need 1..4096 quads and a camera");
+	if (!sc || !cam) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: NULL pointer");
+	const uint64_t nq = sc->n_quads, ns = sc->n_spheres, nm = sc->n_materials;
+	if (nq + ns == 0 || nq > 4096 || ns > 4096 || (nq && !sc->quads) || (ns && !sc->spheres))
+		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: need 1..4096 quads and/or 1..4096 spheres");
+	if ((nm && !sc->materials) || (!sc->materials && ns))
+		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: spheres need a material table");
 	if (cam->width <= 0 || cam->height <= 0) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: bad film size");
+	// host copies: material indices checked, a material table made up for scenes that come without one,
+	// the diffuse reflectance mirrored into the quads (the quad-only kernels read it there)
+	std::vector<float> quads(sc->quads, sc->quads + nq * kQuadStride);
+	std::vector<float> mats;
+	if (sc->materials) {
+		mats.assign(sc->materials, sc->materials + nm * kMaterialStride);
+	} else {
+		mats.assign(nq * kMaterialStride, 0.0f);
+		for (uint64_t q = 0; q < nq; ++q) {
+			for (int c = 0; c < 3; ++c) mats[q * kMaterialStride + 1 + c] = quads[q * kQuadStride + 16 + c];
+			quads[q * kQuadStride + 22] = (float)q;
+		}
+	}
+	const uint64_t n_mats = mats.size() / kMaterialStride;
+	bool general = ns > 0;
+	for (uint64_t m = 0; m < n_mats; ++m) {
+		const float type = mats[m * kMaterialStride];
+		if (type != 0.0f && type != 1.0f) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
+		if (type == 1.0f) {
+			general = true;
+			if (!(mats[m * kMaterialStride + 4] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: roughconductor alpha must be > 0");
+		}
+	}
+	for (uint64_t q = 0; q < nq; ++q) {
+		const float mi = quads[q * kQuadStride + 22];
+		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: quad material index out of range");
+		const float *M = &mats[(uint64_t)mi * kMaterialStride];
+		if (M[0] == 0.0f)
+			for (int c = 0; c < 3; ++c) quads[q * kQuadStride + 16 + c] = M[1 + c];
+	}
+	for (uint64_t s = 0; s < ns; ++s) {
+		const float mi = sc->spheres[s * kSphereStride + 4];
+		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: sphere material index out of range");
+		if (!(sc->spheres[s * kSphereStride + 3] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: sphere radius must be > 0");
+	}
+	std::vector<int32_t> em;
+	for (uint64_t q = 0; q < nq; ++q)
+		if (quads[q * kQuadStride + 15] != 0.0f) em.push_back((int32_t)q);
+	for (uint64_t s = 0; s < ns; ++s)
+		if (sc->spheres[s * kSphereStride + 5] != 0.0f) em.push_back((int32_t)(nq + s));
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	pg_render_state *r = rstate(ctx);
-	PG_HIP(ctx, r->quads.ensure(n_quads * kQuadStride));
-	PG_HIP(ctx, hipMemcpy(r->quads.p, h_quads, n_quads * kQuadStride * sizeof(float), hipMemcpyHostToDevice));
-	r->n_quads = (int)n_quads;
-	r->emitter_quad = -1;
-	for (uint64_t q = 0; q < n_quads; ++q)
-		if (h_quads[q * kQuadStride + 15] != 0.0f) { r->emitter_quad = (int)q; break; }
+	PG_HIP(ctx, r->quads.ensure(nq * kQuadStride)); PG_HIP(ctx, r->spheres.ensure(ns * kSphereStride));
+	PG_HIP(ctx, r->mats.ensure(mats.size())); PG_HIP(ctx, r->emitters.ensure(em.size()));
+	if (nq) PG_HIP(ctx, hipMemcpy(r->quads.p, quads.data(), quads.size() * sizeof(float), hipMemcpyHostToDevice));
+	if (ns) PG_HIP(ctx, hipMemcpy(r->spheres.p, sc->spheres, ns * kSphereStride * sizeof(float), hipMemcpyHostToDevice));
+	PG_HIP(ctx, hipMemcpy(r->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
+	if (!em.empty()) PG_HIP(ctx, hipMemcpy(r->emitters.p, em.data(), em.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	r->n_quads = (int)nq;
+	r->n_spheres = (int)ns;
+	r->n_emitters = (int)em.size();
+	r->general = general;
 	r->cam = *cam;
 	r->have_scene = true;
 	return PG_OK;
@@ -650,9 +1018,13 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	}
 	RenderArgs a;
 	a.tree = ctx->view();
-	a.quads = r->quads.p;
-	a.n_quads = r->n_quads;
-	a.emitter_quad = r->emitter_quad;
+	a.shapes.quads = r->quads.p;
+	a.shapes.spheres = r->spheres.p;
+	a.shapes.n_quads = r->n_quads;
+	a.shapes.n_spheres = r->n_spheres;
+	a.mats = r->mats.p;
+	a.emitters = r->emitters.p;
+	a.n_emitters = r->n_emitters;
 	a.cam = r->cam;
 	a.n_lanes = N;
 	a.n_pixels = P;
@@ -681,8 +1053,13 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		Timed t(r, s, 1);
 		// every launch is sized for the whole wavefront: the live count is only known on the device,
 		// and workgroups past it retire on their first instruction
-		if (it == 0) hipLaunchKernelGGL(k_bounce<true>, grid, dim3(kRBlock), 0, s, a);
-		else hipLaunchKernelGGL(k_bounce<false>, grid, dim3(kRBlock), 0, s, a);
+		if (r->general) {
+			if (it == 0) hipLaunchKernelGGL((k_bounce<true, true>), grid, dim3(kRBlock), 0, s, a);
+			else hipLaunchKernelGGL((k_bounce<false, true>), grid, dim3(kRBlock), 0, s, a);
+		} else {
+			if (it == 0) hipLaunchKernelGGL((k_bounce<true, false>), grid, dim3(kRBlock), 0, s, a);
+			else hipLaunchKernelGGL((k_bounce<false, false>), grid, dim3(kRBlock), 0, s, a);
+		}
 	}
 	PG_HIP(ctx, hipGetLastError());
 	if (record) {

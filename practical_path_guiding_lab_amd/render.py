@@ -67,7 +67,11 @@ class WavefrontScene:
         c.tan_half_fov_x = float(cam.tan_half_fov_x)
         c.width, c.height = int(cam.width), int(cam.height)
         q = np.ascontiguousarray(self.scene.quads, np.float32)
-        N.check(tree._h, tree._lib.pg_scene_set(tree._h, q.shape[0], q.ctypes.data, C.byref(c)))
+        s = np.ascontiguousarray(self.scene.spheres, np.float32)
+        m = None if self.scene.materials is None else np.ascontiguousarray(self.scene.materials, np.float32)
+        d = N.pg_scene_desc(q.shape[0], q.ctypes.data if q.size else None, s.shape[0], s.ctypes.data if s.size else None,
+                            0 if m is None else m.shape[0], None if m is None else m.ctypes.data)
+        N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 
     # image tile of this rank (multi-GPU): (first pixel, pixel count) in row-major order; None = whole film

@@ -19,6 +19,9 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 QUAD_STRIDE = 24  # floats per quad, layout documented in include/pgsd.h (pg_scene_desc)
+SPHERE_STRIDE = 12    # centre 0-2, radius 3, material 4, emitter flag 5, radiance 6-8
+MATERIAL_STRIDE = 12  # type 0, reflectance 1-3, alpha 4, eta 5-7, k 8-10
+MAT_DIFFUSE, MAT_ROUGHCONDUCTOR = 0, 1
 
 
 @dataclass
@@ -42,6 +45,8 @@ class Scene:
     bbox_max: np.ndarray = field(default_factory=lambda: np.ones(3, np.float32))
     names: List[str] = field(default_factory=list)
     rfilter: str = "tent"             # film reconstruction filter: "tent" (radius 1 pixel, the reference's scenes) or "box"
+    spheres: np.ndarray = field(default_factory=lambda: np.zeros((0, SPHERE_STRIDE), np.float32))  # (S, 12)
+    materials: Optional[np.ndarray] = None  # (M, 12); None: quad i is diffuse with quads[i, 16:19]
 
 
 def _f32(v):
@@ -101,10 +106,46 @@ def cube(to_world: np.ndarray, refl) -> List[np.ndarray]:
     return out
 
 
-def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names) -> Scene:
-    q = np.stack(quads).astype(np.float32)
-    corners = np.concatenate([q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]])
-    return Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
+def diffuse_material(reflectance) -> np.ndarray:
+    m = np.zeros(MATERIAL_STRIDE, np.float32)
+    m[0] = MAT_DIFFUSE
+    m[1:4] = _f32(reflectance)
+    return m
+
+
+def roughconductor_material(alpha, eta, k, specular_reflectance=(1.0, 1.0, 1.0)) -> np.ndarray:
+    """Mitsuba `roughconductor`, beckmann distribution, isotropic alpha, sample_visible (its default)."""
+    m = np.zeros(MATERIAL_STRIDE, np.float32)
+    m[0] = MAT_ROUGHCONDUCTOR
+    m[1:4] = _f32(specular_reflectance)
+    m[4] = np.float32(alpha)
+    m[5:8] = _f32(eta)
+    m[8:11] = _f32(k)
+    return m
+
+
+def sphere(center, radius, material_index: int, radiance=None) -> np.ndarray:
+    s = np.zeros(SPHERE_STRIDE, np.float32)
+    s[0:3] = _f32(center)
+    s[3] = np.float32(radius)
+    s[4] = np.float32(material_index)
+    if radiance is not None:
+        s[5] = 1.0
+        s[6:9] = _f32(radiance)
+    return s
+
+
+def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names, spheres=None, materials=None) -> Scene:
+    q = np.stack(quads).astype(np.float32) if quads else np.zeros((0, QUAD_STRIDE), np.float32)
+    corners = [q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]]
+    s = np.stack(spheres).astype(np.float32) if spheres else np.zeros((0, SPHERE_STRIDE), np.float32)
+    if s.shape[0]:
+        corners += [s[:, 0:3] - s[:, 3:4], s[:, 0:3] + s[:, 3:4]]
+    corners = np.concatenate(corners)
+    sc = Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
+    sc.spheres = s
+    sc.materials = np.stack(materials).astype(np.float32) if materials else None
+    return sc
 
 
 def make_camera(to_world: np.ndarray, fov_deg: float, width: int, height: int) -> Camera:
@@ -154,15 +195,30 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
         v = [float(x) for x in node.get("value").replace(",", " ").split()]
         return tuple(v * 3) if len(v) == 1 else tuple(v)
 
-    def diffuse(node):
-        if node.get("type") == "twosided":
-            return diffuse(node.find("bsdf"))
-        if node.get("type") != "diffuse":
-            raise ValueError(f"unsupported bsdf type {node.get('type')}")
-        r = node.find("rgb")
-        return rgb(r) if r is not None else (0.5, 0.5, 0.5)
+    materials: List[np.ndarray] = []
 
-    bsdfs = {b.get("id"): diffuse(b) for b in root.findall("bsdf")}
+    def material(node) -> int:
+        """Index of the material row for a <bsdf> element (every BSDF of the substrate is twosided)."""
+        if node.get("type") == "twosided":
+            return material(node.find("bsdf"))
+        kind = node.get("type")
+        named = {r.get("name"): rgb(r) for r in node.findall("rgb")}
+        if kind == "diffuse":
+            materials.append(diffuse_material(named.get("reflectance", (0.5, 0.5, 0.5))))
+        elif kind == "roughconductor":
+            dist = node.find("string[@name='distribution']")
+            if dist is not None and dist.get("value") != "beckmann":
+                raise ValueError("roughconductor: only the beckmann distribution is built")
+            if node.find("string[@name='material']") is not None or "eta" not in named or "k" not in named:
+                raise ValueError("roughconductor: give eta and k as rgb values (material presets are not built)")
+            a = node.find("float[@name='alpha']")
+            materials.append(roughconductor_material(float(val(a.get("value"))) if a is not None else 0.1, named["eta"], named["k"],
+                                                     named.get("specular_reflectance", (1.0, 1.0, 1.0))))
+        else:
+            raise ValueError(f"unsupported bsdf type {kind}")
+        return len(materials) - 1
+
+    bsdfs = {b.get("id"): material(b) for b in root.findall("bsdf")}
     integ = root.find("integrator")
     props = {i.get("name"): int(val(i.get("value"))) for i in integ.findall("integer")} if integ is not None else {}
     sensor = root.find("sensor")
@@ -173,14 +229,24 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     fw = int(val(film.find("integer[@name='width']").get("value")))
     fh = int(val(film.find("integer[@name='height']").get("value")))
     cam = make_camera(_mat(sensor.find("transform/matrix").get("value")), fov, width or fw, height or fh)
-    quads, names = [], []
+    quads, names, spheres = [], [], []
     for sh in root.findall("shape"):
         kind = sh.get("type")
-        m = _mat(sh.find("transform/matrix").get("value"))
         ref = sh.find("ref")
-        refl = bsdfs[ref.get("id")] if ref is not None else diffuse(sh.find("bsdf"))
+        mi = bsdfs[ref.get("id")] if ref is not None else material(sh.find("bsdf"))
+        refl = materials[mi][1:4]
         em = sh.find("emitter")
+        if em is not None and em.get("type") != "area":
+            raise ValueError(f"unsupported emitter type {em.get('type')}")
         rad = rgb(em.find("rgb")) if em is not None else None
+        if kind == "sphere":
+            if sh.find("transform") is not None:
+                raise ValueError("spheres are given by centre and radius (to_world is not built)")
+            c, r = sh.find("point[@name='center']"), sh.find("float[@name='radius']")
+            center = [float(val(c.get(a, "0"))) for a in ("x", "y", "z")] if c is not None else [0.0, 0.0, 0.0]
+            spheres.append(sphere(center, float(val(r.get("value"))) if r is not None else 1.0, mi, rad))
+            continue
+        m = _mat(sh.find("transform/matrix").get("value"))
         if kind == "rectangle":
             qs = rectangle(m, refl, rad)
         elif kind == "cube":
@@ -189,9 +255,11 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             qs = cube(m, refl)
         else:
             raise ValueError(f"unsupported shape type {kind}")
+        for q in qs:
+            q[22] = np.float32(mi)
         quads += qs
         names += [sh.get("id", kind)] * len(qs)
-    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names)
+    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials)
     rf = film.find("rfilter")
     sc.rfilter = rf.get("type") if rf is not None else "gaussian"  # hdrfilm's default
     if sc.rfilter not in ("tent", "box"):

@@ -70,6 +70,80 @@ def test_cornell_lifecycle_bit_exact(res, max_depth, rr_depth, nee):
     assert g.computeVariance(cumm) >= 0.0
 
 
+def mixed_scene(res, max_depth=6, rr_depth=3):
+    """Every primitive, emitter kind and BSDF of the substrate in one small scene: a diffuse floor
+    and back wall, a rough-conductor plate and cube (two roughnesses), a diffuse and a rough-conductor
+    sphere, one quad light and two sphere lights of very different sizes (scenes/veach-mis in small)."""
+    from practical_path_guiding_lab_amd import scene as S
+
+    mats = [S.diffuse_material((0.6, 0.55, 0.5)), S.diffuse_material((0.0, 0.0, 0.0)),
+            S.roughconductor_material(0.05, (0.200438, 0.924033, 1.10221), (3.91295, 2.45285, 2.14219), (0.3, 0.3, 0.3)),
+            S.roughconductor_material(0.25, (0.200438, 0.924033, 1.10221), (3.91295, 2.45285, 2.14219), (0.9, 0.8, 0.7)),
+            S.diffuse_material((0.2, 0.5, 0.7))]
+
+    def with_mat(qs, mi):
+        for q in qs:
+            q[22] = mi
+        return qs
+
+    def M(*v):
+        return np.array(v, np.float64).reshape(4, 4)
+
+    quads = []
+    quads += with_mat(S.rectangle(M(4, 0, 0, 0, 0, 0, 4, 0, 0, -4, 0, 0, 0, 0, 0, 1), mats[0][1:4]), 0)          # floor y=0
+    quads += with_mat(S.rectangle(M(4, 0, 0, 0, 0, 4, 0, 4, 0, 0, 1, -4, 0, 0, 0, 1), mats[0][1:4]), 0)          # back wall z=-4
+    quads += with_mat(S.rectangle(M(1.5, 0, 0, -1, 0, 0.3, 0.8, 0.6, 0, -1.2, 0.2, 0.5, 0, 0, 0, 1), mats[2][1:4]), 2)  # tilted glossy plate
+    quads += with_mat(S.cube(M(0.5, 0.2, 0, 2, 0, 0, -0.6, 0.6, -0.2, 0.5, 0, -1, 0, 0, 0, 1), mats[3][1:4]), 3)    # rough cube
+    quads += with_mat(S.rectangle(M(0.4, 0, 0, -2.5, 0, 0, -0.4, 3.5, 0, 0.4, 0, -1, 0, 0, 0, 1), mats[1][1:4], (9, 8, 7)), 1)  # quad light, facing down
+    spheres = [S.sphere((0.0, 3.0, 0.5), 0.4, 1, (12.0, 12.0, 12.0)), S.sphere((1.5, 2.5, 1.5), 0.03, 1, (900.0, 700.0, 500.0)),
+               S.sphere((-1.8, 0.5, 1.0), 0.5, 4), S.sphere((0.5, 0.45, 1.8), 0.45, 2)]
+    cam = S.make_camera(M(-1, 0, 0, 0, 0, 0.94, -0.342, 3.0, 0, -0.342, -0.94, 7.5, 0, 0, 0, 1), 40.0, res, res)
+    return S._finish(quads, cam, max_depth, rr_depth, ["q"] * len(quads), spheres, mats)
+
+
+@pytest.mark.parametrize("res,nee", [(40, True), (24, False)])
+def test_spheres_rough_conductors_and_many_emitters_bit_exact(res, nee):
+    """The general kernels (k_bounce<*, true>: spheres, uniform emitter choice with cone-sampled
+    sphere lights, Beckmann rough conductors with visible-normal sampling) against the oracle:
+    radiance, sums, accumulators and refined trees over a guided lifecycle."""
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+
+    sc = mixed_scene(res)
+    D, RR = sc.max_depth, sc.rr_depth
+    bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
+    npix = res * res
+    o = po.OracleSDTreePair()
+    o.setup(bmin, bmax, 20, 20, nee)
+    o_sumL = np.zeros((3, npix), np.float32)
+    o_sumL2 = np.zeros((3, npix), np.float32)
+    g = PathGuidingIntegrator({"max_depth": D, "rr_depth": RR})
+    g.setup(npix, bmin, bmax, sdTreeMaxDepth=20, quadTreeMaxDepth=20, isStoreNEERadiance=nee, bsdfSamplingFraction=0.5)
+    ws = WavefrontScene(sc)
+    cumm = 0
+    for k in range(4):
+        final = k == 3
+        g.setIteration(k, final)
+        for spp in ([1, 3] if k == 0 else [2 ** (k + 2)]):
+            seed = 5000 + cumm
+            Lo, vo = po.render_pass(o, sc.quads, sc.camera, D, RR, k, final, seed, spp, nee, 0.5, o_sumL, o_sumL2,
+                                    spheres=sc.spheres, materials=sc.materials)
+            Lg, vg, _ = g.sample(ws, IndependentSampler(spp, seed))
+            np.testing.assert_array_equal(Lg.cpu().numpy().view(np.uint32), Lo.view(np.uint32))
+            np.testing.assert_array_equal(vg.cpu().numpy(), vo)
+            cumm += spp
+        assert np.isfinite(o_sumL).all() and o_sumL.max() > 0
+        np.testing.assert_array_equal(g.sumL.cpu().numpy().view(np.uint32), o_sumL.view(np.uint32))
+        kd, lo, hi = g.sdTree.exportAccumulators()
+        np.testing.assert_array_equal(kd, o.current.kd_column("count"))
+        np.testing.assert_array_equal(lo, o.current.quad_column("acc_lo"))
+        np.testing.assert_array_equal(hi, o.current.quad_column("acc_hi"))
+        if not final:
+            o.refine_and_prepare(k)
+            g.refineAndPrepareSDTreeForNextIteration()
+            _same_tree(o.prev.export(), g.sdTree.export())
+
+
 def test_guided_render_converges_to_the_ground_truth():
     """main.py's schedule at 256x256 against the reference's ground truth of the same scene
     (tests/golden/cornell_gt_256_f16.npy, from scenes/cornell-box/TungstenRender.exr): the MSE
