@@ -36,14 +36,30 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--res", type=int, default=512, help="film is res x res (cornell-box 512x512)")
-    ap.add_argument("--depth", type=int, default=8, help="max_depth")
+    ap.add_argument("--scene", default="cornell-box", choices=["cornell-box", "veach-mis"],
+                    help="cornell-box 512x512 max_depth 8 (BASELINE configs[1], the default) or veach-mis 1280x720 "
+                         "max_depth 3 (configs[2])")
+    ap.add_argument("--res", type=int, default=None, help="film width (cornell-box: square film; veach-mis: 16:9)")
+    ap.add_argument("--depth", type=int, default=None, help="max_depth (default: 8 / 3)")
     ap.add_argument("--spp-per-pass", type=int, default=8, help="samples per pixel traced by one pass")
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered (untimed) to train the SD-tree")
     ap.add_argument("--cpu-res", type=int, default=256, help="film size of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.res is None:
+        args.res = 512 if args.scene == "cornell-box" else 1280
+    if args.depth is None:
+        args.depth = 8 if args.scene == "cornell-box" else 3
+    return args
+
+
+def make_scene(args, width):
+    from practical_path_guiding_lab_amd import scene as S
+
+    if args.scene == "veach-mis":
+        return S.veach_mis(width, width * 9 // 16, args.depth, 8)
+    return S.cornell_box(width, width, args.depth, 8)
 
 
 def traffic_for(kernel, key):
@@ -123,7 +139,7 @@ def run_render(args):
     # initial_seed + cumm_spp), so N ranks trace N consecutive passes of the same film concurrently,
     # each into its own accumulators, and sum them (int64 all-reduce) before the refine.  Weak
     # scaling: every GPU traces the full res x res film per step.
-    sc = S.cornell_box(args.res, args.res, args.depth, 8)
+    sc = make_scene(args, args.res)
     integ = PathGuidingIntegrator({"max_depth": args.depth, "rr_depth": 8}, device=local_rank)
     tree = integ.sdTree
     npix = sc.camera.width * sc.camera.height
@@ -217,6 +233,12 @@ def run_render(args):
     }
     dom = "k_bounce" if kt.bounce_ms >= kt.splat_ms else "k_process_and_splat"
     cfg_key = f"render res={args.res} depth={args.depth} spp={args.spp_per_pass}"
+    if args.scene != "cornell-box":
+        cfg_key = f"{args.scene} " + cfg_key
+    film = f"{sc.camera.width}x{sc.camera.height}"
+    what = {"cornell-box": "built-in scene (Mitsuba cornell-box parameters), no textures",
+            "veach-mis": "built-in scene (scenes/veach-mis/scene.xml parameters: 3 sphere lamps, 4 Beckmann rough-conductor "
+                         "plates, diffuse floor and wall)"}[args.scene]
     roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 5),
             "traffic": traffic_for(dom, cfg_key),
@@ -226,13 +248,13 @@ def run_render(args):
                     "atomics, not HBM (DESIGN.md 5)"}
     cpu = cpu_baseline_render(args, tree, sc) if (args.cpu_res > 0 and world == 1) else None
     out = {
-        "metric": "Msamples/s guided, cornell-box 512x512 max_depth 8", "value": round(value, 3), "unit": "Msamples/s",
+        "metric": f"Msamples/s guided, {args.scene} {film} max_depth {args.depth}", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"cornell-box {args.res}x{args.res} per GPU, max_depth {args.depth}, guided iteration "
+        "config": {"workload": f"{args.scene} {film} per GPU, max_depth {args.depth}, guided iteration "
                                f"{k} (SD-tree trained by rendering iterations 0-{k - 1}), {args.spp_per_pass} spp per pass; "
                                "full PathGuidingIntegrator.sample(): camera rays, NEE, BSDF/SD-tree MIS, record store, "
-                               "post-process + splat; built-in scene (Mitsuba cornell-box parameters), no textures",
+                               "post-process + splat; " + what,
                    "pixels_per_gpu": my_pixels, "spp_per_pass": args.spp_per_pass,
                    "paths_per_step": paths_per_step, "kd_nodes": stats.n_kd_nodes, "kd_leaves": stats.n_kd_leaves,
                    "quad_records": stats.n_quad_records, "mean_kd_leaf_depth": round(stats.mean_kd_leaf_depth, 3),
@@ -251,23 +273,22 @@ def run_render(args):
 
 def cpu_baseline_render(args, tree, sc_full):
     """The CPU oracle renders one guided pass of the same scene with the same trained tree."""
-    import numpy as np
     from oracle import pg_oracle as po
-    from practical_path_guiding_lab_amd import scene as S
 
     po.build()
     pair = po.OracleSDTreePair()
     pair.prev.load(tree.export())
     pair.current.copy_from(pair.prev)
     pair.current.reset()
-    sc = S.cornell_box(args.cpu_res, args.cpu_res, args.depth, 8)
+    sc = make_scene(args, args.cpu_res)
     spp = args.spp_per_pass
     t0 = time.perf_counter()
-    po.render_pass(pair, sc.quads, sc.camera, args.depth, 8, args.train_iters, False, 12345, spp, True, 0.5)
+    po.render_pass(pair, sc.quads, sc.camera, args.depth, 8, args.train_iters, False, 12345, spp, True, 0.5,
+                   spheres=sc.spheres, materials=sc.materials)
     dt = time.perf_counter() - t0
-    n = args.cpu_res * args.cpu_res * spp
+    n = sc.camera.width * sc.camera.height * spp
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"one guided pass of the same scene and SD-tree at {args.cpu_res}x{args.cpu_res} x {spp} spp "
+            "sample": f"one guided pass of the same scene and SD-tree at {sc.camera.width}x{sc.camera.height} x {spp} spp "
                       f"({n} paths), single-threaded C oracle, {dt:.1f} s"}
 
 

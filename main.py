@@ -15,9 +15,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scene", default=None, help="Mitsuba 3 scene XML; default: built-in cornell-box")
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--scene", default="cornell-box",
+                    help="built-in scene (cornell-box, veach-mis) or a Mitsuba 3 scene XML of the supported subset")
+    ap.add_argument("--width", type=int, default=None, help="film width (default: 512 / 1280 / the XML's)")
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--budget-spp", type=int, default=252)       # main.py:99
     ap.add_argument("--batch-spp", type=int, default=4)          # main.py:123
@@ -33,7 +34,14 @@ def main():
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import WavefrontScene
 
-    sc = S.load_xml(args.scene, args.width, args.height) if args.scene else S.cornell_box(args.width, args.height, 8, 8)
+    if args.scene == "cornell-box":
+        sc = S.cornell_box(args.width or 512, args.height or 512, 8, 8)
+    elif args.scene == "veach-mis":
+        sc = S.veach_mis(args.width or 1280, args.height or 720)
+    else:
+        sc = S.load_xml(args.scene, args.width, args.height)
+    if args.out == "debug/cornell-box" and args.scene != "cornell-box":
+        args.out = "debug/" + os.path.splitext(os.path.basename(os.path.dirname(args.scene) or args.scene))[0]
     if args.max_depth is not None:
         sc.max_depth = args.max_depth
     integ = PathGuidingIntegrator({"max_depth": sc.max_depth, "rr_depth": sc.rr_depth})

@@ -181,6 +181,35 @@ def cornell_box(width: int = 512, height: int = 512, max_depth: int = 8, rr_dept
     return _finish(quads, cam, max_depth, rr_depth, names)
 
 
+def veach_mis(width: int = 1280, height: int = 720, max_depth: int = 3, rr_depth: int = 8) -> Scene:
+    """The veach-mis scene of the reference (scenes/veach-mis/scene.xml: fov 35, four rough-conductor
+    plates of alpha 0.01 / 0.05 / 0.1 / 0.25, a diffuse floor and back wall, three sphere lamps of
+    radius 1, 0.5 and 0.05 whose radiance grows as their area shrinks), from its numeric parameters."""
+    eta, k, spec = (0.200438, 0.924033, 1.10221), (3.91295, 2.45285, 2.14219), (0.3, 0.3, 0.3)
+    mats = [diffuse_material((0.5, 0.5, 0.5)), diffuse_material((0.0, 0.0, 0.0))]
+    mats += [roughconductor_material(a, eta, k, spec) for a in (0.01, 0.05, 0.1, 0.25)]
+    D, N0, SMOOTH, GLOSSY, ROUGH, SUPER = 0, 1, 2, 3, 4, 5
+    shapes = [
+        ("Smooth", "cube", "0.805757 0.0961775 0 0.264069 -0.673242 0.115108 0 4.09801 0 0 4 0 0 0 0 1", SMOOTH),
+        ("Glossy", "cube", "0.972057 0.0567134 0 3.06163 -0.396994 0.138865 0 2.71702 0 0 4 0 0 0 0 1", GLOSSY),
+        ("Rough", "cube", "1.03191 0.0277252 0 7.09981 -0.194077 0.147415 0 1.81891 0 0 4 0 0 0 0 1", ROUGH),
+        ("Diffuse_0001", "rectangle", "9.9 0 0 4.9 0 -4.32743e-007 9.9 0 0 -23.76 -1.03858e-006 0 0 0 0 1", D),
+        ("Diffuse_0002", "rectangle", "-4.32743e-007 -4.32743e-007 9.9 -5 -9.9 1.89158e-014 -4.32743e-007 9.9 0 -23.76 -1.03858e-006 0 0 0 0 1", D),
+        ("SuperRough", "cube", "1.04217 0.0182831 0 10.6769 -0.127982 0.148882 0 1.23376 0 0 4 0 0 0 0 1", SUPER),
+    ]
+    quads, names = [], []
+    for name, kind, m, mi in shapes:
+        qs = rectangle(_mat(m), mats[mi][1:4]) if kind == "rectangle" else cube(_mat(m), mats[mi][1:4])
+        for q in qs:
+            q[22] = np.float32(mi)
+        quads += qs
+        names += [name] * len(qs)
+    spheres = [sphere((0, 6.5, -2.8), 1.0, N0, (7.59909,) * 3), sphere((0, 6.5, 0), 0.5, N0, (30.3964,) * 3),
+               sphere((0, 6.5, 2.7), 0.05, N0, (3039.64,) * 3)]
+    cam = make_camera(_mat("-4.37113e-008 0 -1 28.2792 0 1 0 3.5 1 0 -4.37113e-008 1.23612e-006 0 0 0 1"), 35.0, width, height)
+    return _finish(quads, cam, max_depth, rr_depth, names, spheres, mats)
+
+
 def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None) -> Scene:
     """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world matrix, film size),
     twosided/diffuse bsdfs with rgb reflectance (by id), rectangle/cube shapes with a to_world

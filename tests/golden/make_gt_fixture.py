@@ -22,7 +22,13 @@ def main():
     assert img.shape == (1024, 1024, 3)
     small = img.reshape(256, 4, 256, 4, 3).astype(np.float64).mean(axis=(1, 3))
     np.save(os.path.join(HERE, "cornell_gt_256_f16.npy"), small.astype(np.float16))
-    print("mean radiance", img.mean(), "->", small.mean())
+    print("cornell-box mean radiance", img.mean(), "->", small.mean())
+    # veach-mis: 1280x720 -> 320x180.  The lamps exceed the float16 range: clamp at 60000 (three pixels)
+    img = exr.read_rgb(os.path.join(ref, "scenes", "veach-mis", "TungstenRender.exr"))
+    assert img.shape == (720, 1280, 3)
+    small = img.reshape(180, 4, 320, 4, 3).astype(np.float64).mean(axis=(1, 3))
+    np.save(os.path.join(HERE, "veach_mis_gt_320x180_f16.npy"), np.minimum(small, 60000.0).astype(np.float16))
+    print("veach-mis mean radiance", img.mean(), "->", small.mean(), "max", small.max())
 
 
 if __name__ == "__main__":
