@@ -1,13 +1,16 @@
 /*
  * pg_oracle_render.h -- TEST INFRASTRUCTURE.  CPU restatement of PathGuidingIntegrator.sample()
- * (src/path_guiding_integrator.py:126-431) over a minimal renderer substrate (quads, twosided
- * diffuse BSDFs, one-sided area emitters, perspective camera) that stands in for the Mitsuba 3
- * calls the reference makes (scene.ray_intersect, sample_emitter_direction, bsdf.sample, ...).
+ * (src/path_guiding_integrator.py:126-431) over a minimal renderer substrate (quads and spheres,
+ * twosided diffuse and Beckmann rough-conductor BSDFs, one-sided area emitters, perspective
+ * camera) that stands in for the Mitsuba 3 calls the reference makes (scene.ray_intersect,
+ * sample_emitter_direction, bsdf.sample, ...) in scenes/cornell-box and scenes/veach-mis.
  *
  * PARITY UNPINNED for the substrate: Mitsuba is third-party and absent; the
  * formulas below follow Mitsuba 3's documented behaviour (concentric-disk cosine sampling,
- * area-light solid-angle pdf, Duff et al. frame) but cannot be checked against it here.
- * The integrator loop itself follows the reference line by line.
+ * area-light solid-angle pdf, Duff et al. frame, cone sampling of spheres, visible-normal Beckmann
+ * sampling) but cannot be checked against it here.  What they are checked against: closed-form
+ * direct light, and the reference's ground-truth images of both scenes (tests/test_oracle_substrate.py,
+ * tests/test_host_logic.py).  The integrator loop itself follows the reference line by line.
  */
 #ifndef PG_ORACLE_RENDER_H
 #define PG_ORACLE_RENDER_H

@@ -2,8 +2,9 @@
 // PathGuidingIntegrator.sample() (src/path_guiding_integrator.py:126-431) does per pass, with the
 // Mitsuba calls it makes (scene.ray_intersect :185, emitter eval/pdf :189-198,
 // sample_emitter_direction :213, bsdf.eval_pdf/sample :220, 272, 304, si.to_local/to_world/spawn_ray
-// :219, 277, 352, sampler.next_1d/2d) implemented for the scene subset of scenes/cornell-box:
-// quads, twosided diffuse BSDFs, one-sided area emitters, perspective camera.
+// :219, 277, 352, sampler.next_1d/2d) implemented for the scene subset of scenes/cornell-box
+// (quads, twosided diffuse BSDFs, a one-sided area emitter, perspective camera) and, in the
+// kGeneral instantiations, of scenes/veach-mis (spheres, several emitters, Beckmann rough conductors).
 //
 // One kernel per bounce over the live rays; the SD-tree queries are the same device functions the
 // stand-alone query kernels use, so a bounce costs one KD descent and at most two quadtree descents

@@ -1,10 +1,11 @@
-"""Scene description for the renderer substrate: quads (rectangles and cube faces) with twosided
-diffuse BSDFs, one-sided area emitters and a perspective camera -- the subset of Mitsuba 3 scene
-XML that scenes/cornell-box/scene.xml of the reference uses.
+"""Scene description for the renderer substrate: quads (rectangles and cube faces) and spheres,
+twosided diffuse and Beckmann rough-conductor BSDFs in a material table, one-sided area emitters on
+rectangles and spheres, a perspective camera -- the subset of Mitsuba 3 scene XML that
+scenes/cornell-box/scene.xml and scenes/veach-mis/scene.xml of the reference use.
 
 `load_xml(path)` parses that subset from a Mitsuba 3 XML file (e.g. the reference's own scene
-files, when they are available); `cornell_box()` builds the same scene from its numeric
-parameters so that tests and the benchmark do not need the file.
+files, when they are available); `cornell_box()` and `veach_mis()` build the same scenes from their
+numeric parameters so that tests and the benchmark do not need the files.
 
 This module is plain data preparation (numpy); it is shared by the product and by the tests
 that feed the same arrays to the CPU oracle.
