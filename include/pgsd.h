@@ -286,6 +286,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
  * pixel + its first two sampler draws, which the kernel recomputes.  image_out: Color3f[W*H] planar,
  * sum(w L) / sum(w) over the samples of the pixel's 3x3 neighbourhood, summed in a fixed order. */
 int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream);
+/* The same with a choice of filter: PG_FILTER_TENT, or PG_FILTER_GAUSSIAN = Mitsuba's default
+ * gaussian (stddev 0.5, radius 2, w(d) = max(0, exp(-2 d^2) - exp(-8)) per axis; 5x5 neighbourhood),
+ * the film of scenes/torus/scene.xml:46. */
+#define PG_FILTER_TENT 0
+#define PG_FILTER_GAUSSIAN 1
+int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream);
 
 /* Element-wise evaluation of the library's own fp32 transcendental functions (fixed
  * sequences of double operations, no vendor math library), so that a caller -- the parity tests --

@@ -522,11 +522,16 @@ def bsdf_sample(material, wi, u1, u2):
 
 def film_tent(seed, spp, width, height, L):
     """hdrfilm + tent rfilter reconstruction of one full-frame pass (pgo_film_tent); returns (3, H*W)."""
+    return film("tent", seed, spp, width, height, L)
+
+
+def film(rfilter, seed, spp, width, height, L):
+    """hdrfilm reconstruction of one full-frame pass with the `tent` or `gaussian` rfilter (pgo_film)."""
     lb = lib()
-    lb.pgo_film_tent.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
-    lb.pgo_film_tent.restype = None
+    lb.pgo_film.argtypes = [C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P, _P]
+    lb.pgo_film.restype = None
     L = np.ascontiguousarray(L, np.float32)
     assert L.shape == (3, width * height * spp)
     out = np.zeros((3, width * height), np.float32)
-    lb.pgo_film_tent(int(seed) & 0xFFFFFFFF, int(spp), int(width), int(height), _ptr(L), _ptr(out))
+    lb.pgo_film(("tent", "gaussian").index(rfilter), int(seed) & 0xFFFFFFFF, int(spp), int(width), int(height), _ptr(L), _ptr(out))
     return out

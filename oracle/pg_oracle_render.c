@@ -686,13 +686,27 @@ static float tent1(float d)
  * samples of its 3x3 neighbourhood (rows, then columns, then samples, in ascending order) */
 void pgo_film_tent(uint32_t seed, int32_t spp, int32_t width, int32_t height, const float *L, float *image_out)
 {
+	pgo_film(0, seed, spp, width, height, L, image_out);
+}
+
+/* Mitsuba's gaussian rfilter (hdrfilm's default; scenes/torus/scene.xml:46): stddev 0.5, radius
+ * 4 stddev = 2, w(d) = max(0, exp(-d^2 / (2 stddev^2)) - exp(-radius^2 / (2 stddev^2))) */
+static float gauss1(float d)
+{
+	const float a = pgo_exp(-2.0f * (d * d)) - pgo_exp(-8.0f);
+	return a > 0.0f ? a : 0.0f;
+}
+
+void pgo_film(int32_t filter, uint32_t seed, int32_t spp, int32_t width, int32_t height, const float *L, float *image_out)
+{
 	const size_t npix = (size_t)width * (size_t)height, N = npix * (size_t)spp;
+	const int32_t R = filter == 1 ? 2 : 1; /* pixels a sample can reach on either side */
 	for (int32_t y = 0; y < height; ++y)
 		for (int32_t x = 0; x < width; ++x) {
 			float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
 			const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
-			for (int32_t ny = y - 1; ny <= y + 1; ++ny)
-				for (int32_t nx = x - 1; nx <= x + 1; ++nx) {
+			for (int32_t ny = y - R; ny <= y + R; ++ny)
+				for (int32_t nx = x - R; nx <= x + R; ++nx) {
 					if (nx < 0 || ny < 0 || nx >= width || ny >= height) continue;
 					const size_t pix = (size_t)ny * (size_t)width + (size_t)nx;
 					for (int32_t s = 0; s < spp; ++s) {
@@ -700,7 +714,8 @@ void pgo_film_tent(uint32_t seed, int32_t spp, int32_t width, int32_t height, co
 						pgo_pcg32 rng;
 						pgo_pcg32_seed(&rng, seed, (uint32_t)lane);
 						const float jx = pgo_pcg32_next_f32(&rng), jy = pgo_pcg32_next_f32(&rng);
-						const float w = tent1(cx - ((float)nx + jx)) * tent1(cy - ((float)ny + jy));
+						const float ddx = cx - ((float)nx + jx), ddy = cy - ((float)ny + jy);
+						const float w = filter == 1 ? gauss1(ddx) * gauss1(ddy) : tent1(ddx) * tent1(ddy);
 						acc[0] = acc[0] + w * L[lane];
 						acc[1] = acc[1] + w * L[N + lane];
 						acc[2] = acc[2] + w * L[2 * N + lane];

@@ -86,6 +86,9 @@ void pgo_bsdf_sample(const float *m, const float wi[3], float u1, float u2, floa
  * and the image is sum(w L) / sum(w).  L: Color3f[W*H*spp] planar; image_out: Color3f[W*H] planar.
  * Third-party behaviour (hdrfilm + ImageBlock::put), unpinned like the rest of the substrate. */
 void pgo_film_tent(uint32_t seed, int32_t spp, int32_t width, int32_t height, const float *L, float *image_out);
+/* filter 0: tent (as above); 1: Mitsuba's default gaussian (stddev 0.5, radius 2: 5x5 neighbourhood,
+ * w(d) = max(0, exp(-2 d^2) - exp(-8)) per axis), the film of scenes/torus/scene.xml:46 */
+void pgo_film(int32_t filter, uint32_t seed, int32_t spp, int32_t width, int32_t height, const float *L, float *image_out);
 
 #ifdef __cplusplus
 }

@@ -102,7 +102,7 @@ EXPORTS = (
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
-    "pg_math_eval", "pg_scene_set_ex",
+    "pg_math_eval", "pg_scene_set_ex", "pg_film",
 )
 
 
@@ -166,6 +166,7 @@ def lib() -> C.CDLL:
     L.pg_read_kernel_timing.argtypes = [V, C.POINTER(pg_kernel_timing), I32]
     L.pg_render_live_counts.argtypes = [V, C.POINTER(C.c_uint32), I32]
     L.pg_film_tent.argtypes = [V, U32, I32, V, V, V]
+    L.pg_film.argtypes = [V, I32, U32, I32, V, V, V]
     L.pg_math_eval.argtypes = [V, I32, U64, V, V, V]
     L.pg_scene_set_ex.argtypes = [V, C.POINTER(pg_scene_desc), C.POINTER(pg_camera)]
     for name in EXPORTS:

@@ -141,6 +141,8 @@ int pg_setup(pg_context *ctx, const float bbox_min[3], const float bbox_max[3], 
 	if (!bbox_min || !bbox_max) return fail(ctx, PG_ERR_INVALID, "pg_setup: NULL bbox");
 	if (kd_max_depth < 0 || kd_max_depth > kMaxLevels - 2 || quad_max_depth < 0 || quad_max_depth > kMaxLevels - 2)
 		return fail(ctx, PG_ERR_INVALID, "pg_setup: tree depth limits must be in [0,30]");
+	for (int a = 0; a < 3; ++a)
+		if (!(bbox_min[a] <= bbox_max[a])) return fail(ctx, PG_ERR_INVALID, "pg_setup: bbox_min must be <= bbox_max (and not NaN)");
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	for (int a = 0; a < 3; ++a) { ctx->bmin[a] = bbox_min[a]; ctx->bmax[a] = bbox_max[a]; }
 	ctx->num_rays = num_rays;

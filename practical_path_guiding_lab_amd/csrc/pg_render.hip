@@ -815,24 +815,34 @@ __device__ __forceinline__ float tent1(float d)
 // hdrfilm with <rfilter type="tent"/>: gather form of ImageBlock::put -- pixel (x,y) collects the
 // samples of its 3x3 neighbourhood (rows, then columns, then samples, ascending), so the sums have
 // one order and need no atomics.  The film position of a sample is recomputed from its stream.
-__global__ __launch_bounds__(kRBlock) void k_film_tent(uint32_t seed, int spp, int W, int H,
-                                                       const float *__restrict__ L, float *__restrict__ out)
+// Mitsuba's gaussian rfilter (hdrfilm's default, scenes/torus/scene.xml:46): stddev 0.5, radius 2
+__device__ __forceinline__ float gauss1(float d)
 {
+	const float a = exp_f32(-2.0f * (d * d)) - exp_f32(-8.0f);
+	return a > 0.0f ? a : 0.0f;
+}
+
+template <int kFilter> // 0 tent (3x3 neighbourhood), 1 gaussian (5x5)
+__global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W, int H,
+                                                  const float *__restrict__ L, float *__restrict__ out)
+{
+	constexpr int R = kFilter == 1 ? 2 : 1;
 	const uint64_t npix = (uint64_t)W * (uint64_t)H, N = npix * (uint64_t)spp;
 	const uint64_t o = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	if (o >= npix) return;
 	const int x = (int)(o % (uint64_t)W), y = (int)(o / (uint64_t)W);
 	const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
 	float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;
-	for (int ny = y - 1; ny <= y + 1; ++ny)
-		for (int nx = x - 1; nx <= x + 1; ++nx) {
+	for (int ny = y - R; ny <= y + R; ++ny)
+		for (int nx = x - R; nx <= x + R; ++nx) {
 			if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
 			const uint64_t pix = (uint64_t)ny * (uint64_t)W + (uint64_t)nx;
 			for (int s = 0; s < spp; ++s) {
 				const uint64_t lane = pix * (uint64_t)spp + (uint64_t)s;
 				Pcg32 rng = pcg32_seed(seed, (uint32_t)lane);
 				const float jx = rng.next_f32(), jy = rng.next_f32();
-				const float w = tent1(cx - ((float)nx + jx)) * tent1(cy - ((float)ny + jy));
+				const float ddx = cx - ((float)nx + jx), ddy = cy - ((float)ny + jy);
+				const float w = kFilter == 1 ? gauss1(ddx) * gauss1(ddy) : tent1(ddx) * tent1(ddy);
 				a0 = a0 + w * L[lane];
 				a1 = a1 + w * L[N + lane];
 				a2 = a2 + w * L[2 * N + lane];
@@ -1086,14 +1096,23 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 
 int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)
 {
+	return pg_film(ctx, PG_FILTER_TENT, seed, spp, L, image_out, stream);
+}
+
+int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)
+{
 	if (!ctx) return PG_ERR_INVALID;
-	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_film_tent: call pg_scene_set first");
-	if (!L || !image_out || spp <= 0) return fail(ctx, PG_ERR_INVALID, "pg_film_tent: NULL pointer or spp <= 0");
+	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_film: call pg_scene_set first");
+	if (!L || !image_out || spp <= 0) return fail(ctx, PG_ERR_INVALID, "pg_film: NULL pointer or spp <= 0");
+	if (filter != PG_FILTER_TENT && filter != PG_FILTER_GAUSSIAN) return fail(ctx, PG_ERR_INVALID, "pg_film: unknown filter");
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	const pg_camera &cam = ctx->render->cam;
 	const uint64_t npix = (uint64_t)cam.width * (uint64_t)cam.height;
-	hipLaunchKernelGGL(k_film_tent, dim3((unsigned)((npix + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, (hipStream_t)stream,
-	                   seed, spp, cam.width, cam.height, L, image_out);
+	const dim3 grid((unsigned)((npix + kRBlock - 1) / kRBlock));
+	if (filter == PG_FILTER_GAUSSIAN)
+		hipLaunchKernelGGL(k_film<1>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out);
+	else
+		hipLaunchKernelGGL(k_film<0>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out);
 	PG_HIP(ctx, hipGetLastError());
 	return PG_OK;
 }

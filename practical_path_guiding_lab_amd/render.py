@@ -105,10 +105,11 @@ def render(scene: WavefrontScene, integrator, spp: int, seed: int) -> torch.Tens
     sampler = IndependentSampler(spp, seed)
     L, _, _ = integrator.sample(scene, sampler)
     w, h = scene.film_size
-    if scene.scene.rfilter == "tent" and scene.pixel_range is None:
+    if scene.scene.rfilter in ("tent", "gaussian") and scene.pixel_range is None:
         tree = integrator.sdTree
         img = torch.empty((3, h * w), dtype=torch.float32, device=tree.device)
-        N.check(tree._h, tree._lib.pg_film_tent(tree._h, sampler.seed_value & 0xFFFFFFFF, spp, L.data_ptr(), img.data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream))
+        N.check(tree._h, tree._lib.pg_film(tree._h, ("tent", "gaussian").index(scene.scene.rfilter),
+                                           sampler.seed_value & 0xFFFFFFFF, spp, L.data_ptr(), img.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
         return img.reshape(3, h, w).permute(1, 2, 0).contiguous()
     return L.reshape(3, h, w, spp).mean(dim=3).permute(1, 2, 0).contiguous()

@@ -292,6 +292,6 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials)
     rf = film.find("rfilter")
     sc.rfilter = rf.get("type") if rf is not None else "gaussian"  # hdrfilm's default
-    if sc.rfilter not in ("tent", "box"):
+    if sc.rfilter not in ("tent", "box", "gaussian"):
         raise ValueError(f"unsupported rfilter type {sc.rfilter}")
     return sc

@@ -1,0 +1,114 @@
+"""Error behaviour at the C ABI on a live device: every misuse returns a negative status and leaves a
+message in pg_last_error, nothing is launched, the context stays usable.  (The two Python
+exceptions of the reference, path_guiding_integrator.py:35-41, live in the Python mirror and are
+covered by tests/test_host_logic.py.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx():
+    from practical_path_guiding_lab_amd import _native as N
+
+    L = N.lib()
+    h = C.c_void_p()
+    assert L.pg_create(C.byref(h), 0) == 0
+    yield N, L, h
+    L.pg_destroy(h)
+
+
+def _msg(L, h):
+    return L.pg_last_error(h).decode()
+
+
+def test_calls_before_setup_and_bad_arguments(ctx):
+    import torch
+
+    N, L, h = ctx
+    x = torch.zeros((3, 8), device="cuda")
+    out = torch.zeros(8, device="cuda")
+    # queries and recording need a configured tree
+    assert L.pg_pdf(h, 8, x.data_ptr(), x.data_ptr(), None, out.data_ptr(), None) < 0
+    assert "pg_setup" in _msg(L, h)
+    assert L.pg_refine_and_swap(h, None) < 0
+    lo, hi = (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1)
+    assert L.pg_setup(h, hi, lo, 16, 4, 20, 20, 1, 0.5) < 0          # inverted bounding box
+    assert L.pg_setup(h, lo, hi, 16, 4, -1, 20, 1, 0.5) < 0           # tree depth limits are in [0, 30]
+    assert L.pg_setup(h, lo, hi, 16, 4, 20, 31, 1, 0.5) < 0
+    assert L.pg_setup(h, lo, hi, 16, 4, 20, 20, 1, 0.5) == 0
+    # NULL arrays with a non-zero count
+    assert L.pg_pdf(h, 8, None, x.data_ptr(), None, out.data_ptr(), None) < 0
+    assert L.pg_sample(h, 8, x.data_ptr(), None, None, None, x.data_ptr(), out.data_ptr(), None) < 0
+    # empty batches are fine
+    assert L.pg_pdf(h, 0, None, None, None, None, None) == 0
+    # the context still works
+    assert L.pg_pdf(h, 8, x.data_ptr(), x.data_ptr(), None, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    # NULL context
+    assert L.pg_pdf(None, 8, x.data_ptr(), x.data_ptr(), None, out.data_ptr(), None) < 0
+
+
+def test_scene_and_render_pass_misuse(ctx):
+    import torch
+    from practical_path_guiding_lab_amd import scene as S
+
+    N, L, h = ctx
+    lo, hi = (C.c_float * 3)(-2, -1, -2), (C.c_float * 3)(2, 3, 2)
+    assert L.pg_setup(h, lo, hi, 64, 4, 20, 20, 1, 0.5) == 0
+    sc = S.cornell_box(8, 8, 4, 8)
+    cam = N.pg_camera()
+    for k in ("origin", "axis_x", "axis_y", "axis_z"):
+        setattr(cam, k, (C.c_float * 3)(*[float(v) for v in getattr(sc.camera, k)]))
+    cam.tan_half_fov_x, cam.width, cam.height = float(sc.camera.tan_half_fov_x), 8, 8
+    prm = N.pg_pass_params(1, 1, 8, 0, 0, 0)
+    Lout = torch.zeros((3, 64), device="cuda")
+    assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, None, None, None) < 0
+    assert "pg_scene_set" in _msg(L, h)
+    q = np.ascontiguousarray(sc.quads, np.float32)
+    assert L.pg_scene_set(h, 0, q.ctypes.data, C.byref(cam)) < 0                      # no shapes
+    assert L.pg_scene_set(h, 5000, q.ctypes.data, C.byref(cam)) < 0                   # more than 4096 quads
+    bad_cam = N.pg_camera()
+    C.memmove(C.byref(bad_cam), C.byref(cam), C.sizeof(cam))
+    bad_cam.width = 0
+    assert L.pg_scene_set(h, q.shape[0], q.ctypes.data, C.byref(bad_cam)) < 0
+    # material table: index out of range, unknown type, spheres without materials, bad radius, alpha <= 0
+    mats = np.stack([S.diffuse_material((0.5, 0.5, 0.5)), S.roughconductor_material(0.1, (0.2, 0.9, 1.1), (3.9, 2.4, 2.1))])
+    q2 = q.copy()
+    q2[:, 22] = 7
+    d = N.pg_scene_desc(q2.shape[0], q2.ctypes.data, 0, None, 2, mats.ctypes.data)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "material index" in _msg(L, h)
+    m3 = mats.copy()
+    m3[0, 0] = 9
+    q2[:, 22] = 0
+    d = N.pg_scene_desc(q2.shape[0], q2.ctypes.data, 0, None, 2, m3.ctypes.data)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "material type" in _msg(L, h)
+    m4 = mats.copy()
+    m4[1, 4] = 0.0
+    d = N.pg_scene_desc(q2.shape[0], q2.ctypes.data, 0, None, 2, m4.ctypes.data)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "alpha" in _msg(L, h)
+    sph = S.sphere((0, 1, 0), 0.2, 0)[None].copy()
+    d = N.pg_scene_desc(q.shape[0], q.ctypes.data, 1, sph.ctypes.data, 0, None)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "material table" in _msg(L, h)
+    sph[0, 3] = -1.0
+    d = N.pg_scene_desc(q2.shape[0], q2.ctypes.data, 1, sph.ctypes.data, 2, mats.ctypes.data)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "radius" in _msg(L, h)
+    # a good scene, then pass parameters
+    assert L.pg_scene_set(h, q.shape[0], q.ctypes.data, C.byref(cam)) == 0
+    for bad in (N.pg_pass_params(1, 0, 8, 0, 0, 0), N.pg_pass_params(1, 1, 8, 0, 65, 0), N.pg_pass_params(1, 1, 8, 0, 10, 60)):
+        assert L.pg_render_pass(h, C.byref(bad), Lout.data_ptr(), None, None, None, None) < 0
+    s1 = torch.zeros((3, 64), device="cuda")
+    assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, s1.data_ptr(), None, None) < 0   # sumL without sumL2
+    assert L.pg_render_pass(h, C.byref(prm), None, None, None, None, None) < 0
+    assert L.pg_film_tent(h, 1, 0, Lout.data_ptr(), Lout.data_ptr(), None) < 0
+    assert L.pg_math_eval(h, 9, 4, Lout.data_ptr(), Lout.data_ptr(), None) < 0
+    # and the good call still works afterwards
+    assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, None, None, None) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(Lout).all()) and float(Lout.sum()) > 0
+    live = (C.c_uint32 * 4)()
+    assert L.pg_render_live_counts(h, live, 4) == 0 and live[3] == 0 and live[0] > 0

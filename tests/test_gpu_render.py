@@ -242,6 +242,12 @@ def test_tent_film_matches_the_oracle_bit_for_bit():
     g2.setIteration(0, True)
     out = render(WavefrontScene(sc), g2, spp, seed).cpu().numpy()
     np.testing.assert_array_equal(out.view(np.uint32), exp.reshape(3, h, w).transpose(1, 2, 0).view(np.uint32))
+    # the gaussian film (hdrfilm's default; scenes/torus/scene.xml:46): 5x5 neighbourhood
+    gimg = torch.empty((3, w * h), dtype=torch.float32, device="cuda")
+    N.check(t._h, t._lib.pg_film(t._h, 1, seed, spp, L.data_ptr(), gimg.data_ptr(), None))
+    gexp = po.film("gaussian", seed, spp, w, h, L.cpu().numpy())
+    np.testing.assert_array_equal(gimg.cpu().numpy().view(np.uint32), gexp.view(np.uint32))
+    assert not np.array_equal(gexp, exp) and abs(gexp.mean() - exp.mean()) < 0.05 * exp.mean()
     # a box film is the per-pixel mean
     sc.rfilter = "box"
     g3 = PathGuidingIntegrator({"max_depth": 4})

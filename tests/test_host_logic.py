@@ -34,7 +34,9 @@ def test_xml_subset_parser(tmp_path):
     assert sc.quads.shape == (1 + 6 + 1, S.QUAD_STRIDE) and sc.max_depth == 5 and sc.rr_depth == 3
     assert (sc.camera.width, sc.camera.height) == (32, 16) and sc.rfilter == "box"
     p2 = tmp_path / "gauss.xml"
-    p2.write_text(XML.replace('<rfilter type="box" />', ""))  # hdrfilm's default filter is a gaussian: not built
+    p2.write_text(XML.replace('<rfilter type="box" />', ""))  # hdrfilm's default filter is a gaussian
+    assert S.load_xml(str(p2)).rfilter == "gaussian"
+    p2.write_text(XML.replace('type="box"', 'type="mitchell"'))
     with pytest.raises(ValueError):
         S.load_xml(str(p2))
     assert abs(float(sc.camera.tan_half_fov_x) - np.tan(np.radians(20.0))) < 1e-6
@@ -234,6 +236,19 @@ def test_oracle_tent_film_known_answers():
             assert abs(out[0, y, x] - expect) <= 1e-5 * max(expect, 1e-3), (x, y)
     assert (out[0] > 0).sum() in (1, 2, 4) and out[0, 2, 3] > 0  # at most a 2x2 footprint, its own pixel included
     np.testing.assert_allclose(out[1], out[0] * 0.5, rtol=1e-6)
+    # the gaussian film (stddev 0.5, radius 2): same construction, a footprint of up to 4x4 pixels
+    g = po.film("gaussian", seed, spp, w, h, L).reshape(3, h, w)
+
+    def gw(d):
+        return np.maximum(0.0, np.exp(-2.0 * d * d) - np.exp(-8.0))
+
+    for y in range(h):
+        for x in range(w):
+            wgt = gw(x + 0.5 - px) * gw(y + 0.5 - py)
+            expect = 8.0 * gw(x + 0.5 - sx) * gw(y + 0.5 - sy) / wgt.sum()
+            assert abs(g[0, y, x] - expect) <= 2e-5 * max(expect, 1e-3), (x, y)
+    assert 4 < (g[0] > 0).sum() <= 16
+    np.testing.assert_allclose(po.film("gaussian", seed, spp, w, h, np.full((3, n), 0.25, np.float32)), 0.25, rtol=2e-6)
 
 
 def test_oracle_render_converges_to_the_tungsten_ground_truth():
