@@ -283,8 +283,7 @@ def cpu_baseline_render(args, tree, sc_full):
     sc = make_scene(args, args.cpu_res)
     spp = args.spp_per_pass
     t0 = time.perf_counter()
-    po.render_pass(pair, sc.quads, sc.camera, args.depth, 8, args.train_iters, False, 12345, spp, True, 0.5,
-                   spheres=sc.spheres, materials=sc.materials)
+    po.render_pass(pair, sc, sc.camera, args.depth, 8, args.train_iters, False, 12345, spp, True, 0.5)
     dt = time.perf_counter() - t0
     n = sc.camera.width * sc.camera.height * spp
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",

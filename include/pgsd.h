@@ -234,6 +234,11 @@ int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t
 /* material: 0 type (0 twosided diffuse; 1 twosided roughconductor, beckmann, sample_visible)
  *   1-3 reflectance | specular_reflectance  4 alpha  5-7 eta  8-10 k  11 unused */
 #define PG_MATERIAL_STRIDE 12
+/* box (Mitsuba's `cube`: [-1,1]^3 under an affine to_world), intersected as three slabs in its local
+ * frame instead of six quads: 0-8 rows of A = (linear part of to_world)^-1, 9-11 centre c
+ * (local = A (p - c)), 12-20 outward unit normals of the +x, +y, +z faces (the normalised rows
+ * of A), 21 material index, 22-31 unused by the library */
+#define PG_BOX_STRIDE 32
 typedef struct pg_camera {
 	float origin[3];
 	float axis_x[3], axis_y[3], axis_z[3]; /* columns of the sensor's to_world rotation */
@@ -254,6 +259,8 @@ typedef struct pg_scene_desc {
 	const float *spheres;   /* PG_SPHERE_STRIDE floats each */
 	uint64_t n_materials;
 	const float *materials; /* PG_MATERIAL_STRIDE floats each */
+	uint64_t n_boxes;
+	const float *boxes;     /* PG_BOX_STRIDE floats each; need a material table */
 } pg_scene_desc;
 int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *scene, const pg_camera *cam);
 

@@ -464,25 +464,34 @@ class _RenderParams(C.Structure):
 
 class _Scene(C.Structure):
     _fields_ = [("n_quads", C.c_size_t), ("quads", C.c_void_p), ("n_spheres", C.c_size_t), ("spheres", C.c_void_p),
-                ("n_materials", C.c_size_t), ("materials", C.c_void_p)]
+                ("n_materials", C.c_size_t), ("materials", C.c_void_p), ("n_boxes", C.c_size_t), ("boxes", C.c_void_p)]
 
 
 def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, iteration, is_final, seed, spp=1,
-                store_nee=True, bsdf_sampling_fraction=0.5, sumL=None, sumL2=None, spheres=None, materials=None):
+                store_nee=True, bsdf_sampling_fraction=0.5, sumL=None, sumL2=None, spheres=None, materials=None,
+                boxes=None):
     """One pass of PathGuidingIntegrator.sample() (path_guiding_integrator.py:126-431) on the CPU.
+    quads: (Q,24) array, or a scene object with .quads/.spheres/.materials/.boxes (then all its shapes are used).
     cam: object with origin/axis_x/axis_y/axis_z/tan_half_fov_x/width/height.  Returns (L (3,N), valid (N,)).
-    spheres (S,12) / materials (M,12): the optional parts of pgo_scene (pg_oracle_render.h)."""
+    spheres (S,12) / materials (M,12) / boxes (B,32): the optional parts of pgo_scene (pg_oracle_render.h)."""
     L = lib()
     L.pgo_render_pass_scene.argtypes = [_P, _P, C.POINTER(_Scene), C.POINTER(_Camera), C.POINTER(_RenderParams), _P, _P, _P, _P]
     L.pgo_render_pass_scene.restype = None
+    if hasattr(quads, "quads"):  # a scene object (practical_path_guiding_lab_amd.scene.Scene): all of its shapes
+        scene_obj = quads
+        quads = scene_obj.quads
+        spheres = scene_obj.spheres if spheres is None else spheres
+        materials = scene_obj.materials if materials is None else materials
+        boxes = scene_obj.boxes if boxes is None else boxes
     quads = np.ascontiguousarray(quads, np.float32).reshape(-1, 24)
     spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros((0, 12)), np.float32).reshape(-1, 12)
     mats = None if materials is None else np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
-    if mats is None and spheres.shape[0]:
-        raise ValueError("spheres need a material table")
+    boxes = np.ascontiguousarray(boxes if boxes is not None else np.zeros((0, 32)), np.float32).reshape(-1, 32)
+    if mats is None and (spheres.shape[0] or boxes.shape[0]):
+        raise ValueError("spheres and boxes need a material table")
     sc = _Scene(quads.shape[0], quads.ctypes.data if quads.size else None, spheres.shape[0],
                 spheres.ctypes.data if spheres.size else None, 0 if mats is None else mats.shape[0],
-                None if mats is None else mats.ctypes.data)
+                None if mats is None else mats.ctypes.data, boxes.shape[0], boxes.ctypes.data if boxes.size else None)
     c = _Camera()
     for k in ("origin", "axis_x", "axis_y", "axis_z"):
         setattr(c, k, (C.c_float * 3)(*[float(v) for v in getattr(cam, k)]))

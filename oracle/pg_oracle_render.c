@@ -103,8 +103,44 @@ static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 		const float t = (float)(x0 > 0.0 ? x0 : x1);
 		if (t > 0.0f && t < bt) { bt = t; best = (int)(nq + s); }
 	}
+	/* boxes: three slabs in the box's local frame (t is the same in both frames: A is linear) */
+	for (size_t b = 0; b < sc->n_boxes; ++b) {
+		const float *B = sc->boxes + b * PGO_BOX_STRIDE;
+		const v3 oc = vsub(o, ld3(B + 9));
+		const float ol[3] = { dot3(ld3(B), oc), dot3(ld3(B + 3), oc), dot3(ld3(B + 6), oc) };
+		const float dl[3] = { dot3(ld3(B), d), dot3(ld3(B + 3), d), dot3(ld3(B + 6), d) };
+		float tn = -INFINITY, tf = INFINITY;
+		int an = 0, af = 0, miss = 0;
+		for (int k = 0; k < 3; ++k) {
+			if (dl[k] == 0.0f) { /* parallel to this slab: inside it or never */
+				if (!(ol[k] >= -1.0f && ol[k] <= 1.0f)) miss = 1;
+				continue;
+			}
+			const float inv = 1.0f / dl[k];
+			const float t1 = (-1.0f - ol[k]) * inv, t2 = (1.0f - ol[k]) * inv;
+			const float lo = dl[k] > 0.0f ? t1 : t2, hi = dl[k] > 0.0f ? t2 : t1;
+			if (lo > tn) { tn = lo; an = k; }
+			if (hi < tf) { tf = hi; af = k; }
+		}
+		if (miss || !(tn <= tf)) continue;
+		const int entering = tn > 0.0f;
+		const float t = entering ? tn : tf;
+		if (!(t > 0.0f && t < bt)) continue;
+		/* the face crossed: entering through the side that faces the ray, leaving through the one it points to */
+		const int axis = entering ? an : af;
+		const int negative = entering ? dl[axis] > 0.0f : dl[axis] < 0.0f;
+		bt = t;
+		best = (int)(nq + sc->n_spheres + 6 * b) + 2 * axis + negative;
+	}
 	*t_out = bt;
 	return best;
+}
+
+/* outward unit normal of box face `face` (2 axis + negative) */
+static v3 box_face_normal(const float *B, int face)
+{
+	const v3 n = ld3(B + 12 + 3 * (face >> 1));
+	return (face & 1) ? V(-n.x, -n.y, -n.z) : n;
 }
 
 /* ---- surface description at a hit ---- */
@@ -135,6 +171,12 @@ static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
 		s.radiance = ld3(Q + 19);
 		if (!sc->materials) { s.m.type = 0; s.m.refl = ld3(Q + 16); return s; }
 		mi = (int)Q[22];
+	} else if ((size_t)prim >= sc->n_quads + sc->n_spheres) {
+		const size_t f = (size_t)prim - sc->n_quads - sc->n_spheres;
+		const float *B = sc->boxes + (f / 6) * PGO_BOX_STRIDE;
+		s.p = vadd(o, vscale(d, t));
+		s.n = box_face_normal(B, (int)(f % 6));
+		mi = (int)B[21];
 	} else {
 		const float *S = sc->spheres + ((size_t)prim - sc->n_quads) * PGO_SPHERE_STRIDE;
 		const v3 c = ld3(S);
@@ -457,7 +499,7 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
                      const pgo_camera *cam, const pgo_render_params *prm, float *L_out, uint8_t *valid_out,
                      float *sumL, float *sumL2)
 {
-	const pgo_scene sc = { nq, quads, 0, NULL, 0, NULL };
+	const pgo_scene sc = { nq, quads, 0, NULL, 0, NULL, 0, NULL };
 	pgo_render_pass_scene(prev, current, &sc, cam, prm, L_out, valid_out, sumL, sumL2);
 }
 

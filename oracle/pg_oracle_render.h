@@ -35,7 +35,15 @@ extern "C" {
  *  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta  8-10 k  11 pad                 */
 #define PGO_MATERIAL_STRIDE 12
 
-/* Shapes are numbered quads first, then spheres; emitters in that order too.  Sphere support
+/* one box (Mitsuba's `cube` shape, [-1,1]^3 under an affine to_world), intersected as three slabs
+ * in its local frame instead of six quads:
+ *  0-8 rows of A = (linear part of to_world)^-1  9-11 centre c   (local = A (p - c))
+ *  12-20 outward unit normals of the +x, +y, +z faces (= normalised rows of A)
+ *  21 material index  22-31 pad                                                             */
+#define PGO_BOX_STRIDE 32
+
+/* Shapes are numbered quads first, then spheres, then box FACES (6 per box: 2 axis + (outward
+ * normal negative ? 1 : 0)); emitters are flagged quads, then flagged spheres.  Sphere support
  * follows Mitsuba 3's sphere.h as documented: double-precision quadratic, cone sampling of the
  * visible cap from outside (no emitter sampling from inside), one-sided emission. */
 typedef struct pgo_scene {
@@ -44,7 +52,9 @@ typedef struct pgo_scene {
 	size_t n_spheres;
 	const float *spheres;
 	size_t n_materials;
-	const float *materials; /* NULL: quad i is diffuse with quads[i][16..18] (and there are no spheres) */
+	const float *materials; /* NULL: quad i is diffuse with quads[i][16..18] (and there are no spheres or boxes) */
+	size_t n_boxes;
+	const float *boxes;
 } pgo_scene;
 
 typedef struct pgo_camera {

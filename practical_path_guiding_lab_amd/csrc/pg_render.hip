@@ -83,11 +83,20 @@ constexpr int kMaterialStride = 12;                     // PG_MATERIAL_STRIDE
 __device__ __forceinline__ float safe_sqrtf(float v) { return __builtin_sqrtf(v > 0.0f ? v : 0.0f); }
 __device__ __forceinline__ v3 normalize3(v3 v) { return vdivs(v, __builtin_sqrtf(dot3(v, v))); }
 
-// The shapes of a scene: quads, then spheres (shape number = quad index, or n_quads + sphere index)
+constexpr int kBoxStride = 32; // PG_BOX_STRIDE
+
+// The shapes of a scene: quads, then spheres, then box faces (shape number = quad index,
+// n_quads + sphere index, or n_quads + n_spheres + 6 box + 2 axis + (outward normal negative))
 struct Shapes {
-	const float *quads, *spheres;
-	int n_quads, n_spheres;
+	const float *quads, *spheres, *boxes;
+	int n_quads, n_spheres, n_boxes;
 };
+
+__device__ __forceinline__ v3 box_face_normal(const float *B, int face)
+{
+	const v3 n = ld3(B + 12 + 3 * (face >> 1));
+	return (face & 1) ? V(-n.x, -n.y, -n.z) : n;
+}
 
 // closest hit over all shapes, 0 < t < tmax (scene.ray_intersect / ray_test).  kGeneral = false is
 // the quad-only scene (cornell-box): the sphere loop and its double arithmetic are compiled out.
@@ -132,6 +141,38 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 			if (t > 0.0f && t < bt) { bt = t; best = nq + s; }
 		}
 	}
+	// boxes (Mitsuba `cube` shapes): three slabs in the box's local frame, one reciprocal per axis,
+	// instead of six quad tests (t is the same in both frames: the map is linear)
+	for (int b = 0; b < sh.n_boxes; ++b) {
+		const float *B = sh.boxes + b * kBoxStride;
+		const v3 oc = vsub(o, ld3(B + 9));
+		const float ol[3] = {dot3(ld3(B), oc), dot3(ld3(B + 3), oc), dot3(ld3(B + 6), oc)};
+		const float dl[3] = {dot3(ld3(B), d), dot3(ld3(B + 3), d), dot3(ld3(B + 6), d)};
+		float tn = -__builtin_huge_valf(), tf = __builtin_huge_valf();
+		int an = 0, af = 0;
+		bool miss = false;
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			if (dl[k] == 0.0f) { // parallel to this slab: inside it or never
+				if (!(ol[k] >= -1.0f && ol[k] <= 1.0f)) miss = true;
+				continue;
+			}
+			const float inv = 1.0f / dl[k];
+			const float t1 = (-1.0f - ol[k]) * inv, t2 = (1.0f - ol[k]) * inv;
+			const float lo = dl[k] > 0.0f ? t1 : t2, hi = dl[k] > 0.0f ? t2 : t1;
+			if (lo > tn) { tn = lo; an = k; }
+			if (hi < tf) { tf = hi; af = k; }
+		}
+		if (miss || !(tn <= tf)) continue;
+		const bool entering = tn > 0.0f;
+		const float t = entering ? tn : tf;
+		if (!(t > 0.0f && t < bt)) continue;
+		const int axis = entering ? an : af;
+		const float da = axis == 0 ? dl[0] : (axis == 1 ? dl[1] : dl[2]);
+		const int negative = entering ? (da > 0.0f) : (da < 0.0f);
+		bt = t;
+		best = nq + sh.n_spheres + 6 * b + 2 * axis + negative;
+	}
 	t_out = bt;
 	return best;
 }
@@ -153,7 +194,15 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 {
 	Surface s;
 	const float *M;
-	if (!kGeneral || prim < sh.n_quads) {
+	if (prim >= sh.n_quads + sh.n_spheres) { // a box face
+		const int f = prim - sh.n_quads - sh.n_spheres;
+		const float *B = sh.boxes + (f / 6) * kBoxStride;
+		s.p = vadd(o, vscale(d, t));
+		s.n = box_face_normal(B, f % 6);
+		s.is_em = false;
+		s.radiance = V(0, 0, 0);
+		M = mats + (int)B[21] * kMaterialStride;
+	} else if (!kGeneral || prim < sh.n_quads) {
 		const float *Q = sh.quads + prim * kQuadStride;
 		s.p = vadd(o, vscale(d, t));
 		s.n = ld3(Q + 9);
@@ -178,7 +227,7 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 		s.radiance = ld3(S + 6);
 		M = mats + (int)S[4] * kMaterialStride;
 	}
-	s.m.type = (int)M[0];
+	s.m.type = kGeneral ? (int)M[0] : 0; // a scene with a rough conductor anywhere runs the general kernels
 	s.m.refl = ld3(M + 1);
 	s.m.M = M;
 	return s;
@@ -188,6 +237,10 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 template <bool kGeneral>
 __device__ __forceinline__ v3 normal_at(const Shapes &sh, int prim, v3 p)
 {
+	if (prim >= sh.n_quads + sh.n_spheres) {
+		const int f = prim - sh.n_quads - sh.n_spheres;
+		return box_face_normal(sh.boxes + (f / 6) * kBoxStride, f % 6);
+	}
 	if (!kGeneral || prim < sh.n_quads) return ld3(sh.quads + prim * kQuadStride + 9);
 	return normalize3(vsub(p, ld3(sh.spheres + (prim - sh.n_quads) * kSphereStride)));
 }
@@ -861,9 +914,9 @@ using namespace pg;
 
 // library-owned renderer state
 struct pg_render_state {
-	DevBuf<float> quads, spheres, mats;
+	DevBuf<float> quads, spheres, mats, boxes;
 	DevBuf<int32_t> emitters;
-	int n_quads = 0, n_spheres = 0, n_emitters = 0;
+	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0;
 	bool general = false; // spheres or rough conductors present: the general kernels are launched
 	pg_camera cam;
 	bool have_scene = false;
@@ -922,6 +975,7 @@ int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const 
 	d.n_quads = n_quads; d.quads = h_quads;
 	d.n_spheres = 0; d.spheres = nullptr;
 	d.n_materials = 0; d.materials = nullptr;
+	d.n_boxes = 0; d.boxes = nullptr;
 	return pg_scene_set_ex(ctx, &d, cam);
 }
 
@@ -929,11 +983,11 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 {
 	if (!ctx) return PG_ERR_INVALID;
 	if (!sc || !cam) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: NULL pointer");
-	const uint64_t nq = sc->n_quads, ns = sc->n_spheres, nm = sc->n_materials;
-	if (nq + ns == 0 || nq > 4096 || ns > 4096 || (nq && !sc->quads) || (ns && !sc->spheres))
-		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: need 1..4096 quads and/or 1..4096 spheres");
-	if ((nm && !sc->materials) || (!sc->materials && ns))
-		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: spheres need a material table");
+	const uint64_t nq = sc->n_quads, ns = sc->n_spheres, nm = sc->n_materials, nb = sc->n_boxes;
+	if (nq + ns + nb == 0 || nq > 4096 || ns > 4096 || nb > 4096 || (nq && !sc->quads) || (ns && !sc->spheres) || (nb && !sc->boxes))
+		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: need 1..4096 quads, spheres and/or boxes");
+	if ((nm && !sc->materials) || (!sc->materials && (ns || nb)))
+		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: spheres and boxes need a material table");
 	if (cam->width <= 0 || cam->height <= 0) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: bad film size");
 	// host copies: material indices checked, a material table made up for scenes that come without one,
 	// the diffuse reflectance mirrored into the quads (the quad-only kernels read it there)
@@ -972,6 +1026,14 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: sphere material index out of range");
 		if (!(sc->spheres[s * kSphereStride + 3] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: sphere radius must be > 0");
 	}
+	for (uint64_t b = 0; b < nb; ++b) {
+		const float mi = sc->boxes[b * kBoxStride + 21];
+		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: box material index out of range");
+		for (int k = 0; k < 21; ++k)
+			if (!(sc->boxes[b * kBoxStride + k] == sc->boxes[b * kBoxStride + k]) || fabsf(sc->boxes[b * kBoxStride + k]) > 3.0e38f)
+				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: box transform is not finite");
+	}
 	std::vector<int32_t> em;
 	for (uint64_t q = 0; q < nq; ++q)
 		if (quads[q * kQuadStride + 15] != 0.0f) em.push_back((int32_t)q);
@@ -981,6 +1043,9 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	pg_render_state *r = rstate(ctx);
 	PG_HIP(ctx, r->quads.ensure(nq * kQuadStride)); PG_HIP(ctx, r->spheres.ensure(ns * kSphereStride));
 	PG_HIP(ctx, r->mats.ensure(mats.size())); PG_HIP(ctx, r->emitters.ensure(em.size()));
+	PG_HIP(ctx, r->boxes.ensure(nb * kBoxStride));
+	if (nb) PG_HIP(ctx, hipMemcpy(r->boxes.p, sc->boxes, nb * kBoxStride * sizeof(float), hipMemcpyHostToDevice));
+	r->n_boxes = (int)nb;
 	if (nq) PG_HIP(ctx, hipMemcpy(r->quads.p, quads.data(), quads.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (ns) PG_HIP(ctx, hipMemcpy(r->spheres.p, sc->spheres, ns * kSphereStride * sizeof(float), hipMemcpyHostToDevice));
 	PG_HIP(ctx, hipMemcpy(r->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1031,8 +1096,10 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.tree = ctx->view();
 	a.shapes.quads = r->quads.p;
 	a.shapes.spheres = r->spheres.p;
+	a.shapes.boxes = r->boxes.p;
 	a.shapes.n_quads = r->n_quads;
 	a.shapes.n_spheres = r->n_spheres;
+	a.shapes.n_boxes = r->n_boxes;
 	a.mats = r->mats.p;
 	a.emitters = r->emitters.p;
 	a.n_emitters = r->n_emitters;

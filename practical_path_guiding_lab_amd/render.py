@@ -69,8 +69,10 @@ class WavefrontScene:
         q = np.ascontiguousarray(self.scene.quads, np.float32)
         s = np.ascontiguousarray(self.scene.spheres, np.float32)
         m = None if self.scene.materials is None else np.ascontiguousarray(self.scene.materials, np.float32)
+        b = np.ascontiguousarray(self.scene.boxes, np.float32)
         d = N.pg_scene_desc(q.shape[0], q.ctypes.data if q.size else None, s.shape[0], s.ctypes.data if s.size else None,
-                            0 if m is None else m.shape[0], None if m is None else m.ctypes.data)
+                            0 if m is None else m.shape[0], None if m is None else m.ctypes.data,
+                            b.shape[0], b.ctypes.data if b.size else None)
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 

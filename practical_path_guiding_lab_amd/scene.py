@@ -22,6 +22,7 @@ import numpy as np
 QUAD_STRIDE = 24  # floats per quad, layout documented in include/pgsd.h (pg_scene_desc)
 SPHERE_STRIDE = 12    # centre 0-2, radius 3, material 4, emitter flag 5, radiance 6-8
 MATERIAL_STRIDE = 12  # type 0, reflectance 1-3, alpha 4, eta 5-7, k 8-10
+BOX_STRIDE = 32       # rows of the inverse linear map 0-8, centre 9-11, +x/+y/+z face normals 12-20, material 21
 MAT_DIFFUSE, MAT_ROUGHCONDUCTOR = 0, 1
 
 
@@ -48,6 +49,7 @@ class Scene:
     rfilter: str = "tent"             # film reconstruction filter: "tent" (radius 1 pixel, the reference's scenes) or "box"
     spheres: np.ndarray = field(default_factory=lambda: np.zeros((0, SPHERE_STRIDE), np.float32))  # (S, 12)
     materials: Optional[np.ndarray] = None  # (M, 12); None: quad i is diffuse with quads[i, 16:19]
+    boxes: np.ndarray = field(default_factory=lambda: np.zeros((0, BOX_STRIDE), np.float32))        # (B, 32)
 
 
 def _f32(v):
@@ -136,15 +138,39 @@ def sphere(center, radius, material_index: int, radiance=None) -> np.ndarray:
     return s
 
 
-def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names, spheres=None, materials=None) -> Scene:
+def box(to_world: np.ndarray, material_index: int) -> np.ndarray:
+    """Mitsuba `cube` ([-1,1]^3 under an affine to_world) as ONE primitive: the renderer intersects
+    three slabs in the box's local frame instead of six quads.  Needs a material table."""
+    m = np.asarray(to_world, np.float64)
+    a = np.linalg.inv(m[:3, :3])
+    b = np.zeros(BOX_STRIDE, np.float32)
+    b[0:9] = a.reshape(-1).astype(np.float32)
+    b[9:12] = m[:3, 3].astype(np.float32)
+    for k in range(3):  # outward normal of the +k face: the k-th row of the inverse, normalised
+        b[12 + 3 * k:15 + 3 * k] = (a[k] / np.linalg.norm(a[k])).astype(np.float32)
+    b[21] = np.float32(material_index)
+    b[22:25] = m[:3, 0].astype(np.float32)  # the three half-edges, kept for the bounding box (not read by the kernels)
+    b[25:28] = m[:3, 1].astype(np.float32)
+    b[28:31] = m[:3, 2].astype(np.float32)
+    return b
+
+
+def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names, spheres=None, materials=None,
+            boxes=None) -> Scene:
     q = np.stack(quads).astype(np.float32) if quads else np.zeros((0, QUAD_STRIDE), np.float32)
     corners = [q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]]
     s = np.stack(spheres).astype(np.float32) if spheres else np.zeros((0, SPHERE_STRIDE), np.float32)
     if s.shape[0]:
         corners += [s[:, 0:3] - s[:, 3:4], s[:, 0:3] + s[:, 3:4]]
+    bx = np.stack(boxes).astype(np.float32) if boxes else np.zeros((0, BOX_STRIDE), np.float32)
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                corners.append(bx[:, 9:12] + sx * bx[:, 22:25] + sy * bx[:, 25:28] + sz * bx[:, 28:31])
     corners = np.concatenate(corners)
     sc = Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
     sc.spheres = s
+    sc.boxes = bx
     sc.materials = np.stack(materials).astype(np.float32) if materials else None
     return sc
 
@@ -159,9 +185,11 @@ def _mat(values: str) -> np.ndarray:
     return np.array([float(v) for v in values.replace(",", " ").split()], np.float64).reshape(4, 4)
 
 
-def cornell_box(width: int = 512, height: int = 512, max_depth: int = 8, rr_depth: int = 8) -> Scene:
+def cornell_box(width: int = 512, height: int = 512, max_depth: int = 8, rr_depth: int = 8, boxes: bool = True) -> Scene:
     """The cornell-box of the reference (scenes/cornell-box/scene.xml: fov 19.5, camera at
-    (0,1,6.8) looking down -z, five walls, two boxes, one ceiling light of radiance (17,12,4))."""
+    (0,1,6.8) looking down -z, five walls, two boxes, one ceiling light of radiance (17,12,4)).
+    boxes=True: the two `cube` shapes are box primitives (and the scene carries a material table);
+    boxes=False: six quads each and no material table (the plain pg_scene_set form)."""
     white, red, green = (0.725, 0.71, 0.68), (0.63, 0.065, 0.05), (0.14, 0.45, 0.091)
     shapes = [
         ("Floor", "rectangle", "-4.37114e-008 1 4.37114e-008 0 0 -8.74228e-008 2 0 1 4.37114e-008 1.91069e-015 0 0 0 0 1", white, None),
@@ -173,16 +201,24 @@ def cornell_box(width: int = 512, height: int = 512, max_depth: int = 8, rr_dept
         ("TallBox", "cube", "0.286776 0.098229 -2.29282e-015 -0.335439 -4.36233e-009 1.23382e-008 -0.6 0.6 -0.0997984 0.282266 2.62268e-008 -0.291415 0 0 0 1", white, None),
         ("Light", "rectangle", "0.235 -1.66103e-008 -7.80685e-009 -0.005 -2.05444e-008 3.90343e-009 -0.0893 1.98 2.05444e-008 0.19 8.30516e-009 -0.03 0 0 0 1", (0, 0, 0), (17, 12, 4)),
     ]
-    quads, names = [], []
+    quads, names, bxs = [], [], []
+    colors = [white, red, green, (0, 0, 0)]
     for name, kind, m, refl, rad in shapes:
+        if kind == "cube" and boxes:
+            bxs.append(box(_mat(m), colors.index(refl)))
+            continue
         qs = rectangle(_mat(m), refl, rad) if kind == "rectangle" else cube(_mat(m), refl)
+        for q in qs:
+            q[22] = np.float32(colors.index(refl)) if boxes else 0.0
         quads += qs
         names += [name] * len(qs)
     cam = make_camera(_mat("-1 0 0 0 0 1 0 1 0 0 -1 6.8 0 0 0 1"), 19.5, width, height)
-    return _finish(quads, cam, max_depth, rr_depth, names)
+    if not boxes:
+        return _finish(quads, cam, max_depth, rr_depth, names)
+    return _finish(quads, cam, max_depth, rr_depth, names, None, [diffuse_material(c) for c in colors], bxs)
 
 
-def veach_mis(width: int = 1280, height: int = 720, max_depth: int = 3, rr_depth: int = 8) -> Scene:
+def veach_mis(width: int = 1280, height: int = 720, max_depth: int = 3, rr_depth: int = 8, boxes: bool = True) -> Scene:
     """The veach-mis scene of the reference (scenes/veach-mis/scene.xml: fov 35, four rough-conductor
     plates of alpha 0.01 / 0.05 / 0.1 / 0.25, a diffuse floor and back wall, three sphere lamps of
     radius 1, 0.5 and 0.05 whose radiance grows as their area shrinks), from its numeric parameters."""
@@ -198,8 +234,11 @@ def veach_mis(width: int = 1280, height: int = 720, max_depth: int = 3, rr_depth
         ("Diffuse_0002", "rectangle", "-4.32743e-007 -4.32743e-007 9.9 -5 -9.9 1.89158e-014 -4.32743e-007 9.9 0 -23.76 -1.03858e-006 0 0 0 0 1", D),
         ("SuperRough", "cube", "1.04217 0.0182831 0 10.6769 -0.127982 0.148882 0 1.23376 0 0 4 0 0 0 0 1", SUPER),
     ]
-    quads, names = [], []
+    quads, names, bxs = [], [], []
     for name, kind, m, mi in shapes:
+        if kind == "cube" and boxes:
+            bxs.append(box(_mat(m), mi))
+            continue
         qs = rectangle(_mat(m), mats[mi][1:4]) if kind == "rectangle" else cube(_mat(m), mats[mi][1:4])
         for q in qs:
             q[22] = np.float32(mi)
@@ -208,13 +247,15 @@ def veach_mis(width: int = 1280, height: int = 720, max_depth: int = 3, rr_depth
     spheres = [sphere((0, 6.5, -2.8), 1.0, N0, (7.59909,) * 3), sphere((0, 6.5, 0), 0.5, N0, (30.3964,) * 3),
                sphere((0, 6.5, 2.7), 0.05, N0, (3039.64,) * 3)]
     cam = make_camera(_mat("-4.37113e-008 0 -1 28.2792 0 1 0 3.5 1 0 -4.37113e-008 1.23612e-006 0 0 0 1"), 35.0, width, height)
-    return _finish(quads, cam, max_depth, rr_depth, names, spheres, mats)
+    return _finish(quads, cam, max_depth, rr_depth, names, spheres, mats, bxs)
 
 
-def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None) -> Scene:
-    """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world matrix, film size),
-    twosided/diffuse bsdfs with rgb reflectance (by id), rectangle/cube shapes with a to_world
-    matrix, optional area emitter.  Anything else raises ValueError."""
+def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None, boxes: bool = True) -> Scene:
+    """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world matrix, film size, rfilter),
+    twosided diffuse / roughconductor(beckmann) bsdfs with rgb parameters (by id), rectangle / cube
+    shapes with a to_world matrix, spheres by centre and radius, area emitters on rectangles and
+    spheres.  Anything else raises ValueError.  boxes: `cube` shapes become box primitives (else
+    six quads each)."""
     root = ET.parse(path).getroot()
     defaults: Dict[str, str] = {d.get("name"): d.get("value") for d in root.findall("default")}
 
@@ -259,7 +300,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     fw = int(val(film.find("integer[@name='width']").get("value")))
     fh = int(val(film.find("integer[@name='height']").get("value")))
     cam = make_camera(_mat(sensor.find("transform/matrix").get("value")), fov, width or fw, height or fh)
-    quads, names, spheres = [], [], []
+    quads, names, spheres, bxs = [], [], [], []
     for sh in root.findall("shape"):
         kind = sh.get("type")
         ref = sh.find("ref")
@@ -282,6 +323,9 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
         elif kind == "cube":
             if rad is not None:
                 raise ValueError("emitting cubes are not supported")
+            if boxes:
+                bxs.append(box(m, mi))
+                continue
             qs = cube(m, refl)
         else:
             raise ValueError(f"unsupported shape type {kind}")
@@ -289,7 +333,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             q[22] = np.float32(mi)
         quads += qs
         names += [sh.get("id", kind)] * len(qs)
-    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials)
+    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials, bxs)
     rf = film.find("rfilter")
     sc.rfilter = rf.get("type") if rf is not None else "gaussian"  # hdrfilm's default
     if sc.rfilter not in ("tent", "box", "gaussian"):

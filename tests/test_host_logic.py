@@ -30,7 +30,15 @@ XML = """<scene version="3.0.0">
 def test_xml_subset_parser(tmp_path):
     p = tmp_path / "scene.xml"
     p.write_text(XML)
-    sc = S.load_xml(str(p))
+    sb = S.load_xml(str(p))  # default: the cube is one box primitive
+    assert sb.quads.shape == (1 + 1, S.QUAD_STRIDE) and sb.boxes.shape == (1, S.BOX_STRIDE)
+    bx = sb.boxes[0]
+    np.testing.assert_allclose(bx[0:9].reshape(3, 3), np.diag([2.0, 4.0, 2.0]), atol=1e-6)   # inverse of diag(0.5, 0.25, 0.5)
+    np.testing.assert_allclose(bx[9:12], [0, 0.25, 0])
+    np.testing.assert_allclose(bx[12:21].reshape(3, 3), np.eye(3), atol=1e-7)               # face normals
+    assert bx[21] == 0 and sb.materials[int(bx[21])][1] == np.float32(0.63)
+    np.testing.assert_allclose(sb.bbox_min, [-1, 0, -1]); np.testing.assert_allclose(sb.bbox_max, [1, 2, 0.5])
+    sc = S.load_xml(str(p), boxes=False)  # the cube as six quads
     assert sc.quads.shape == (1 + 6 + 1, S.QUAD_STRIDE) and sc.max_depth == 5 and sc.rr_depth == 3
     assert (sc.camera.width, sc.camera.height) == (32, 16) and sc.rfilter == "box"
     p2 = tmp_path / "gauss.xml"
@@ -60,8 +68,16 @@ def test_xml_subset_parser(tmp_path):
 
 
 def test_builtin_cornell_box_matches_reference_scene_facts():
-    sc = S.cornell_box(64, 48, 8, 8)
-    assert sc.quads.shape[0] == 6 + 12 and sum(sc.quads[:, 15] != 0) == 1
+    sb = S.cornell_box(64, 48, 8, 8)  # default: walls + light as quads, the two cubes as box primitives
+    assert sb.quads.shape[0] == 6 and sb.boxes.shape[0] == 2 and sb.materials.shape == (4, S.MATERIAL_STRIDE)
+    np.testing.assert_allclose(sb.bbox_min, [-1, 0, -1], atol=1e-6)
+    np.testing.assert_allclose(sb.bbox_max, [1, 2, 1], atol=1e-6)
+    tall = sb.boxes[1]
+    np.testing.assert_allclose(tall[9:12], [-0.335439, 0.6, -0.291415], rtol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(tall[12:21].reshape(3, 3), axis=1), 1, atol=1e-6)
+    np.testing.assert_allclose(np.abs(tall[18:21]), [0, 1, 0], atol=1e-6)  # its local z axis is the world's y: it stands on the floor
+    sc = S.cornell_box(64, 48, 8, 8, boxes=False)
+    assert sc.quads.shape[0] == 6 + 12 and sum(sc.quads[:, 15] != 0) == 1 and sc.materials is None
     names = sc.names
     assert names[0] == "Floor" and names[-1] == "Light" and names.count("TallBox") == 6
     # room spans [-1,1] x [0,2] x [-1,1] (scenes/cornell-box/scene.xml shapes), the light sits below the ceiling
@@ -129,8 +145,8 @@ def test_oracle_render_pass_is_deterministic_and_unbiased_between_iterations():
     sc = S.cornell_box(24, 24, 6, 8)
     pair = po.OracleSDTreePair()
     pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
-    L1, v1 = po.render_pass(pair, sc.quads, sc.camera, 6, 8, 0, True, seed=5, spp=2)
-    L2, v2 = po.render_pass(pair, sc.quads, sc.camera, 6, 8, 0, True, seed=5, spp=2)
+    L1, v1 = po.render_pass(pair, sc, sc.camera, 6, 8, 0, True, seed=5, spp=2)
+    L2, v2 = po.render_pass(pair, sc, sc.camera, 6, 8, 0, True, seed=5, spp=2)
     np.testing.assert_array_equal(L1.view(np.uint32), L2.view(np.uint32))
     assert v1.all() and np.isfinite(L1).all() and (L1 >= 0).all()
     means = []
@@ -138,7 +154,7 @@ def test_oracle_render_pass_is_deterministic_and_unbiased_between_iterations():
     for k in range(4):
         acc = []
         for _ in range(2 ** (k + 2) * 4):
-            L, _ = po.render_pass(pair, sc.quads, sc.camera, 6, 8, k, False, seed=100 + cumm, spp=1)
+            L, _ = po.render_pass(pair, sc, sc.camera, 6, 8, k, False, seed=100 + cumm, spp=1)
             acc.append(L.mean())
             cumm += 1
         means.append(float(np.mean(acc)))
@@ -266,7 +282,7 @@ def test_oracle_render_converges_to_the_tungsten_ground_truth():
     spp = 0
     for k in range(5):
         for _ in range(2 ** (k + 2)):
-            po.render_pass(pair, sc.quads, sc.camera, 12, 12, k, False, 500 + spp, 1, True, 0.5, sumL, sumL2)
+            po.render_pass(pair, sc, sc.camera, 12, 12, k, False, 500 + spp, 1, True, 0.5, sumL, sumL2)
             spp += 1
         pair.refine_and_prepare(k)
     img = (sumL / spp).T.reshape(64, 64, 3)

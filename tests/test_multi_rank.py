@@ -185,7 +185,7 @@ def test_two_ranks_render_like_one(tmp_path, mode, port):
     cumm, keepL = 0, []
     for k in range(3):
         for p in range(2 ** (k + 2)):
-            L, _ = po.render_pass(o, sc.quads, sc.camera, 6, 8, k, False, 77 + cumm + p, 1, True, 0.5, sumL, sumL2)
+            L, _ = po.render_pass(o, sc, sc.camera, 6, 8, k, False, 77 + cumm + p, 1, True, 0.5, sumL, sumL2)
             if k == 2 and p < 2:
                 keepL.append(L)
         cumm += 2 ** (k + 2)

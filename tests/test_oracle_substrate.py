@@ -91,8 +91,7 @@ def test_direct_light_of_a_sphere_emitter_has_its_closed_form(radius, height):
     pair = po.OracleSDTreePair()
     pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
     spp = 4000
-    L, valid = po.render_pass(pair, sc.quads, sc.camera, 2, 8, 0, True, 99, spp, True, 0.5,
-                              spheres=sc.spheres, materials=sc.materials)
+    L, valid = po.render_pass(pair, sc, sc.camera, 2, 8, 0, True, 99, spp, True, 0.5)
     assert valid.all()
     expect = 0.5 * Le * (radius / height) ** 2
     got = L.astype(np.float64).mean(axis=1)
@@ -106,7 +105,7 @@ def test_two_emitters_are_chosen_uniformly_and_add_up():
     sc.spheres = np.concatenate([sc.spheres, S.sphere((0.0, 5.0, 0.0), 0.6, 1, (Le, 0.5 * Le, 0.0))[None]])
     pair = po.OracleSDTreePair()
     pair.setup(np.float32([-60, -1, -60]), np.float32([60, 7, 60]), 20, 20, True)
-    L, _ = po.render_pass(pair, sc.quads, sc.camera, 2, 8, 0, True, 7, 6000, True, 0.5, spheres=sc.spheres, materials=sc.materials)
+    L, _ = po.render_pass(pair, sc, sc.camera, 2, 8, 0, True, 7, 6000, True, 0.5)
     # the far lamp is partly hidden by the near one: from the floor point the near lamp covers
     # sin^2 = 0.01 and the far one 0.0144, concentric -> only the ring between them is seen
     seen_far = (0.6 / 5.0) ** 2 - (0.3 / 3.0) ** 2
@@ -125,11 +124,12 @@ def test_oracle_veach_mis_direct_light_against_the_tungsten_ground_truth():
     gt = np.load(os.path.join(os.path.dirname(__file__), "golden", "veach_mis_gt_320x180_f16.npy")).astype(np.float64)
     gt = gt.reshape(90, 2, 160, 2, 3).mean(axis=(1, 3))
     sc = S.veach_mis(160, 90, max_depth=2)
-    assert sc.quads.shape[0] == 26 and sc.spheres.shape[0] == 3 and sc.materials.shape[0] == 6
+    assert sc.quads.shape[0] == 2 and sc.boxes.shape[0] == 4 and sc.spheres.shape[0] == 3 and sc.materials.shape[0] == 6
+    assert S.veach_mis(160, 90, boxes=False).quads.shape[0] == 26
     pair = po.OracleSDTreePair()
     pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
     spp = 48
-    L, valid = po.render_pass(pair, sc.quads, sc.camera, 2, 8, 0, True, 17, spp, True, 0.5, spheres=sc.spheres, materials=sc.materials)
+    L, valid = po.render_pass(pair, sc, sc.camera, 2, 8, 0, True, 17, spp, True, 0.5)
     img = L.astype(np.float64).reshape(3, 90, 160, spp).mean(axis=3).transpose(1, 2, 0)
     assert np.isfinite(img).all()
     lum = gt.mean(axis=2)
@@ -163,7 +163,8 @@ def test_xml_with_spheres_and_rough_conductors(tmp_path):
     </scene>"""
     p = tmp_path / "s.xml"
     p.write_text(xml)
-    sc = S.load_xml(str(p))
+    assert S.load_xml(str(p)).boxes.shape == (1, S.BOX_STRIDE) and S.load_xml(str(p)).boxes[0, 21] == 1.0
+    sc = S.load_xml(str(p), boxes=False)
     assert sc.quads.shape == (7, S.QUAD_STRIDE) and sc.spheres.shape == (1, S.SPHERE_STRIDE) and sc.materials.shape == (3, S.MATERIAL_STRIDE)
     assert sc.max_depth == 3 and (sc.camera.width, sc.camera.height) == (128, 72) and sc.rfilter == "tent"
     assert list(sc.quads[:6, 22]) == [1.0] * 6 and sc.quads[6, 22] == 0.0
