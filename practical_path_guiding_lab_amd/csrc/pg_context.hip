@@ -77,6 +77,8 @@ static int install(pg_context *ctx, const HostForest &h)
 	f.level_off = h.level_off;
 	int rc = zero_accumulators(ctx, nullptr);
 	if (rc != PG_OK) return rc;
+	rc = rebuild_jump(ctx, nullptr);
+	if (rc != PG_OK) return rc;
 	PG_HIP(ctx, hipDeviceSynchronize());
 	return PG_OK;
 }

@@ -62,6 +62,8 @@ struct Forest {
 	DevBuf<TreeHead> head;
 	DevBuf<float> tree_thr;          // refinementThreshold of each tree (export only)
 	uint32_t n_trees = 0;
+	DevBuf<QuadJump> jump;           // n_trees * kJumpCells entries, rebuilt whenever rec/head change
+	bool jump_valid = false;
 	// accumulators of the running iteration: [rec_acc | root_acc | leaf_count]
 	DevBuf<long long> acc;
 	uint64_t acc_count() const
@@ -103,6 +105,7 @@ struct pg_context {
 		t.kd = f.kd.p;
 		t.rec = f.rec.p;
 		t.head = f.head.p;
+		t.jump = f.jump_valid ? f.jump.p : nullptr;
 		for (int a = 0; a < 3; ++a) { t.bmin[a] = bmin[a]; t.bmax[a] = bmax[a]; }
 		t.n_kd = f.n_kd;
 		t.n_rec = f.n_rec;
@@ -114,6 +117,7 @@ struct pg_context {
 namespace pg {
 // pg_refine.hip
 int refine_and_swap(pg_context *ctx, hipStream_t s);
+int rebuild_jump(pg_context *ctx, hipStream_t s); // after every change of the quadtree records or heads
 // pg_render.hip
 void destroy_render_state(pg_context *ctx);
 // helpers shared by pg_context.hip / pg_refine.hip

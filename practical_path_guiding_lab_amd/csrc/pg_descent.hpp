@@ -136,9 +136,25 @@ __device__ __forceinline__ void quadrant(float cx, float cy, float mx, float my,
 	last = t3 ? 3 : (t2 ? 2 : (t1 ? 1 : (t0 ? 0 : -1)));
 }
 
+// The cell of the jump table a canonical position falls strictly inside of, or false (on a cell
+// boundary, outside the unit square, NaN): 2^kJumpBits * c is exact in fp32.
+__device__ __forceinline__ bool jump_cell(float cx, float cy, uint32_t &cell, float &lox, float &loy)
+{
+	constexpr float S = (float)(1 << kJumpBits);
+	const float fx = cx * S, fy = cy * S;
+	if (!(fx > 0.0f && fx < S && fy > 0.0f && fy < S)) return false;
+	const float ix = __builtin_floorf(fx), iy = __builtin_floorf(fy);
+	if (fx == ix || fy == iy) return false;
+	cell = ((uint32_t)iy << kJumpBits) | (uint32_t)ix;
+	lox = ix * (1.0f / S);
+	loy = iy * (1.0f / S);
+	return true;
+}
+
 // QuadTree.pdfQuadTree (quadtree.py:1001-1101) for canonical position (cx,cy) in [0,1]^2.
-__device__ __forceinline__ float quad_pdf(const QuadRec *rec, TreeHead head, float cx, float cy,
-                                          uint32_t &levels)
+// jump/tree: the quadtree's jump table (nullptr: every level is walked).
+__device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                          float cx, float cy, uint32_t &levels)
 {
 	float pdf = 1.0f;
 	levels = 0;
@@ -146,7 +162,23 @@ __device__ __forceinline__ float quad_pdf(const QuadRec *rec, TreeHead head, flo
 	uint32_t r = head.root_rec;
 	float node_irr = head.root_irr;
 	float lox = 0.0f, loy = 0.0f, h = 0.5f;
-	for (int it = 0; it < kMaxLevels; ++it) {
+	int it0 = 0;
+	uint32_t cell;
+	float jx, jy;
+	if (jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) {
+		const uint4 e = *reinterpret_cast<const uint4 *>(jump + (size_t)tree * kJumpCells + cell);
+		if (!((e.w >> 30) & 1u)) { // the product is defined along this path
+			levels = (e.w >> 26) & 15u;
+			if (e.x == kNoRecord) return __uint_as_float(e.y); // a leaf within the table: the final value
+			r = e.x;
+			pdf = __uint_as_float(e.y);
+			node_irr = __uint_as_float(e.z);
+			lox = jx; loy = jy;
+			h = 0.5f / (float)(1 << kJumpBits);
+			it0 = kJumpBits;
+		}
+	}
+	for (int it = it0; it < kMaxLevels; ++it) {
 		const QuadLoad q = load_rec(rec, r);
 		const float mx = lox + h, my = loy + h;
 		int first, last;
@@ -172,8 +204,8 @@ __device__ __forceinline__ float quad_pdf(const QuadRec *rec, TreeHead head, flo
 // (quadtree.py:956, 980).  The pdf along the sampled path is accumulated on the way down;
 // it equals pdfQuadTree(dir) whenever the round trip dir -> canonical lands strictly inside
 // the sampled leaf cell, otherwise the literal second descent is taken.
-__device__ __forceinline__ void quad_sample(const QuadRec *rec, TreeHead head, Pcg32 &rng,
-                                            float &dx, float &dy, float &dz, float &pdf_out,
+__device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                            Pcg32 &rng, float &dx, float &dy, float &dz, float &pdf_out,
                                             uint32_t &levels)
 {
 	float px = 0.0f, py = 0.0f;
@@ -232,7 +264,7 @@ __device__ __forceinline__ void quad_sample(const QuadRec *rec, TreeHead head, P
 		pdf_out = dead ? 0.0f : pdf * kInvFourPiF;
 	} else {
 		uint32_t lv;
-		pdf_out = quad_pdf(rec, head, qx, qy, lv);
+		pdf_out = quad_pdf(rec, jump, tree, head, qx, qy, lv);
 	}
 }
 
@@ -274,7 +306,8 @@ struct LeafCursor {
 	bool walking, found, is_root;
 };
 
-__device__ __forceinline__ LeafCursor leaf_cursor(TreeHead head, float cx, float cy, bool enable)
+__device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t tree, TreeHead head, float cx, float cy,
+                                                  bool enable)
 {
 	LeafCursor c;
 	c.r = head.root_rec;
@@ -286,6 +319,21 @@ __device__ __forceinline__ LeafCursor leaf_cursor(TreeHead head, float cx, float
 	c.is_root = head.root_rec == kNoRecord;
 	c.found = inside && c.is_root;
 	c.walking = inside && !c.is_root;
+	uint32_t cell;
+	float jx, jy;
+	if (c.walking && jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) { // skip the levels the table covers
+		const uint4 e = *reinterpret_cast<const uint4 *>(jump + (size_t)tree * kJumpCells + cell);
+		c.levels = (e.w >> 26) & 15u;
+		if (e.x == kNoRecord) {
+			c.slot = e.w & kJumpSlotMask;
+			c.found = true;
+			c.walking = false;
+		} else {
+			c.r = e.x;
+			c.lox = jx; c.loy = jy;
+			c.h = 0.5f / (float)(1 << kJumpBits);
+		}
+	}
 	return c;
 }
 

@@ -31,6 +31,9 @@ void launch_compact_lanes(uint64_t n, const uint8_t *select, const uint8_t *nee_
 void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state, uint64_t *inc,
                      hipStream_t s);
 
+// (re)builds the quadtree jump table of `t` into out[t.n_trees * kJumpCells] (t.jump is not read)
+void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s);
+
 // ---- recording (pg_kernels_splat.hip) ----
 void launch_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t m,
                   const pg_records &rec, const uint32_t *d_count, DepthCounters *dc, hipStream_t s);

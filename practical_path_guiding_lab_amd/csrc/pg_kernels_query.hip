@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(TreeView t, uint64_t n, const
 			KdNode leaf;
 			kd_descend(t.kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			Pcg32 rng = {rng_state[i], rng_inc[i]};
-			quad_sample(t.rec, load_head(t.head, leaf.tree), rng, dx, dy, dz, pdf, q_lv);
+			quad_sample(t.rec, t.jump, leaf.tree, load_head(t.head, leaf.tree), rng, dx, dy, dz, pdf, q_lv);
 			rng_state[i] = rng.state;
 			did = 1;
 		}
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_pdf(TreeView t, uint64_t n, const fl
 			kd_descend(t.kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			float cx, cy;
 			dir_to_canonical(dir[i], dir[n + i], dir[2 * n + i], cx, cy);
-			pdf = quad_pdf(t.rec, load_head(t.head, leaf.tree), cx, cy, q_lv);
+			pdf = quad_pdf(t.rec, t.jump, leaf.tree, load_head(t.head, leaf.tree), cx, cy, q_lv);
 			did = 1;
 		}
 		pdf_out[i] = pdf;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 				float cx, cy;
 				uint32_t lv;
 				dir_to_canonical(dir_nee[i], dir_nee[n + i], dir_nee[2 * n + i], cx, cy);
-				pdf_nee = quad_pdf(t.rec, head, cx, cy, lv);
+				pdf_nee = quad_pdf(t.rec, t.jump, leaf.tree, head, cx, cy, lv);
 				q_lv += lv;
 				++q_q;
 			}
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 				Pcg32 rng = {rng_state[i], rng_inc[i]};
 				float dx, dy, dz;
 				uint32_t lv;
-				quad_sample(t.rec, head, rng, dx, dy, dz, pdf, lv);
+				quad_sample(t.rec, t.jump, leaf.tree, head, rng, dx, dy, dz, pdf, lv);
 				rng_state[i] = rng.state;
 				dir_io[i] = dx;
 				dir_io[n + i] = dy;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 				float cx, cy;
 				uint32_t lv;
 				dir_to_canonical(dir_io[i], dir_io[n + i], dir_io[2 * n + i], cx, cy);
-				pdf = quad_pdf(t.rec, head, cx, cy, lv);
+				pdf = quad_pdf(t.rec, t.jump, leaf.tree, head, cx, cy, lv);
 				q_lv += lv;
 				++q_q;
 			}
@@ -262,7 +262,64 @@ __global__ __launch_bounds__(kBlock) void k_rng_seed(uint64_t n, uint32_t seed, 
 	inc[i] = r.inc;
 }
 
+// Jump-table entry of (tree, cell): the state of pdfQuadTree's loop (quadtree.py:1020-1098) and of
+// addIrradiancePropagate's walk (quadtree.py:398-441) after the kJumpBits levels a point strictly
+// inside the cell passes through, computed by that very loop for the cell's centre.
+__global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= (uint64_t)t.n_trees * kJumpCells) return;
+	const uint32_t tree = (uint32_t)(i / kJumpCells), cell = (uint32_t)(i % kJumpCells);
+	constexpr float S = (float)(1 << kJumpBits);
+	const float cx = ((float)(cell & ((1u << kJumpBits) - 1u)) + 0.5f) / S, cy = ((float)(cell >> kJumpBits) + 0.5f) / S;
+	const TreeHead head = load_head(t.head, tree);
+	QuadJump e;
+	e.next = kNoRecord;
+	e.pdf = kInvFourPiF; // 1.0f * 1/(4 pi): the root is a leaf (never read: such trees return before the table)
+	e.irr = head.root_irr;
+	e.info = 0;
+	if (head.root_rec != kNoRecord) {
+		uint32_t r = head.root_rec, levels = 0, slot = 0;
+		float pdf = 1.0f, node_irr = head.root_irr, lox = 0.0f, loy = 0.0f, h = 0.5f;
+		bool dead = false, ended = false;
+		for (int it = 0; it < kJumpBits; ++it) {
+			const QuadLoad q = load_rec(t.rec, r);
+			const float mx = lox + h, my = loy + h;
+			int first, last;
+			quadrant(cx, cy, mx, my, first, last); // first == last: the centre lies on no boundary
+			const float child_irr = sel4f(first, q.i0, q.i1, q.i2, q.i3);
+			pdf = pdf * ((4.0f * child_irr) / node_irr);
+			if (pdf != pdf) dead = true; // quadtree.py:1090-1092 ends the pdf loop here; the splat's walk goes on
+			++levels;
+			node_irr = sel4f(last, q.i0, q.i1, q.i2, q.i3);
+			const uint32_t c = sel4u(last, q.c0, q.c1, q.c2, q.c3);
+			if (last == 0 || last == 3) lox = mx;
+			if (last == 0 || last == 1) loy = my;
+			h *= 0.5f;
+			if (c == 0) { // the child is a leaf
+				slot = r * 4u + (uint32_t)last;
+				pdf = pdf * kInvFourPiF;
+				ended = true;
+				break;
+			}
+			r = c;
+		}
+		e.next = ended ? kNoRecord : r;
+		e.pdf = pdf;
+		e.irr = node_irr;
+		e.info = (ended ? (slot & kJumpSlotMask) : 0u) | (levels << 26) | (dead ? (1u << 30) : 0u);
+	}
+	out[i] = e;
+}
+
 static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s)
+{
+	const uint64_t n = (uint64_t)t.n_trees * kJumpCells;
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_build_jump, grid_for(n), dim3(kBlock), 0, s, t, out);
+}
 
 void launch_leaf_index(const TreeView &t, uint64_t n, const float *p, const uint8_t *active,
                        uint32_t *node_out, hipStream_t s)

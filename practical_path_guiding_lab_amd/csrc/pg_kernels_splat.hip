@@ -60,7 +60,7 @@ __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &
 	const TreeHead head = load_head_s(t.head, tree);
 	const float w = wo_pdf > 0.0f ? radiance / wo_pdf : 0.0f;   // quadtree.py:451
 	const float wn = wo_pdf > 0.0f ? nee_lum / wo_pdf : 0.0f;   // quadtree.py:462
-	LeafCursor cp = leaf_cursor(head, dx, dy, true), cn = leaf_cursor(head, nx, ny, store_nee != 0);
+	LeafCursor cp = leaf_cursor(t.jump, tree, head, dx, dy, true), cn = leaf_cursor(t.jump, tree, head, nx, ny, store_nee != 0);
 	quad_find_leaf_slots2(t.rec, cp, cn);
 	path = plan_dir(a, tree, cp, w, inside ? 1 : 0);
 	q_lv += cp.levels;

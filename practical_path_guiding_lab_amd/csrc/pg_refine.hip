@@ -593,7 +593,24 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 	f.level_off = new_level_off;
 	PG_HIP(ctx, f.acc.ensure(f.acc_count(), 1.25));
 	PG_HIP(ctx, hipMemsetAsync(f.acc.p, 0, f.acc_count() * sizeof(long long), s));
+	const int rc_jump = rebuild_jump(ctx, s);
+	if (rc_jump != PG_OK) return rc_jump;
 	PG_HIP(ctx, hipStreamSynchronize(s));
+	return PG_OK;
+}
+
+// The jump table follows the quadtree records: built after setup, import and every refine.
+int rebuild_jump(pg_context *ctx, hipStream_t s)
+{
+	Forest &f = ctx->f;
+	f.jump_valid = false;
+	// accumulator slots are packed into 26 bits of an entry; forests beyond that walk every level
+	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask) return PG_OK;
+	PG_HIP(ctx, f.jump.ensure((size_t)f.n_trees * kJumpCells, 1.25));
+	TreeView t = ctx->view();
+	launch_build_jump(t, f.jump.p, s);
+	PG_HIP(ctx, hipGetLastError());
+	f.jump_valid = true;
 	return PG_OK;
 }
 

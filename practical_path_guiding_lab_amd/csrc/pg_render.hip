@@ -522,7 +522,11 @@ __device__ __forceinline__ void sample_emitter(const Shapes &sh, const int32_t *
 		const float sdist = __builtin_sqrtf(dot3(sd, sd));
 		const v3 sdn = vdivs(sd, sdist);
 		float th;
+#ifdef PG_ABLATE_SHADOW // timing experiment only: no shadow rays
+		const bool occ = false; (void)th; (void)sdn;
+#else
 		const bool occ = intersect<kGeneral>(sh, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
+#endif
 		if (!occ) em_weight = vscale(vdivs(radiance, pdf), count);
 	}
 }
@@ -643,6 +647,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const bool active_sd_em = active_em && a.guided;
 	const float pdf_diffuse = 1.0f; // :222-241
 	TreeHead head = {kNoRecord, 0.0f};
+	uint32_t tree_id = 0;
 	bool tree_known = false;
 	float sdtree_pdf_em = 1.0f;
 	uint32_t lv;
@@ -660,7 +665,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
 		tree_known = true;
-		sdtree_pdf_em = quad_pdf(a.tree.rec, head, nee_cx, nee_cy, lv);
+		tree_id = leaf.tree;
+		sdtree_pdf_em = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, nee_cx, nee_cy, lv);
 		c_q += lv; ++c_qq;
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
@@ -690,10 +696,11 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
+		tree_id = leaf.tree;
 	}
 	if (smp_tree) { // :301-304
 		float dx, dy, dz;
-		quad_sample(a.tree.rec, head, rng, dx, dy, dz, sdtree_pdf, lv);
+		quad_sample(a.tree.rec, a.tree.jump, tree_id, head, rng, dx, dy, dz, sdtree_pdf, lv);
 		c_q += lv; ++c_qq;
 		wo_world = V(dx, dy, dz);
 		wo_local = to_local(fr, wo_world);
@@ -703,7 +710,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	float wo_cx = 0.0f, wo_cy = 0.0f;
 	if (bsdf_mis || do_record) dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, wo_cx, wo_cy);
 	if (bsdf_mis) { // :307
-		sdtree_pdf = quad_pdf(a.tree.rec, head, wo_cx, wo_cy, lv);
+		sdtree_pdf = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, wo_cx, wo_cy, lv);
 		c_q += lv; ++c_qq;
 	}
 	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)

@@ -43,11 +43,29 @@ struct alignas(8) TreeHead {
 	float root_irr;
 };
 
+// Jump table over the top kJumpBits levels of every quadtree: entry (tree, iy, ix) describes where
+// a descent for a point strictly inside cell (ix, iy) of the 2^kJumpBits grid stands after those
+// levels -- one 16-byte gather instead of two per level.  The path to such a cell is unique (no
+// tie rule applies off the cell boundaries), and the pdf product is formed at build time by the
+// same operations in the same order as the level-by-level loop, so results are bit-identical;
+// points on a cell boundary or outside the unit square take the loop from the root.
+constexpr int kJumpBits = 4;
+constexpr uint32_t kJumpCells = 1u << (2 * kJumpBits); // entries per tree
+struct alignas(16) QuadJump {
+	uint32_t next;  // record to continue from; kNoRecord: the walk ended in a leaf within the table
+	float pdf;      // product of 4*child/node over the levels taken (final value incl. 1/(4 pi) when ended)
+	float irr;      // energy of the node reached (the next level's denominator)
+	uint32_t info;  // bits 0-25 accumulator slot of the leaf (when ended), 26-29 levels taken, 30 pdf undefined
+	                // (a 0/0 on the way: take the loop), 31 unused
+};
+constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
+
 // Read-only view handed to the query kernels (sdTree_prev).
 struct TreeView {
 	const KdNode *kd;
 	const QuadRec *rec;
 	const TreeHead *head;
+	const QuadJump *jump; // n_trees * kJumpCells entries, or nullptr
 	float bmin[3], bmax[3]; // root bounding box (kdtree.py:138)
 	uint32_t n_kd, n_rec, n_trees;
 };
