@@ -67,8 +67,9 @@ def traffic_for(kernel, key):
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         j = json.load(open(pmc))
-        if j.get("config") == key and kernel in j.get("kernels", {}):
-            return j["kernels"][kernel]["hbm_bytes_per_launch"]
+        k = j.get("configs", {}).get(key, {})
+        if kernel in k:
+            return k[kernel]["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None

@@ -11,6 +11,7 @@ import shutil
 import sys
 
 src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
+BOUNCES = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # k_bounce launches per pass = max_depth
 os.makedirs(dst, exist_ok=True)
 KERNELS = ("k_bounce", "k_process_and_splat", "k_finish")
 
@@ -36,7 +37,7 @@ for r in csv.DictReader(open(trace)):
 trace_summary = {}
 for k, v in dur.items():
     v.sort()
-    per_pass = {"k_bounce": 8}.get(k, 1)
+    per_pass = {"k_bounce": BOUNCES}.get(k, 1)
     last = [d for _, d in v[-10 * per_pass:]]
     trace_summary[k] = {"launches_in_timed_region": len(last), "avg_us": round(sum(last) / len(last) / 1e3, 2),
                         "min_us": round(min(last) / 1e3, 2), "max_us": round(max(last) / 1e3, 2)}
@@ -57,7 +58,7 @@ def agg(sub):
             if k:
                 d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k in d:
-            per_pass = {"k_bounce": 8}.get(k, 1)
+            per_pass = {"k_bounce": BOUNCES}.get(k, 1)
             for c in d[k]:
                 d[k][c] = d[k][c][-PMC_STEPS * per_pass:]
     return d
@@ -86,6 +87,14 @@ for k in KERNELS:
             e[c] = round(m(sq, c))
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-json.dump({"config": cfg, "kernels": {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in out["kernels"].items()}},
-          open(os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_traffic.json"), "w"), indent=1)
+# profiles/pmc_traffic.json: {"configs": {config key: {kernel: {"hbm_bytes_per_launch": ...}}}}, read by bench.py
+tpath = os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_traffic.json")
+try:
+    traffic = json.load(open(tpath))
+    if "configs" not in traffic:
+        traffic = {"configs": {}}
+except Exception:
+    traffic = {"configs": {}}
+traffic["configs"][cfg] = {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in out["kernels"].items()}
+json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps(out, indent=1))
