@@ -464,7 +464,8 @@ class _RenderParams(C.Structure):
 
 class _Scene(C.Structure):
     _fields_ = [("n_quads", C.c_size_t), ("quads", C.c_void_p), ("n_spheres", C.c_size_t), ("spheres", C.c_void_p),
-                ("n_materials", C.c_size_t), ("materials", C.c_void_p), ("n_boxes", C.c_size_t), ("boxes", C.c_void_p)]
+                ("n_materials", C.c_size_t), ("materials", C.c_void_p), ("n_boxes", C.c_size_t), ("boxes", C.c_void_p),
+                ("n_tris", C.c_size_t), ("tris", C.c_void_p), ("n_bvh_nodes", C.c_size_t), ("bvh", C.c_void_p)]
 
 
 def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, iteration, is_final, seed, spp=1,
@@ -477,21 +478,25 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
     L = lib()
     L.pgo_render_pass_scene.argtypes = [_P, _P, C.POINTER(_Scene), C.POINTER(_Camera), C.POINTER(_RenderParams), _P, _P, _P, _P]
     L.pgo_render_pass_scene.restype = None
+    tris, bvh = np.zeros((0, 16), np.float32), np.zeros((0, 8), np.uint32)
     if hasattr(quads, "quads"):  # a scene object (practical_path_guiding_lab_amd.scene.Scene): all of its shapes
         scene_obj = quads
         quads = scene_obj.quads
         spheres = scene_obj.spheres if spheres is None else spheres
         materials = scene_obj.materials if materials is None else materials
         boxes = scene_obj.boxes if boxes is None else boxes
+        tris = np.ascontiguousarray(getattr(scene_obj, "tris", tris), np.float32).reshape(-1, 16)
+        bvh = np.ascontiguousarray(getattr(scene_obj, "bvh", bvh), np.uint32).reshape(-1, 8)
     quads = np.ascontiguousarray(quads, np.float32).reshape(-1, 24)
     spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros((0, 12)), np.float32).reshape(-1, 12)
     mats = None if materials is None else np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
     boxes = np.ascontiguousarray(boxes if boxes is not None else np.zeros((0, 32)), np.float32).reshape(-1, 32)
-    if mats is None and (spheres.shape[0] or boxes.shape[0]):
-        raise ValueError("spheres and boxes need a material table")
+    if mats is None and (spheres.shape[0] or boxes.shape[0] or tris.shape[0]):
+        raise ValueError("spheres, boxes and meshes need a material table")
     sc = _Scene(quads.shape[0], quads.ctypes.data if quads.size else None, spheres.shape[0],
                 spheres.ctypes.data if spheres.size else None, 0 if mats is None else mats.shape[0],
-                None if mats is None else mats.ctypes.data, boxes.shape[0], boxes.ctypes.data if boxes.size else None)
+                None if mats is None else mats.ctypes.data, boxes.shape[0], boxes.ctypes.data if boxes.size else None,
+                tris.shape[0], tris.ctypes.data if tris.size else None, bvh.shape[0], bvh.ctypes.data if bvh.size else None)
     c = _Camera()
     for k in ("origin", "axis_x", "axis_y", "axis_z"):
         setattr(c, k, (C.c_float * 3)(*[float(v) for v in getattr(cam, k)]))

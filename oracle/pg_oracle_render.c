@@ -132,6 +132,51 @@ static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 		bt = t;
 		best = (int)(nq + sc->n_spheres + 6 * b) + 2 * axis + negative;
 	}
+	/* triangle meshes: ordered traversal of the binary BVH (near child first, by the sign of the ray
+	 * direction on the node's split axis), slab test padded as Ize 2013, Moeller-Trumbore triangles */
+	if (sc->n_bvh_nodes) {
+		const size_t tri_base = nq + sc->n_spheres + 6 * sc->n_boxes;
+		const float inv[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+		const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+		uint32_t stack[64];
+		int sp = 0;
+		stack[sp++] = 0;
+		while (sp) {
+			const uint32_t *N = sc->bvh + (size_t)stack[--sp] * PGO_BVH_STRIDE;
+			float tmin = 0.0f, tmax = bt;
+			for (int k = 0; k < 3; ++k) {
+				const float t0 = (pgo_u2f(N[k]) - oo[k]) * inv[k], t1 = (pgo_u2f(N[4 + k]) - oo[k]) * inv[k];
+				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+				tmin = lo > tmin ? lo : tmin;
+				tmax = hi < tmax ? hi : tmax;
+			}
+			if (!(tmin <= tmax * 1.0000004f)) continue;
+			if (N[7] & 0x80000000u) {
+				const uint32_t first = N[3], count = N[7] & 0x7fffffffu;
+				for (uint32_t i = first; i < first + count; ++i) {
+					const float *T = sc->tris + (size_t)i * PGO_TRI_STRIDE;
+					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
+					const v3 p = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
+					const float det = dot3(e1, p);
+					if (det == 0.0f) continue;
+					const float inv_det = 1.0f / det;
+					const v3 s = vsub(o, ld3(T));
+					const float u = dot3(s, p) * inv_det;
+					if (!(u >= 0.0f && u <= 1.0f)) continue;
+					const v3 q = V(s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x);
+					const float v = dot3(d, q) * inv_det;
+					if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+					const float t = dot3(e2, q) * inv_det;
+					if (t > 0.0f && t < bt) { bt = t; best = (int)(tri_base + i); }
+				}
+			} else {
+				const uint32_t left = N[3], right = N[7] & 0x1fffffffu, axis = (N[7] >> 29) & 3u;
+				const int right_first = dd[axis] < 0.0f;
+				stack[sp++] = right_first ? left : right; /* the far child is popped later */
+				stack[sp++] = right_first ? right : left;
+			}
+		}
+	}
 	*t_out = bt;
 	return best;
 }
@@ -171,6 +216,11 @@ static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
 		s.radiance = ld3(Q + 19);
 		if (!sc->materials) { s.m.type = 0; s.m.refl = ld3(Q + 16); return s; }
 		mi = (int)Q[22];
+	} else if ((size_t)prim >= sc->n_quads + sc->n_spheres + 6 * sc->n_boxes) {
+		const float *T = sc->tris + ((size_t)prim - sc->n_quads - sc->n_spheres - 6 * sc->n_boxes) * PGO_TRI_STRIDE;
+		s.p = vadd(o, vscale(d, t));
+		s.n = ld3(T + 9); /* face normals */
+		mi = (int)T[12];
 	} else if ((size_t)prim >= sc->n_quads + sc->n_spheres) {
 		const size_t f = (size_t)prim - sc->n_quads - sc->n_spheres;
 		const float *B = sc->boxes + (f / 6) * PGO_BOX_STRIDE;
@@ -499,7 +549,7 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
                      const pgo_camera *cam, const pgo_render_params *prm, float *L_out, uint8_t *valid_out,
                      float *sumL, float *sumL2)
 {
-	const pgo_scene sc = { nq, quads, 0, NULL, 0, NULL, 0, NULL };
+	const pgo_scene sc = { nq, quads, 0, NULL, 0, NULL, 0, NULL, 0, NULL, 0, NULL };
 	pgo_render_pass_scene(prev, current, &sc, cam, prm, L_out, valid_out, sumL, sumL2);
 }
 

@@ -87,9 +87,13 @@ constexpr int kBoxStride = 32; // PG_BOX_STRIDE
 
 // The shapes of a scene: quads, then spheres, then box faces (shape number = quad index,
 // n_quads + sphere index, or n_quads + n_spheres + 6 box + 2 axis + (outward normal negative))
+// ... then the triangles of the meshes, in BVH leaf order (general scenes only)
+constexpr int kTriStride = 16; // PG_TRI_STRIDE
+constexpr int kBvhStride = 8;  // PG_BVH_STRIDE
 struct Shapes {
-	const float *quads, *spheres, *boxes;
-	int n_quads, n_spheres, n_boxes;
+	const float *quads, *spheres, *boxes, *tris;
+	const uint32_t *bvh;
+	int n_quads, n_spheres, n_boxes, n_bvh_nodes;
 };
 
 __device__ __forceinline__ v3 box_face_normal(const float *B, int face)
@@ -173,6 +177,66 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 		bt = t;
 		best = nq + sh.n_spheres + 6 * b + 2 * axis + negative;
 	}
+	// triangle meshes: ordered traversal of the binary BVH (near child first, by the sign of the ray
+	// direction on the node's split axis), slab test padded as Ize 2013, Moeller-Trumbore triangles
+	if (kGeneral && sh.n_bvh_nodes) {
+		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
+		const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+		// pg_scene_set_ex has checked the tree: children follow their parent, depth <= 60, so the walk
+		// visits every node at most once and the stack cannot overflow; the counter is a second fence
+		uint32_t stack[64];
+		int sp = 0;
+		stack[sp++] = 0;
+		for (int visited = 0; sp && visited < sh.n_bvh_nodes; ++visited) {
+			const uint4 *N = reinterpret_cast<const uint4 *>(sh.bvh + (size_t)stack[--sp] * kBvhStride);
+			const uint4 n0 = N[0], n1 = N[1];
+			float tmin = 0.0f, tmax = bt;
+			{
+				const float t0 = (__uint_as_float(n0.x) - o.x) * ix, t1 = (__uint_as_float(n1.x) - o.x) * ix;
+				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+				tmin = lo > tmin ? lo : tmin;
+				tmax = hi < tmax ? hi : tmax;
+			}
+			{
+				const float t0 = (__uint_as_float(n0.y) - o.y) * iy, t1 = (__uint_as_float(n1.y) - o.y) * iy;
+				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+				tmin = lo > tmin ? lo : tmin;
+				tmax = hi < tmax ? hi : tmax;
+			}
+			{
+				const float t0 = (__uint_as_float(n0.z) - o.z) * iz, t1 = (__uint_as_float(n1.z) - o.z) * iz;
+				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+				tmin = lo > tmin ? lo : tmin;
+				tmax = hi < tmax ? hi : tmax;
+			}
+			if (!(tmin <= tmax * 1.0000004f)) continue;
+			if (n1.w & 0x80000000u) {
+				const uint32_t first = n0.w, count = n1.w & 0x7fffffffu;
+				for (uint32_t i = first; i < first + count; ++i) {
+					const float *T = sh.tris + (size_t)i * kTriStride;
+					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
+					const v3 p = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
+					const float det = dot3(e1, p);
+					if (det == 0.0f) continue;
+					const float inv_det = 1.0f / det;
+					const v3 s = vsub(o, ld3(T));
+					const float u = dot3(s, p) * inv_det;
+					if (!(u >= 0.0f && u <= 1.0f)) continue;
+					const v3 q = V(s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x);
+					const float v = dot3(d, q) * inv_det;
+					if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+					const float t = dot3(e2, q) * inv_det;
+					if (t > 0.0f && t < bt) { bt = t; best = tri_base + (int)i; }
+				}
+			} else {
+				const uint32_t left = n0.w, right = n1.w & 0x1fffffffu, axis = (n1.w >> 29) & 3u;
+				const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+				const bool right_first = da < 0.0f;
+				stack[sp++] = right_first ? left : right; // the far child is popped later
+				stack[sp++] = right_first ? right : left;
+			}
+		}
+	}
 	t_out = bt;
 	return best;
 }
@@ -194,7 +258,14 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 {
 	Surface s;
 	const float *M;
-	if (prim >= sh.n_quads + sh.n_spheres) { // a box face
+	if (kGeneral && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes) { // a mesh triangle (face normals)
+		const float *T = sh.tris + (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes) * kTriStride;
+		s.p = vadd(o, vscale(d, t));
+		s.n = ld3(T + 9);
+		s.is_em = false;
+		s.radiance = V(0, 0, 0);
+		M = mats + (int)T[12] * kMaterialStride;
+	} else if (prim >= sh.n_quads + sh.n_spheres) { // a box face
 		const int f = prim - sh.n_quads - sh.n_spheres;
 		const float *B = sh.boxes + (f / 6) * kBoxStride;
 		s.p = vadd(o, vscale(d, t));
@@ -237,6 +308,8 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 template <bool kGeneral>
 __device__ __forceinline__ v3 normal_at(const Shapes &sh, int prim, v3 p)
 {
+	if (kGeneral && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes)
+		return ld3(sh.tris + (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes) * kTriStride + 9);
 	if (prim >= sh.n_quads + sh.n_spheres) {
 		const int f = prim - sh.n_quads - sh.n_spheres;
 		return box_face_normal(sh.boxes + (f / 6) * kBoxStride, f % 6);
@@ -552,7 +625,7 @@ struct RenderArgs {
 	// state: it is the previous vertex pushed off its quad (:352 spawn_ray), recomputed from prev_p
 	// and the quad id; depth is the launch index; ior stays 1 (every BSDF of the substrate has eta 1)
 	float *ray_d, *thr, *L, *prev_p, *prev_pdf;
-	uint16_t *prev_quad;
+	uint32_t *prev_quad; // shape number of the previous vertex
 	uint8_t *hit0; // the first bounce hit something (the `valid` flag, :400)
 	uint64_t *rng_state, *rng_inc;
 	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth
@@ -774,7 +847,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
 		a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
 		a.prev_pdf[lane] = woPdf;
-		a.prev_quad[lane] = (uint16_t)q;
+		a.prev_quad[lane] = (uint32_t)q;
 	}
 	return active_next;
 }
@@ -921,14 +994,15 @@ using namespace pg;
 
 // library-owned renderer state
 struct pg_render_state {
-	DevBuf<float> quads, spheres, mats, boxes;
+	DevBuf<float> quads, spheres, mats, boxes, tris;
+	DevBuf<uint32_t> bvh;
 	DevBuf<int32_t> emitters;
-	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0;
+	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0, n_bvh_nodes = 0;
 	bool general = false; // spheres or rough conductors present: the general kernels are launched
 	pg_camera cam;
 	bool have_scene = false;
 	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
-	DevBuf<uint16_t> prev_quad;
+	DevBuf<uint32_t> prev_quad;
 	DevBuf<uint8_t> hit0;
 	DevBuf<uint64_t> rng_state, rng_inc;
 	DevBuf<uint32_t> order[2], live_count;
@@ -983,6 +1057,8 @@ int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const 
 	d.n_spheres = 0; d.spheres = nullptr;
 	d.n_materials = 0; d.materials = nullptr;
 	d.n_boxes = 0; d.boxes = nullptr;
+	d.n_tris = 0; d.tris = nullptr;
+	d.n_bvh_nodes = 0; d.bvh = nullptr;
 	return pg_scene_set_ex(ctx, &d, cam);
 }
 
@@ -991,7 +1067,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	if (!ctx) return PG_ERR_INVALID;
 	if (!sc || !cam) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: NULL pointer");
 	const uint64_t nq = sc->n_quads, ns = sc->n_spheres, nm = sc->n_materials, nb = sc->n_boxes;
-	if (nq + ns + nb == 0 || nq > 4096 || ns > 4096 || nb > 4096 || (nq && !sc->quads) || (ns && !sc->spheres) || (nb && !sc->boxes))
+	if (nq + ns + nb + sc->n_tris == 0 || nq > 4096 || ns > 4096 || nb > 4096 || (nq && !sc->quads) || (ns && !sc->spheres) || (nb && !sc->boxes))
 		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: need 1..4096 quads, spheres and/or boxes");
 	if ((nm && !sc->materials) || (!sc->materials && (ns || nb)))
 		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: spheres and boxes need a material table");
@@ -1041,6 +1117,39 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			if (!(sc->boxes[b * kBoxStride + k] == sc->boxes[b * kBoxStride + k]) || fabsf(sc->boxes[b * kBoxStride + k]) > 3.0e38f)
 				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: box transform is not finite");
 	}
+	// triangle meshes: the kernels walk the BVH with a fixed-size stack and trust it, so check it here:
+	// children follow their parent (no cycles), leaves stay inside the triangle array, depth <= 60
+	const uint64_t nt = sc->n_tris, nn = sc->n_bvh_nodes;
+	if ((nt == 0) != (nn == 0) || (nt && (!sc->tris || !sc->bvh)) || nt > 0x0fffffffull || nn > 0x1fffffffull)
+		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangles and BVH nodes go together");
+	if (nt && !sc->materials) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: meshes need a material table");
+	if (nn) {
+		std::vector<uint8_t> depth(nn, 0);
+		std::vector<uint8_t> seen(nn, 0);
+		seen[0] = 1;
+		for (uint64_t i = 0; i < nn; ++i) {
+			if (!seen[i]) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node without a parent");
+			const uint32_t *N = sc->bvh + i * kBvhStride;
+			if (N[7] & 0x80000000u) {
+				const uint64_t first = N[3], count = N[7] & 0x7fffffffu;
+				if (count == 0 || first + count > nt) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH leaf outside the triangle array");
+			} else {
+				const uint64_t left = N[3], right = N[7] & 0x1fffffffu;
+				if (left <= i || right <= i || left >= nn || right >= nn || left == right || ((N[7] >> 29) & 3u) > 2u)
+					return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH children must follow their parent");
+				if (seen[left] || seen[right]) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node with two parents");
+				if (depth[i] >= 60) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH deeper than 60 levels");
+				seen[left] = seen[right] = 1;
+				depth[left] = depth[right] = (uint8_t)(depth[i] + 1);
+			}
+		}
+		for (uint64_t t = 0; t < nt; ++t) {
+			const float mi = sc->tris[t * kTriStride + 12];
+			if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
+				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangle material index out of range");
+		}
+		general = true;
+	}
 	std::vector<int32_t> em;
 	for (uint64_t q = 0; q < nq; ++q)
 		if (quads[q * kQuadStride + 15] != 0.0f) em.push_back((int32_t)q);
@@ -1053,6 +1162,10 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	PG_HIP(ctx, r->boxes.ensure(nb * kBoxStride));
 	if (nb) PG_HIP(ctx, hipMemcpy(r->boxes.p, sc->boxes, nb * kBoxStride * sizeof(float), hipMemcpyHostToDevice));
 	r->n_boxes = (int)nb;
+	PG_HIP(ctx, r->tris.ensure(nt * kTriStride)); PG_HIP(ctx, r->bvh.ensure(nn * kBvhStride));
+	if (nt) PG_HIP(ctx, hipMemcpy(r->tris.p, sc->tris, nt * kTriStride * sizeof(float), hipMemcpyHostToDevice));
+	if (nn) PG_HIP(ctx, hipMemcpy(r->bvh.p, sc->bvh, nn * kBvhStride * sizeof(uint32_t), hipMemcpyHostToDevice));
+	r->n_bvh_nodes = (int)nn;
 	if (nq) PG_HIP(ctx, hipMemcpy(r->quads.p, quads.data(), quads.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (ns) PG_HIP(ctx, hipMemcpy(r->spheres.p, sc->spheres, ns * kSphereStride * sizeof(float), hipMemcpyHostToDevice));
 	PG_HIP(ctx, hipMemcpy(r->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1104,6 +1217,9 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.quads = r->quads.p;
 	a.shapes.spheres = r->spheres.p;
 	a.shapes.boxes = r->boxes.p;
+	a.shapes.tris = r->tris.p;
+	a.shapes.bvh = r->bvh.p;
+	a.shapes.n_bvh_nodes = r->n_bvh_nodes;
 	a.shapes.n_quads = r->n_quads;
 	a.shapes.n_spheres = r->n_spheres;
 	a.shapes.n_boxes = r->n_boxes;

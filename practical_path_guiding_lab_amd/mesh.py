@@ -1,0 +1,139 @@
+"""Triangle meshes for the renderer substrate: OBJ reading, triangle records and a binary BVH in
+the flat layout the kernels (csrc/pg_render.hip) and the CPU oracle (oracle/pg_oracle_render.c)
+traverse -- the `obj` / `serialized` shapes of the reference's scenes (scenes/veach-ajar,
+scenes/torus), with face normals.
+
+Layouts (include/pgsd.h):
+  triangle, PG_TRI_STRIDE = 16 floats: v0 (0-2), e1 = v1 - v0 (3-5), e2 = v2 - v0 (6-8),
+      unit geometric normal (9-11), material index (12), 13-15 unused
+  BVH node, PG_BVH_STRIDE = 8 x 32 bit: bmin (0-2, f32), a (3, u32), bmax (4-6, f32), b (7, u32)
+      inner node: a = left child, b = right child | split axis << 29
+      leaf:       a = first triangle, b = 0x80000000 | count
+  Node 0 is the root; triangles are stored in leaf order.
+
+Plain numpy; shared by the product and by the tests that hand the same arrays to the oracle.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+TRI_STRIDE = 16
+BVH_STRIDE = 8
+LEAF_FLAG = 0x80000000
+MAX_LEAF = 4
+
+
+def read_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Vertices (V,3) float64 and triangles (F,3) int (polygons are fanned); only `v` and `f` are read."""
+    verts: List[List[float]] = []
+    faces: List[List[int]] = []
+    with open(path) as f:
+        for line in f:
+            s = line.split()
+            if not s:
+                continue
+            if s[0] == "v":
+                verts.append([float(s[1]), float(s[2]), float(s[3])])
+            elif s[0] == "f":
+                idx = [int(tok.split("/")[0]) for tok in s[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    return np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int64).reshape(-1, 3)
+
+
+def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, material_index: int) -> np.ndarray:
+    """(F,16) triangle records in world space; degenerate triangles are dropped."""
+    m = np.asarray(to_world, np.float64)
+    v = np.asarray(vertices, np.float64) @ m[:3, :3].T + m[:3, 3]
+    v = v.astype(np.float32)  # the kernels see fp32 vertices: derive everything from those
+    a, b, c = v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]]
+    e1, e2 = (b - a).astype(np.float32), (c - a).astype(np.float32)
+    n = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+    ln = np.linalg.norm(n, axis=1)
+    keep = ln > 0
+    out = np.zeros((int(keep.sum()), TRI_STRIDE), np.float32)
+    out[:, 0:3], out[:, 3:6], out[:, 6:9] = a[keep], e1[keep], e2[keep]
+    out[:, 9:12] = (n[keep] / ln[keep, None]).astype(np.float32)
+    out[:, 12] = np.float32(material_index)
+    return out
+
+
+def build_bvh(tris: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Median-split BVH over triangle records; returns (nodes (M,8) uint32 bit patterns, triangles in leaf order)."""
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, TRI_STRIDE)
+    n = tris.shape[0]
+    if n == 0:
+        return np.zeros((0, BVH_STRIDE), np.uint32), tris
+    v0, v1, v2 = tris[:, 0:3], tris[:, 0:3] + tris[:, 3:6], tris[:, 0:3] + tris[:, 6:9]
+    lo = np.minimum(np.minimum(v0, v1), v2)
+    hi = np.maximum(np.maximum(v0, v1), v2)
+    cen = 0.5 * (lo.astype(np.float64) + hi.astype(np.float64))
+    order = np.arange(n)
+    nodes: List[List[int]] = []
+    bounds: List[Tuple[np.ndarray, np.ndarray]] = []
+
+    def rec(first: int, count: int) -> int:
+        me = len(nodes)
+        idx = order[first:first + count]
+        bmin, bmax = lo[idx].min(axis=0), hi[idx].max(axis=0)
+        nodes.append([0, 0])
+        bounds.append((bmin, bmax))
+        if count <= MAX_LEAF:
+            nodes[me] = [first, LEAF_FLAG | count]
+            return me
+        c = cen[idx]
+        ext = c.max(axis=0) - c.min(axis=0)
+        axis = int(np.argmax(ext))
+        if ext[axis] == 0.0:  # all centroids coincide: split by position in the list
+            mid = count // 2
+        else:
+            srt = np.argsort(c[:, axis], kind="stable")
+            order[first:first + count] = idx[srt]
+            mid = count // 2
+        left = rec(first, mid)
+        right = rec(first + mid, count - mid)
+        nodes[me] = [left, right | (axis << 29)]
+        return me
+
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    rec(0, n)
+    out = np.zeros((len(nodes), BVH_STRIDE), np.uint32)
+    for i, ((a, b), (bmin, bmax)) in enumerate(zip(nodes, bounds)):
+        out[i, 0:3] = bmin.astype(np.float32).view(np.uint32)
+        out[i, 3] = a
+        out[i, 4:7] = bmax.astype(np.float32).view(np.uint32)
+        out[i, 7] = b
+    return out, np.ascontiguousarray(tris[order])
+
+
+def icosphere(subdivisions: int = 2) -> Tuple[np.ndarray, np.ndarray]:
+    """Unit icosphere (vertices, faces): a closed test mesh."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    verts = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    faces = [tuple(x) for x in f]
+    for _ in range(subdivisions):
+        cache = {}
+
+        def mid(i, j):
+            key = (min(i, j), max(i, j))
+            if key not in cache:
+                m = verts[i] + verts[j]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        nf = []
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = nf
+    return np.asarray(verts), np.asarray(faces, np.int64)

@@ -73,6 +73,10 @@ class WavefrontScene:
         d = N.pg_scene_desc(q.shape[0], q.ctypes.data if q.size else None, s.shape[0], s.ctypes.data if s.size else None,
                             0 if m is None else m.shape[0], None if m is None else m.ctypes.data,
                             b.shape[0], b.ctypes.data if b.size else None)
+        t = np.ascontiguousarray(self.scene.tris, np.float32)
+        n = np.ascontiguousarray(self.scene.bvh, np.uint32)
+        d.n_tris, d.tris = t.shape[0], (t.ctypes.data if t.size else None)
+        d.n_bvh_nodes, d.bvh = n.shape[0], (n.ctypes.data if n.size else None)
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 

@@ -50,6 +50,8 @@ class Scene:
     spheres: np.ndarray = field(default_factory=lambda: np.zeros((0, SPHERE_STRIDE), np.float32))  # (S, 12)
     materials: Optional[np.ndarray] = None  # (M, 12); None: quad i is diffuse with quads[i, 16:19]
     boxes: np.ndarray = field(default_factory=lambda: np.zeros((0, BOX_STRIDE), np.float32))        # (B, 32)
+    tris: np.ndarray = field(default_factory=lambda: np.zeros((0, 16), np.float32))                 # (T, 16), in BVH leaf order
+    bvh: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.uint32))                    # (M, 8) nodes, mesh.py
 
 
 def _f32(v):
@@ -156,7 +158,7 @@ def box(to_world: np.ndarray, material_index: int) -> np.ndarray:
 
 
 def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names, spheres=None, materials=None,
-            boxes=None) -> Scene:
+            boxes=None, tris=None) -> Scene:
     q = np.stack(quads).astype(np.float32) if quads else np.zeros((0, QUAD_STRIDE), np.float32)
     corners = [q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]]
     s = np.stack(spheres).astype(np.float32) if spheres else np.zeros((0, SPHERE_STRIDE), np.float32)
@@ -167,8 +169,14 @@ def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int,
         for sy in (-1, 1):
             for sz in (-1, 1):
                 corners.append(bx[:, 9:12] + sx * bx[:, 22:25] + sy * bx[:, 25:28] + sz * bx[:, 28:31])
+    tr = np.concatenate(tris).astype(np.float32) if tris else np.zeros((0, 16), np.float32)
+    if tr.shape[0]:
+        corners += [tr[:, 0:3], tr[:, 0:3] + tr[:, 3:6], tr[:, 0:3] + tr[:, 6:9]]
     corners = np.concatenate(corners)
     sc = Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
+    if tr.shape[0]:
+        from .mesh import build_bvh
+        sc.bvh, sc.tris = build_bvh(tr)
     sc.spheres = s
     sc.boxes = bx
     sc.materials = np.stack(materials).astype(np.float32) if materials else None

@@ -1,0 +1,107 @@
+"""Triangle meshes of the substrate (practical_path_guiding_lab_amd/mesh.py): OBJ reading, triangle
+records, the flat BVH the kernels and the oracle traverse, and the oracle's mesh path against the
+analytic sphere it approximates."""
+import numpy as np
+import pytest
+
+from oracle import pg_oracle as po
+from practical_path_guiding_lab_amd import mesh as M
+from practical_path_guiding_lab_amd import scene as S
+
+
+def test_read_obj_fans_polygons_and_resolves_negative_indices(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("# a quad and a triangle\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nvt 0 0\n"
+                 "f 1/1/1 2/1/1 3/1/1 4/1/1\nf -1 -5 -4\n")
+    v, f = M.read_obj(str(p))
+    assert v.shape == (5, 3) and f.tolist() == [[0, 1, 2], [0, 2, 3], [4, 0, 1]]
+    t = M.triangles(v, f, np.eye(4), 7)
+    assert t.shape == (3, M.TRI_STRIDE) and (t[:, 12] == 7).all()
+    np.testing.assert_allclose(t[0, 9:12], [0, 0, 1])
+    np.testing.assert_allclose(np.linalg.norm(t[:, 9:12], axis=1), 1, atol=1e-6)
+    # degenerate triangles are dropped; the transform is applied
+    t2 = M.triangles(v, np.array([[0, 0, 1], [0, 1, 2]]), np.diag([2.0, 3.0, 1.0, 1.0]), 0)
+    assert t2.shape[0] == 1
+    np.testing.assert_allclose(t2[0, 3:6], [2, 0, 0]); np.testing.assert_allclose(t2[0, 6:9], [2, 3, 0])
+
+
+def _check_bvh(nodes, tris):
+    n = nodes.shape[0]
+    seen = np.zeros(n, bool); seen[0] = True
+    covered = np.zeros(tris.shape[0], int)
+    v0, v1, v2 = tris[:, 0:3], tris[:, 0:3] + tris[:, 3:6], tris[:, 0:3] + tris[:, 6:9]
+    lo, hi = np.minimum(np.minimum(v0, v1), v2), np.maximum(np.maximum(v0, v1), v2)
+
+    def bounds(i):
+        return nodes[i, 0:3].view(np.float32), nodes[i, 4:7].view(np.float32)
+
+    def rec(i, depth):
+        bmin, bmax = bounds(i)
+        if nodes[i, 7] & M.LEAF_FLAG:
+            first, count = int(nodes[i, 3]), int(nodes[i, 7] & 0x7FFFFFFF)
+            assert 1 <= count <= M.MAX_LEAF
+            covered[first:first + count] += 1
+            assert (lo[first:first + count] >= bmin - 1e-6).all() and (hi[first:first + count] <= bmax + 1e-6).all()
+            return depth
+        left, right, axis = int(nodes[i, 3]), int(nodes[i, 7] & 0x1FFFFFFF), int(nodes[i, 7] >> 29) & 3
+        assert i < left < n and i < right < n and axis <= 2 and not seen[left] and not seen[right]
+        seen[left] = seen[right] = True
+        for c in (left, right):
+            cmin, cmax = bounds(c)
+            assert (cmin >= bmin).all() and (cmax <= bmax).all()
+        return max(rec(left, depth + 1), rec(right, depth + 1))
+
+    d = rec(0, 0)
+    assert seen.all() and (covered == 1).all()
+    return d
+
+
+@pytest.mark.parametrize("sub", [0, 2, 4])
+def test_bvh_is_a_tree_over_all_triangles(sub):
+    v, f = M.icosphere(sub)
+    assert f.shape[0] == 20 * 4 ** sub
+    t = M.triangles(v, f, np.diag([1.0, 2.0, 0.5, 1.0]), 0)
+    nodes, tris = M.build_bvh(t)
+    assert tris.shape == t.shape and nodes.dtype == np.uint32
+    depth = _check_bvh(nodes, tris)
+    assert depth <= 2 + np.ceil(np.log2(max(f.shape[0] / M.MAX_LEAF, 1))) + 1
+    # the reordering is a permutation of the input records
+    assert sorted(map(bytes, tris)) == sorted(map(bytes, t))
+
+
+def test_bvh_of_coincident_triangles_terminates():
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+    t = M.triangles(v, np.array([[0, 1, 2]] * 37), np.eye(4), 0)
+    nodes, tris = M.build_bvh(t)
+    _check_bvh(nodes, tris)
+
+
+def test_oracle_mesh_matches_the_sphere_it_tessellates():
+    """A diffuse ball under a sphere lamp, once as the analytic sphere and once as a 5120-triangle
+    icosphere behind the BVH: block means of the two renders agree (the tessellation error is 0.1 %)."""
+    mats = [S.diffuse_material((0.5, 0.5, 0.5)), S.diffuse_material((0, 0, 0)), S.diffuse_material((0.7, 0.3, 0.2))]
+    floor = S.rectangle(np.array([[6, 0, 0, 0], [0, 0, 6, 0], [0, -6, 0, 0], [0, 0, 0, 1]], np.float64), mats[0][1:4])
+    for q in floor:
+        q[22] = 0
+    lamp = S.sphere((2.0, 4.0, 1.0), 0.5, 1, (40, 40, 40))
+    o, tgt = np.array([0.0, 2.5, 7.0]), np.array([0, 0.8, 0.0])
+    z = (tgt - o) / np.linalg.norm(tgt - o)
+    x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+    tw = np.eye(4); tw[:3, 0], tw[:3, 1], tw[:3, 2], tw[:3, 3] = x, np.cross(z, x), z, o
+    cam = S.make_camera(tw, 35.0, 64, 48)
+    analytic = S._finish(list(floor), cam, 4, 8, ["f"], [lamp, S.sphere((0, 1.0, 0), 1.0, 2)], mats)
+    v, f = M.icosphere(4)
+    tw2 = np.eye(4); tw2[:3, 3] = [0, 1.0, 0]
+    meshed = S._finish(list(floor), cam, 4, 8, ["f"], [lamp], mats, None, [M.triangles(v, f, tw2, 2)])
+    assert meshed.tris.shape == (5120, 16) and meshed.bvh.shape[0] > 2000
+    np.testing.assert_allclose(meshed.bbox_min, analytic.bbox_min, atol=1e-3)
+    imgs = []
+    for sc in (analytic, meshed):
+        pair = po.OracleSDTreePair()
+        pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
+        L, valid = po.render_pass(pair, sc, sc.camera, 4, 8, 0, True, 11, 48, True, 0.5)
+        imgs.append(L.astype(np.float64).reshape(3, 48, 64, 48).mean(axis=3))
+    a = imgs[0].reshape(3, 4, 12, 4, 16).mean(axis=(0, 2, 4))
+    b = imgs[1].reshape(3, 4, 12, 4, 16).mean(axis=(0, 2, 4))
+    assert np.abs(a - b).max() < 0.01 * a.max() + 2e-3, (a, b)
+    assert abs(imgs[0].mean() - imgs[1].mean()) < 0.005 * imgs[0].mean()
