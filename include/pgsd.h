@@ -231,8 +231,9 @@ int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t
 #define PG_QUAD_STRIDE 24
 /* sphere: 0-2 centre  3 radius  4 material index  5 emitter flag  6-8 emitted radiance  9-11 unused */
 #define PG_SPHERE_STRIDE 12
-/* material: 0 type (0 twosided diffuse; 1 twosided roughconductor, beckmann, sample_visible)
- *   1-3 reflectance | specular_reflectance  4 alpha  5-7 eta  8-10 k  11 unused */
+/* material: 0 type (0 diffuse; 1 roughconductor, beckmann, sample_visible; 2 smooth conductor;
+ *   3 smooth dielectric)  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta (dielectric:
+ *   5 = int_ior / ext_ior)  8-10 k  11 one-sided flag (0 = wrapped in `twosided`) */
 #define PG_MATERIAL_STRIDE 12
 /* box (Mitsuba's `cube`: [-1,1]^3 under an affine to_world), intersected as three slabs in its local
  * frame instead of six quads: 0-8 rows of A = (linear part of to_world)^-1, 9-11 centre c
@@ -273,7 +274,15 @@ typedef struct pg_scene_desc {
 	const float *tris;
 	uint64_t n_bvh_nodes;
 	const uint32_t *bvh;
+	/* `directional` emitters (scenes/torus/scene.xml), PG_DIRLIGHT_STRIDE floats each: 0-2 unit
+	 * direction the light travels in, 3-5 irradiance.  They follow the area emitters in the uniform
+	 * emitter choice.  bsphere: centre and radius of the scene's bounding sphere (Mitsuba places a
+	 * directional sample two radii up the light's direction). */
+	uint64_t n_dir_lights;
+	const float *dir_lights;
+	float bsphere[4];
 } pg_scene_desc;
+#define PG_DIRLIGHT_STRIDE 8
 #define PG_TRI_STRIDE 16
 #define PG_BVH_STRIDE 8
 int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *scene, const pg_camera *cam);

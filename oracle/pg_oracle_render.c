@@ -189,7 +189,7 @@ static v3 box_face_normal(const float *B, int face)
 }
 
 /* ---- surface description at a hit ---- */
-typedef struct { int type; v3 refl; float alpha; v3 eta, k; } material;
+typedef struct { int type; v3 refl; float alpha; v3 eta, k; int one_sided; } material;
 typedef struct { v3 p, n; int is_em; v3 radiance; material m; } surface;
 
 static material load_material(const float *M)
@@ -200,6 +200,7 @@ static material load_material(const float *M)
 	m.alpha = M[4];
 	m.eta = ld3(M + 5);
 	m.k = ld3(M + 8);
+	m.one_sided = M[11] != 0.0f;
 	return m;
 }
 
@@ -273,17 +274,38 @@ static float emitter_hit_pdf(const pgo_scene *sc, int prim, v3 ref, v3 p, v3 n, 
  * emitter (e1 is reused after the choice), then a point on it; returns ds.d, ds.pdf and
  * radiance / pdf (zero when occluded, facing away, or from inside a sphere) */
 static void sample_emitter(const pgo_scene *sc, const int *em, int n_em, v3 p, v3 n, float e1, float e2, v3 *ds_d,
-                           float *ds_pdf, v3 *em_weight)
+                           float *ds_pdf, v3 *em_weight, int *ds_delta)
 {
 	*ds_d = V(0, 0, 0);
 	*ds_pdf = 0.0f;
 	*em_weight = V(0, 0, 0);
+	*ds_delta = 0;
 	if (n_em <= 0) return;
 	const float count = (float)n_em, inv_count = 1.0f / count;
 	uint32_t idx = (uint32_t)(e1 * count);
 	if (idx > (uint32_t)(n_em - 1)) idx = (uint32_t)(n_em - 1);
 	e1 = e1 * count - (float)idx;
 	const int prim = em[idx];
+	if (prim < 0) { /* directional.cpp sample_direction: a point 2 radii up the light's direction, pdf 1, delta */
+		const float *Dl = sc->dir_lights + (size_t)(-1 - prim) * PGO_DIRLIGHT_STRIDE;
+		const v3 dl = ld3(Dl);
+		const v3 cd = vsub(p, V(sc->bsphere[0], sc->bsphere[1], sc->bsphere[2]));
+		const float dc = sqrtf(dot3(cd, cd));
+		const float dist = 2.0f * (sc->bsphere[3] > dc ? sc->bsphere[3] : dc);
+		const v3 pl = vsub(p, vscale(dl, dist));
+		*ds_d = V(-dl.x, -dl.y, -dl.z);
+		*ds_delta = 1;
+		*ds_pdf = 1.0f * inv_count;
+		float mag = (1.0f + max3(V(fabsf(p.x), fabsf(p.y), fabsf(p.z)))) * RAY_EPS_F;
+		if (dot3(n, *ds_d) < 0.0f) mag = -mag;
+		const v3 so = vadd(p, vscale(n, mag));
+		const v3 sd = vsub(pl, so);
+		const float sdist = sqrtf(dot3(sd, sd));
+		float th;
+		const int occ = intersect(sc, so, vdivs(sd, sdist), sdist * (1.0f - SHADOW_EPS_F), &th) >= 0;
+		if (!occ) *em_weight = vscale(ld3(Dl + 3), count);
+		return;
+	}
 	v3 pl, ln, radiance;
 	float pdf_cone = 0.0f; /* spheres: density over directions, known before the geometry term */
 	int is_sphere = (size_t)prim >= sc->n_quads;
@@ -479,36 +501,75 @@ static void rc_sample(const material *mt, v3 wi, float u1, float u2, v3 *wo, flo
 	*weight = vmul(F, vscale(mt->refl, rc_G1(o, m, mt->alpha)));
 }
 
-/* twosided(bsdf).eval_pdf: value includes cos(theta_o) */
+/* Mitsuba fresnel(cos_theta_i, eta): unpolarised reflectance of a dielectric interface, the signed
+ * cosine of the transmitted direction, and the relative index along / against the ray */
+static float fresnel_dielectric(float cos_i, float eta, float *cos_t, float *eta_it, float *eta_ti)
+{
+	const int outside = cos_i >= 0.0f;
+	const float rcp_eta = 1.0f / eta;
+	*eta_it = outside ? eta : rcp_eta;
+	*eta_ti = outside ? rcp_eta : eta;
+	const float cos_t_sqr = 1.0f - ((1.0f - cos_i * cos_i) * (*eta_ti * *eta_ti));
+	const float ci = fabsf(cos_i), ct = safe_sqrtf(cos_t_sqr);
+	const float a_s = (*eta_it * ct - ci) / (*eta_it * ct + ci);
+	const float a_p = (*eta_it * ci - ct) / (*eta_it * ci + ct);
+	float r = 0.5f * (a_s * a_s + a_p * a_p);
+	if (eta == 1.0f) r = 0.0f;
+	else if (ci == 0.0f) r = 1.0f;
+	*cos_t = cos_i >= 0.0f ? -ct : ct; /* on the other side of the interface */
+	return r;
+}
+
+/* BSDF flags: does the material have a non-delta lobe (BSDFFlags.Smooth, :210)? */
+static inline int material_is_smooth(const material *mt) { return mt->type != 2 && mt->type != 3; }
+
+/* bsdf.eval_pdf (twosided unless the material says otherwise): value includes cos(theta_o) */
 static inline void bsdf_eval_pdf(const material *mt, v3 wi, v3 wo, int active, v3 *value, float *pdf)
 {
+	*value = V(0, 0, 0);
+	*pdf = 0.0f;
+	if (!active) return;
+	if (mt->type == 2 || mt->type == 3) return; /* smooth conductor / dielectric: delta lobes only */
+	if (wi.z < 0.0f && !mt->one_sided) { wi.z = -wi.z; wo.z = -wo.z; }
 	if (mt->type == 1) {
-		*value = V(0, 0, 0);
-		*pdf = 0.0f;
-		if (!active) return;
-		if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
 		rc_eval_pdf(mt, wi, wo, value, pdf);
 		return;
 	}
 	const v3 refl = mt->refl;
-	*value = V(0, 0, 0);
-	*pdf = 0.0f;
-	if (!active) return;
-	if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
 	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
 	*value = vscale(vscale(refl, INV_PI_F), wo.z);
 	*pdf = INV_PI_F * wo.z;
 }
 
-/* twosided(bsdf).sample: returns wo (local), pdf, weight = value/pdf */
-static inline void bsdf_sample(const material *mt, v3 wi, float u, float v, int active, v3 *wo, float *pdf, v3 *weight,
-                               float *eta)
+/* bsdf.sample(ctx, si, u1, (u, v)): wo (local), pdf, weight = value/pdf, relative index along the
+ * sampled direction, and whether a delta lobe was sampled (BSDFFlags.Delta, :282) */
+static inline void bsdf_sample(const material *mt, v3 wi, float u1, float u, float v, int active, v3 *wo, float *pdf,
+                               v3 *weight, float *eta, int *delta)
 {
-	*wo = V(0, 0, 0); *pdf = 0.0f; *weight = V(0, 0, 0); *eta = 0.0f;
+	*wo = V(0, 0, 0); *pdf = 0.0f; *weight = V(0, 0, 0); *eta = 0.0f; *delta = 0;
 	if (!active) return;
-	int flip = wi.z < 0.0f;
+	if (mt->type == 3) { /* smooth dielectric (dielectric.cpp), radiance transport */
+		float cos_t, eta_it, eta_ti;
+		const float r_i = fresnel_dielectric(wi.z, mt->eta.x, &cos_t, &eta_it, &eta_ti);
+		const int reflect = u1 <= r_i;
+		*delta = 1;
+		*pdf = reflect ? r_i : 1.0f - r_i;
+		*wo = reflect ? V(-wi.x, -wi.y, wi.z) : V(-eta_ti * wi.x, -eta_ti * wi.y, cos_t);
+		*eta = reflect ? 1.0f : eta_it;
+		*weight = reflect ? V(1, 1, 1) : V(eta_ti * eta_ti, eta_ti * eta_ti, eta_ti * eta_ti);
+		return;
+	}
+	int flip = wi.z < 0.0f && !mt->one_sided;
 	float cos_i = flip ? -wi.z : wi.z;
 	if (!(cos_i > 0.0f)) return;
+	if (mt->type == 2) { /* smooth conductor (conductor.cpp): the mirror direction, weighted by Fresnel */
+		*delta = 1;
+		*pdf = 1.0f;
+		*eta = 1.0f;
+		*wo = V(-wi.x, -wi.y, wi.z);
+		*weight = vmul(rc_fresnel(mt, cos_i), mt->refl);
+		return;
+	}
 	if (mt->type == 1) {
 		v3 o;
 		rc_sample(mt, V(wi.x, wi.y, cos_i), u, v, &o, pdf, weight);
@@ -537,10 +598,21 @@ void pgo_bsdf_eval_pdf(const float *m, const float wi[3], const float wo[3], flo
 
 void pgo_bsdf_sample(const float *m, const float wi[3], float u1, float u2, float wo[3], float *pdf, float weight[3])
 {
+	float eta;
+	int delta;
+	pgo_bsdf_sample_full(m, wi, 0.5f, u1, u2, wo, pdf, weight, &eta, &delta);
+}
+
+void pgo_bsdf_sample_full(const float *m, const float wi[3], float lobe, float u1, float u2, float wo[3], float *pdf,
+                          float weight[3], float *eta_out, int *delta_out)
+{
 	const material mt = load_material(m);
 	v3 o, w;
 	float eta;
-	bsdf_sample(&mt, ld3(wi), u1, u2, 1, &o, pdf, &w, &eta);
+	int delta;
+	bsdf_sample(&mt, ld3(wi), lobe, u1, u2, 1, &o, pdf, &w, &eta, &delta);
+	*eta_out = eta;
+	*delta_out = delta;
 	wo[0] = o.x; wo[1] = o.y; wo[2] = o.z;
 	weight[0] = w.x; weight[1] = w.y; weight[2] = w.z;
 }
@@ -549,7 +621,10 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t nq, const f
                      const pgo_camera *cam, const pgo_render_params *prm, float *L_out, uint8_t *valid_out,
                      float *sumL, float *sumL2)
 {
-	const pgo_scene sc = { nq, quads, 0, NULL, 0, NULL, 0, NULL, 0, NULL, 0, NULL };
+	pgo_scene sc;
+	memset(&sc, 0, sizeof sc);
+	sc.n_quads = nq;
+	sc.quads = quads;
 	pgo_render_pass_scene(prev, current, &sc, cam, prm, L_out, valid_out, sumL, sumL2);
 }
 
@@ -558,12 +633,13 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
                            float *sumL, float *sumL2)
 {
 	/* emitters: flagged quads, then flagged spheres */
-	int *em = malloc((sc->n_quads + sc->n_spheres + 1) * sizeof(int));
+	int *em = malloc((sc->n_quads + sc->n_spheres + sc->n_dir_lights + 1) * sizeof(int));
 	int n_em = 0;
 	for (size_t q = 0; q < sc->n_quads; ++q)
 		if (sc->quads[q * PGO_QUAD_STRIDE + 15] != 0.0f) em[n_em++] = (int)q;
 	for (size_t s = 0; s < sc->n_spheres; ++s)
 		if (sc->spheres[s * PGO_SPHERE_STRIDE + 5] != 0.0f) em[n_em++] = (int)(sc->n_quads + s);
+	for (size_t k = 0; k < sc->n_dir_lights; ++k) em[n_em++] = -1 - (int)k; /* directional lights: negative codes */
 	const float inv_em_count = n_em > 0 ? 1.0f / (float)n_em : 0.0f;
 	const int W = cam->width, H = cam->height, spp = prm->spp, D = prm->max_depth;
 	const size_t npix = (size_t)W * H, N = npix * (size_t)spp, S = N * (size_t)(D > 0 ? D : 1);
@@ -623,11 +699,12 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
 			v3 Le = vmul(vscale(thr, mis), em_radiance);
 			/* ---- :207-220 emitter sampling ---- */
 			int active_next = (depth + 1 < (uint32_t)D) && valid;
-			int active_em = active_next; /* diffuse: BSDFFlags.Smooth */
+			int active_em = active_next && material_is_smooth(mt); /* :210 BSDFFlags.Smooth */
 			float e1 = pgo_pcg32_next_f32(&rng), e2 = pgo_pcg32_next_f32(&rng); /* :214 next_2d, unmasked */
 			v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 			float ds_pdf = 0.0f;
-			if (active_em) sample_emitter(sc, em, n_em, p, n, e1, e2, &ds_d, &ds_pdf, &em_weight);
+			int ds_delta = 0;
+			if (active_em) sample_emitter(sc, em, n_em, p, n, e1, e2, &ds_d, &ds_pdf, &em_weight, &ds_delta);
 			active_em = active_em && (ds_pdf != 0.0f); /* :216 */
 			v3 wo_em = to_local(&fr, ds_d);
 			v3 bsdf_value_em;
@@ -648,20 +725,19 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
 			}
 			float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
 			if (!guided) surface_pdf_em = bsdf_pdf_em;
-			float mis_em = mis_weight(ds_pdf, surface_pdf_em);
+			float mis_em = ds_delta ? 1.0f : mis_weight(ds_pdf, surface_pdf_em); /* :253 */
 			v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em), em_weight);
 			L = vadd(L, vadd(Le, Lr_dir)); /* :261 */
 			/* ---- :272-311 next direction ---- */
 			float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
 			if (active_next) { s1 = pgo_pcg32_next_f32(&rng); s2x = pgo_pcg32_next_f32(&rng); s2y = pgo_pcg32_next_f32(&rng); }
-			(void)s1;
 			v3 wo_local, bsdf_weight;
 			float bsdf_pdf, eta;
-			bsdf_sample(mt, wi, s2x, s2y, active_next, &wo_local, &bsdf_pdf, &bsdf_weight, &eta);
+			int delta;
+			bsdf_sample(mt, wi, s1, s2x, s2y, active_next, &wo_local, &bsdf_pdf, &bsdf_weight, &eta, &delta);
 			v3 bsdf_value = vscale(bsdf_weight, bsdf_pdf);
 			float woPdf = bsdf_pdf;
 			v3 wo_world = to_world(&fr, wo_local);
-			int delta = 0;
 			int do_mis = active_next && !delta && guided;
 			int pick_tree = 0;
 			if (active_next) pick_tree = pgo_pcg32_next_f32(&rng) > f; /* :286 */

@@ -31,8 +31,9 @@ extern "C" {
 #define PGO_QUAD_STRIDE 24
 /* one sphere: 0-2 centre  3 radius  4 material index  5 emitter flag  6-8 emitted radiance  9-11 pad */
 #define PGO_SPHERE_STRIDE 12
-/* one material: 0 type (0 twosided diffuse, 1 twosided roughconductor/beckmann, sample_visible)
- *  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta  8-10 k  11 pad                 */
+/* one material: 0 type (0 diffuse, 1 roughconductor/beckmann/sample_visible, 2 smooth conductor,
+ *  3 smooth dielectric)  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta (dielectric: 5 =
+ *  int_ior / ext_ior)  8-10 k  11 one-sided flag (0 = wrapped in `twosided`; dielectrics never are) */
 #define PGO_MATERIAL_STRIDE 12
 
 /* one box (Mitsuba's `cube` shape, [-1,1]^3 under an affine to_world), intersected as three slabs
@@ -61,7 +62,14 @@ typedef struct pgo_scene {
 	const float *tris;       /* PGO_TRI_STRIDE floats each, in BVH leaf order */
 	size_t n_bvh_nodes;
 	const uint32_t *bvh;     /* PGO_BVH_STRIDE words each; node 0 is the root */
+	/* `directional` emitters (scenes/torus/scene.xml): 8 floats each -- 0-2 unit direction the light
+	 * travels in, 3-5 irradiance, 6-7 pad; they follow the area emitters in the emitter list.
+	 * bsphere: centre and radius of the scene's bounding sphere (where their samples are placed) */
+	size_t n_dir_lights;
+	const float *dir_lights;
+	float bsphere[4];
 } pgo_scene;
+#define PGO_DIRLIGHT_STRIDE 8
 #define PGO_TRI_STRIDE 16
 #define PGO_BVH_STRIDE 8
 
@@ -96,6 +104,9 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
  * eval_pdf -> value (incl. cos theta_o) and pdf; sample -> wo, pdf, weight = value/pdf. */
 void pgo_bsdf_eval_pdf(const float *m, const float wi[3], const float wo[3], float value[3], float *pdf);
 void pgo_bsdf_sample(const float *m, const float wi[3], float u1, float u2, float wo[3], float *pdf, float weight[3]);
+/* ... with the lobe-selection sample (bsdf.sample's sample1), the relative index along wo, and the delta flag */
+void pgo_bsdf_sample_full(const float *m, const float wi[3], float lobe, float u1, float u2, float wo[3], float *pdf,
+                          float weight[3], float *eta_out, int *delta_out);
 
 /* Film reconstruction of one full-frame pass with Mitsuba's `tent` reconstruction filter, radius one
  * pixel (the <rfilter type="tent"/> of scenes/cornell-box/scene.xml:27): what mi.render returns at

@@ -243,9 +243,10 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 
 // ---- surface description at a hit ----
 struct Material {
-	int type;        // 0 twosided diffuse, 1 twosided roughconductor (Beckmann, visible normals)
+	int type;        // 0 diffuse, 1 roughconductor (Beckmann, visible normals), 2 smooth conductor, 3 smooth dielectric
 	v3 refl;         // reflectance | specular_reflectance
-	const float *M;  // the material row: alpha, eta, k are read where the rough BSDF needs them
+	const float *M;  // the material row: alpha, eta, k are read where the BSDF needs them
+	bool one_sided;  // not wrapped in `twosided` (row word 11)
 };
 struct Surface {
 	v3 p, n, radiance;
@@ -283,6 +284,7 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 			s.m.type = 0;
 			s.m.refl = ld3(Q + 16);
 			s.m.M = nullptr;
+			s.m.one_sided = false;
 			return s;
 		}
 		M = mats + (int)Q[22] * kMaterialStride;
@@ -298,7 +300,8 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 		s.radiance = ld3(S + 6);
 		M = mats + (int)S[4] * kMaterialStride;
 	}
-	s.m.type = kGeneral ? (int)M[0] : 0; // a scene with a rough conductor anywhere runs the general kernels
+	s.m.type = kGeneral ? (int)M[0] : 0; // a scene with anything but twosided diffuse runs the general kernels
+	s.m.one_sided = kGeneral && M[11] != 0.0f;
 	s.m.refl = ld3(M + 1);
 	s.m.M = M;
 	return s;
@@ -478,14 +481,37 @@ __device__ __forceinline__ void rc_sample(const Material &mt, v3 wi, float u1, f
 	weight = vmul(F, vscale(mt.refl, rc_G1(o, m, alpha)));
 }
 
-// twosided(bsdf).eval_pdf: value includes cos(theta_o)
+// Mitsuba fresnel(cos_theta_i, eta): unpolarised reflectance of a dielectric interface, the signed
+// cosine of the transmitted direction, the relative index along / against the ray
+__device__ __forceinline__ float fresnel_dielectric(float cos_i, float eta, float &cos_t, float &eta_it, float &eta_ti)
+{
+	const bool outside = cos_i >= 0.0f;
+	const float rcp_eta = 1.0f / eta;
+	eta_it = outside ? eta : rcp_eta;
+	eta_ti = outside ? rcp_eta : eta;
+	const float cos_t_sqr = 1.0f - ((1.0f - cos_i * cos_i) * (eta_ti * eta_ti));
+	const float ci = fabs_(cos_i), ct = safe_sqrtf(cos_t_sqr);
+	const float a_s = (eta_it * ct - ci) / (eta_it * ct + ci);
+	const float a_p = (eta_it * ci - ct) / (eta_it * ci + ct);
+	float r = 0.5f * (a_s * a_s + a_p * a_p);
+	if (eta == 1.0f) r = 0.0f;
+	else if (ci == 0.0f) r = 1.0f;
+	cos_t = cos_i >= 0.0f ? -ct : ct;
+	return r;
+}
+
+// BSDFFlags.Smooth (:210): does the material have a non-delta lobe?
+__device__ __forceinline__ bool material_is_smooth(const Material &mt) { return mt.type != 2 && mt.type != 3; }
+
+// bsdf.eval_pdf (twosided unless the material says otherwise): value includes cos(theta_o)
 template <bool kGeneral>
 __device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, bool active, v3 &value, float &pdf)
 {
 	value = V(0, 0, 0);
 	pdf = 0.0f;
 	if (!active) return;
-	if (wi.z < 0.0f) { wi.z = -wi.z; wo.z = -wo.z; }
+	if (kGeneral && (mt.type == 2 || mt.type == 3)) return; // smooth conductor / dielectric: delta lobes only
+	if (wi.z < 0.0f && !(kGeneral && mt.one_sided)) { wi.z = -wi.z; wo.z = -wo.z; }
 	if (kGeneral && mt.type == 1) {
 		rc_eval_pdf(mt, wi, wo, value, pdf);
 		return;
@@ -496,16 +522,37 @@ __device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, 
 	pdf = kInvPiF * wo.z;
 }
 
-// twosided(bsdf).sample: wo (local), pdf, weight = value / pdf
+// bsdf.sample(ctx, si, u1, (u, v)): wo (local), pdf, weight = value / pdf, the relative index along
+// wo, and whether a delta lobe was sampled (BSDFFlags.Delta, :282)
 template <bool kGeneral>
-__device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u, float v, bool active, v3 &wo, float &pdf,
-                                            v3 &weight, float &eta)
+__device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u1, float u, float v, bool active, v3 &wo,
+                                            float &pdf, v3 &weight, float &eta, bool &delta)
 {
-	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta = 0.0f;
+	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta = 0.0f; delta = false;
 	if (!active) return;
-	const bool flip = wi.z < 0.0f;
+	if (kGeneral && mt.type == 3) { // smooth dielectric (dielectric.cpp), radiance transport
+		float cos_t, eta_it, eta_ti;
+		const float r_i = fresnel_dielectric(wi.z, mt.M[5], cos_t, eta_it, eta_ti);
+		const bool reflect = u1 <= r_i;
+		const float sc = eta_ti * eta_ti;
+		delta = true;
+		pdf = reflect ? r_i : 1.0f - r_i;
+		wo = reflect ? V(-wi.x, -wi.y, wi.z) : V(-eta_ti * wi.x, -eta_ti * wi.y, cos_t);
+		eta = reflect ? 1.0f : eta_it;
+		weight = reflect ? V(1, 1, 1) : V(sc, sc, sc);
+		return;
+	}
+	const bool flip = wi.z < 0.0f && !(kGeneral && mt.one_sided);
 	const float cos_i = flip ? -wi.z : wi.z;
 	if (!(cos_i > 0.0f)) return;
+	if (kGeneral && mt.type == 2) { // smooth conductor (conductor.cpp): the mirror direction, weighted by Fresnel
+		delta = true;
+		pdf = 1.0f;
+		eta = 1.0f;
+		wo = V(-wi.x, -wi.y, wi.z);
+		weight = vmul(rc_fresnel(mt.M, cos_i), mt.refl);
+		return;
+	}
 	if (kGeneral && mt.type == 1) {
 		v3 o;
 		rc_sample(mt, V(wi.x, wi.y, cos_i), u, v, o, pdf, weight);
@@ -527,19 +574,47 @@ __device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u, 
 // scene.sample_emitter_direction(si, (e1, e2), test_visibility=True): uniform choice of one emitter
 // (e1 is reused after the choice), then a point on it; returns ds.d, ds.pdf and radiance / pdf
 // (zero when occluded, facing away, or from inside a sphere)
+// Directional emitters of a scene (scenes/torus/scene.xml) and the bounding sphere their samples sit on
+struct DirLights {
+	const float *lights; // 8 floats each: 0-2 unit direction the light travels in, 3-5 irradiance
+	float bsphere[4];    // centre, radius
+};
+
 template <bool kGeneral>
-__device__ __forceinline__ void sample_emitter(const Shapes &sh, const int32_t *__restrict__ emitters, int n_em, v3 p,
-                                               v3 n, float e1, float e2, v3 &ds_d, float &ds_pdf, v3 &em_weight)
+__device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights &dls, const int32_t *__restrict__ emitters,
+                                               int n_em, v3 p, v3 n, float e1, float e2, v3 &ds_d, float &ds_pdf,
+                                               v3 &em_weight, bool &ds_delta)
 {
 	ds_d = V(0, 0, 0);
 	ds_pdf = 0.0f;
 	em_weight = V(0, 0, 0);
+	ds_delta = false;
 	if (n_em <= 0) return;
 	const float count = (float)n_em, inv_count = 1.0f / count;
 	uint32_t idx = (uint32_t)(e1 * count);
 	if (idx > (uint32_t)(n_em - 1)) idx = (uint32_t)(n_em - 1);
 	e1 = e1 * count - (float)idx;
 	const int prim = emitters[idx];
+	if (kGeneral && prim < 0) { // directional.cpp sample_direction: a point two radii up the light's direction, pdf 1, delta
+		const float *Dl = dls.lights + (size_t)(-1 - prim) * 8;
+		const v3 dl = ld3(Dl);
+		const v3 cd = vsub(p, V(dls.bsphere[0], dls.bsphere[1], dls.bsphere[2]));
+		const float dc = __builtin_sqrtf(dot3(cd, cd));
+		const float dist = 2.0f * (dls.bsphere[3] > dc ? dls.bsphere[3] : dc);
+		const v3 pl = vsub(p, vscale(dl, dist));
+		ds_d = V(-dl.x, -dl.y, -dl.z);
+		ds_delta = true;
+		ds_pdf = 1.0f * inv_count;
+		float mag = (1.0f + max3(V(fabs_(p.x), fabs_(p.y), fabs_(p.z)))) * kRayEps;
+		if (dot3(n, ds_d) < 0.0f) mag = -mag;
+		const v3 so = vadd(p, vscale(n, mag));
+		const v3 sd = vsub(pl, so);
+		const float sdist = __builtin_sqrtf(dot3(sd, sd));
+		float th;
+		const bool occ = intersect<kGeneral>(sh, so, vdivs(sd, sdist), sdist * (1.0f - kShadowEps), th) >= 0;
+		if (!occ) em_weight = vscale(ld3(Dl + 3), count);
+		return;
+	}
 	v3 pl, ln, radiance;
 	float pdf_cone = 0.0f, area = 1.0f;
 	const bool is_sphere = kGeneral && prim >= sh.n_quads;
@@ -608,8 +683,10 @@ struct RenderArgs {
 	TreeView tree;
 	Shapes shapes;
 	const float *mats;          // material table (general scenes)
-	const int32_t *emitters;    // shape numbers of the emitters: flagged quads, then flagged spheres
+	const int32_t *emitters;    // the emitters: shape numbers of flagged quads, then flagged spheres, then -1-k for directional light k
 	int n_emitters;
+	DirLights dir_lights;
+	float *ior;                 // general scenes: running product of the relative indices along the path (:357)
 	pg_camera cam;
 	uint64_t n_lanes, n_pixels;      // of this pass (tile)
 	uint64_t pixel_begin, film_pixels; // first pixel of the tile, pixels of the whole film
@@ -649,7 +726,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	Pcg32 rng;
 	v3 ray_o, ray_d, thr, L, prev_p;
 	float prev_bsdf_pdf;
-	const bool prev_delta = kFirst;
+	bool prev_delta = kFirst; // general scenes: bit 31 of the stored shape number (a delta lobe was sampled)
+	float ior = 1.0f;         // general scenes: a.ior
 	if (kFirst) {
 		// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
 		// the full-frame pass would, whatever the number of ranks
@@ -678,7 +756,12 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		prev_p = V(a.prev_p[lane], a.prev_p[N + lane], a.prev_p[2 * N + lane]);
 		prev_bsdf_pdf = a.prev_pdf[lane];
 		// :352 spawn_ray of the previous vertex: the same three operations that produced the origin
-		const v3 pn = normal_at<kGeneral>(sh, (int)a.prev_quad[lane], prev_p);
+		const uint32_t pq = a.prev_quad[lane];
+		if (kGeneral) {
+			prev_delta = (pq >> 31) != 0u;
+			ior = a.ior[lane];
+		}
+		const v3 pn = normal_at<kGeneral>(sh, (int)(pq & 0x7fffffffu), prev_p);
 		float mag = (1.0f + max3(V(fabs_(prev_p.x), fabs_(prev_p.y), fabs_(prev_p.z)))) * kRayEps;
 		if (dot3(pn, ray_d) < 0.0f) mag = -mag;
 		ray_o = vadd(prev_p, vscale(pn, mag));
@@ -690,7 +773,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const bool valid = q >= 0;
 	Surface sf;
 	sf.p = V(0, 0, 0); sf.n = V(0, 0, 1); sf.radiance = V(0, 0, 0); sf.is_em = false;
-	sf.m.type = 0; sf.m.refl = V(0, 0, 0); sf.m.M = nullptr;
+	sf.m.type = 0; sf.m.refl = V(0, 0, 0); sf.m.M = nullptr; sf.m.one_sided = false;
 	if (valid) sf = surface_at<kGeneral>(sh, a.mats, q, ray_o, ray_d, t_hit);
 	const v3 p = sf.p, n = sf.n;
 	const Material &mt = sf.m;
@@ -706,11 +789,13 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const v3 Le = vmul(vscale(thr, mis), em_radiance);
 	// ---- :207-220 emitter sampling ----
 	bool active_next = (depth + 1 < (uint32_t)D) && valid;
-	bool active_em = active_next;
+	bool active_em = active_next && (!kGeneral || material_is_smooth(mt)); // :210 BSDFFlags.Smooth
 	const float e1 = rng.next_f32(), e2 = rng.next_f32(); // :214, unmasked
 	v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 	float ds_pdf = 0.0f;
-	if (active_em) sample_emitter<kGeneral>(sh, a.emitters, a.n_emitters, p, n, e1, e2, ds_d, ds_pdf, em_weight);
+	bool ds_delta = false;
+	if (active_em)
+		sample_emitter<kGeneral>(sh, a.dir_lights, a.emitters, a.n_emitters, p, n, e1, e2, ds_d, ds_pdf, em_weight, ds_delta);
 	active_em = active_em && (ds_pdf != 0.0f); // :216
 	const v3 wo_em = to_local(fr, ds_d);
 	v3 bsdf_value_em;
@@ -744,19 +829,25 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
 	if (!a.guided) surface_pdf_em = bsdf_pdf_em;
-	const float mis_em = mis_weight(ds_pdf, surface_pdf_em);
+	const float mis_em = (kGeneral && ds_delta) ? 1.0f : mis_weight(ds_pdf, surface_pdf_em); // :253
 	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em), em_weight);
 	L = vadd(L, vadd(Le, Lr_dir)); // :261
 	// ---- :272-311 next direction ----
-	float s2x = 0.0f, s2y = 0.0f;
-	if (active_next) { rng.skip(); s2x = rng.next_f32(); s2y = rng.next_f32(); } // next_1d (unused by diffuse), next_2d
+	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
+	if (active_next) { // next_1d (lobe choice: only the dielectric reads it), next_2d
+		if (kGeneral) s1 = rng.next_f32();
+		else rng.skip();
+		s2x = rng.next_f32();
+		s2y = rng.next_f32();
+	}
 	v3 wo_local, bsdf_weight;
 	float bsdf_pdf, eta;
-	bsdf_sample<kGeneral>(mt, wi, s2x, s2y, active_next, wo_local, bsdf_pdf, bsdf_weight, eta);
+	bool delta;
+	bsdf_sample<kGeneral>(mt, wi, s1, s2x, s2y, active_next, wo_local, bsdf_pdf, bsdf_weight, eta, delta);
 	v3 bsdf_value = vscale(bsdf_weight, bsdf_pdf);
 	float woPdf = bsdf_pdf;
 	v3 wo_world = to_world(fr, wo_local);
-	const bool do_mis = active_next && a.guided; // no delta lobes in this substrate
+	const bool do_mis = active_next && !delta && a.guided; // :283
 	bool pick_tree = false;
 	if (active_next) pick_tree = rng.next_f32() > f; // :286
 	const bool smp_tree = pick_tree && do_mis;
@@ -825,13 +916,13 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		a.r_wp[g] = woPdf;
 	}
 	// ---- :352-381 advance ----
-	// ior: every BSDF of the substrate returns eta = 1 to a sampled direction, so :357's running
-	// product stays exactly 1 and the Russian-roulette probability is max(throughput) * 1 * 1
-	(void)eta;
+	// ior (:357): without a dielectric every sampled direction has eta = 1, the running product stays
+	// exactly 1 and is not carried; general scenes carry it
+	if (kGeneral) ior = ior * eta;
 	thr = vmul(thr, bsdf_weight);
 	const float tmax = max3(thr);
 	active_next = active_next && (tmax != 0.0f);
-	float rr_prob = tmax * (1.0f * 1.0f);
+	float rr_prob = tmax * (ior * ior);
 	if (!(rr_prob < 0.95f)) rr_prob = 0.95f;
 	const bool rr_active = depth >= (uint32_t)a.rr_depth;
 	const float rr = rng.next_f32(); // :377, unmasked
@@ -847,7 +938,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
 		a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
 		a.prev_pdf[lane] = woPdf;
-		a.prev_quad[lane] = (uint32_t)q;
+		a.prev_quad[lane] = (uint32_t)q | ((kGeneral && delta) ? 0x80000000u : 0u);
+		if (kGeneral) a.ior[lane] = ior;
 	}
 	return active_next;
 }
@@ -994,7 +1086,8 @@ using namespace pg;
 
 // library-owned renderer state
 struct pg_render_state {
-	DevBuf<float> quads, spheres, mats, boxes, tris;
+	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior;
+	float bsphere[4] = {0, 0, 0, 0};
 	DevBuf<uint32_t> bvh;
 	DevBuf<int32_t> emitters;
 	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0, n_bvh_nodes = 0;
@@ -1059,6 +1152,8 @@ int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const 
 	d.n_boxes = 0; d.boxes = nullptr;
 	d.n_tris = 0; d.tris = nullptr;
 	d.n_bvh_nodes = 0; d.bvh = nullptr;
+	d.n_dir_lights = 0; d.dir_lights = nullptr;
+	d.bsphere[0] = d.bsphere[1] = d.bsphere[2] = d.bsphere[3] = 0.0f;
 	return pg_scene_set_ex(ctx, &d, cam);
 }
 
@@ -1089,12 +1184,18 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	bool general = ns > 0;
 	for (uint64_t m = 0; m < n_mats; ++m) {
 		const float type = mats[m * kMaterialStride];
-		if (type != 0.0f && type != 1.0f) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
-		if (type == 1.0f) {
-			general = true;
-			if (!(mats[m * kMaterialStride + 4] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: roughconductor alpha must be > 0");
-		}
+		if (type != 0.0f && type != 1.0f && type != 2.0f && type != 3.0f)
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
+		if (type != 0.0f || mats[m * kMaterialStride + 11] != 0.0f) general = true; // anything but twosided diffuse
+		if (type == 1.0f && !(mats[m * kMaterialStride + 4] > 0.0f))
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: roughconductor alpha must be > 0");
+		if (type == 3.0f && !(mats[m * kMaterialStride + 5] > 0.0f))
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: dielectric index ratio must be > 0");
 	}
+	const uint64_t nd = sc->n_dir_lights;
+	if (nd > 64 || (nd && !sc->dir_lights)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: at most 64 directional lights");
+	if (nd && !(sc->bsphere[3] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: directional lights need the scene's bounding sphere");
+	if (nd) general = true;
 	for (uint64_t q = 0; q < nq; ++q) {
 		const float mi = quads[q * kQuadStride + 22];
 		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
@@ -1155,8 +1256,12 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 		if (quads[q * kQuadStride + 15] != 0.0f) em.push_back((int32_t)q);
 	for (uint64_t s = 0; s < ns; ++s)
 		if (sc->spheres[s * kSphereStride + 5] != 0.0f) em.push_back((int32_t)(nq + s));
+	for (uint64_t k = 0; k < nd; ++k) em.push_back(-1 - (int32_t)k);
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	pg_render_state *r = rstate(ctx);
+	PG_HIP(ctx, r->dir_lights.ensure(nd * 8));
+	if (nd) PG_HIP(ctx, hipMemcpy(r->dir_lights.p, sc->dir_lights, nd * 8 * sizeof(float), hipMemcpyHostToDevice));
+	for (int c = 0; c < 4; ++c) r->bsphere[c] = sc->bsphere[c];
 	PG_HIP(ctx, r->quads.ensure(nq * kQuadStride)); PG_HIP(ctx, r->spheres.ensure(ns * kSphereStride));
 	PG_HIP(ctx, r->mats.ensure(mats.size())); PG_HIP(ctx, r->emitters.ensure(em.size()));
 	PG_HIP(ctx, r->boxes.ensure(nb * kBoxStride));
@@ -1204,6 +1309,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
 	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
 	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
+	if (r->general) PG_HIP(ctx, r->ior.ensure(N));
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
 	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D));
 	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, (size_t)D * sizeof(uint32_t), s));
@@ -1226,6 +1332,9 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.mats = r->mats.p;
 	a.emitters = r->emitters.p;
 	a.n_emitters = r->n_emitters;
+	a.dir_lights.lights = r->dir_lights.p;
+	for (int c = 0; c < 4; ++c) a.dir_lights.bsphere[c] = r->bsphere[c];
+	a.ior = r->ior.p;
 	a.cam = r->cam;
 	a.n_lanes = N;
 	a.n_pixels = P;

@@ -77,6 +77,10 @@ class WavefrontScene:
         n = np.ascontiguousarray(self.scene.bvh, np.uint32)
         d.n_tris, d.tris = t.shape[0], (t.ctypes.data if t.size else None)
         d.n_bvh_nodes, d.bvh = n.shape[0], (n.ctypes.data if n.size else None)
+        dl = np.ascontiguousarray(self.scene.dir_lights, np.float32)
+        d.n_dir_lights, d.dir_lights = dl.shape[0], (dl.ctypes.data if dl.size else None)
+        if dl.shape[0]:
+            d.bsphere = (C.c_float * 4)(*[float(v) for v in self.scene.bounding_sphere()])
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 

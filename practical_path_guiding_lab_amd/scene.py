@@ -23,7 +23,10 @@ QUAD_STRIDE = 24  # floats per quad, layout documented in include/pgsd.h (pg_sce
 SPHERE_STRIDE = 12    # centre 0-2, radius 3, material 4, emitter flag 5, radiance 6-8
 MATERIAL_STRIDE = 12  # type 0, reflectance 1-3, alpha 4, eta 5-7, k 8-10
 BOX_STRIDE = 32       # rows of the inverse linear map 0-8, centre 9-11, +x/+y/+z face normals 12-20, material 21
-MAT_DIFFUSE, MAT_ROUGHCONDUCTOR = 0, 1
+MAT_DIFFUSE, MAT_ROUGHCONDUCTOR, MAT_CONDUCTOR, MAT_DIELECTRIC = 0, 1, 2, 3
+# RGB indices of refraction Mitsuba's `material` presets resolve to in an RGB variant
+CONDUCTOR_PRESETS = {"Al": ((1.657460, 0.880369, 0.521229), (9.223869, 6.269523, 4.837001))}
+IOR_PRESETS = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "acrylic glass": 1.49, "bk7": 1.5046, "diamond": 2.419}
 
 
 @dataclass
@@ -52,6 +55,14 @@ class Scene:
     boxes: np.ndarray = field(default_factory=lambda: np.zeros((0, BOX_STRIDE), np.float32))        # (B, 32)
     tris: np.ndarray = field(default_factory=lambda: np.zeros((0, 16), np.float32))                 # (T, 16), in BVH leaf order
     bvh: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.uint32))                    # (M, 8) nodes, mesh.py
+    dir_lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.float32))            # (K, 8): direction, irradiance
+
+    def bounding_sphere(self) -> np.ndarray:
+        """Mitsuba's scene.bbox().bounding_sphere(): centre and radius (x, y, z, r), fp32."""
+        lo, hi = self.bbox_min.astype(np.float32), self.bbox_max.astype(np.float32)
+        c = ((lo + hi) * np.float32(0.5)).astype(np.float32)
+        r = np.float32(np.sqrt(np.float32(((hi - c) ** 2).sum())))
+        return np.array([c[0], c[1], c[2], r], np.float32)
 
 
 def _f32(v):
@@ -111,11 +122,42 @@ def cube(to_world: np.ndarray, refl) -> List[np.ndarray]:
     return out
 
 
-def diffuse_material(reflectance) -> np.ndarray:
+def diffuse_material(reflectance, twosided: bool = True) -> np.ndarray:
     m = np.zeros(MATERIAL_STRIDE, np.float32)
     m[0] = MAT_DIFFUSE
     m[1:4] = _f32(reflectance)
+    m[11] = 0.0 if twosided else 1.0
     return m
+
+
+def conductor_material(eta, k, specular_reflectance=(1.0, 1.0, 1.0), twosided: bool = False) -> np.ndarray:
+    """Mitsuba `conductor`: a perfect mirror weighted by the conductor's Fresnel term (a delta lobe)."""
+    m = np.zeros(MATERIAL_STRIDE, np.float32)
+    m[0] = MAT_CONDUCTOR
+    m[1:4] = _f32(specular_reflectance)
+    m[5:8] = _f32(eta)
+    m[8:11] = _f32(k)
+    m[11] = 0.0 if twosided else 1.0
+    return m
+
+
+def dielectric_material(int_ior: float, ext_ior: float = 1.000277) -> np.ndarray:
+    """Mitsuba `dielectric`: smooth interface, delta reflection and refraction, never twosided."""
+    m = np.zeros(MATERIAL_STRIDE, np.float32)
+    m[0] = MAT_DIELECTRIC
+    m[1:4] = 1.0
+    m[5] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
+    m[11] = 1.0
+    return m
+
+
+def directional_light(direction, irradiance) -> np.ndarray:
+    """Mitsuba `directional` emitter: `direction` is where the light travels (its to_world applied to +z)."""
+    d = np.asarray(direction, np.float64)
+    out = np.zeros(8, np.float32)
+    out[0:3] = (d / np.linalg.norm(d)).astype(np.float32)
+    out[3:6] = _f32(irradiance)
+    return out
 
 
 def roughconductor_material(alpha, eta, k, specular_reflectance=(1.0, 1.0, 1.0)) -> np.ndarray:
@@ -158,7 +200,7 @@ def box(to_world: np.ndarray, material_index: int) -> np.ndarray:
 
 
 def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names, spheres=None, materials=None,
-            boxes=None, tris=None) -> Scene:
+            boxes=None, tris=None, dir_lights=None) -> Scene:
     q = np.stack(quads).astype(np.float32) if quads else np.zeros((0, QUAD_STRIDE), np.float32)
     corners = [q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]]
     s = np.stack(spheres).astype(np.float32) if spheres else np.zeros((0, SPHERE_STRIDE), np.float32)
@@ -179,6 +221,8 @@ def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int,
         sc.bvh, sc.tris = build_bvh(tr)
     sc.spheres = s
     sc.boxes = bx
+    if dir_lights:
+        sc.dir_lights = np.stack(dir_lights).astype(np.float32)
     sc.materials = np.stack(materials).astype(np.float32) if materials else None
     return sc
 

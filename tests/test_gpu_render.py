@@ -105,8 +105,17 @@ def mixed_scene(res, max_depth=6, rr_depth=3):
     v, f = MS.icosphere(2)                                                                                 # 320 triangles behind a BVH
     tris = [MS.triangles(v, f, M(0.6, 0, 0, 1.2, 0, 0.5, 0, 1.6, 0, 0, 0.6, -0.5, 0, 0, 0, 1), 3),         # glossy ellipsoid
             MS.triangles(v[:12], np.array([[0, 11, 5], [0, 5, 1], [3, 9, 4], [3, 4, 2]]), M(0.5, 0, 0, -0.5, 0, 0.5, 0, 2.2, 0, 0, 0.5, 2.0, 0, 0, 0, 1), 4)]  # loose diffuse triangles
+    # delta lobes, a one-sided surface and a delta light (scenes/torus): an aluminium mirror, a glass ball and
+    # a glass block, a one-sided diffuse card, a directional light next to the area lights
+    mats += [S.conductor_material(*S.CONDUCTOR_PRESETS["Al"]), S.dielectric_material(1.5, 1.000277),
+             S.diffuse_material((0.8, 0.8, 0.4), twosided=False)]
+    quads += with_mat(S.rectangle(M(0.9, 0, 0, 3.0, 0, 0.9, 0.3, 2.0, 0, -0.3, 0.9, -3.2, 0, 0, 0, 1), mats[5][1:4]), 5)      # mirror
+    quads += with_mat(S.rectangle(M(0.7, 0, 0, -3.0, 0, 0.7, 0, 2.4, 0, 0, 0.7, -2.0, 0, 0, 0, 1), mats[7][1:4]), 7)          # one-sided card
+    spheres.append(S.sphere((-0.4, 0.5, 2.6), 0.5, 6))
+    boxes.append(S.box(M(0.5, 0, 0, 2.2, 0, 0.35, 0, 0.36, 0, 0, 0.5, 2.4, 0, 0, 0, 1), 6))
+    lights = [S.directional_light((0.4, -1.0, -0.3), (1.5, 1.4, 1.2))]
     cam = S.make_camera(M(-1, 0, 0, 0, 0, 0.94, -0.342, 3.0, 0, -0.342, -0.94, 7.5, 0, 0, 0, 1), 40.0, res, res)
-    return S._finish(quads, cam, max_depth, rr_depth, ["q"] * len(quads), spheres, mats, boxes, tris)
+    return S._finish(quads, cam, max_depth, rr_depth, ["q"] * len(quads), spheres, mats, boxes, tris, lights)
 
 
 @pytest.mark.parametrize("res,nee", [(40, True), (24, False)])

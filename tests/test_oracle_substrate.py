@@ -179,3 +179,101 @@ def test_xml_with_spheres_and_rough_conductors(tmp_path):
     with pytest.raises(ValueError):
         p.write_text(xml.replace("beckmann", "ggx"))
         S.load_xml(str(p))
+
+
+# ---- delta lobes and the directional emitter (scenes/torus: `conductor`, `dielectric`, `directional`) ----
+def _look_at(o, target, fov, res=4):
+    o, target = np.asarray(o, float), np.asarray(target, float)
+    z = (target - o) / np.linalg.norm(target - o)
+    up = np.array([0, 1.0, 0]) if abs(z[1]) < 0.99 else np.array([1.0, 0, 0])
+    x = np.cross(up, z); x /= np.linalg.norm(x)
+    tw = np.eye(4); tw[:3, 0], tw[:3, 1], tw[:3, 2], tw[:3, 3] = x, np.cross(z, x), z, o
+    return S.make_camera(tw, fov, res, res)
+
+
+def _render_mean(sc, max_depth, spp, seed=5):
+    pair = po.OracleSDTreePair()
+    pair.setup(sc.bbox_min - np.float32(1e-3), sc.bbox_max + np.float32(1e-3), 20, 20, True)
+    L, valid = po.render_pass(pair, sc, sc.camera, max_depth, 8, 0, True, seed, spp, True, 0.5)
+    assert np.isfinite(L).all()
+    return L.astype(np.float64).mean(axis=1)
+
+
+def _floor(mi, size=50.0):
+    qs = S.rectangle(np.array([[size, 0, 0, 0], [0, 0, size, 0], [0, -size, 0, 0], [0, 0, 0, 1]], np.float64), (0, 0, 0))
+    for q in qs:
+        q[22] = mi
+    return qs
+
+
+def test_directional_light_on_a_diffuse_floor_has_its_closed_form():
+    """`directional` emitter (irradiance E on a plane facing it): a one-sided diffuse floor tilted by
+    theta returns rho/pi * E * cos(theta); the light is a delta emitter (pdf 1, no MIS, :253)."""
+    d = np.array([0.3, -1.0, 0.2])
+    cos_t = -d[1] / np.linalg.norm(d)
+    mats = [S.diffuse_material((0.6, 0.5, 0.4), twosided=False)]
+    sc = S._finish(_floor(0), _look_at((1, 3, 4), (0, 0, 0), 0.2), 2, 8, ["floor"], None, mats, None, None,
+                   [S.directional_light(d, (2.0, 2.0, 1.8))])
+    got = _render_mean(sc, 2, 64)
+    exp = np.array([0.6, 0.5, 0.4]) / np.pi * np.array([2.0, 2.0, 1.8]) * cos_t
+    np.testing.assert_allclose(got, exp, rtol=2e-5)   # no randomness is left: every sample returns the same value
+    # from below, a one-sided surface is black
+    sc.camera = _look_at((1, -3, 4), (0, 0, 0), 0.2)
+    assert _render_mean(sc, 2, 8).max() == 0.0
+
+
+def _fresnel_conductor(c, eta, k):
+    c2, s2 = c * c, 1 - c * c
+    t1 = eta * eta - k * k - s2
+    a2pb2 = np.sqrt(t1 * t1 + 4 * k * k * eta * eta)
+    a = np.sqrt(0.5 * (a2pb2 + t1))
+    rs = (a2pb2 + c2 - 2 * c * a) / (a2pb2 + c2 + 2 * c * a)
+    rp = rs * (a2pb2 * c2 + s2 * s2 - 2 * c * a * s2) / (a2pb2 * c2 + s2 * s2 + 2 * c * a * s2)
+    return 0.5 * (rs + rp)
+
+
+def test_mirror_shows_the_lamp_weighted_by_the_conductor_fresnel_term():
+    """A smooth aluminium floor (`conductor`, a delta lobe): the camera sees a sphere lamp in it at
+    45 degrees with radiance F(45 deg) * Le; nothing is sampled towards the lamp (no NEE on a
+    delta-only BSDF, :210) and the hit after a delta bounce carries MIS weight 1 (:196)."""
+    eta, k = S.CONDUCTOR_PRESETS["Al"]
+    mats = [S.conductor_material(eta, k), S.diffuse_material((0, 0, 0))]
+    lamp = S.sphere((2.0, 2.0, 0.0), 0.4, 1, (10.0, 8.0, 6.0))
+    sc = S._finish(_floor(0), _look_at((-2, 2, 0), (0, 0, 0), 0.5), 3, 8, ["floor"], [lamp], mats)
+    got = _render_mean(sc, 3, 32)
+    F = np.array([_fresnel_conductor(np.cos(np.pi / 4), e, kk) for e, kk in zip(eta, k)])
+    np.testing.assert_allclose(got, F * np.array([10.0, 8.0, 6.0]), rtol=2e-4)
+    assert (F > 0.8).all() and (F < 1).all()
+
+
+def test_glass_slab_transmits_one_minus_r_over_one_plus_r():
+    """A lamp seen through a glass box (`dielectric`, int_ior 1.5 in vacuum) at normal incidence: all
+    orders of internal reflection add up to (1 - R)/(1 + R) with R = 0.04; the radiance scale
+    eta^2 of entering and leaving cancels.  Lobe choice by the BSDF's 1-D sample (:272)."""
+    mats = [S.dielectric_material(1.5, 1.0), S.diffuse_material((0, 0, 0))]
+    slab = S.box(np.array([[2.0, 0, 0, 0], [0, 2.0, 0, 0], [0, 0, 0.25, 0], [0, 0, 0, 1]]), 0)
+    lamp = S.sphere((0.0, 0.0, -6.0), 1.0, 1, (5.0, 5.0, 5.0))
+    sc = S._finish([], _look_at((0, 0, 8), (0, 0, 0), 0.3, res=2), 24, 30, [], [lamp], mats, [slab])
+    got = _render_mean(sc, 24, 20000, seed=9)
+    R = ((1.5 - 1) / (1.5 + 1)) ** 2
+    np.testing.assert_allclose(got, 5.0 * (1 - R) / (1 + R), rtol=0.01)
+    # lobes and weights of one interaction
+    wi = np.array([0.0, 0.6, 0.8], np.float32)
+    lb = po.lib()
+    import ctypes as C
+    lb.pgo_bsdf_sample_full.restype = None
+    outs = []
+    for lobe in (0.01, 0.9):
+        wo, pdf, w = np.zeros(3, np.float32), np.zeros(1, np.float32), np.zeros(3, np.float32)
+        eta_o, delta = C.c_float(), C.c_int()
+        lb.pgo_bsdf_sample_full(mats[0].ctypes.data_as(C.c_void_p), wi.ctypes.data_as(C.c_void_p), C.c_float(lobe), C.c_float(0.3),
+                                C.c_float(0.3), wo.ctypes.data_as(C.c_void_p), pdf.ctypes.data_as(C.c_void_p),
+                                w.ctypes.data_as(C.c_void_p), C.byref(eta_o), C.byref(delta))
+        outs.append((wo.copy(), float(pdf[0]), w.copy(), eta_o.value, delta.value))
+    (wr, pr, wgr, er, dr), (wt, pt, wgt, et, dt) = outs
+    assert dr == 1 and dt == 1 and abs(pr + pt - 1) < 1e-6 and pr < 0.1
+    np.testing.assert_allclose(wr, [0, -0.6, 0.8], atol=1e-7)            # mirror direction
+    assert er == 1.0 and abs(et - 1.5) < 1e-6
+    np.testing.assert_allclose(np.linalg.norm(wt), 1, atol=1e-6)
+    np.testing.assert_allclose(wt[1], -0.6 / 1.5, rtol=1e-6)               # Snell
+    assert wt[2] < 0 and np.allclose(wgr, 1) and np.allclose(wgt, 1 / 1.5 ** 2, rtol=1e-6)
