@@ -102,9 +102,12 @@ __device__ __forceinline__ v3 box_face_normal(const float *B, int face)
 	return (face & 1) ? V(-n.x, -n.y, -n.z) : n;
 }
 
-// closest hit over all shapes, 0 < t < tmax (scene.ray_intersect / ray_test).  kGeneral = false is
-// the quad-only scene (cornell-box): the sphere loop and its double arithmetic are compiled out.
-template <bool kGeneral>
+// closest hit over all shapes, 0 < t < tmax (scene.ray_intersect / ray_test).  kGeneral is the
+// feature level the kernel is compiled for: 0 = quads and boxes with twosided diffuse BSDFs
+// (cornell-box), 1 = + spheres and rough conductors (veach-mis), 2 = + triangle meshes, delta
+// lobes, one-sided BSDFs, directional lights and the running index of refraction (torus-class
+// scenes).  What a level does not need is compiled out.
+template <int kGeneral>
 __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out)
 {
 	const int nq = sh.n_quads;
@@ -179,7 +182,7 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 	}
 	// triangle meshes: ordered traversal of the binary BVH (near child first, by the sign of the ray
 	// direction on the node's split axis), slab test padded as Ize 2013, Moeller-Trumbore triangles
-	if (kGeneral && sh.n_bvh_nodes) {
+	if (kGeneral >= 2 && sh.n_bvh_nodes) {
 		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
 		const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
 		// pg_scene_set_ex has checked the tree: children follow their parent, depth <= 60, so the walk
@@ -254,12 +257,12 @@ struct Surface {
 	Material m;
 };
 
-template <bool kGeneral>
+template <int kGeneral>
 __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mats, int prim, v3 o, v3 d, float t)
 {
 	Surface s;
 	const float *M;
-	if (kGeneral && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes) { // a mesh triangle (face normals)
+	if (kGeneral >= 2 && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes) { // a mesh triangle (face normals)
 		const float *T = sh.tris + (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes) * kTriStride;
 		s.p = vadd(o, vscale(d, t));
 		s.n = ld3(T + 9);
@@ -301,17 +304,17 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 		M = mats + (int)S[4] * kMaterialStride;
 	}
 	s.m.type = kGeneral ? (int)M[0] : 0; // a scene with anything but twosided diffuse runs the general kernels
-	s.m.one_sided = kGeneral && M[11] != 0.0f;
+	s.m.one_sided = kGeneral >= 2 && M[11] != 0.0f;
 	s.m.refl = ld3(M + 1);
 	s.m.M = M;
 	return s;
 }
 
 // normal of shape `prim` at the surface point p (quads: constant; spheres: as surface_at defines it)
-template <bool kGeneral>
+template <int kGeneral>
 __device__ __forceinline__ v3 normal_at(const Shapes &sh, int prim, v3 p)
 {
-	if (kGeneral && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes)
+	if (kGeneral >= 2 && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes)
 		return ld3(sh.tris + (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes) * kTriStride + 9);
 	if (prim >= sh.n_quads + sh.n_spheres) {
 		const int f = prim - sh.n_quads - sh.n_spheres;
@@ -323,7 +326,7 @@ __device__ __forceinline__ v3 normal_at(const Shapes &sh, int prim, v3 p)
 
 // scene.pdf_emitter_direction(prev, ds) for a hit on emitter shape `prim` at p (normal n) seen from
 // `ref`, times the 1/count of the uniform emitter choice
-template <bool kGeneral>
+template <int kGeneral>
 __device__ __forceinline__ float emitter_hit_pdf(const Shapes &sh, int prim, v3 ref, v3 p, v3 n, float inv_count)
 {
 	const v3 dd = vsub(p, ref);
@@ -504,14 +507,14 @@ __device__ __forceinline__ float fresnel_dielectric(float cos_i, float eta, floa
 __device__ __forceinline__ bool material_is_smooth(const Material &mt) { return mt.type != 2 && mt.type != 3; }
 
 // bsdf.eval_pdf (twosided unless the material says otherwise): value includes cos(theta_o)
-template <bool kGeneral>
+template <int kGeneral>
 __device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, bool active, v3 &value, float &pdf)
 {
 	value = V(0, 0, 0);
 	pdf = 0.0f;
 	if (!active) return;
-	if (kGeneral && (mt.type == 2 || mt.type == 3)) return; // smooth conductor / dielectric: delta lobes only
-	if (wi.z < 0.0f && !(kGeneral && mt.one_sided)) { wi.z = -wi.z; wo.z = -wo.z; }
+	if (kGeneral >= 2 && (mt.type == 2 || mt.type == 3)) return; // smooth conductor / dielectric: delta lobes only
+	if (wi.z < 0.0f && !(kGeneral >= 2 && mt.one_sided)) { wi.z = -wi.z; wo.z = -wo.z; }
 	if (kGeneral && mt.type == 1) {
 		rc_eval_pdf(mt, wi, wo, value, pdf);
 		return;
@@ -524,13 +527,13 @@ __device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, 
 
 // bsdf.sample(ctx, si, u1, (u, v)): wo (local), pdf, weight = value / pdf, the relative index along
 // wo, and whether a delta lobe was sampled (BSDFFlags.Delta, :282)
-template <bool kGeneral>
+template <int kGeneral>
 __device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u1, float u, float v, bool active, v3 &wo,
                                             float &pdf, v3 &weight, float &eta, bool &delta)
 {
 	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta = 0.0f; delta = false;
 	if (!active) return;
-	if (kGeneral && mt.type == 3) { // smooth dielectric (dielectric.cpp), radiance transport
+	if (kGeneral >= 2 && mt.type == 3) { // smooth dielectric (dielectric.cpp), radiance transport
 		float cos_t, eta_it, eta_ti;
 		const float r_i = fresnel_dielectric(wi.z, mt.M[5], cos_t, eta_it, eta_ti);
 		const bool reflect = u1 <= r_i;
@@ -542,10 +545,10 @@ __device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u1,
 		weight = reflect ? V(1, 1, 1) : V(sc, sc, sc);
 		return;
 	}
-	const bool flip = wi.z < 0.0f && !(kGeneral && mt.one_sided);
+	const bool flip = wi.z < 0.0f && !(kGeneral >= 2 && mt.one_sided);
 	const float cos_i = flip ? -wi.z : wi.z;
 	if (!(cos_i > 0.0f)) return;
-	if (kGeneral && mt.type == 2) { // smooth conductor (conductor.cpp): the mirror direction, weighted by Fresnel
+	if (kGeneral >= 2 && mt.type == 2) { // smooth conductor (conductor.cpp): the mirror direction, weighted by Fresnel
 		delta = true;
 		pdf = 1.0f;
 		eta = 1.0f;
@@ -580,7 +583,7 @@ struct DirLights {
 	float bsphere[4];    // centre, radius
 };
 
-template <bool kGeneral>
+template <int kGeneral>
 __device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights &dls, const int32_t *__restrict__ emitters,
                                                int n_em, v3 p, v3 n, float e1, float e2, v3 &ds_d, float &ds_pdf,
                                                v3 &em_weight, bool &ds_delta)
@@ -595,7 +598,7 @@ __device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights
 	if (idx > (uint32_t)(n_em - 1)) idx = (uint32_t)(n_em - 1);
 	e1 = e1 * count - (float)idx;
 	const int prim = emitters[idx];
-	if (kGeneral && prim < 0) { // directional.cpp sample_direction: a point two radii up the light's direction, pdf 1, delta
+	if (kGeneral >= 2 && prim < 0) { // directional.cpp sample_direction: a point two radii up the light's direction, pdf 1, delta
 		const float *Dl = dls.lights + (size_t)(-1 - prim) * 8;
 		const v3 dl = ld3(Dl);
 		const v3 cd = vsub(p, V(dls.bsphere[0], dls.bsphere[1], dls.bsphere[2]));
@@ -714,7 +717,7 @@ struct RenderArgs {
 // kFirst: the camera ray is generated here (mi.render's sensor.sample_ray_differential: one 2-D
 // jitter draw per sample, box reconstruction) instead of being read back from a generate kernel.
 // kGeneral: the scene has spheres or rough conductors; false compiles the all-diffuse quad scene only.
-template <bool kFirst, bool kGeneral>
+template <bool kFirst, int kGeneral>
 __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_kd, const uint64_t lane,
                                             const uint64_t rec_slot)
 {
@@ -757,7 +760,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		prev_bsdf_pdf = a.prev_pdf[lane];
 		// :352 spawn_ray of the previous vertex: the same three operations that produced the origin
 		const uint32_t pq = a.prev_quad[lane];
-		if (kGeneral) {
+		if (kGeneral >= 2) {
 			prev_delta = (pq >> 31) != 0u;
 			ior = a.ior[lane];
 		}
@@ -789,7 +792,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const v3 Le = vmul(vscale(thr, mis), em_radiance);
 	// ---- :207-220 emitter sampling ----
 	bool active_next = (depth + 1 < (uint32_t)D) && valid;
-	bool active_em = active_next && (!kGeneral || material_is_smooth(mt)); // :210 BSDFFlags.Smooth
+	bool active_em = active_next && (kGeneral < 2 || material_is_smooth(mt)); // :210 BSDFFlags.Smooth
 	const float e1 = rng.next_f32(), e2 = rng.next_f32(); // :214, unmasked
 	v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 	float ds_pdf = 0.0f;
@@ -829,13 +832,13 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
 	if (!a.guided) surface_pdf_em = bsdf_pdf_em;
-	const float mis_em = (kGeneral && ds_delta) ? 1.0f : mis_weight(ds_pdf, surface_pdf_em); // :253
+	const float mis_em = (kGeneral >= 2 && ds_delta) ? 1.0f : mis_weight(ds_pdf, surface_pdf_em); // :253
 	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em), em_weight);
 	L = vadd(L, vadd(Le, Lr_dir)); // :261
 	// ---- :272-311 next direction ----
 	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
 	if (active_next) { // next_1d (lobe choice: only the dielectric reads it), next_2d
-		if (kGeneral) s1 = rng.next_f32();
+		if (kGeneral >= 2) s1 = rng.next_f32();
 		else rng.skip();
 		s2x = rng.next_f32();
 		s2y = rng.next_f32();
@@ -918,7 +921,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	// ---- :352-381 advance ----
 	// ior (:357): without a dielectric every sampled direction has eta = 1, the running product stays
 	// exactly 1 and is not carried; general scenes carry it
-	if (kGeneral) ior = ior * eta;
+	if (kGeneral >= 2) ior = ior * eta;
 	thr = vmul(thr, bsdf_weight);
 	const float tmax = max3(thr);
 	active_next = active_next && (tmax != 0.0f);
@@ -938,8 +941,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
 		a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
 		a.prev_pdf[lane] = woPdf;
-		a.prev_quad[lane] = (uint32_t)q | ((kGeneral && delta) ? 0x80000000u : 0u);
-		if (kGeneral) a.ior[lane] = ior;
+		a.prev_quad[lane] = (uint32_t)q | ((kGeneral >= 2 && delta) ? 0x80000000u : 0u);
+		if (kGeneral >= 2) a.ior[lane] = ior;
 	}
 	return active_next;
 }
@@ -954,7 +957,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 #else
 #define PG_BOUNCE_ATTR
 #endif
-template <bool kFirst, bool kGeneral>
+template <bool kFirst, int kGeneral>
 __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
@@ -1091,7 +1094,7 @@ struct pg_render_state {
 	DevBuf<uint32_t> bvh;
 	DevBuf<int32_t> emitters;
 	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0, n_bvh_nodes = 0;
-	bool general = false; // spheres or rough conductors present: the general kernels are launched
+	int general = 0; // feature level of the kernels to launch (0 cornell-box class, 1 veach-mis class, 2 everything)
 	pg_camera cam;
 	bool have_scene = false;
 	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
@@ -1181,12 +1184,13 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 		}
 	}
 	const uint64_t n_mats = mats.size() / kMaterialStride;
-	bool general = ns > 0;
+	int general = ns > 0 ? 1 : 0; // feature level, see intersect()
 	for (uint64_t m = 0; m < n_mats; ++m) {
 		const float type = mats[m * kMaterialStride];
 		if (type != 0.0f && type != 1.0f && type != 2.0f && type != 3.0f)
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
-		if (type != 0.0f || mats[m * kMaterialStride + 11] != 0.0f) general = true; // anything but twosided diffuse
+		if (type == 1.0f && general < 1) general = 1;                                  // rough conductor
+		if (type >= 2.0f || mats[m * kMaterialStride + 11] != 0.0f) general = 2;       // delta lobes, one-sided BSDFs
 		if (type == 1.0f && !(mats[m * kMaterialStride + 4] > 0.0f))
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: roughconductor alpha must be > 0");
 		if (type == 3.0f && !(mats[m * kMaterialStride + 5] > 0.0f))
@@ -1195,7 +1199,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	const uint64_t nd = sc->n_dir_lights;
 	if (nd > 64 || (nd && !sc->dir_lights)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: at most 64 directional lights");
 	if (nd && !(sc->bsphere[3] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: directional lights need the scene's bounding sphere");
-	if (nd) general = true;
+	if (nd) general = 2;
 	for (uint64_t q = 0; q < nq; ++q) {
 		const float mi = quads[q * kQuadStride + 22];
 		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
@@ -1249,7 +1253,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
 				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangle material index out of range");
 		}
-		general = true;
+		general = 2;
 	}
 	std::vector<int32_t> em;
 	for (uint64_t q = 0; q < nq; ++q)
@@ -1309,7 +1313,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
 	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
 	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
-	if (r->general) PG_HIP(ctx, r->ior.ensure(N));
+	if (r->general >= 2) PG_HIP(ctx, r->ior.ensure(N));
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
 	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D));
 	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, (size_t)D * sizeof(uint32_t), s));
@@ -1363,12 +1367,15 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		Timed t(r, s, 1);
 		// every launch is sized for the whole wavefront: the live count is only known on the device,
 		// and workgroups past it retire on their first instruction
-		if (r->general) {
-			if (it == 0) hipLaunchKernelGGL((k_bounce<true, true>), grid, dim3(kRBlock), 0, s, a);
-			else hipLaunchKernelGGL((k_bounce<false, true>), grid, dim3(kRBlock), 0, s, a);
+		if (r->general >= 2) {
+			if (it == 0) hipLaunchKernelGGL((k_bounce<true, 2>), grid, dim3(kRBlock), 0, s, a);
+			else hipLaunchKernelGGL((k_bounce<false, 2>), grid, dim3(kRBlock), 0, s, a);
+		} else if (r->general == 1) {
+			if (it == 0) hipLaunchKernelGGL((k_bounce<true, 1>), grid, dim3(kRBlock), 0, s, a);
+			else hipLaunchKernelGGL((k_bounce<false, 1>), grid, dim3(kRBlock), 0, s, a);
 		} else {
-			if (it == 0) hipLaunchKernelGGL((k_bounce<true, false>), grid, dim3(kRBlock), 0, s, a);
-			else hipLaunchKernelGGL((k_bounce<false, false>), grid, dim3(kRBlock), 0, s, a);
+			if (it == 0) hipLaunchKernelGGL((k_bounce<true, 0>), grid, dim3(kRBlock), 0, s, a);
+			else hipLaunchKernelGGL((k_bounce<false, 0>), grid, dim3(kRBlock), 0, s, a);
 		}
 	}
 	PG_HIP(ctx, hipGetLastError());
