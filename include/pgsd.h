@@ -281,6 +281,10 @@ typedef struct pg_scene_desc {
 	uint64_t n_dir_lights;
 	const float *dir_lights;
 	float bsphere[4];
+	/* optional unit vertex normals, 9 floats per triangle in the order of `tris` (NULL: face
+	 * normals).  The shading frame follows the interpolated normal, ray offsets the geometric one
+	 * (Mitsuba's si.sh_frame.n and si.n). */
+	const float *tri_normals;
 } pg_scene_desc;
 #define PG_DIRLIGHT_STRIDE 8
 #define PG_TRI_STRIDE 16

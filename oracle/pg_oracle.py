@@ -466,7 +466,8 @@ class _Scene(C.Structure):
     _fields_ = [("n_quads", C.c_size_t), ("quads", C.c_void_p), ("n_spheres", C.c_size_t), ("spheres", C.c_void_p),
                 ("n_materials", C.c_size_t), ("materials", C.c_void_p), ("n_boxes", C.c_size_t), ("boxes", C.c_void_p),
                 ("n_tris", C.c_size_t), ("tris", C.c_void_p), ("n_bvh_nodes", C.c_size_t), ("bvh", C.c_void_p),
-                ("n_dir_lights", C.c_size_t), ("dir_lights", C.c_void_p), ("bsphere", C.c_float * 4)]
+                ("n_dir_lights", C.c_size_t), ("dir_lights", C.c_void_p), ("bsphere", C.c_float * 4),
+                ("tri_normals", C.c_void_p)]
 
 
 def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, iteration, is_final, seed, spp=1,
@@ -490,8 +491,11 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
         bvh = np.ascontiguousarray(getattr(scene_obj, "bvh", bvh), np.uint32).reshape(-1, 8)
         dir_lights = np.ascontiguousarray(getattr(scene_obj, "dir_lights", np.zeros((0, 8))), np.float32).reshape(-1, 8)
         bsphere = [float(v) for v in scene_obj.bounding_sphere()] if dir_lights.shape[0] else [0.0] * 4
+        tn = getattr(scene_obj, "tri_normals", None)
+        tri_normals = None if tn is None else np.ascontiguousarray(tn, np.float32).reshape(-1, 9)
+        assert tri_normals is None or tri_normals.shape[0] == tris.shape[0]
     else:
-        dir_lights, bsphere = np.zeros((0, 8), np.float32), [0.0] * 4
+        dir_lights, bsphere, tri_normals = np.zeros((0, 8), np.float32), [0.0] * 4, None
     quads = np.ascontiguousarray(quads, np.float32).reshape(-1, 24)
     spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros((0, 12)), np.float32).reshape(-1, 12)
     mats = None if materials is None else np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
@@ -502,7 +506,8 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
                 spheres.ctypes.data if spheres.size else None, 0 if mats is None else mats.shape[0],
                 None if mats is None else mats.ctypes.data, boxes.shape[0], boxes.ctypes.data if boxes.size else None,
                 tris.shape[0], tris.ctypes.data if tris.size else None, bvh.shape[0], bvh.ctypes.data if bvh.size else None,
-                dir_lights.shape[0], dir_lights.ctypes.data if dir_lights.size else None, (C.c_float * 4)(*bsphere))
+                dir_lights.shape[0], dir_lights.ctypes.data if dir_lights.size else None, (C.c_float * 4)(*bsphere),
+                None if tri_normals is None else tri_normals.ctypes.data)
     c = _Camera()
     for k in ("origin", "axis_x", "axis_y", "axis_z"):
         setattr(c, k, (C.c_float * 3)(*[float(v) for v in getattr(cam, k)]))

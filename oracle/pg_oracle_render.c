@@ -190,7 +190,7 @@ static v3 box_face_normal(const float *B, int face)
 
 /* ---- surface description at a hit ---- */
 typedef struct { int type; v3 refl; float alpha; v3 eta, k; int one_sided; } material;
-typedef struct { v3 p, n; int is_em; v3 radiance; material m; } surface;
+typedef struct { v3 p, n, ng; int is_em; v3 radiance; material m; } surface; /* n: shading normal, ng: geometric */
 
 static material load_material(const float *M)
 {
@@ -218,9 +218,29 @@ static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
 		if (!sc->materials) { s.m.type = 0; s.m.refl = ld3(Q + 16); return s; }
 		mi = (int)Q[22];
 	} else if ((size_t)prim >= sc->n_quads + sc->n_spheres + 6 * sc->n_boxes) {
-		const float *T = sc->tris + ((size_t)prim - sc->n_quads - sc->n_spheres - 6 * sc->n_boxes) * PGO_TRI_STRIDE;
+		const size_t ti = (size_t)prim - sc->n_quads - sc->n_spheres - 6 * sc->n_boxes;
+		const float *T = sc->tris + ti * PGO_TRI_STRIDE;
 		s.p = vadd(o, vscale(d, t));
-		s.n = ld3(T + 9); /* face normals */
+		s.n = ld3(T + 9); /* face normal */
+		if (sc->tri_normals) { /* interpolated vertex normals: the barycentrics of the hit, by the intersection's own formulas */
+			const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
+			const v3 pp = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
+			const float inv_det = 1.0f / dot3(e1, pp);
+			const v3 sv = vsub(o, ld3(T));
+			const float u = dot3(sv, pp) * inv_det;
+			const v3 qq = V(sv.y * e1.z - sv.z * e1.y, sv.z * e1.x - sv.x * e1.z, sv.x * e1.y - sv.y * e1.x);
+			const float v = dot3(d, qq) * inv_det;
+			const float *Nn = sc->tri_normals + ti * 9;
+			const v3 ns = vadd(vadd(vscale(ld3(Nn), (1.0f - u) - v), vscale(ld3(Nn + 3), u)), vscale(ld3(Nn + 6), v));
+			const float l2 = dot3(ns, ns);
+			if (l2 > 0.0f) {
+				s.ng = s.n;
+				s.n = vdivs(ns, sqrtf(l2));
+				mi = (int)T[12];
+				s.m = load_material(sc->materials + (size_t)mi * PGO_MATERIAL_STRIDE);
+				return s;
+			}
+		}
 		mi = (int)T[12];
 	} else if ((size_t)prim >= sc->n_quads + sc->n_spheres) {
 		const size_t f = (size_t)prim - sc->n_quads - sc->n_spheres;
@@ -684,7 +704,8 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
 			memset(&sf, 0, sizeof sf);
 			sf.n = V(0, 0, 1);
 			if (valid) sf = surface_at(sc, q, ray_o, ray_d, t_hit);
-			const v3 p = sf.p, n = sf.n;
+			if (sf.ng.x == 0.0f && sf.ng.y == 0.0f && sf.ng.z == 0.0f) sf.ng = sf.n; /* every shape but a smooth-shaded triangle */
+			const v3 p = sf.p, n = sf.n, ng = sf.ng;
 			const material *mt = &sf.m;
 			frame fr;
 			fr.n = n;
@@ -704,7 +725,7 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
 			v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 			float ds_pdf = 0.0f;
 			int ds_delta = 0;
-			if (active_em) sample_emitter(sc, em, n_em, p, n, e1, e2, &ds_d, &ds_pdf, &em_weight, &ds_delta);
+			if (active_em) sample_emitter(sc, em, n_em, p, ng, e1, e2, &ds_d, &ds_pdf, &em_weight, &ds_delta);
 			active_em = active_em && (ds_pdf != 0.0f); /* :216 */
 			v3 wo_em = to_local(&fr, ds_d);
 			v3 bsdf_value_em;
@@ -789,8 +810,8 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
 			/* ---- :352-381 advance ---- */
 			{
 				float mag = (1.0f + max3(V(fabsf(p.x), fabsf(p.y), fabsf(p.z)))) * RAY_EPS_F;
-				if (dot3(n, wo_world) < 0.0f) mag = -mag;
-				ray_o = vadd(p, vscale(n, mag));
+				if (dot3(ng, wo_world) < 0.0f) mag = -mag;
+				ray_o = vadd(p, vscale(ng, mag));
 				ray_d = wo_world;
 			}
 			ior = ior * eta;

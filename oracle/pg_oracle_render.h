@@ -68,6 +68,10 @@ typedef struct pgo_scene {
 	size_t n_dir_lights;
 	const float *dir_lights;
 	float bsphere[4];
+	/* optional vertex normals of the triangles (9 floats each, same order as `tris`), NULL = face
+	 * normals: the shading frame then follows the interpolated normal, ray offsets keep using the
+	 * geometric one (Mitsuba's si.sh_frame.n vs si.n) */
+	const float *tri_normals;
 } pgo_scene;
 #define PGO_DIRLIGHT_STRIDE 8
 #define PGO_TRI_STRIDE 16

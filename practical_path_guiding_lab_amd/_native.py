@@ -76,7 +76,8 @@ class pg_scene_desc(C.Structure):
     _fields_ = [("n_quads", C.c_uint64), ("quads", C.c_void_p), ("n_spheres", C.c_uint64), ("spheres", C.c_void_p),
                 ("n_materials", C.c_uint64), ("materials", C.c_void_p), ("n_boxes", C.c_uint64), ("boxes", C.c_void_p),
                 ("n_tris", C.c_uint64), ("tris", C.c_void_p), ("n_bvh_nodes", C.c_uint64), ("bvh", C.c_void_p),
-                ("n_dir_lights", C.c_uint64), ("dir_lights", C.c_void_p), ("bsphere", C.c_float * 4)]
+                ("n_dir_lights", C.c_uint64), ("dir_lights", C.c_void_p), ("bsphere", C.c_float * 4),
+                ("tri_normals", C.c_void_p)]
 
 
 class pg_pass_params(C.Structure):

@@ -92,6 +92,7 @@ constexpr int kTriStride = 16; // PG_TRI_STRIDE
 constexpr int kBvhStride = 8;  // PG_BVH_STRIDE
 struct Shapes {
 	const float *quads, *spheres, *boxes, *tris;
+	const float *tri_normals; // 9 per triangle, or nullptr (face normals)
 	const uint32_t *bvh;
 	int n_quads, n_spheres, n_boxes, n_bvh_nodes;
 };
@@ -252,7 +253,8 @@ struct Material {
 	bool one_sided;  // not wrapped in `twosided` (row word 11)
 };
 struct Surface {
-	v3 p, n, radiance;
+	v3 p, n, radiance; // n: the normal of the shading frame
+	v3 ng;             // geometric normal (ray offsets); differs from n on smooth-shaded triangles only
 	bool is_em;
 	Material m;
 };
@@ -263,9 +265,24 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 	Surface s;
 	const float *M;
 	if (kGeneral >= 2 && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes) { // a mesh triangle (face normals)
-		const float *T = sh.tris + (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes) * kTriStride;
+		const size_t ti = (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes);
+		const float *T = sh.tris + ti * kTriStride;
 		s.p = vadd(o, vscale(d, t));
 		s.n = ld3(T + 9);
+		s.ng = s.n;
+		if (sh.tri_normals) { // interpolated vertex normals: the barycentrics of the hit, by the intersection's own formulas
+			const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
+			const v3 pp = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
+			const float inv_det = 1.0f / dot3(e1, pp);
+			const v3 sv = vsub(o, ld3(T));
+			const float u = dot3(sv, pp) * inv_det;
+			const v3 qq = V(sv.y * e1.z - sv.z * e1.y, sv.z * e1.x - sv.x * e1.z, sv.x * e1.y - sv.y * e1.x);
+			const float v = dot3(d, qq) * inv_det;
+			const float *Nn = sh.tri_normals + ti * 9;
+			const v3 ns = vadd(vadd(vscale(ld3(Nn), (1.0f - u) - v), vscale(ld3(Nn + 3), u)), vscale(ld3(Nn + 6), v));
+			const float l2 = dot3(ns, ns);
+			if (l2 > 0.0f) s.n = vdivs(ns, __builtin_sqrtf(l2));
+		}
 		s.is_em = false;
 		s.radiance = V(0, 0, 0);
 		M = mats + (int)T[12] * kMaterialStride;
@@ -274,6 +291,7 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 		const float *B = sh.boxes + (f / 6) * kBoxStride;
 		s.p = vadd(o, vscale(d, t));
 		s.n = box_face_normal(B, f % 6);
+		s.ng = s.n;
 		s.is_em = false;
 		s.radiance = V(0, 0, 0);
 		M = mats + (int)B[21] * kMaterialStride;
@@ -281,6 +299,7 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 		const float *Q = sh.quads + prim * kQuadStride;
 		s.p = vadd(o, vscale(d, t));
 		s.n = ld3(Q + 9);
+		s.ng = s.n;
 		s.is_em = Q[15] != 0.0f;
 		s.radiance = ld3(Q + 19);
 		if (!kGeneral) { // all-diffuse quad scene: the reflectance sits in the quad itself (pg_scene_set keeps it there)
@@ -299,6 +318,7 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 		const v3 n0 = normalize3(vsub(vadd(o, vscale(d, t)), c));
 		s.p = vadd(c, vscale(n0, S[3]));
 		s.n = normalize3(vsub(s.p, c));
+		s.ng = s.n;
 		s.is_em = S[5] != 0.0f;
 		s.radiance = ld3(S + 6);
 		M = mats + (int)S[4] * kMaterialStride;
@@ -775,7 +795,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const int q = intersect<kGeneral>(sh, ray_o, ray_d, __builtin_huge_valf(), t_hit);
 	const bool valid = q >= 0;
 	Surface sf;
-	sf.p = V(0, 0, 0); sf.n = V(0, 0, 1); sf.radiance = V(0, 0, 0); sf.is_em = false;
+	sf.p = V(0, 0, 0); sf.n = V(0, 0, 1); sf.ng = V(0, 0, 1); sf.radiance = V(0, 0, 0); sf.is_em = false;
 	sf.m.type = 0; sf.m.refl = V(0, 0, 0); sf.m.M = nullptr; sf.m.one_sided = false;
 	if (valid) sf = surface_at<kGeneral>(sh, a.mats, q, ray_o, ray_d, t_hit);
 	const v3 p = sf.p, n = sf.n;
@@ -798,7 +818,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	float ds_pdf = 0.0f;
 	bool ds_delta = false;
 	if (active_em)
-		sample_emitter<kGeneral>(sh, a.dir_lights, a.emitters, a.n_emitters, p, n, e1, e2, ds_d, ds_pdf, em_weight, ds_delta);
+		sample_emitter<kGeneral>(sh, a.dir_lights, a.emitters, a.n_emitters, p, sf.ng, e1, e2, ds_d, ds_pdf, em_weight, ds_delta);
 	active_em = active_em && (ds_pdf != 0.0f); // :216
 	const v3 wo_em = to_local(fr, ds_d);
 	v3 bsdf_value_em;
@@ -1089,7 +1109,8 @@ using namespace pg;
 
 // library-owned renderer state
 struct pg_render_state {
-	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior;
+	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior, tri_normals;
+	bool have_tri_normals = false;
 	float bsphere[4] = {0, 0, 0, 0};
 	DevBuf<uint32_t> bvh;
 	DevBuf<int32_t> emitters;
@@ -1157,6 +1178,7 @@ int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const 
 	d.n_bvh_nodes = 0; d.bvh = nullptr;
 	d.n_dir_lights = 0; d.dir_lights = nullptr;
 	d.bsphere[0] = d.bsphere[1] = d.bsphere[2] = d.bsphere[3] = 0.0f;
+	d.tri_normals = nullptr;
 	return pg_scene_set_ex(ctx, &d, cam);
 }
 
@@ -1275,6 +1297,11 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	if (nt) PG_HIP(ctx, hipMemcpy(r->tris.p, sc->tris, nt * kTriStride * sizeof(float), hipMemcpyHostToDevice));
 	if (nn) PG_HIP(ctx, hipMemcpy(r->bvh.p, sc->bvh, nn * kBvhStride * sizeof(uint32_t), hipMemcpyHostToDevice));
 	r->n_bvh_nodes = (int)nn;
+	r->have_tri_normals = nt && sc->tri_normals;
+	if (r->have_tri_normals) {
+		PG_HIP(ctx, r->tri_normals.ensure(nt * 9));
+		PG_HIP(ctx, hipMemcpy(r->tri_normals.p, sc->tri_normals, nt * 9 * sizeof(float), hipMemcpyHostToDevice));
+	}
 	if (nq) PG_HIP(ctx, hipMemcpy(r->quads.p, quads.data(), quads.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (ns) PG_HIP(ctx, hipMemcpy(r->spheres.p, sc->spheres, ns * kSphereStride * sizeof(float), hipMemcpyHostToDevice));
 	PG_HIP(ctx, hipMemcpy(r->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1328,6 +1355,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.spheres = r->spheres.p;
 	a.shapes.boxes = r->boxes.p;
 	a.shapes.tris = r->tris.p;
+	a.shapes.tri_normals = r->have_tri_normals ? r->tri_normals.p : nullptr;
 	a.shapes.bvh = r->bvh.p;
 	a.shapes.n_bvh_nodes = r->n_bvh_nodes;
 	a.shapes.n_quads = r->n_quads;

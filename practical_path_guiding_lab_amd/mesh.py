@@ -44,8 +44,10 @@ def read_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
     return np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int64).reshape(-1, 3)
 
 
-def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, material_index: int) -> np.ndarray:
-    """(F,16) triangle records in world space; degenerate triangles are dropped."""
+def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, material_index: int,
+              vertex_normals: np.ndarray = None):
+    """(F,16) triangle records in world space; degenerate triangles are dropped.  With per-vertex
+    normals (V,3) it returns (records, (F,9) world-space unit vertex normals per triangle)."""
     m = np.asarray(to_world, np.float64)
     v = np.asarray(vertices, np.float64) @ m[:3, :3].T + m[:3, 3]
     v = v.astype(np.float32)  # the kernels see fp32 vertices: derive everything from those
@@ -58,15 +60,23 @@ def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, mat
     out[:, 0:3], out[:, 3:6], out[:, 6:9] = a[keep], e1[keep], e2[keep]
     out[:, 9:12] = (n[keep] / ln[keep, None]).astype(np.float32)
     out[:, 12] = np.float32(material_index)
-    return out
+    if vertex_normals is None:
+        return out
+    nw = np.asarray(vertex_normals, np.float64) @ np.linalg.inv(m[:3, :3])  # normals transform by the inverse transpose
+    nl = np.linalg.norm(nw, axis=1)
+    nw = np.where(nl[:, None] > 0, nw / np.maximum(nl[:, None], 1e-300), 0.0)
+    fn = np.concatenate([nw[faces[:, 0]], nw[faces[:, 1]], nw[faces[:, 2]]], axis=1)[keep].astype(np.float32)
+    return out, fn
 
 
-def build_bvh(tris: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Median-split BVH over triangle records; returns (nodes (M,8) uint32 bit patterns, triangles in leaf order)."""
+def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
+    """Median-split BVH over triangle records; returns (nodes (M,8) uint32 bit patterns, triangles in
+    leaf order); with `per_triangle` (T, k) data also that array in the same order."""
     tris = np.ascontiguousarray(tris, np.float32).reshape(-1, TRI_STRIDE)
     n = tris.shape[0]
     if n == 0:
-        return np.zeros((0, BVH_STRIDE), np.uint32), tris
+        empty = np.zeros((0, BVH_STRIDE), np.uint32)
+        return (empty, tris) if per_triangle is None else (empty, tris, per_triangle)
     v0, v1, v2 = tris[:, 0:3], tris[:, 0:3] + tris[:, 3:6], tris[:, 0:3] + tris[:, 6:9]
     lo = np.minimum(np.minimum(v0, v1), v2)
     hi = np.maximum(np.maximum(v0, v1), v2)
@@ -107,7 +117,9 @@ def build_bvh(tris: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         out[i, 3] = a
         out[i, 4:7] = bmax.astype(np.float32).view(np.uint32)
         out[i, 7] = b
-    return out, np.ascontiguousarray(tris[order])
+    if per_triangle is None:
+        return out, np.ascontiguousarray(tris[order])
+    return out, np.ascontiguousarray(tris[order]), np.ascontiguousarray(np.asarray(per_triangle)[order])
 
 
 def icosphere(subdivisions: int = 2) -> Tuple[np.ndarray, np.ndarray]:

@@ -81,6 +81,10 @@ class WavefrontScene:
         d.n_dir_lights, d.dir_lights = dl.shape[0], (dl.ctypes.data if dl.size else None)
         if dl.shape[0]:
             d.bsphere = (C.c_float * 4)(*[float(v) for v in self.scene.bounding_sphere()])
+        tn = None if self.scene.tri_normals is None else np.ascontiguousarray(self.scene.tri_normals, np.float32)
+        if tn is not None:
+            assert tn.shape == (t.shape[0], 9)
+            d.tri_normals = tn.ctypes.data
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 

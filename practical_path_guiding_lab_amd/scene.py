@@ -56,6 +56,7 @@ class Scene:
     tris: np.ndarray = field(default_factory=lambda: np.zeros((0, 16), np.float32))                 # (T, 16), in BVH leaf order
     bvh: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.uint32))                    # (M, 8) nodes, mesh.py
     dir_lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.float32))            # (K, 8): direction, irradiance
+    tri_normals: Optional[np.ndarray] = None  # (T, 9) vertex normals per triangle in `tris` order; None: face normals
 
     def bounding_sphere(self) -> np.ndarray:
         """Mitsuba's scene.bbox().bounding_sphere(): centre and radius (x, y, z, r), fp32."""
@@ -211,14 +212,21 @@ def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int,
         for sy in (-1, 1):
             for sz in (-1, 1):
                 corners.append(bx[:, 9:12] + sx * bx[:, 22:25] + sy * bx[:, 25:28] + sz * bx[:, 28:31])
-    tr = np.concatenate(tris).astype(np.float32) if tris else np.zeros((0, 16), np.float32)
+    # meshes: arrays of triangle records, or (records, vertex normals) pairs from mesh.triangles
+    recs = [t[0] if isinstance(t, tuple) else t for t in (tris or [])]
+    smooth = any(isinstance(t, tuple) for t in (tris or []))
+    tr = np.concatenate(recs).astype(np.float32) if recs else np.zeros((0, 16), np.float32)
     if tr.shape[0]:
         corners += [tr[:, 0:3], tr[:, 0:3] + tr[:, 3:6], tr[:, 0:3] + tr[:, 6:9]]
     corners = np.concatenate(corners)
     sc = Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
     if tr.shape[0]:
         from .mesh import build_bvh
-        sc.bvh, sc.tris = build_bvh(tr)
+        if smooth:  # flat-shaded meshes among smooth ones carry their face normal three times
+            nrm = np.concatenate([t[1] if isinstance(t, tuple) else np.tile(t[:, 9:12], (1, 3)) for t in tris]).astype(np.float32)
+            sc.bvh, sc.tris, sc.tri_normals = build_bvh(tr, nrm)
+        else:
+            sc.bvh, sc.tris = build_bvh(tr)
     sc.spheres = s
     sc.boxes = bx
     if dir_lights:

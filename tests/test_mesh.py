@@ -105,3 +105,23 @@ def test_oracle_mesh_matches_the_sphere_it_tessellates():
     b = imgs[1].reshape(3, 4, 12, 4, 16).mean(axis=(0, 2, 4))
     assert np.abs(a - b).max() < 0.01 * a.max() + 2e-3, (a, b)
     assert abs(imgs[0].mean() - imgs[1].mean()) < 0.005 * imgs[0].mean()
+    # a coarse ball (320 triangles): with interpolated vertex normals its shading is that of the sphere,
+    # with face normals it is visibly faceted
+    # (under a directional light and at max_depth 2 a sample's value is a function of its hit point alone:
+    # rho/pi * E * cos between the shading normal and the light -- no Monte Carlo noise to hide facets)
+    v2, f2 = M.icosphere(2)
+    sun = [S.directional_light((0.3, -1.0, -0.4), (3.0, 3.0, 3.0))]
+
+    def shade(spheres, tris):
+        sc = S._finish([], cam, 2, 8, [], spheres, mats, None, tris, sun)
+        pair = po.OracleSDTreePair()
+        pair.setup(sc.bbox_min - np.float32(1e-3), sc.bbox_max + np.float32(1e-3), 20, 20, True)
+        L, _ = po.render_pass(pair, sc, sc.camera, 2, 8, 0, True, 3, 4, True, 0.5)
+        return L.astype(np.float64).reshape(3, 48, 64, 4).mean(axis=3)
+
+    ref = shade([S.sphere((0, 1.0, 0), 1.0, 2)], None)
+    smooth = shade(None, [M.triangles(v2, f2, tw2, 2, v2)])
+    flat = shade(None, [M.triangles(v2, f2, tw2, 2)])
+    inner = np.s_[:, 18:30, 26:38]  # well inside the silhouette
+    e_smooth, e_flat = np.abs(smooth[inner] - ref[inner]).mean(), np.abs(flat[inner] - ref[inner]).mean()
+    assert ref[inner].mean() > 0.05 and e_smooth < 0.25 * e_flat and e_smooth < 0.02 * ref[inner].mean(), (e_smooth, e_flat)
