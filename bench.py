@@ -36,11 +36,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="cornell-box", choices=["cornell-box", "veach-mis"],
-                    help="cornell-box 512x512 max_depth 8 (BASELINE configs[1], the default) or veach-mis 1280x720 "
-                         "max_depth 3 (configs[2])")
-    ap.add_argument("--res", type=int, default=None, help="film width (cornell-box: square film; veach-mis: 16:9)")
-    ap.add_argument("--depth", type=int, default=None, help="max_depth (default: 8 / 3)")
+    ap.add_argument("--scene", default="cornell-box", choices=["cornell-box", "veach-mis", "torus"],
+                    help="cornell-box 512x512 max_depth 8 (BASELINE configs[1], the default), veach-mis 1280x720 "
+                         "max_depth 3 (configs[2]) or torus 1024x768 max_depth 30 (configs[4])")
+    ap.add_argument("--res", type=int, default=None, help="film width (cornell-box: square film; veach-mis: 16:9; torus: 4:3)")
+    ap.add_argument("--depth", type=int, default=None, help="max_depth (default: 8 / 3 / 30)")
     ap.add_argument("--spp-per-pass", type=int, default=8, help="samples per pixel traced by one pass")
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered (untimed) to train the SD-tree")
     ap.add_argument("--cpu-res", type=int, default=256, help="film size of the cpu_baseline sample (0 = skip)")
@@ -48,9 +48,9 @@ def parse():
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
     if args.res is None:
-        args.res = 512 if args.scene == "cornell-box" else 1280
+        args.res = {"cornell-box": 512, "veach-mis": 1280, "torus": 1024}[args.scene]
     if args.depth is None:
-        args.depth = 8 if args.scene == "cornell-box" else 3
+        args.depth = {"cornell-box": 8, "veach-mis": 3, "torus": 30}[args.scene]
     return args
 
 
@@ -59,6 +59,8 @@ def make_scene(args, width):
 
     if args.scene == "veach-mis":
         return S.veach_mis(width, width * 9 // 16, args.depth, 8)
+    if args.scene == "torus":
+        return S.torus(width, width * 3 // 4, args.depth, 8)
     return S.cornell_box(width, width, args.depth, 8)
 
 
@@ -239,7 +241,10 @@ def run_render(args):
     film = f"{sc.camera.width}x{sc.camera.height}"
     what = {"cornell-box": "built-in scene (Mitsuba cornell-box parameters), no textures",
             "veach-mis": "built-in scene (scenes/veach-mis/scene.xml parameters: 3 sphere lamps, 4 Beckmann rough-conductor "
-                         "plates, diffuse floor and wall)"}[args.scene]
+                         "plates, diffuse floor and wall)",
+            "torus": "built-in scene (scenes/torus/scene.xml parameters; its five meshes, 23614 triangles, from "
+                     "tests/golden/torus_meshes.npz behind a BVH: diffuse donut in a frosted-glass case, aluminium "
+                     "brackets, directional light)"}[args.scene]
     roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 5),
             "traffic": traffic_for(dom, cfg_key),

@@ -232,8 +232,9 @@ int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t
 /* sphere: 0-2 centre  3 radius  4 material index  5 emitter flag  6-8 emitted radiance  9-11 unused */
 #define PG_SPHERE_STRIDE 12
 /* material: 0 type (0 diffuse; 1 roughconductor, beckmann, sample_visible; 2 smooth conductor;
- *   3 smooth dielectric)  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta (dielectric:
- *   5 = int_ior / ext_ior)  8-10 k  11 one-sided flag (0 = wrapped in `twosided`) */
+ *   3 smooth dielectric; 4 roughdielectric, beckmann, sample_visible)  1-3 reflectance |
+ *   specular_reflectance  4 alpha  5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
+ *   11 one-sided flag (0 = wrapped in `twosided`) */
 #define PG_MATERIAL_STRIDE 12
 /* box (Mitsuba's `cube`: [-1,1]^3 under an affine to_world), intersected as three slabs in its local
  * frame instead of six quads: 0-8 rows of A = (linear part of to_world)^-1, 9-11 centre c

@@ -16,8 +16,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="cornell-box",
-                    help="built-in scene (cornell-box, veach-mis) or a Mitsuba 3 scene XML of the supported subset")
-    ap.add_argument("--width", type=int, default=None, help="film width (default: 512 / 1280 / the XML's)")
+                    help="built-in scene (cornell-box, veach-mis, torus) or a Mitsuba 3 scene XML of the supported subset")
+    ap.add_argument("--width", type=int, default=None, help="film width (default: 512 / 1280 / 1024 / the XML's)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--budget-spp", type=int, default=252)       # main.py:99
@@ -38,6 +38,8 @@ def main():
         sc = S.cornell_box(args.width or 512, args.height or 512, 8, 8)
     elif args.scene == "veach-mis":
         sc = S.veach_mis(args.width or 1280, args.height or 720)
+    elif args.scene == "torus":
+        sc = S.torus(args.width or 1024, args.height or 768)
     else:
         sc = S.load_xml(args.scene, args.width, args.height)
     if args.out == "debug/cornell-box" and args.scene != "cornell-box":

@@ -545,6 +545,19 @@ def bsdf_sample(material, wi, u1, u2):
     return wo, float(pdf[0]), w
 
 
+def bsdf_sample_full(material, wi, lobe, u1, u2):
+    """-> (wo (3,), pdf, weight (3,), eta, delta) of pgo_bsdf_sample_full: `lobe` is the 1-D sample
+    that picks reflection or transmission of a dielectric."""
+    lb = lib()
+    lb.pgo_bsdf_sample_full.argtypes = [_P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P]
+    lb.pgo_bsdf_sample_full.restype = None
+    m, a = _f32(material), _f32(wi)
+    wo, pdf, w = np.zeros(3, np.float32), np.zeros(1, np.float32), np.zeros(3, np.float32)
+    eta, delta = np.zeros(1, np.float32), np.zeros(1, np.int32)
+    lb.pgo_bsdf_sample_full(_ptr(m), _ptr(a), float(lobe), float(u1), float(u2), _ptr(wo), _ptr(pdf), _ptr(w), _ptr(eta), _ptr(delta))
+    return wo, float(pdf[0]), w, float(eta[0]), int(delta[0])
+
+
 def film_tent(seed, spp, width, height, L):
     """hdrfilm + tent rfilter reconstruction of one full-frame pass (pgo_film_tent); returns (3, H*W)."""
     return film("tent", seed, spp, width, height, L)

@@ -540,6 +540,87 @@ static float fresnel_dielectric(float cos_i, float eta, float *cos_t, float *eta
 	return r;
 }
 
+/* ---- roughdielectric (Beckmann, isotropic, sample_visible) after Mitsuba 3's roughdielectric.cpp:
+ * reflection and transmission through a rough interface, radiance transport.  wi may be on either
+ * side; eta = int_ior / ext_ior ---- */
+static inline v3 vflip_if(v3 v, int c) { return c ? V(-v.x, -v.y, -v.z) : v; }
+
+static v3 rd_half_vector(v3 wi, v3 wo, float eta_side, int reflect)
+{
+	v3 m = normalize3(vadd(wi, vscale(wo, reflect ? 1.0f : eta_side)));
+	return vflip_if(m, m.z < 0.0f); /* into the hemisphere of the macro-surface normal */
+}
+
+static void rd_eval_pdf(const material *mt, v3 wi, v3 wo, v3 *value, float *pdf)
+{
+	*value = V(0, 0, 0);
+	*pdf = 0.0f;
+	const float alpha = mt->alpha, eta_m = mt->eta.x;
+	const float ci = wi.z, co = wo.z;
+	if (ci == 0.0f) return;
+	const int reflect = ci * co > 0.0f;
+	const float eta = ci > 0.0f ? eta_m : 1.0f / eta_m, inv_eta = ci > 0.0f ? 1.0f / eta_m : eta_m;
+	const v3 m = rd_half_vector(wi, wo, eta, reflect);
+	const float D = rc_D(m, alpha);
+	float cos_t, eta_it, eta_ti;
+	const float wim = dot3(wi, m), wom = dot3(wo, m);
+	const float F = fresnel_dielectric(wim, eta_m, &cos_t, &eta_it, &eta_ti);
+	const float G = rc_G1(wi, m, alpha) * rc_G1(wo, m, alpha);
+	float val;
+	if (reflect) val = ((F * D) * G) / (4.0f * fabsf(ci));
+	else {
+		const float denom = wim + eta * wom;
+		val = fabsf(((((((inv_eta * inv_eta) * (1.0f - F)) * D) * G) * (eta * eta)) * (wim * wom)) / (ci * (denom * denom)));
+	}
+	if (!(val == val)) val = 0.0f;
+	*value = V(val, val, val);
+	/* pdf: the micro- and macro-surface must agree on the sides */
+	if (!(wim * ci > 0.0f && wom * co > 0.0f)) return;
+	const float denom = wim + eta * wom;
+	const float dwh_dwo = reflect ? 1.0f / (4.0f * wom) : ((eta * eta) * wom) / (denom * denom);
+	const v3 wiu = vflip_if(wi, ci < 0.0f);
+	float prob = ((D * rc_G1(wiu, m, alpha)) * fabsf(dot3(wiu, m))) / wiu.z;
+	prob = prob * (reflect ? F : 1.0f - F);
+	float p = prob * fabsf(dwh_dwo);
+	if (!(p == p)) p = 0.0f;
+	*pdf = p;
+}
+
+static void rd_sample(const material *mt, v3 wi, float u1, float u, float v, v3 *wo, float *pdf, v3 *weight, float *eta_out)
+{
+	*wo = V(0, 0, 0); *pdf = 0.0f; *weight = V(0, 0, 0); *eta_out = 0.0f;
+	const float alpha = mt->alpha, eta_m = mt->eta.x;
+	const float ci = wi.z;
+	if (ci == 0.0f) return;
+	float pdf_m;
+	const v3 m = rc_sample_m(vflip_if(wi, ci < 0.0f), alpha, u, v, &pdf_m);
+	if (!(pdf_m != 0.0f)) return;
+	float cos_t, eta_it, eta_ti;
+	const float wim = dot3(wi, m);
+	const float F = fresnel_dielectric(wim, eta_m, &cos_t, &eta_it, &eta_ti);
+	const int reflect = u1 <= F;
+	float p = pdf_m * (reflect ? F : 1.0f - F);
+	v3 o;
+	float w = 1.0f, dwh_dwo;
+	if (reflect) {
+		o = vsub(vscale(m, 2.0f * wim), wi);
+		dwh_dwo = 1.0f / (4.0f * dot3(o, m));
+		*eta_out = 1.0f;
+	} else {
+		o = vsub(vscale(m, wim * eta_ti + cos_t), vscale(wi, eta_ti)); /* refract(wi, m, cos_theta_t, eta_ti) */
+		w = eta_ti * eta_ti;
+		const float om = dot3(o, m), denom = wim + eta_it * om;
+		dwh_dwo = ((eta_it * eta_it) * om) / (denom * denom);
+		*eta_out = eta_it;
+	}
+	w = w * rc_G1(o, m, alpha);
+	p = p * fabsf(dwh_dwo);
+	if (!(p == p) || !(w == w)) return;
+	*wo = o;
+	*pdf = p;
+	*weight = V(w, w, w);
+}
+
 /* BSDF flags: does the material have a non-delta lobe (BSDFFlags.Smooth, :210)? */
 static inline int material_is_smooth(const material *mt) { return mt->type != 2 && mt->type != 3; }
 
@@ -550,6 +631,10 @@ static inline void bsdf_eval_pdf(const material *mt, v3 wi, v3 wo, int active, v
 	*pdf = 0.0f;
 	if (!active) return;
 	if (mt->type == 2 || mt->type == 3) return; /* smooth conductor / dielectric: delta lobes only */
+	if (mt->type == 4) {
+		rd_eval_pdf(mt, wi, wo, value, pdf);
+		return;
+	}
 	if (wi.z < 0.0f && !mt->one_sided) { wi.z = -wi.z; wo.z = -wo.z; }
 	if (mt->type == 1) {
 		rc_eval_pdf(mt, wi, wo, value, pdf);
@@ -577,6 +662,10 @@ static inline void bsdf_sample(const material *mt, v3 wi, float u1, float u, flo
 		*wo = reflect ? V(-wi.x, -wi.y, wi.z) : V(-eta_ti * wi.x, -eta_ti * wi.y, cos_t);
 		*eta = reflect ? 1.0f : eta_it;
 		*weight = reflect ? V(1, 1, 1) : V(eta_ti * eta_ti, eta_ti * eta_ti, eta_ti * eta_ti);
+		return;
+	}
+	if (mt->type == 4) {
+		rd_sample(mt, wi, u1, u, v, wo, pdf, weight, eta);
 		return;
 	}
 	int flip = wi.z < 0.0f && !mt->one_sided;

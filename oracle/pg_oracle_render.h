@@ -32,8 +32,9 @@ extern "C" {
 /* one sphere: 0-2 centre  3 radius  4 material index  5 emitter flag  6-8 emitted radiance  9-11 pad */
 #define PGO_SPHERE_STRIDE 12
 /* one material: 0 type (0 diffuse, 1 roughconductor/beckmann/sample_visible, 2 smooth conductor,
- *  3 smooth dielectric)  1-3 reflectance | specular_reflectance  4 alpha  5-7 eta (dielectric: 5 =
- *  int_ior / ext_ior)  8-10 k  11 one-sided flag (0 = wrapped in `twosided`; dielectrics never are) */
+ *  3 smooth dielectric, 4 roughdielectric/beckmann/sample_visible)  1-3 reflectance |
+ *  specular_reflectance  4 alpha  5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
+ *  11 one-sided flag (0 = wrapped in `twosided`; dielectrics never are) */
 #define PGO_MATERIAL_STRIDE 12
 
 /* one box (Mitsuba's `cube` shape, [-1,1]^3 under an affine to_world), intersected as three slabs

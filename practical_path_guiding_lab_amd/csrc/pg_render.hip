@@ -247,7 +247,7 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 
 // ---- surface description at a hit ----
 struct Material {
-	int type;        // 0 diffuse, 1 roughconductor (Beckmann, visible normals), 2 smooth conductor, 3 smooth dielectric
+	int type;        // 0 diffuse, 1 roughconductor (Beckmann, visible normals), 2 smooth conductor, 3 smooth dielectric, 4 roughdielectric
 	v3 refl;         // reflectance | specular_reflectance
 	const float *M;  // the material row: alpha, eta, k are read where the BSDF needs them
 	bool one_sided;  // not wrapped in `twosided` (row word 11)
@@ -523,6 +523,79 @@ __device__ __forceinline__ float fresnel_dielectric(float cos_i, float eta, floa
 	return r;
 }
 
+// ---- roughdielectric (Beckmann, isotropic, sample_visible) after Mitsuba 3's roughdielectric.cpp:
+// reflection and transmission through a rough interface, radiance transport; wi on either side,
+// M[4] = alpha, M[5] = int_ior / ext_ior.  Out of line: only scenes with such a material get here.
+__device__ __forceinline__ v3 vflip_if(v3 v, bool c) { return c ? V(-v.x, -v.y, -v.z) : v; }
+
+__device__ __noinline__ void rd_eval_pdf(const float *M, v3 wi, v3 wo, v3 &value, float &pdf)
+{
+	value = V(0, 0, 0);
+	pdf = 0.0f;
+	const float alpha = M[4], eta_m = M[5];
+	const float ci = wi.z, co = wo.z;
+	if (ci == 0.0f) return;
+	const bool reflect = ci * co > 0.0f;
+	const float eta = ci > 0.0f ? eta_m : 1.0f / eta_m, inv_eta = ci > 0.0f ? 1.0f / eta_m : eta_m;
+	v3 m = normalize3(vadd(wi, vscale(wo, reflect ? 1.0f : eta)));
+	m = vflip_if(m, m.z < 0.0f); // into the hemisphere of the macro-surface normal
+	const float D = rc_D(m, alpha);
+	float cos_t, eta_it, eta_ti;
+	const float wim = dot3(wi, m), wom = dot3(wo, m);
+	const float F = fresnel_dielectric(wim, eta_m, cos_t, eta_it, eta_ti);
+	const float G = rc_G1(wi, m, alpha) * rc_G1(wo, m, alpha);
+	const float denom = wim + eta * wom;
+	float val;
+	if (reflect) val = ((F * D) * G) / (4.0f * fabs_(ci));
+	else val = fabs_(((((((inv_eta * inv_eta) * (1.0f - F)) * D) * G) * (eta * eta)) * (wim * wom)) / (ci * (denom * denom)));
+	if (!(val == val)) val = 0.0f;
+	value = V(val, val, val);
+	if (!(wim * ci > 0.0f && wom * co > 0.0f)) return; // the micro- and macro-surface must agree on the sides
+	const float dwh_dwo = reflect ? 1.0f / (4.0f * wom) : ((eta * eta) * wom) / (denom * denom);
+	const v3 wiu = vflip_if(wi, ci < 0.0f);
+	float prob = ((D * rc_G1(wiu, m, alpha)) * fabs_(dot3(wiu, m))) / wiu.z;
+	prob = prob * (reflect ? F : 1.0f - F);
+	float p = prob * fabs_(dwh_dwo);
+	if (!(p == p)) p = 0.0f;
+	pdf = p;
+}
+
+__device__ __noinline__ void rd_sample(const float *M, v3 wi, float u1, float u, float v, v3 &wo, float &pdf, v3 &weight, float &eta_out)
+{
+	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta_out = 0.0f;
+	const float alpha = M[4], eta_m = M[5];
+	const float ci = wi.z;
+	if (ci == 0.0f) return;
+	float pdf_m;
+	const v3 m = rc_sample_m(vflip_if(wi, ci < 0.0f), alpha, u, v, pdf_m);
+	if (!(pdf_m != 0.0f)) return;
+	float cos_t, eta_it, eta_ti;
+	const float wim = dot3(wi, m);
+	const float F = fresnel_dielectric(wim, eta_m, cos_t, eta_it, eta_ti);
+	const bool reflect = u1 <= F;
+	float p = pdf_m * (reflect ? F : 1.0f - F);
+	v3 o;
+	float w = 1.0f, dwh_dwo, e;
+	if (reflect) {
+		o = vsub(vscale(m, 2.0f * wim), wi);
+		dwh_dwo = 1.0f / (4.0f * dot3(o, m));
+		e = 1.0f;
+	} else {
+		o = vsub(vscale(m, wim * eta_ti + cos_t), vscale(wi, eta_ti)); // refract(wi, m, cos_theta_t, eta_ti)
+		w = eta_ti * eta_ti;
+		const float om = dot3(o, m), denom = wim + eta_it * om;
+		dwh_dwo = ((eta_it * eta_it) * om) / (denom * denom);
+		e = eta_it;
+	}
+	eta_out = e;
+	w = w * rc_G1(o, m, alpha);
+	p = p * fabs_(dwh_dwo);
+	if (!(p == p) || !(w == w)) return;
+	wo = o;
+	pdf = p;
+	weight = V(w, w, w);
+}
+
 // BSDFFlags.Smooth (:210): does the material have a non-delta lobe?
 __device__ __forceinline__ bool material_is_smooth(const Material &mt) { return mt.type != 2 && mt.type != 3; }
 
@@ -534,6 +607,10 @@ __device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, 
 	pdf = 0.0f;
 	if (!active) return;
 	if (kGeneral >= 2 && (mt.type == 2 || mt.type == 3)) return; // smooth conductor / dielectric: delta lobes only
+	if (kGeneral >= 2 && mt.type == 4) {
+		rd_eval_pdf(mt.M, wi, wo, value, pdf);
+		return;
+	}
 	if (wi.z < 0.0f && !(kGeneral >= 2 && mt.one_sided)) { wi.z = -wi.z; wo.z = -wo.z; }
 	if (kGeneral && mt.type == 1) {
 		rc_eval_pdf(mt, wi, wo, value, pdf);
@@ -563,6 +640,10 @@ __device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u1,
 		wo = reflect ? V(-wi.x, -wi.y, wi.z) : V(-eta_ti * wi.x, -eta_ti * wi.y, cos_t);
 		eta = reflect ? 1.0f : eta_it;
 		weight = reflect ? V(1, 1, 1) : V(sc, sc, sc);
+		return;
+	}
+	if (kGeneral >= 2 && mt.type == 4) {
+		rd_sample(mt.M, wi, u1, u, v, wo, pdf, weight, eta);
 		return;
 	}
 	const bool flip = wi.z < 0.0f && !(kGeneral >= 2 && mt.one_sided);
@@ -1209,13 +1290,13 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	int general = ns > 0 ? 1 : 0; // feature level, see intersect()
 	for (uint64_t m = 0; m < n_mats; ++m) {
 		const float type = mats[m * kMaterialStride];
-		if (type != 0.0f && type != 1.0f && type != 2.0f && type != 3.0f)
+		if (type != 0.0f && type != 1.0f && type != 2.0f && type != 3.0f && type != 4.0f)
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
 		if (type == 1.0f && general < 1) general = 1;                                  // rough conductor
-		if (type >= 2.0f || mats[m * kMaterialStride + 11] != 0.0f) general = 2;       // delta lobes, one-sided BSDFs
-		if (type == 1.0f && !(mats[m * kMaterialStride + 4] > 0.0f))
-			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: roughconductor alpha must be > 0");
-		if (type == 3.0f && !(mats[m * kMaterialStride + 5] > 0.0f))
+		if (type >= 2.0f || mats[m * kMaterialStride + 11] != 0.0f) general = 2;       // transmission, delta lobes, one-sided BSDFs
+		if ((type == 1.0f || type == 4.0f) && !(mats[m * kMaterialStride + 4] > 0.0f))
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: microfacet alpha must be > 0");
+		if ((type == 3.0f || type == 4.0f) && !(mats[m * kMaterialStride + 5] > 0.0f))
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: dielectric index ratio must be > 0");
 	}
 	const uint64_t nd = sc->n_dir_lights;

@@ -44,6 +44,58 @@ def read_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
     return np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int64).reshape(-1, 3)
 
 
+def read_serialized(path: str, shape_index: int):
+    """One mesh of a Mitsuba `.serialized` file (the `serialized` shapes of scenes/torus/scene.xml):
+    returns (vertices (V,3) float64, faces (F,3) int64, vertex normals (V,3) float64 or None).
+    Layout: per mesh a uint16 magic 0x041C, a uint16 version (3 or 4), then a zlib stream holding
+    uint32 flags, (v4) a NUL-terminated name, uint64 vertex and triangle counts, positions, optional
+    normals / texcoords / colours (single or double precision by flag), uint32 indices; the file
+    ends with the mesh offsets (uint64 for v4, uint32 for v3) and a uint32 mesh count."""
+    import struct
+    import zlib
+
+    data = open(path, "rb").read()
+    count = struct.unpack("<I", data[-4:])[0]
+    if not 0 <= shape_index < count:
+        raise ValueError(f"{path} holds {count} meshes, shape_index {shape_index} asked")
+    version = struct.unpack("<HH", data[:4])[1]
+    if version == 4:
+        offsets = struct.unpack(f"<{count}Q", data[-4 - 8 * count:-4])
+    elif version == 3:
+        offsets = struct.unpack(f"<{count}I", data[-4 - 4 * count:-4])
+    else:
+        raise ValueError(f"unsupported .serialized version {version}")
+    start = offsets[shape_index]
+    magic, ver = struct.unpack("<HH", data[start:start + 4])
+    if magic != 0x041C:
+        raise ValueError("not a Mitsuba .serialized mesh")
+    raw = zlib.decompressobj().decompress(data[start + 4:])
+    pos = 0
+    flags = struct.unpack_from("<I", raw, pos)[0]; pos += 4
+    if ver == 4:
+        end = raw.index(b"\0", pos)
+        pos = end + 1
+    nv, nt = struct.unpack_from("<QQ", raw, pos); pos += 16
+    dt = np.dtype("<f8") if flags & 0x2000 else np.dtype("<f4")
+
+    def take(n, dtype):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype=dtype, count=n, offset=pos)
+        pos += n * dtype.itemsize
+        return a
+
+    verts = take(3 * nv, dt).reshape(nv, 3).astype(np.float64)
+    normals = take(3 * nv, dt).reshape(nv, 3).astype(np.float64) if flags & 0x0001 else None
+    if flags & 0x0002:
+        take(2 * nv, dt)
+    if flags & 0x0008:
+        take(3 * nv, dt)
+    faces = take(3 * nt, np.dtype("<u4")).reshape(nt, 3).astype(np.int64)
+    if flags & 0x0010:  # face normals requested by the file: ignore the stored vertex normals
+        normals = None
+    return verts, faces, normals
+
+
 def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, material_index: int,
               vertex_normals: np.ndarray = None):
     """(F,16) triangle records in world space; degenerate triangles are dropped.  With per-vertex

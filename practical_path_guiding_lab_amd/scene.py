@@ -23,7 +23,7 @@ QUAD_STRIDE = 24  # floats per quad, layout documented in include/pgsd.h (pg_sce
 SPHERE_STRIDE = 12    # centre 0-2, radius 3, material 4, emitter flag 5, radiance 6-8
 MATERIAL_STRIDE = 12  # type 0, reflectance 1-3, alpha 4, eta 5-7, k 8-10
 BOX_STRIDE = 32       # rows of the inverse linear map 0-8, centre 9-11, +x/+y/+z face normals 12-20, material 21
-MAT_DIFFUSE, MAT_ROUGHCONDUCTOR, MAT_CONDUCTOR, MAT_DIELECTRIC = 0, 1, 2, 3
+MAT_DIFFUSE, MAT_ROUGHCONDUCTOR, MAT_CONDUCTOR, MAT_DIELECTRIC, MAT_ROUGHDIELECTRIC = 0, 1, 2, 3, 4
 # RGB indices of refraction Mitsuba's `material` presets resolve to in an RGB variant
 CONDUCTOR_PRESETS = {"Al": ((1.657460, 0.880369, 0.521229), (9.223869, 6.269523, 4.837001))}
 IOR_PRESETS = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "acrylic glass": 1.49, "bk7": 1.5046, "diamond": 2.419}
@@ -147,6 +147,18 @@ def dielectric_material(int_ior: float, ext_ior: float = 1.000277) -> np.ndarray
     m = np.zeros(MATERIAL_STRIDE, np.float32)
     m[0] = MAT_DIELECTRIC
     m[1:4] = 1.0
+    m[5] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
+    m[11] = 1.0
+    return m
+
+
+def roughdielectric_material(alpha, int_ior: float, ext_ior: float = 1.000277) -> np.ndarray:
+    """Mitsuba `roughdielectric`, beckmann distribution, isotropic alpha, sample_visible: a rough
+    interface that reflects and refracts (scenes/torus/scene.xml `glass`); never twosided."""
+    m = np.zeros(MATERIAL_STRIDE, np.float32)
+    m[0] = MAT_ROUGHDIELECTRIC
+    m[1:4] = 1.0
+    m[4] = np.float32(alpha)
     m[5] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
     m[11] = 1.0
     return m
@@ -310,41 +322,151 @@ def veach_mis(width: int = 1280, height: int = 720, max_depth: int = 3, rr_depth
     return _finish(quads, cam, max_depth, rr_depth, names, spheres, mats, bxs)
 
 
+def look_at(origin, target, up) -> np.ndarray:
+    """Mitsuba's Transform::look_at: columns left, up', forward, origin."""
+    o, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))
+    d = (t - o) / np.linalg.norm(t - o)
+    left = np.cross(u, d)
+    left /= np.linalg.norm(left)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, np.cross(d, left), d, o
+    return m
+
+
+def rotation(axis, angle_deg: float) -> np.ndarray:
+    """Mitsuba's Transform::rotate (Rodrigues, degrees)."""
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    s, c = math.sin(math.radians(angle_deg)), math.cos(math.radians(angle_deg))
+    k = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    m = np.eye(4)
+    m[:3, :3] = c * np.eye(3) + s * k + (1 - c) * np.outer(a, a)
+    return m
+
+
+def _torus_mesh_file() -> str:
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "torus_meshes.npz")
+
+
+def torus(width: int = 1024, height: int = 768, max_depth: int = 30, rr_depth: int = 8, meshes: Optional[str] = None) -> Scene:
+    """The torus scene of the reference (scenes/torus/scene.xml): a one-sided diffuse donut inside a
+    frosted acrylic-glass case (roughdielectric, alpha 0.01) held by two aluminium brackets (smooth
+    conductor) on a diffuse floor, lit by one directional light, gaussian film filter, z up.
+    `meshes`: the five meshes of meshes.serialized as arrays (tests/golden/torus_meshes.npz, made by
+    tests/golden/make_torus_fixture.py)."""
+    from .mesh import triangles
+    data = np.load(meshes or _torus_mesh_file())
+    mats = [diffuse_material((0.725, 0.71, 0.68), twosided=False), diffuse_material((0.8, 0.8, 0.4), twosided=False),
+            roughdielectric_material(0.01, IOR_PRESETS["acrylic glass"], IOR_PRESETS["air"]),
+            conductor_material(*CONDUCTOR_PRESETS["Al"])]
+    floor_tw = np.eye(4)
+    floor_tw[0, 0], floor_tw[1, 1], floor_tw[0, 3], floor_tw[1, 3] = 0.4, 0.428, 10.0, 24.4
+    parts = [("floor", floor_tw, 0), ("donut", np.eye(4), 1), ("glass", np.eye(4), 2), ("metal_a", np.eye(4), 3), ("metal_b", np.eye(4), 3)]
+    tris = [triangles(data[f"{n}_v"], data[f"{n}_f"].astype(np.int64), tw, mi, data[f"{n}_n"]) for n, tw, mi in parts]
+    sun_tw = rotation((0, 0, 1), -45.0) @ rotation((0, 1, 0), 45.0) @ rotation((0, 1, 0), 180.0)
+    sun = directional_light(sun_tw[:3, 2], (2.0, 2.0, 1.8))
+    cam = make_camera(look_at((-24.173, -38.184, 30.0076), (-23.7753, -37.4261, 29.4905), (0.261433, 0.446628, 0.855673)),
+                      34.6222, width, height)
+    sc = _finish([], cam, max_depth, rr_depth, [], None, mats, None, tris, [sun])
+    sc.rfilter = "gaussian"
+    return sc
+
+
 def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None, boxes: bool = True) -> Scene:
-    """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world matrix, film size, rfilter),
-    twosided diffuse / roughconductor(beckmann) bsdfs with rgb parameters (by id), rectangle / cube
-    shapes with a to_world matrix, spheres by centre and radius, area emitters on rectangles and
-    spheres.  Anything else raises ValueError.  boxes: `cube` shapes become box primitives (else
-    six quads each)."""
+    """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world, film size, rfilter); diffuse,
+    roughconductor / roughdielectric (beckmann), conductor and dielectric bsdfs (by id or inline;
+    `twosided` wrappers honoured, a bare BSDF is one-sided as in Mitsuba); rectangle / cube shapes,
+    spheres by centre and radius, `serialized` and `obj` meshes; area emitters on rectangles and
+    spheres, `directional` emitters; transforms from matrix / lookat / scale / translate / rotate.
+    Anything else raises ValueError.  boxes: `cube` shapes become box primitives (else six quads
+    each)."""
+    import os
     root = ET.parse(path).getroot()
+    base = os.path.dirname(os.path.abspath(path))
     defaults: Dict[str, str] = {d.get("name"): d.get("value") for d in root.findall("default")}
 
     def val(s: str) -> str:
         return defaults[s[1:]] if s.startswith("$") else s
 
     def rgb(node) -> Tuple[float, float, float]:
-        v = [float(x) for x in node.get("value").replace(",", " ").split()]
+        v = [float(x) for x in val(node.get("value")).replace(",", " ").split()]
         return tuple(v * 3) if len(v) == 1 else tuple(v)
+
+    def vec(node, default: float) -> List[float]:
+        if node.get("value") is not None:
+            v = [float(x) for x in val(node.get("value")).replace(",", " ").split()]
+            return v * 3 if len(v) == 1 else v
+        return [float(val(node.get(a, str(default)))) for a in ("x", "y", "z")]
+
+    def transform(node) -> np.ndarray:
+        """to_world: the child operations are applied in document order (each multiplies from the left)."""
+        m = np.eye(4)
+        for op in (node if node is not None else []):
+            if op.tag == "matrix":
+                t = _mat(op.get("value"))
+            elif op.tag == "lookat":
+                t = look_at(*[[float(x) for x in op.get(k).replace(",", " ").split()] for k in ("origin", "target", "up")])
+            elif op.tag == "scale":
+                t = np.diag(vec(op, 1.0) + [1.0])
+            elif op.tag == "translate":
+                t = np.eye(4)
+                t[:3, 3] = vec(op, 0.0)
+            elif op.tag == "rotate":
+                t = rotation([float(op.get(a, "0")) for a in ("x", "y", "z")], float(val(op.get("angle"))))
+            else:
+                raise ValueError(f"unsupported transform element {op.tag}")
+            m = t @ m
+        return m
 
     materials: List[np.ndarray] = []
 
-    def material(node) -> int:
-        """Index of the material row for a <bsdf> element (every BSDF of the substrate is twosided)."""
+    def ior(node, name: str, default: float) -> float:
+        s, f = node.find(f"string[@name='{name}']"), node.find(f"float[@name='{name}']")
+        if s is not None:
+            if s.get("value") not in IOR_PRESETS:
+                raise ValueError(f"unknown index of refraction preset {s.get('value')}")
+            return IOR_PRESETS[s.get("value")]
+        return float(val(f.get("value"))) if f is not None else default
+
+    def material(node, twosided: bool = False) -> int:
+        """Index of the material row for a <bsdf> element."""
         if node.get("type") == "twosided":
-            return material(node.find("bsdf"))
+            return material(node.find("bsdf"), True)
         kind = node.get("type")
         named = {r.get("name"): rgb(r) for r in node.findall("rgb")}
-        if kind == "diffuse":
-            materials.append(diffuse_material(named.get("reflectance", (0.5, 0.5, 0.5))))
-        elif kind == "roughconductor":
+
+        def eta_k():
+            preset = node.find("string[@name='material']")
+            if preset is not None:
+                if preset.get("value") not in CONDUCTOR_PRESETS:
+                    raise ValueError(f"unknown conductor preset {preset.get('value')}")
+                return CONDUCTOR_PRESETS[preset.get("value")]
+            if "eta" not in named or "k" not in named:
+                raise ValueError(f"{kind}: give eta and k as rgb values or a known `material` preset")
+            return named["eta"], named["k"]
+
+        def alpha():
             dist = node.find("string[@name='distribution']")
             if dist is not None and dist.get("value") != "beckmann":
-                raise ValueError("roughconductor: only the beckmann distribution is built")
-            if node.find("string[@name='material']") is not None or "eta" not in named or "k" not in named:
-                raise ValueError("roughconductor: give eta and k as rgb values (material presets are not built)")
+                raise ValueError(f"{kind}: only the beckmann distribution is built")
             a = node.find("float[@name='alpha']")
-            materials.append(roughconductor_material(float(val(a.get("value"))) if a is not None else 0.1, named["eta"], named["k"],
-                                                     named.get("specular_reflectance", (1.0, 1.0, 1.0))))
+            return float(val(a.get("value"))) if a is not None else 0.1
+
+        if kind == "diffuse":
+            materials.append(diffuse_material(named.get("reflectance", (0.5, 0.5, 0.5)), twosided))
+        elif kind == "roughconductor":
+            if not twosided:
+                raise ValueError("roughconductor: only the twosided form is built")
+            e, k = eta_k()
+            materials.append(roughconductor_material(alpha(), e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0))))
+        elif kind == "conductor":
+            e, k = eta_k()
+            materials.append(conductor_material(e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0)), twosided))
+        elif kind == "dielectric":
+            materials.append(dielectric_material(ior(node, "int_ior", IOR_PRESETS["bk7"]), ior(node, "ext_ior", IOR_PRESETS["air"])))
+        elif kind == "roughdielectric":
+            materials.append(roughdielectric_material(alpha(), ior(node, "int_ior", IOR_PRESETS["bk7"]), ior(node, "ext_ior", IOR_PRESETS["air"])))
         else:
             raise ValueError(f"unsupported bsdf type {kind}")
         return len(materials) - 1
@@ -355,12 +477,15 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     sensor = root.find("sensor")
     if sensor is None or sensor.get("type") != "perspective":
         raise ValueError("need a perspective sensor")
+    axis = sensor.find("string[@name='fov_axis']")
+    if axis is not None and axis.get("value") != "x":
+        raise ValueError("only fov_axis = x is built")
     fov = float(val(sensor.find("float[@name='fov']").get("value")))
     film = sensor.find("film")
     fw = int(val(film.find("integer[@name='width']").get("value")))
     fh = int(val(film.find("integer[@name='height']").get("value")))
-    cam = make_camera(_mat(sensor.find("transform/matrix").get("value")), fov, width or fw, height or fh)
-    quads, names, spheres, bxs = [], [], [], []
+    cam = make_camera(transform(sensor.find("transform")), fov, width or fw, height or fh)
+    quads, names, spheres, bxs, tris = [], [], [], [], []
     for sh in root.findall("shape"):
         kind = sh.get("type")
         ref = sh.find("ref")
@@ -377,7 +502,23 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             center = [float(val(c.get(a, "0"))) for a in ("x", "y", "z")] if c is not None else [0.0, 0.0, 0.0]
             spheres.append(sphere(center, float(val(r.get("value"))) if r is not None else 1.0, mi, rad))
             continue
-        m = _mat(sh.find("transform/matrix").get("value"))
+        m = transform(sh.find("transform"))
+        if kind in ("serialized", "obj"):
+            if rad is not None:
+                raise ValueError("emitting meshes are not supported")
+            from .mesh import read_obj, read_serialized, triangles
+            fname = os.path.join(base, sh.find("string[@name='filename']").get("value"))
+            if kind == "obj":
+                v, f = read_obj(fname)
+                nrm = None
+            else:
+                si = sh.find("integer[@name='shape_index']")
+                v, f, nrm = read_serialized(fname, int(val(si.get("value"))) if si is not None else 0)
+            fn = sh.find("boolean[@name='face_normals']")
+            if fn is not None and fn.get("value") == "true":
+                nrm = None
+            tris.append(triangles(v, f, m, mi, nrm))
+            continue
         if kind == "rectangle":
             qs = rectangle(m, refl, rad)
         elif kind == "cube":
@@ -393,7 +534,15 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             q[22] = np.float32(mi)
         quads += qs
         names += [sh.get("id", kind)] * len(qs)
-    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials, bxs)
+    lights = []
+    for em in root.findall("emitter"):
+        if em.get("type") != "directional":
+            raise ValueError(f"unsupported emitter type {em.get('type')}")
+        d = em.find("vector[@name='direction']")
+        direction = vec(d, 0.0) if d is not None else transform(em.find("transform"))[:3, 2]
+        irr = em.find("rgb[@name='irradiance']")
+        lights.append(directional_light(direction, rgb(irr) if irr is not None else (1.0, 1.0, 1.0)))
+    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials, bxs, tris, lights)
     rf = film.find("rfilter")
     sc.rfilter = rf.get("type") if rf is not None else "gaussian"  # hdrfilm's default
     if sc.rfilter not in ("tent", "box", "gaussian"):

@@ -29,6 +29,16 @@ def main():
     small = img.reshape(180, 4, 320, 4, 3).astype(np.float64).mean(axis=(1, 3))
     np.save(os.path.join(HERE, "veach_mis_gt_320x180_f16.npy"), np.minimum(small, 60000.0).astype(np.float16))
     print("veach-mis mean radiance", img.mean(), "->", small.mean(), "max", small.max())
+    # torus: the reference ships an 8-bit sRGB image only (scenes/torus/TungstenRender.png, 1024x768);
+    # linearised (inverse sRGB curve), box-downsampled 4x4 to 256x192, stored as float16.  Values that
+    # were clipped at 1.0 in the PNG stay clipped: tests skip blocks holding them.
+    from PIL import Image
+    png = np.asarray(Image.open(os.path.join(ref, "scenes", "torus", "TungstenRender.png")).convert("RGB")).astype(np.float64) / 255.0
+    assert png.shape == (768, 1024, 3)
+    lin = np.where(png <= 0.04045, png / 12.92, ((png + 0.055) / 1.055) ** 2.4)
+    small = lin.reshape(192, 4, 256, 4, 3).mean(axis=(1, 3))
+    np.save(os.path.join(HERE, "torus_gt_256x192_f16.npy"), small.astype(np.float16))
+    print("torus mean (linearised sRGB)", lin.mean(), "->", small.mean())
 
 
 if __name__ == "__main__":

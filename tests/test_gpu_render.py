@@ -113,6 +113,9 @@ def mixed_scene(res, max_depth=6, rr_depth=3):
     quads += with_mat(S.rectangle(M(0.7, 0, 0, -3.0, 0, 0.7, 0, 2.4, 0, 0, 0.7, -2.0, 0, 0, 0, 1), mats[7][1:4]), 7)          # one-sided card
     spheres.append(S.sphere((-0.4, 0.5, 2.6), 0.5, 6))
     boxes.append(S.box(M(0.5, 0, 0, 2.2, 0, 0.35, 0, 0.36, 0, 0, 0.5, 2.4, 0, 0, 0, 1), 6))
+    mats.append(S.roughdielectric_material(0.1, 1.49, 1.000277))                                           # frosted glass (scenes/torus)
+    spheres.append(S.sphere((1.0, 0.4, 3.2), 0.4, 8))
+    tris.append(MS.triangles(v, f, M(0.35, 0, 0, -1.6, 0, 0.35, 0, 0.36, 0, 0, 0.35, 3.0, 0, 0, 0, 1), 8, v))  # and a smooth-shaded frosted mesh
     lights = [S.directional_light((0.4, -1.0, -0.3), (1.5, 1.4, 1.2))]
     cam = S.make_camera(M(-1, 0, 0, 0, 0, 0.94, -0.342, 3.0, 0, -0.342, -0.94, 7.5, 0, 0, 0, 1), 40.0, res, res)
     return S._finish(quads, cam, max_depth, rr_depth, ["q"] * len(quads), spheres, mats, boxes, tris, lights)
@@ -123,13 +126,24 @@ def test_spheres_rough_conductors_and_many_emitters_bit_exact(res, nee):
     """The general kernels (k_bounce<*, true>: spheres, uniform emitter choice with cone-sampled
     sphere lights, Beckmann rough conductors with visible-normal sampling) against the oracle:
     radiance, sums, accumulators and refined trees over a guided lifecycle."""
+    _guided_lifecycle_bit_exact(mixed_scene(res), nee)
+
+
+def test_torus_scene_bit_exact():
+    """scenes/torus at 48x36 (23614 triangles behind the BVH, smooth normals, frosted glass, mirrors,
+    one-sided diffuse, the directional light, max_depth 30 with roulette from depth 8): the device
+    against the oracle over a guided lifecycle."""
+    from practical_path_guiding_lab_amd.scene import torus
+    _guided_lifecycle_bit_exact(torus(48, 36), True)
+
+
+def _guided_lifecycle_bit_exact(sc, nee):
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
-    sc = mixed_scene(res)
     D, RR = sc.max_depth, sc.rr_depth
     bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
-    npix = res * res
+    npix = sc.camera.width * sc.camera.height
     o = po.OracleSDTreePair()
     o.setup(bmin, bmax, 20, 20, nee)
     o_sumL = np.zeros((3, npix), np.float32)
@@ -204,6 +218,29 @@ def test_veach_mis_direct_light_matches_the_tungsten_ground_truth():
     res3 = run_guided_render(WavefrontScene(sc3), g3, 124, initial_seed=3, training_spp_per_pass=4, log=lambda s: None)
     r3 = _block_ratios(res3["image"].cpu().numpy().astype(np.float64), np.load(gt_path).astype(np.float64), 15, 20)
     assert r3.mean() > 1.04 and r3.min() > 0.99
+
+
+def test_torus_matches_the_tungsten_image_where_it_converges():
+    """scenes/torus at 256x192 through main.py's schedule against the reference's image of it
+    (tests/golden/torus_gt_256x192_f16.npy, the linearised TungstenRender.png): the floor in the sun,
+    in front of and behind the case, and the case's shadow."""
+    import os
+    from test_oracle_substrate import TORUS_BLOCKS, TORUS_RTOL, torus_block_means
+    from practical_path_guiding_lab_amd.driver import run_guided_render
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import WavefrontScene
+    from practical_path_guiding_lab_amd.scene import torus
+
+    sc = torus(256, 192)
+    sc.rfilter = "box"  # block means of raw pixel estimates
+    gt = np.load(os.path.join(os.path.dirname(__file__), "golden", "torus_gt_256x192_f16.npy")).astype(np.float64)
+    g = PathGuidingIntegrator({"max_depth": 30, "rr_depth": 8})
+    res = run_guided_render(WavefrontScene(sc), g, 124, initial_seed=1, training_spp_per_pass=4, log=lambda s: None)
+    img = res["image"].cpu().numpy().astype(np.float64)
+    assert img.shape == (192, 256, 3) and np.isfinite(img).all()
+    ours, theirs = torus_block_means(img), torus_block_means(gt)
+    for k in TORUS_BLOCKS:
+        np.testing.assert_allclose(ours[k], theirs[k], rtol=TORUS_RTOL[k], err_msg=k)
 
 
 def test_guided_render_converges_to_the_ground_truth():

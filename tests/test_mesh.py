@@ -25,6 +25,73 @@ def test_read_obj_fans_polygons_and_resolves_negative_indices(tmp_path):
     np.testing.assert_allclose(t2[0, 3:6], [2, 0, 0]); np.testing.assert_allclose(t2[0, 6:9], [2, 3, 0])
 
 
+def _write_serialized(path, meshes, version):
+    """A Mitsuba .serialized file made by hand: per mesh magic, version, zlib(flags, [name], counts,
+    positions, [normals], [uvs], faces); then the offset table and the mesh count."""
+    import struct
+    import zlib
+    blob, offsets = b"", []
+    for v, f, n, double, uv in meshes:
+        flags = (0x2000 if double else 0x1000) | (0x0001 if n is not None else 0) | (0x0002 if uv else 0)
+        ft = "<f8" if double else "<f4"
+        raw = struct.pack("<I", flags)
+        if version == 4:
+            raw += b"a mesh\0"
+        raw += struct.pack("<QQ", len(v), len(f)) + np.asarray(v, ft).tobytes()
+        if n is not None:
+            raw += np.asarray(n, ft).tobytes()
+        if uv:
+            raw += np.zeros((len(v), 2), ft).tobytes()
+        raw += np.asarray(f, "<u4").tobytes()
+        offsets.append(len(blob))
+        blob += struct.pack("<HH", 0x041C, version) + zlib.compress(raw)
+    blob += struct.pack(f"<{len(offsets)}{'Q' if version == 4 else 'I'}", *offsets) + struct.pack("<I", len(offsets))
+    open(path, "wb").write(blob)
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_read_serialized_meshes(tmp_path, version):
+    v0 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    f0 = np.array([[0, 1, 2], [0, 2, 3]])
+    n0 = np.array([[0, 0, 1.0]] * 4)
+    v1, f1 = M.icosphere(1)
+    p = str(tmp_path / "m.serialized")
+    _write_serialized(p, [(v0, f0, n0, False, True), (v1, f1, None, True, False), (v1 * 2, f1, v1, False, False)], version)
+    v, f, n = M.read_serialized(p, 0)
+    assert np.array_equal(v, v0) and np.array_equal(f, f0) and np.array_equal(n, n0)
+    v, f, n = M.read_serialized(p, 1)
+    assert np.array_equal(v, v1) and np.array_equal(f, f1) and n is None          # double precision survives
+    v, f, n = M.read_serialized(p, 2)
+    np.testing.assert_allclose(v, v1 * 2, rtol=1e-6)
+    np.testing.assert_allclose(n, v1, rtol=1e-6)
+    with pytest.raises(ValueError):
+        M.read_serialized(p, 3)
+
+
+def test_torus_scene_from_its_fixture_and_from_the_xml():
+    """scene.torus() (meshes from tests/golden/torus_meshes.npz) against the scene file itself where
+    the reference is mounted; the fixture's sizes either way."""
+    import os
+    sc = S.torus(64, 48)
+    assert sc.tris.shape == (23614, 16) and sc.tri_normals.shape == (23614, 9) and sc.bvh.shape[1] == 8
+    assert sc.rfilter == "gaussian" and sc.max_depth == 30 and sc.rr_depth == 8 and sc.dir_lights.shape == (1, 8)
+    np.testing.assert_allclose(sc.dir_lights[0, :3], [-0.5, 0.5, -np.sqrt(0.5)], atol=1e-7)
+    assert [int(m[0]) for m in sc.materials] == [S.MAT_DIFFUSE, S.MAT_DIFFUSE, S.MAT_ROUGHDIELECTRIC, S.MAT_CONDUCTOR]
+    assert (sc.materials[:, 11] == 1).all()                                         # nothing is twosided in this scene
+    _check_bvh(sc.bvh, sc.tris)
+    xml = "/root/reference/scenes/torus/scene.xml"
+    if not os.path.exists(xml):
+        return
+    ref = S.load_xml(xml, 64, 48)
+    for k in ("bvh", "tri_normals", "dir_lights", "bbox_min", "bbox_max"):
+        assert np.array_equal(getattr(sc, k), getattr(ref, k)), k
+    assert np.array_equal(sc.tris[:, :12], ref.tris[:, :12])
+    assert np.array_equal(sc.materials[sc.tris[:, 12].astype(int)], ref.materials[ref.tris[:, 12].astype(int)])
+    assert sc.camera.width == ref.camera.width and ref.rfilter == "gaussian" and ref.max_depth == 30
+    for k in ("origin", "axis_x", "axis_y", "axis_z"):
+        assert np.array_equal(getattr(sc.camera, k), getattr(ref.camera, k))
+
+
 def _check_bvh(nodes, tris):
     n = nodes.shape[0]
     seen = np.zeros(n, bool); seen[0] = True

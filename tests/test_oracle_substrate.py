@@ -51,6 +51,94 @@ def test_rough_conductor_sampling_matches_its_pdf_and_eval(alpha, theta):
     assert po.bsdf_eval_pdf(m, wi, grid[0] * flip)[1] == 0.0
 
 
+@pytest.mark.parametrize("alpha,theta,side", [(0.3, 0.4, 1), (0.3, 1.2, 1), (0.3, 0.4, -1), (0.3, 1.0, -1), (0.05, 0.8, 1)])
+def test_rough_dielectric_sampling_matches_its_pdf_and_eval(alpha, theta, side):
+    """`roughdielectric` (the torus scene's glass): the sampled direction's pdf and value are those
+    eval_pdf gives for it, on either side of the interface and for both lobes; the pdf integrates
+    to the fraction of valid samples; without the eta^2 radiance scale no energy is created."""
+    m = S.roughdielectric_material(alpha, 1.49, 1.000277)
+    eta_m = float(m[5])
+    wi = np.array([np.sin(theta) * np.cos(0.7), np.sin(theta) * np.sin(0.7), side * np.cos(theta)], np.float32)
+    rng = np.random.default_rng(7)
+    n, hits, n_refl, albedo, mean = 5000, 0, 0, 0.0, np.zeros(3)
+    for _ in range(n):
+        wo, pdf, w, eta, delta = po.bsdf_sample_full(m, wi, rng.random(), rng.random(), rng.random())
+        assert delta == 0
+        if pdf > 0 and w[0] > 0:
+            hits += 1
+            mean += wo
+            refl = wo[2] * wi[2] > 0
+            n_refl += refl
+            assert abs(np.linalg.norm(wo) - 1) < 1e-5
+            assert eta == 1.0 if refl else abs(eta - (eta_m if side > 0 else 1 / eta_m)) < 1e-6
+            val, pdf2 = po.bsdf_eval_pdf(m, wi, wo)
+            assert abs(pdf2 - pdf) <= 3e-4 * pdf
+            assert np.abs(val - w * pdf).max() <= 3e-4 * np.abs(val).max()
+            albedo += w[0] if refl else w[0] * eta * eta      # undo the radiance scale eta_ti^2 = 1 / eta^2
+            assert w[0] * (1.0 if refl else eta * eta) <= 1.0 + 1e-4   # G1's rational fit peaks at 1.00005
+    assert albedo / n <= 1.0 and albedo / n > 0.8
+    # total internal reflection from inside at 1.0 rad (critical angle 0.74): mostly reflection
+    if side < 0 and theta > 0.9:
+        assert n_refl > 0.75 * hits
+    if side > 0 and theta < 0.5:
+        assert n_refl < 0.08 * hits                               # F(0.4) ~ 0.04
+    up, dA = _hemi_grid(160 if alpha < 0.1 else 90)
+    grid = np.concatenate([up, up * np.array([1, 1, -1], np.float32)])
+    pdfs = np.array([po.bsdf_eval_pdf(m, wi, wo)[1] for wo in grid])
+    total = pdfs.sum() * dA
+    tol = 0.03 if alpha < 0.1 else 0.02
+    assert abs(total - hits / n) < tol and total <= 1.0 + tol
+    quad_mean = (grid * pdfs[:, None]).sum(axis=0) * dA
+    assert np.abs(mean / n - quad_mean).max() < tol
+
+
+def test_rough_glass_slab_of_small_roughness_transmits_like_the_smooth_one():
+    """A lamp seen through a slab of `roughdielectric` glass with alpha 0.01: (1 - R)/(1 + R) of its
+    radiance, as through smooth glass -- here the light is found both by BSDF sampling and by
+    emitter sampling at the exit face (a rough interface has no delta lobe), weighted by MIS."""
+    mats = [S.roughdielectric_material(0.01, 1.5, 1.0), S.diffuse_material((0, 0, 0))]
+    slab = S.box(np.array([[2.0, 0, 0, 0], [0, 2.0, 0, 0], [0, 0, 0.25, 0], [0, 0, 0, 1]]), 0)
+    lamp = S.sphere((0.0, 0.0, -6.0), 1.5, 1, (5.0, 5.0, 5.0))
+    sc = S._finish([], _look_at((0, 0, 8), (0, 0, 0), 0.3, res=2), 24, 30, [], [lamp], mats, [slab])
+    got = _render_mean(sc, 24, 20000, seed=4)
+    R = ((1.5 - 1) / (1.5 + 1)) ** 2
+    np.testing.assert_allclose(got, 5.0 * (1 - R) / (1 + R), rtol=0.015)
+
+
+TORUS_BLOCKS = {  # (y0, y1, x0, x1) as fractions of the film: regions of the torus image that converge quickly
+    "floor in front": (0.90, 0.99, 0.05, 0.30), "floor behind": (0.02, 0.08, 0.02, 0.12), "floor at the left": (0.30, 0.40, 0.02, 0.10),
+    "shadow of the case": (0.46, 0.54, 0.16, 0.28)}
+TORUS_RTOL = {"floor in front": 0.04, "floor behind": 0.01, "floor at the left": 0.01, "shadow of the case": 0.08}
+
+
+def torus_block_means(img, blocks=TORUS_BLOCKS):
+    h, w = img.shape[:2]
+    return {k: img[int(a * h):int(b * h), int(c * w):int(d * w)].reshape(-1, 3).mean(axis=0) for k, (a, b, c, d) in blocks.items()}
+
+
+def test_oracle_torus_against_the_tungsten_image():
+    """scenes/torus (meshes behind a BVH with smooth normals, one-sided diffuse, frosted glass,
+    aluminium mirrors, a directional light): the floor in the sun, in the case's shadow and far
+    behind agree with the reference's TungstenRender.png (8-bit sRGB, linearised; fixture
+    tests/golden/torus_gt_256x192_f16.npy).  The donut behind the glass is lit by caustic paths that
+    plain path tracing finds with huge variance -- that is what the scene is for -- so it is not
+    compared at this sample count."""
+    import os
+    gt = np.load(os.path.join(os.path.dirname(__file__), "golden", "torus_gt_256x192_f16.npy")).astype(np.float64)
+    W, H, spp = 128, 96, 24
+    sc = S.torus(W, H)
+    pair = po.OracleSDTreePair()
+    pair.setup(sc.bbox_min - np.float32(1e-3), sc.bbox_max + np.float32(1e-3), 20, 20, True)
+    L, valid = po.render_pass(pair, sc, sc.camera, 30, 8, 0, True, 1, spp, True, 0.5)
+    assert np.isfinite(L).all()
+    img = L.reshape(3, H, W, spp).astype(np.float64).mean(axis=3).transpose(1, 2, 0)
+    ours, theirs = torus_block_means(img), torus_block_means(gt)
+    for k in TORUS_BLOCKS:
+        np.testing.assert_allclose(ours[k], theirs[k], rtol=TORUS_RTOL[k], err_msg=k)
+    # the sunlit floor has its closed form: rho / pi * E * cos(45 deg)
+    np.testing.assert_allclose(ours["floor behind"], np.array([0.725, 0.71, 0.68]) / np.pi * np.array([2, 2, 1.8]) * np.sqrt(0.5), rtol=0.02)
+
+
 def test_diffuse_material_row_is_the_cornell_bsdf():
     m = S.diffuse_material((0.2, 0.4, 0.6))
     wi = np.array([0.3, -0.2, 0.933], np.float32)
