@@ -1,11 +1,12 @@
-"""Scene description for the renderer substrate: quads (rectangles and cube faces) and spheres,
-twosided diffuse and Beckmann rough-conductor BSDFs in a material table, one-sided area emitters on
-rectangles and spheres, a perspective camera -- the subset of Mitsuba 3 scene XML that
-scenes/cornell-box/scene.xml and scenes/veach-mis/scene.xml of the reference use.
+"""Scene description for the renderer substrate: quads (rectangles and cube faces), spheres, box
+primitives and triangle meshes; diffuse, Beckmann rough-conductor / rough-dielectric, smooth
+conductor and dielectric BSDFs in a material table (twosided or not); one-sided area emitters on
+rectangles and spheres, directional emitters; a perspective camera -- the subset of Mitsuba 3 scene
+XML that scenes/cornell-box, scenes/veach-mis and scenes/torus of the reference use.
 
 `load_xml(path)` parses that subset from a Mitsuba 3 XML file (e.g. the reference's own scene
-files, when they are available); `cornell_box()` and `veach_mis()` build the same scenes from their
-numeric parameters so that tests and the benchmark do not need the files.
+files, when they are available); `cornell_box()`, `veach_mis()` and `torus()` build the same scenes
+from their numeric parameters so that tests and the benchmark do not need the files.
 
 This module is plain data preparation (numpy); it is shared by the product and by the tests
 that feed the same arrays to the CPU oracle.
