@@ -67,7 +67,22 @@ static inline v3 to_world(const frame *f, v3 v)
 static inline float safe_sqrtf(float v) { return sqrtf(v > 0.0f ? v : 0.0f); }
 static inline v3 normalize3(v3 v) { return vdivs(v, sqrtf(dot3(v, v))); }
 
-/* closest hit over all shapes: 0 < t < tmax; returns the shape number (quads, then spheres) */
+/* does the ray reach the box of BVH node N before bt?  *tmin = where it enters (>= 0) */
+static int bvh_box_hit(const uint32_t *N, const float oo[3], const float inv[3], float bt, float *tmin_out)
+{
+	float tmin = 0.0f, tmax = bt;
+	for (int k = 0; k < 3; ++k) {
+		const float t0 = (pgo_u2f(N[k]) - oo[k]) * inv[k], t1 = (pgo_u2f(N[4 + k]) - oo[k]) * inv[k];
+		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+		tmin = lo > tmin ? lo : tmin;
+		tmax = hi < tmax ? hi : tmax;
+	}
+	*tmin_out = tmin;
+	return tmin <= tmax * 1.0000004f;
+}
+
+/* closest hit over all shapes: 0 < t < tmax; returns the shape number (quads, spheres, box faces,
+ * triangles) */
 static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 {
 	const size_t nq = sc->n_quads;
@@ -132,26 +147,32 @@ static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 		bt = t;
 		best = (int)(nq + sc->n_spheres + 6 * b) + 2 * axis + negative;
 	}
-	/* triangle meshes: ordered traversal of the binary BVH (near child first, by the sign of the ray
-	 * direction on the node's split axis), slab test padded as Ize 2013, Moeller-Trumbore triangles */
+	/* triangle meshes: the binary BVH, walked near child first: both children of an inner node are
+	 * tested, the walk goes on in the nearer one that is hit and the farther one waits on the stack,
+	 * to be tested again against the then shorter ray when it is popped.  Slab test padded as Ize
+	 * 2013, Moeller-Trumbore triangles.  (The order matters only for which of several equally near
+	 * triangles is reported: the first one met.) */
 	if (sc->n_bvh_nodes) {
 		const size_t tri_base = nq + sc->n_spheres + 6 * sc->n_boxes;
 		const float inv[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
-		const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+		const float oo[3] = { o.x, o.y, o.z };
 		uint32_t stack[64];
 		int sp = 0;
-		stack[sp++] = 0;
-		while (sp) {
-			const uint32_t *N = sc->bvh + (size_t)stack[--sp] * PGO_BVH_STRIDE;
-			float tmin = 0.0f, tmax = bt;
-			for (int k = 0; k < 3; ++k) {
-				const float t0 = (pgo_u2f(N[k]) - oo[k]) * inv[k], t1 = (pgo_u2f(N[4 + k]) - oo[k]) * inv[k];
-				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-				tmin = lo > tmin ? lo : tmin;
-				tmax = hi < tmax ? hi : tmax;
+		float tn;
+		const uint32_t *N = sc->bvh;
+		int have = bvh_box_hit(N, oo, inv, bt, &tn);
+		for (;;) {
+			while (have && !(N[7] & 0x80000000u)) { /* inner node: test both children */
+				const uint32_t left = N[3], right = N[7] & 0x1fffffffu;
+				const uint32_t *Lc = sc->bvh + (size_t)left * PGO_BVH_STRIDE, *Rc = sc->bvh + (size_t)right * PGO_BVH_STRIDE;
+				float tl, tr;
+				const int hl = bvh_box_hit(Lc, oo, inv, bt, &tl), hr = bvh_box_hit(Rc, oo, inv, bt, &tr);
+				const int right_near = hr && (!hl || tr < tl);
+				if (hl && hr) stack[sp++] = right_near ? left : right;
+				N = right_near ? Rc : Lc;
+				have = hl || hr;
 			}
-			if (!(tmin <= tmax * 1.0000004f)) continue;
-			if (N[7] & 0x80000000u) {
+			if (have) {
 				const uint32_t first = N[3], count = N[7] & 0x7fffffffu;
 				for (uint32_t i = first; i < first + count; ++i) {
 					const float *T = sc->tris + (size_t)i * PGO_TRI_STRIDE;
@@ -169,12 +190,13 @@ static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 					const float t = dot3(e2, q) * inv_det;
 					if (t > 0.0f && t < bt) { bt = t; best = (int)(tri_base + i); }
 				}
-			} else {
-				const uint32_t left = N[3], right = N[7] & 0x1fffffffu, axis = (N[7] >> 29) & 3u;
-				const int right_first = dd[axis] < 0.0f;
-				stack[sp++] = right_first ? left : right; /* the far child is popped later */
-				stack[sp++] = right_first ? right : left;
 			}
+			have = 0;
+			while (sp && !have) { /* next node that the (now shorter) ray still reaches */
+				N = sc->bvh + (size_t)stack[--sp] * PGO_BVH_STRIDE;
+				have = bvh_box_hit(N, oo, inv, bt, &tn);
+			}
+			if (!have) break;
 		}
 	}
 	*t_out = bt;

@@ -108,7 +108,35 @@ __device__ __forceinline__ v3 box_face_normal(const float *B, int face)
 // (cornell-box), 1 = + spheres and rough conductors (veach-mis), 2 = + triangle meshes, delta
 // lobes, one-sided BSDFs, directional lights and the running index of refraction (torus-class
 // scenes).  What a level does not need is compiled out.
-template <int kGeneral>
+// Does the ray reach the box of BVH node (n0, n1) before bt?  tmin = where it enters (>= 0).
+__device__ __forceinline__ bool bvh_box_hit(const uint4 &n0, const uint4 &n1, v3 o, v3 inv, float bt, float &tmin_out)
+{
+	float tmin = 0.0f, tmax = bt;
+	{
+		const float t0 = (__uint_as_float(n0.x) - o.x) * inv.x, t1 = (__uint_as_float(n1.x) - o.x) * inv.x;
+		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+		tmin = lo > tmin ? lo : tmin;
+		tmax = hi < tmax ? hi : tmax;
+	}
+	{
+		const float t0 = (__uint_as_float(n0.y) - o.y) * inv.y, t1 = (__uint_as_float(n1.y) - o.y) * inv.y;
+		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+		tmin = lo > tmin ? lo : tmin;
+		tmax = hi < tmax ? hi : tmax;
+	}
+	{
+		const float t0 = (__uint_as_float(n0.z) - o.z) * inv.z, t1 = (__uint_as_float(n1.z) - o.z) * inv.z;
+		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+		tmin = lo > tmin ? lo : tmin;
+		tmax = hi < tmax ? hi : tmax;
+	}
+	tmin_out = tmin;
+	return tmin <= tmax * 1.0000004f;
+}
+
+// kAny: the caller asks whether anything is hit (shadow rays): the BVH walk stops at its first
+// triangle.  The answer is that of the closest-hit walk, which visits the same nodes until then.
+template <int kGeneral, bool kAny = false>
 __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out)
 {
 	const int nq = sh.n_quads;
@@ -181,41 +209,41 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 		bt = t;
 		best = nq + sh.n_spheres + 6 * b + 2 * axis + negative;
 	}
-	// triangle meshes: ordered traversal of the binary BVH (near child first, by the sign of the ray
-	// direction on the node's split axis), slab test padded as Ize 2013, Moeller-Trumbore triangles
-	if (kGeneral >= 2 && sh.n_bvh_nodes) {
+	// triangle meshes: the binary BVH.  Both children of an inner node are tested at once (the builder
+	// stores siblings next to each other: one 64-byte line), the walk goes on in the nearer one that is
+	// hit -- its node is already in registers -- and the farther one waits on the stack, to be tested
+	// again against the then shorter ray when it is popped.  Slab test padded as Ize 2013,
+	// Moeller-Trumbore triangles.  The oracle visits the same nodes in the same order, so the first of
+	// several equally near triangles is the same one in both.
+	if (kGeneral >= 2 && sh.n_bvh_nodes && !(kAny && best >= 0)) {
 		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
-		const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+		const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+		const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(sh.bvh);
 		// pg_scene_set_ex has checked the tree: children follow their parent, depth <= 60, so the walk
-		// visits every node at most once and the stack cannot overflow; the counter is a second fence
+		// visits every node at most once and the stack (far children only) cannot overflow; the budget
+		// is a second fence
 		uint32_t stack[64];
 		int sp = 0;
-		stack[sp++] = 0;
-		for (int visited = 0; sp && visited < sh.n_bvh_nodes; ++visited) {
-			const uint4 *N = reinterpret_cast<const uint4 *>(sh.bvh + (size_t)stack[--sp] * kBvhStride);
-			const uint4 n0 = N[0], n1 = N[1];
-			float tmin = 0.0f, tmax = bt;
-			{
-				const float t0 = (__uint_as_float(n0.x) - o.x) * ix, t1 = (__uint_as_float(n1.x) - o.x) * ix;
-				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-				tmin = lo > tmin ? lo : tmin;
-				tmax = hi < tmax ? hi : tmax;
+		int budget = 2 * sh.n_bvh_nodes + 2; // a node is tested once as a child and at most once more when popped
+		uint4 c0 = nodes[0], c1 = nodes[1];
+		float tn;
+		bool have = bvh_box_hit(c0, c1, o, inv, bt, tn);
+		while (true) {
+			while (have && !(c1.w & 0x80000000u) && budget > 0) { // inner node: test both children
+				const uint32_t left = c0.w, right = c1.w & 0x1fffffffu;
+				const uint4 l0 = nodes[2 * (size_t)left], l1 = nodes[2 * (size_t)left + 1];
+				const uint4 r0 = nodes[2 * (size_t)right], r1 = nodes[2 * (size_t)right + 1];
+				float tl, tr;
+				const bool hl = bvh_box_hit(l0, l1, o, inv, bt, tl), hr = bvh_box_hit(r0, r1, o, inv, bt, tr);
+				budget -= 2;
+				const bool right_near = hr && (!hl || tr < tl);
+				if (hl && hr) stack[sp++] = right_near ? left : right;
+				c0 = right_near ? r0 : l0;
+				c1 = right_near ? r1 : l1;
+				have = hl || hr;
 			}
-			{
-				const float t0 = (__uint_as_float(n0.y) - o.y) * iy, t1 = (__uint_as_float(n1.y) - o.y) * iy;
-				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-				tmin = lo > tmin ? lo : tmin;
-				tmax = hi < tmax ? hi : tmax;
-			}
-			{
-				const float t0 = (__uint_as_float(n0.z) - o.z) * iz, t1 = (__uint_as_float(n1.z) - o.z) * iz;
-				const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-				tmin = lo > tmin ? lo : tmin;
-				tmax = hi < tmax ? hi : tmax;
-			}
-			if (!(tmin <= tmax * 1.0000004f)) continue;
-			if (n1.w & 0x80000000u) {
-				const uint32_t first = n0.w, count = n1.w & 0x7fffffffu;
+			if (have && (c1.w & 0x80000000u)) {
+				const uint32_t first = c0.w, count = c1.w & 0x7fffffffu;
 				for (uint32_t i = first; i < first + count; ++i) {
 					const float *T = sh.tris + (size_t)i * kTriStride;
 					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
@@ -232,13 +260,17 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 					const float t = dot3(e2, q) * inv_det;
 					if (t > 0.0f && t < bt) { bt = t; best = tri_base + (int)i; }
 				}
-			} else {
-				const uint32_t left = n0.w, right = n1.w & 0x1fffffffu, axis = (n1.w >> 29) & 3u;
-				const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-				const bool right_first = da < 0.0f;
-				stack[sp++] = right_first ? left : right; // the far child is popped later
-				stack[sp++] = right_first ? right : left;
+				if (kAny && best >= 0) break; // a shadow ray needs one occluder, not the nearest
 			}
+			have = false;
+			while (sp && !have && budget > 0) { // next node that the (now shorter) ray still reaches
+				const uint32_t idx = stack[--sp];
+				c0 = nodes[2 * (size_t)idx];
+				c1 = nodes[2 * (size_t)idx + 1];
+				have = bvh_box_hit(c0, c1, o, inv, bt, tn);
+				--budget;
+			}
+			if (!have) break;
 		}
 	}
 	t_out = bt;
@@ -715,7 +747,7 @@ __device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights
 		const v3 sd = vsub(pl, so);
 		const float sdist = __builtin_sqrtf(dot3(sd, sd));
 		float th;
-		const bool occ = intersect<kGeneral>(sh, so, vdivs(sd, sdist), sdist * (1.0f - kShadowEps), th) >= 0;
+		const bool occ = intersect<kGeneral, true>(sh, so, vdivs(sd, sdist), sdist * (1.0f - kShadowEps), th) >= 0;
 		if (!occ) em_weight = vscale(ld3(Dl + 3), count);
 		return;
 	}
@@ -777,7 +809,7 @@ __device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights
 #ifdef PG_ABLATE_SHADOW // timing experiment only: no shadow rays
 		const bool occ = false; (void)th; (void)sdn;
 #else
-		const bool occ = intersect<kGeneral>(sh, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
+		const bool occ = intersect<kGeneral, true>(sh, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
 #endif
 		if (!occ) em_weight = vscale(vdivs(radiance, pdf), count);
 	}

@@ -9,7 +9,8 @@ Layouts (include/pgsd.h):
   BVH node, PG_BVH_STRIDE = 8 x 32 bit: bmin (0-2, f32), a (3, u32), bmax (4-6, f32), b (7, u32)
       inner node: a = left child, b = right child | split axis << 29
       leaf:       a = first triangle, b = 0x80000000 | count
-  Node 0 is the root; triangles are stored in leaf order.
+  Node 0 is the root, children come after their parent, siblings are neighbours (right = left + 1
+  in what build_bvh makes; the kernels do not rely on it); triangles are stored in leaf order.
 
 Plain numpy; shared by the product and by the tests that hand the same arrays to the oracle.
 """
@@ -122,8 +123,9 @@ def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, mat
 
 
 def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
-    """Median-split BVH over triangle records; returns (nodes (M,8) uint32 bit patterns, triangles in
-    leaf order); with `per_triangle` (T, k) data also that array in the same order."""
+    """BVH over triangle records (surface-area heuristic, <= MAX_LEAF triangles per leaf, depth <= 60,
+    siblings stored next to each other); returns (nodes (M,8) uint32 bit patterns, triangles in leaf
+    order); with `per_triangle` (T, k) data also that array in the same order."""
     tris = np.ascontiguousarray(tris, np.float32).reshape(-1, TRI_STRIDE)
     n = tris.shape[0]
     if n == 0:
@@ -132,37 +134,59 @@ def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
     v0, v1, v2 = tris[:, 0:3], tris[:, 0:3] + tris[:, 3:6], tris[:, 0:3] + tris[:, 6:9]
     lo = np.minimum(np.minimum(v0, v1), v2)
     hi = np.maximum(np.maximum(v0, v1), v2)
-    cen = 0.5 * (lo.astype(np.float64) + hi.astype(np.float64))
+    lo64, hi64 = lo.astype(np.float64), hi.astype(np.float64)
+    cen = 0.5 * (lo64 + hi64)
     order = np.arange(n)
-    nodes: List[List[int]] = []
-    bounds: List[Tuple[np.ndarray, np.ndarray]] = []
+    nodes: List[List[int]] = [[0, 0]]
+    bounds: List[Tuple[np.ndarray, np.ndarray]] = [(None, None)]
 
-    def rec(first: int, count: int) -> int:
-        me = len(nodes)
+    def half_area(a, b):
+        e = b - a
+        return e[..., 0] * e[..., 1] + e[..., 1] * e[..., 2] + e[..., 2] * e[..., 0]
+
+    def sah_split(idx):
+        """Full-sweep surface-area heuristic over the three axes: (cost, axis, sorted indices, position)."""
+        best = None
+        cnt = idx.shape[0]
+        k = np.arange(1, cnt, dtype=np.float64)
+        for axis in range(3):
+            srt = idx[np.argsort(cen[idx, axis], kind="stable")]
+            l, h = lo64[srt], hi64[srt]
+            left = half_area(np.minimum.accumulate(l, axis=0), np.maximum.accumulate(h, axis=0))[:-1]
+            right = half_area(np.minimum.accumulate(l[::-1], axis=0)[::-1], np.maximum.accumulate(h[::-1], axis=0)[::-1])[1:]
+            cost = left * k + right * (cnt - k)
+            pos = int(np.argmin(cost))
+            if best is None or cost[pos] < best[0]:
+                best = (float(cost[pos]), axis, srt, pos + 1)
+        return best
+
+    # Children are allocated in pairs (siblings are neighbours: one 64-byte line for the walk's test
+    # of both), a node's children after the node itself.  Big nodes split by the surface-area
+    # heuristic, small ones (and very deep ones, to bound the depth) at the median of the widest axis.
+    todo = [(0, 0, n, 0)]
+    while todo:
+        me, first, count, depth = todo.pop()
         idx = order[first:first + count]
-        bmin, bmax = lo[idx].min(axis=0), hi[idx].max(axis=0)
-        nodes.append([0, 0])
-        bounds.append((bmin, bmax))
+        bounds[me] = (lo[idx].min(axis=0), hi[idx].max(axis=0))
         if count <= MAX_LEAF:
             nodes[me] = [first, LEAF_FLAG | count]
-            return me
-        c = cen[idx]
-        ext = c.max(axis=0) - c.min(axis=0)
-        axis = int(np.argmax(ext))
-        if ext[axis] == 0.0:  # all centroids coincide: split by position in the list
-            mid = count // 2
+            continue
+        if count > 2 * MAX_LEAF and depth < 40:
+            _, axis, srt, mid = sah_split(idx)
+            order[first:first + count] = srt
         else:
-            srt = np.argsort(c[:, axis], kind="stable")
-            order[first:first + count] = idx[srt]
+            c = cen[idx]
+            ext = c.max(axis=0) - c.min(axis=0)
+            axis = int(np.argmax(ext))
+            if ext[axis] != 0.0:  # (all centroids coincide: split by position in the list)
+                order[first:first + count] = idx[np.argsort(c[:, axis], kind="stable")]
             mid = count // 2
-        left = rec(first, mid)
-        right = rec(first + mid, count - mid)
-        nodes[me] = [left, right | (axis << 29)]
-        return me
-
-    import sys
-    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
-    rec(0, n)
+        left = len(nodes)
+        nodes += [[0, 0], [0, 0]]
+        bounds += [(None, None), (None, None)]
+        nodes[me] = [left, (left + 1) | (axis << 29)]
+        todo.append((left + 1, first + mid, count - mid, depth + 1))
+        todo.append((left, first, mid, depth + 1))
     out = np.zeros((len(nodes), BVH_STRIDE), np.uint32)
     for i, ((a, b), (bmin, bmax)) in enumerate(zip(nodes, bounds)):
         out[i, 0:3] = bmin.astype(np.float32).view(np.uint32)
