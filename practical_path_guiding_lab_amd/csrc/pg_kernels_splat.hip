@@ -94,9 +94,31 @@ __device__ __forceinline__ void coop_add(const SlotAdd &s, long long *s_val, uns
 	s_val[4 * t + 1] = s.w1;
 	s_val[4 * t + 2] = s.w2;
 	s_val[4 * t + 3] = s.w3;
-	s_ptr[t] = reinterpret_cast<unsigned long long>(s.ptr);
+	const unsigned long long mine = reinterpret_cast<unsigned long long>(s.ptr);
+	s_ptr[t] = mine;
 	wave_lds_sync();
 	const unsigned lane = t & 63u, wbase = t & ~63u, word = lane & 3u;
+	// Neighbouring lanes hold neighbouring path vertices, which often add to the same accumulator
+	// (the NEE direction of a delta light is the same for a whole surface; coarse quadtree cells):
+	// the first lane of a run of equal targets sums the run (exact, integer) and the others drop
+	// out -- one update instead of a run of same-address updates, which the memory side serialises.
+	const bool follower = mine != 0 && lane != 0 && s_ptr[t - 1] == mine;
+	if (mine != 0 && !follower && lane != 63u && s_ptr[t + 1] == mine) {
+		long long a0 = s.w0, a1 = s.w1, a2 = s.w2, a3 = s.w3;
+		for (unsigned j = t + 1; j < wbase + 64u && s_ptr[j] == mine; ++j) {
+			a0 += s_val[4 * j + 0];
+			a1 += s_val[4 * j + 1];
+			a2 += s_val[4 * j + 2];
+			a3 += s_val[4 * j + 3];
+		}
+		s_val[4 * t + 0] = a0;
+		s_val[4 * t + 1] = a1;
+		s_val[4 * t + 2] = a2;
+		s_val[4 * t + 3] = a3;
+	}
+	wave_lds_sync(); // every run has been read
+	if (follower) s_ptr[t] = 0;
+	wave_lds_sync();
 #pragma unroll
 	for (unsigned r = 0; r < 4; ++r) {
 		const unsigned src = wbase + r * 16u + (lane >> 2);
@@ -230,6 +252,12 @@ __global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, i
 // of the per-bounce live counts, known only on the device.
 constexpr uint32_t kNoRay = 0xffffffffu;
 
+// The number of entries is known only on the device, so the grid is fixed (kSplatGroupsPerCu
+// workgroups per CU, enough of them to even out tiles of unequal cost) and every workgroup strides
+// over the 256-entry tiles: a grid sized for the worst case N * max_depth would be 93 % empty
+// workgroups at max_depth 30 (0.8 ms of launch work on the torus scene), the top of the KD-tree is
+// staged once per workgroup instead of once per tile, and the first iteration's single accumulator
+// gets four atomics per workgroup.
 template <bool kList>
 __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumView a, int store_nee,
                                                               uint64_t num_rays, int32_t max_depth,
@@ -249,37 +277,45 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 		if ((uint64_t)blockIdx.x * kBlock >= total) return;
 	}
 	stage_kd_top(s_kd, t.kd, t.n_kd);
-	const uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
+	// First iteration: one KD leaf owning a single-leaf quadtree (kdtree.py:122, quadtree.py:355), so
+	// every record of the pass lands in the same accumulator.  One word takes ~11 ns per atomic;
+	// sum inside the workgroup and send four atomics per workgroup instead of two per record.
+	const bool single = t.n_rec == 0 && t.n_trees == 1;
+	long long v[4] = {0, 0, 0, 0};
 	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
-	SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
-	bool keep = false;
-	if (g < total) {
-		uint64_t ray;
-		bool active;
-		if (kList) {
-			const uint32_t rr = ray_of[g];
-			active = rr != kNoRay;
-			ray = active ? rr : 0;
-		} else {
-			ray = g / (uint64_t)max_depth;
-			active = r.active[g] != 0;
+	for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += (uint64_t)gridDim.x * kBlock) {
+		const uint64_t g = base + threadIdx.x;
+		float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
+		SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
+		bool keep = false;
+		if (g < total) {
+			uint64_t ray;
+			bool active;
+			if (kList) {
+				const uint32_t rr = ray_of[g];
+				active = rr != kNoRay;
+				ray = active ? rr : 0;
+			} else {
+				ray = g / (uint64_t)max_depth;
+				active = r.active[g] != 0;
+			}
+			keep = process_slot(g, S, num_rays, ray, active, l_final, r, radiance, nee_lum, wp);
 		}
-		keep = process_slot(g, S, num_rays, ray, active, l_final, r, radiance, nee_lum, wp);
+		if (keep) {
+			plan_record(t, a, s_kd, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
+			            r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum, path, nee,
+			            kd_lv, q_lv, q_q);
+			++did;
+		}
+		if (single) {
+			if (path.ptr) { v[0] += path.w0; v[1] += path.w1; v[2] += path.w2; v[3] += path.w3; }
+			if (nee.ptr) { v[0] += nee.w0; v[1] += nee.w1; v[2] += nee.w2; v[3] += nee.w3; }
+		} else {
+			coop_add(path, s_val, s_ptr);
+			if (store_nee) coop_add(nee, s_val, s_ptr);
+		}
 	}
-	if (keep) {
-		plan_record(t, a, s_kd, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
-		            r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum, path, nee,
-		            kd_lv, q_lv, q_q);
-		did = 1;
-	}
-	if (t.n_rec == 0 && t.n_trees == 1) {
-		// First iteration: one KD leaf owning a single-leaf quadtree (kdtree.py:122, quadtree.py:355), so
-		// every record of the pass lands in the same accumulator.  One word takes ~11 ns per atomic;
-		// sum inside the workgroup and send four atomics per workgroup instead of two per record.
-		long long v[4] = {0, 0, 0, 0};
-		if (path.ptr) { v[0] += path.w0; v[1] += path.w1; v[2] += path.w2; v[3] += path.w3; }
-		if (nee.ptr) { v[0] += nee.w0; v[1] += nee.w1; v[2] += nee.w2; v[3] += nee.w3; }
+	if (single) {
 		__syncthreads();
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -292,12 +328,14 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 			for (int w = 0; w < kBlock / 64; ++w) tot += (unsigned long long)s_val[w * 4 + threadIdx.x];
 			if (tot) atomicAdd(reinterpret_cast<unsigned long long *>(a.root_acc + threadIdx.x), tot);
 		}
-	} else {
-		coop_add(path, s_val, s_ptr);
-		if (store_nee) coop_add(nee, s_val, s_ptr);
 	}
 	count_depths_s(dc, kd_lv, did, q_lv, q_q);
 }
+
+#ifndef PG_SPLAT_GROUPS_PER_CU
+#define PG_SPLAT_GROUPS_PER_CU 64 // measured (tools/exp_splat_grid.sh): 8 -> 847, 16 -> 798, 32 -> 746, 64 -> 726, 128 -> 755 us on cornell-box
+#endif
+constexpr unsigned kSplatGroupsPerCu = PG_SPLAT_GROUPS_PER_CU;
 
 static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
@@ -328,12 +366,22 @@ void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_n
 {
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	if (S == 0) return;
-	// the list variant is sized for the worst case too: workgroups past the device-side count retire at once
+	// a fixed grid striding over the tiles (the list's length is known only on the device)
+	static int cus[64] = {0};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	int n_cu = (dev >= 0 && dev < 64) ? cus[dev] : 0;
+	if (n_cu <= 0) {
+		if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+		if (dev >= 0 && dev < 64) cus[dev] = n_cu;
+	}
+	const uint64_t tiles = (S + kBlock - 1) / kBlock, cap = (uint64_t)n_cu * kSplatGroupsPerCu;
+	const dim3 grid((unsigned)(tiles < cap ? tiles : cap));
 	if (ray_of)
-		hipLaunchKernelGGL(k_process_and_splat<true>, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
+		hipLaunchKernelGGL(k_process_and_splat<true>, grid, dim3(kBlock), 0, s, t, a, store_nee, num_rays,
 		                   max_depth, l_final, rec, dc, ray_of, live_count);
 	else
-		hipLaunchKernelGGL(k_process_and_splat<false>, grid_for(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays,
+		hipLaunchKernelGGL(k_process_and_splat<false>, grid, dim3(kBlock), 0, s, t, a, store_nee, num_rays,
 		                   max_depth, l_final, rec, dc, ray_of, live_count);
 }
 
