@@ -833,7 +833,7 @@ struct RenderArgs {
 	int bounce, last;          // index of this launch = path depth of every live lane; last launch of the pass
 	const uint32_t *order_in;  // live-ray list written by the previous bounce (unused by the first)
 	uint32_t *order_out;       // live-ray list for the next bounce
-	uint32_t *live_count;      // [max_depth]: live_count[b] = lanes alive after bounce b (zeroed per pass)
+	uint32_t *live_count;      // [max_depth + 1]: live_count[b] = lanes alive after bounce b; [max_depth]: see k_bounce_tail (zeroed per pass)
 	// per-lane state (planar), 57 B in and out per live lane and bounce.  The ray origin is not
 	// state: it is the previous vertex pushed off its quad (:352 spawn_ray), recomputed from prev_p
 	// and the quad id; depth is the launch index; ior stays 1 (every BSDF of the substrate has eta 1)
@@ -852,13 +852,12 @@ struct RenderArgs {
 // kGeneral: the scene has spheres or rough conductors; false compiles the all-diffuse quad scene only.
 template <bool kFirst, int kGeneral>
 __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_kd, const uint64_t lane,
-                                            const uint64_t rec_slot)
+                                            const uint64_t rec_slot, const uint32_t depth)
 {
 	const uint64_t N = a.n_lanes;
 	const int D = a.max_depth;
 	const float f = a.frac;
 	const Shapes &sh = a.shapes;
-	const uint32_t depth = (uint32_t)a.bounce;
 	Pcg32 rng;
 	v3 ray_o, ray_d, thr, L, prev_p;
 	float prev_bsdf_pdf;
@@ -1090,6 +1089,33 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 #else
 #define PG_BOUNCE_ATTR
 #endif
+
+// The tail of a long path (max_depth 30 in scenes/torus): a launch cannot be shorter than the slowest
+// single path's bounce (0.1-0.3 ms when that is two BVH walks inside a glass case), so a few
+// thousand survivors would cost that floor once per bounce.  At fixed checkpoints the host also
+// launches k_bounce_tail: when no more than kTailPaths paths are alive it takes all of them over
+// and every lane follows its own path to its end in this one launch; the per-bounce launches after
+// it find that out from the same counts and retire.
+#ifndef PG_TAIL_PATHS
+#define PG_TAIL_PATHS (128u * 1024u) // torus (tools/exp_tail.sh): 32 Ki -> 12.9, 128 Ki -> 12.4, 512 Ki -> 13.2, 2 Mi -> 13.2 ms per pass
+#endif
+constexpr uint32_t kTailPaths = PG_TAIL_PATHS;
+__host__ __device__ constexpr bool tail_checkpoint(int bounce, int max_depth)
+{
+	return max_depth > 8 && bounce >= 4 && bounce + 1 < max_depth &&
+	       (bounce < 8 || (bounce < 16 && bounce % 2 == 0) || bounce % 4 == 0);
+}
+// Did a tail launch at a checkpoint <= bounce take the paths over?  live_count[c-1] is final when
+// checkpoint c is launched, and the first checkpoint that fires decides: the entries a tail launch
+// adds to afterwards are never looked at before one that already said yes.
+__device__ __forceinline__ bool tail_took_over(const RenderArgs &a, int bounce)
+{
+	if (a.max_depth <= 8) return false;
+	for (int c = 4; c <= bounce; ++c)
+		if (tail_checkpoint(c, a.max_depth) && a.live_count[c - 1] <= kTailPaths) return true;
+	return false;
+}
+
 template <bool kFirst, int kGeneral>
 __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 {
@@ -1099,6 +1125,7 @@ __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
+	if (!kFirst && tail_took_over(a, a.bounce)) return;  // a tail launch is finishing these paths
 	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
 	const bool alive = tid < live;
 	const uint64_t lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
@@ -1109,7 +1136,7 @@ __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
 	}
 	bool cont = false;
-	if (alive) cont = bounce_lane<kFirst, kGeneral>(a, s_kd, lane, rec_base + tid);
+	if (alive) cont = bounce_lane<kFirst, kGeneral>(a, s_kd, lane, rec_base + tid, (uint32_t)a.bounce);
 	if (a.last) return; // nothing survives the last bounce
 	const unsigned long long ballot = __ballot(cont);
 	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -1125,6 +1152,44 @@ __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 		uint32_t off = s_base + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
 		for (unsigned w = 0; w < wv; ++w) off += s_wave[w];
 		a.order_out[off] = (uint32_t)lane;
+	}
+}
+
+// See tail_checkpoint: launched before the per-bounce launch of bounce a.bounce with a grid for
+// kTailPaths lanes.  The first bounce done here reads the live list like k_bounce would; after it a
+// lane keeps its path (the state still goes through its global slots: the same thread reads back
+// what it wrote).  Record entries of the later bounces are handed out wave by wave behind the
+// entries of bounce a.bounce (a.live_count[max_depth] counts them), and the survivors of every
+// bounce are added to live_count[] as the per-bounce launches would have, so the splat finds
+// N + sum(live_count) entries and pg_render_live_counts reports the same numbers either way.
+template <int kGeneral>
+__global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
+{
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	const uint64_t live = (uint64_t)a.live_count[a.bounce - 1];
+	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
+	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
+	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	bool alive = tid < live;
+	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
+	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce
+	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+	const uint64_t tail_base = rec_base + live; // behind the entries of bounce a.bounce
+	uint64_t slot = rec_base + tid;
+	const unsigned wl = threadIdx.x & 63u;
+	for (int depth = a.bounce; depth < a.max_depth; ++depth) {
+		if (alive) alive = bounce_lane<false, kGeneral>(a, s_kd, lane, slot, (uint32_t)depth);
+		const unsigned long long ballot = __ballot(alive);
+		if (ballot == 0ull) break; // (nothing survives the last bounce)
+		const uint32_t n = (uint32_t)__popcll(ballot);
+		uint32_t off = 0;
+		if (wl == (unsigned)__builtin_ctzll(ballot)) {
+			atomicAdd(&a.live_count[depth], n);
+			off = atomicAdd(&a.live_count[a.max_depth], n);
+		}
+		off = __shfl(off, __builtin_ctzll(ballot), 64);
+		slot = tail_base + off + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
 	}
 }
 
@@ -1455,8 +1520,8 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
 	if (r->general >= 2) PG_HIP(ctx, r->ior.ensure(N));
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
-	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D));
-	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, (size_t)D * sizeof(uint32_t), s));
+	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D + 1));
+	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, ((size_t)D + 1) * sizeof(uint32_t), s)); // [D]: entries handed out by k_bounce_tail
 	if (record) {
 		PG_HIP(ctx, r->ray_of.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
 		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
@@ -1506,6 +1571,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		a.order_in = r->order[it & 1].p;
 		a.order_out = r->order[(it + 1) & 1].p;
 		Timed t(r, s, 1);
+		if (tail_checkpoint(it, D)) { // finishes every path in one launch once few are left (see k_bounce_tail)
+			const dim3 tgrid((unsigned)((kTailPaths + kRBlock - 1) / kRBlock));
+			if (r->general >= 2) hipLaunchKernelGGL((k_bounce_tail<2>), tgrid, dim3(kRBlock), 0, s, a);
+			else if (r->general == 1) hipLaunchKernelGGL((k_bounce_tail<1>), tgrid, dim3(kRBlock), 0, s, a);
+			else hipLaunchKernelGGL((k_bounce_tail<0>), tgrid, dim3(kRBlock), 0, s, a);
+		}
 		// every launch is sized for the whole wavefront: the live count is only known on the device,
 		// and workgroups past it retire on their first instruction
 		if (r->general >= 2) {
