@@ -263,14 +263,17 @@ typedef struct pg_scene_desc {
 	const float *materials; /* PG_MATERIAL_STRIDE floats each */
 	uint64_t n_boxes;
 	const float *boxes;     /* PG_BOX_STRIDE floats each; need a material table */
-	/* triangle meshes (`obj` / `serialized` shapes of the reference's scenes, face normals) behind
-	 * one binary BVH, built by the caller (practical_path_guiding_lab_amd/mesh.py):
+	/* triangle meshes (`obj` / `serialized` shapes of the reference's scenes) behind one four-wide
+	 * BVH, built by the caller (practical_path_guiding_lab_amd/mesh.py):
 	 *   triangle, PG_TRI_STRIDE floats: 0-2 v0, 3-5 v1 - v0, 6-8 v2 - v0, 9-11 unit geometric
 	 *     normal, 12 material index; stored in BVH leaf order
-	 *   node, PG_BVH_STRIDE 32-bit words: 0-2 bmin (f32), 3 a (u32), 4-6 bmax (f32), 7 b (u32);
-	 *     inner: a = left child, b = right child | split axis << 29; leaf: a = first triangle,
-	 *     b = 0x80000000 | count.  Node 0 is the root, children have larger indices than their
-	 *     parent, depth <= 60 (checked).  Shape numbers of triangles follow the box faces. */
+	 *   node, PG_BVH_STRIDE 32-bit words (128 bytes): 0-23 (f32) the boxes of its up to four
+	 *     children, lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4] hi_z[4]; 24-27 (u32) the children: a node
+	 *     index, or 0x80000000 | (count-1) << 28 | first triangle for a leaf of 1..8 triangles, or
+	 *     0xffffffff for none; 28-31 unused by the library.  Node 0 is the root (also when it holds
+	 *     a single leaf), children have larger indices than their parent and one parent each, leaves
+	 *     stay inside the triangle array, no root-to-node path leaves more than 64 siblings waiting
+	 *     (all checked).  Shape numbers of triangles follow the box faces. */
 	uint64_t n_tris;
 	const float *tris;
 	uint64_t n_bvh_nodes;
@@ -289,7 +292,7 @@ typedef struct pg_scene_desc {
 } pg_scene_desc;
 #define PG_DIRLIGHT_STRIDE 8
 #define PG_TRI_STRIDE 16
-#define PG_BVH_STRIDE 8
+#define PG_BVH_STRIDE 32
 int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *scene, const pg_camera *cam);
 
 typedef struct pg_pass_params {

@@ -480,7 +480,7 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
     L = lib()
     L.pgo_render_pass_scene.argtypes = [_P, _P, C.POINTER(_Scene), C.POINTER(_Camera), C.POINTER(_RenderParams), _P, _P, _P, _P]
     L.pgo_render_pass_scene.restype = None
-    tris, bvh = np.zeros((0, 16), np.float32), np.zeros((0, 8), np.uint32)
+    tris, bvh = np.zeros((0, 16), np.float32), np.zeros((0, 32), np.uint32)
     if hasattr(quads, "quads"):  # a scene object (practical_path_guiding_lab_amd.scene.Scene): all of its shapes
         scene_obj = quads
         quads = scene_obj.quads
@@ -488,7 +488,7 @@ def render_pass(pair: "OracleSDTreePair", quads, cam, max_depth, rr_depth, itera
         materials = scene_obj.materials if materials is None else materials
         boxes = scene_obj.boxes if boxes is None else boxes
         tris = np.ascontiguousarray(getattr(scene_obj, "tris", tris), np.float32).reshape(-1, 16)
-        bvh = np.ascontiguousarray(getattr(scene_obj, "bvh", bvh), np.uint32).reshape(-1, 8)
+        bvh = np.ascontiguousarray(getattr(scene_obj, "bvh", bvh), np.uint32).reshape(-1, 32)
         dir_lights = np.ascontiguousarray(getattr(scene_obj, "dir_lights", np.zeros((0, 8))), np.float32).reshape(-1, 8)
         bsphere = [float(v) for v in scene_obj.bounding_sphere()] if dir_lights.shape[0] else [0.0] * 4
         tn = getattr(scene_obj, "tri_normals", None)

@@ -67,12 +67,12 @@ static inline v3 to_world(const frame *f, v3 v)
 static inline float safe_sqrtf(float v) { return sqrtf(v > 0.0f ? v : 0.0f); }
 static inline v3 normalize3(v3 v) { return vdivs(v, sqrtf(dot3(v, v))); }
 
-/* does the ray reach the box of BVH node N before bt?  *tmin = where it enters (>= 0) */
-static int bvh_box_hit(const uint32_t *N, const float oo[3], const float inv[3], float bt, float *tmin_out)
+/* does the ray reach the box of child c of BVH node N before bt?  *tmin = where it enters (>= 0) */
+static int bvh_box_hit(const uint32_t *N, int c, const float oo[3], const float inv[3], float bt, float *tmin_out)
 {
 	float tmin = 0.0f, tmax = bt;
 	for (int k = 0; k < 3; ++k) {
-		const float t0 = (pgo_u2f(N[k]) - oo[k]) * inv[k], t1 = (pgo_u2f(N[4 + k]) - oo[k]) * inv[k];
+		const float t0 = (pgo_u2f(N[4 * k + c]) - oo[k]) * inv[k], t1 = (pgo_u2f(N[12 + 4 * k + c]) - oo[k]) * inv[k];
 		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
 		tmin = lo > tmin ? lo : tmin;
 		tmax = hi < tmax ? hi : tmax;
@@ -147,33 +147,48 @@ static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 		bt = t;
 		best = (int)(nq + sc->n_spheres + 6 * b) + 2 * axis + negative;
 	}
-	/* triangle meshes: the binary BVH, walked near child first: both children of an inner node are
-	 * tested, the walk goes on in the nearer one that is hit and the farther one waits on the stack,
-	 * to be tested again against the then shorter ray when it is popped.  Slab test padded as Ize
-	 * 2013, Moeller-Trumbore triangles.  (The order matters only for which of several equally near
-	 * triangles is reported: the first one met.) */
+	/* triangle meshes: the four-wide BVH.  A node's (up to four) children are tested at once and
+	 * ordered by where the ray enters them (a fixed five-comparator network, so that product and
+	 * oracle agree on ties); the walk goes on in the nearest, the others wait on the stack with their
+	 * entry distance, farthest at the bottom, and are dropped when popped if the ray has become
+	 * shorter than that.  Slab test padded as Ize 2013, Moeller-Trumbore triangles.  (The order
+	 * matters only for which of several equally near triangles is reported: the first one met.) */
 	if (sc->n_bvh_nodes) {
 		const size_t tri_base = nq + sc->n_spheres + 6 * sc->n_boxes;
 		const float inv[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
 		const float oo[3] = { o.x, o.y, o.z };
-		uint32_t stack[64];
+		const uint32_t NONE = 0xffffffffu;
+		uint32_t st_ref[64];
+		float st_t[64];
 		int sp = 0;
-		float tn;
-		const uint32_t *N = sc->bvh;
-		int have = bvh_box_hit(N, oo, inv, bt, &tn);
+		uint32_t next = 0; /* the root node */
 		for (;;) {
-			while (have && !(N[7] & 0x80000000u)) { /* inner node: test both children */
-				const uint32_t left = N[3], right = N[7] & 0x1fffffffu;
-				const uint32_t *Lc = sc->bvh + (size_t)left * PGO_BVH_STRIDE, *Rc = sc->bvh + (size_t)right * PGO_BVH_STRIDE;
-				float tl, tr;
-				const int hl = bvh_box_hit(Lc, oo, inv, bt, &tl), hr = bvh_box_hit(Rc, oo, inv, bt, &tr);
-				const int right_near = hr && (!hl || tr < tl);
-				if (hl && hr) stack[sp++] = right_near ? left : right;
-				N = right_near ? Rc : Lc;
-				have = hl || hr;
+			if (next == NONE) { /* next candidate from the stack */
+				if (!sp) break;
+				--sp;
+				if (!(st_t[sp] <= bt * 1.0000004f)) continue;
+				next = st_ref[sp];
 			}
-			if (have) {
-				const uint32_t first = N[3], count = N[7] & 0x7fffffffu;
+			if (!(next & 0x80000000u)) { /* a node: test its children, go on in the nearest */
+				const uint32_t *N = sc->bvh + (size_t)next * PGO_BVH_STRIDE;
+				uint32_t r[4];
+				float t[4];
+				for (int c = 0; c < 4; ++c) {
+					r[c] = N[24 + c];
+					t[c] = INFINITY;
+					if (r[c] != NONE && !bvh_box_hit(N, c, oo, inv, bt, &t[c])) { r[c] = NONE; t[c] = INFINITY; }
+				}
+#define PGO_CSWAP(a, b) if (t[a] > t[b]) { const float tt = t[a]; t[a] = t[b]; t[b] = tt; const uint32_t rr = r[a]; r[a] = r[b]; r[b] = rr; }
+				PGO_CSWAP(0, 1) PGO_CSWAP(2, 3) PGO_CSWAP(0, 2) PGO_CSWAP(1, 3) PGO_CSWAP(1, 2)
+#undef PGO_CSWAP
+				for (int c = 3; c >= 1; --c)
+					if (r[c] != NONE) { st_ref[sp] = r[c]; st_t[sp] = t[c]; ++sp; }
+				next = r[0];
+				continue;
+			}
+			{ /* a leaf */
+				const uint32_t first = next & 0x0fffffffu, count = ((next >> 28) & 7u) + 1u;
+				next = NONE;
 				for (uint32_t i = first; i < first + count; ++i) {
 					const float *T = sc->tris + (size_t)i * PGO_TRI_STRIDE;
 					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
@@ -191,12 +206,6 @@ static int intersect(const pgo_scene *sc, v3 o, v3 d, float tmax, float *t_out)
 					if (t > 0.0f && t < bt) { bt = t; best = (int)(tri_base + i); }
 				}
 			}
-			have = 0;
-			while (sp && !have) { /* next node that the (now shorter) ray still reaches */
-				N = sc->bvh + (size_t)stack[--sp] * PGO_BVH_STRIDE;
-				have = bvh_box_hit(N, oo, inv, bt, &tn);
-			}
-			if (!have) break;
 		}
 	}
 	*t_out = bt;

@@ -57,8 +57,10 @@ typedef struct pgo_scene {
 	const float *materials; /* NULL: quad i is diffuse with quads[i][16..18] (and there are no spheres or boxes) */
 	size_t n_boxes;
 	const float *boxes;
-	/* triangle meshes (`obj` / `serialized` shapes, face normals) behind one binary BVH; shape
-	 * numbers continue after the box faces.  Layouts: practical_path_guiding_lab_amd/mesh.py */
+	/* triangle meshes (`obj` / `serialized` shapes) behind one four-wide BVH; shape numbers continue
+	 * after the box faces.  Layouts: practical_path_guiding_lab_amd/mesh.py (node = 32 words: the four
+	 * children's boxes lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4] hi_z[4], then their references: node
+	 * index | 0x80000000 + (count-1) << 28 + first triangle | 0xffffffff = none) */
 	size_t n_tris;
 	const float *tris;       /* PGO_TRI_STRIDE floats each, in BVH leaf order */
 	size_t n_bvh_nodes;
@@ -76,7 +78,7 @@ typedef struct pgo_scene {
 } pgo_scene;
 #define PGO_DIRLIGHT_STRIDE 8
 #define PGO_TRI_STRIDE 16
-#define PGO_BVH_STRIDE 8
+#define PGO_BVH_STRIDE 32
 
 typedef struct pgo_camera {
 	float origin[3];

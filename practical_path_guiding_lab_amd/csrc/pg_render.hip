@@ -89,7 +89,7 @@ constexpr int kBoxStride = 32; // PG_BOX_STRIDE
 // n_quads + sphere index, or n_quads + n_spheres + 6 box + 2 axis + (outward normal negative))
 // ... then the triangles of the meshes, in BVH leaf order (general scenes only)
 constexpr int kTriStride = 16; // PG_TRI_STRIDE
-constexpr int kBvhStride = 8;  // PG_BVH_STRIDE
+constexpr int kBvhStride = 32; // PG_BVH_STRIDE
 struct Shapes {
 	const float *quads, *spheres, *boxes, *tris;
 	const float *tri_normals; // 9 per triangle, or nullptr (face normals)
@@ -108,30 +108,39 @@ __device__ __forceinline__ v3 box_face_normal(const float *B, int face)
 // (cornell-box), 1 = + spheres and rough conductors (veach-mis), 2 = + triangle meshes, delta
 // lobes, one-sided BSDFs, directional lights and the running index of refraction (torus-class
 // scenes).  What a level does not need is compiled out.
-// Does the ray reach the box of BVH node (n0, n1) before bt?  tmin = where it enters (>= 0).
-__device__ __forceinline__ bool bvh_box_hit(const uint4 &n0, const uint4 &n1, v3 o, v3 inv, float bt, float &tmin_out)
+// Does the ray reach the box [lo, hi] before bt?  tmin = where it enters (>= 0).  Slab test padded as Ize 2013.
+__device__ __forceinline__ bool bvh_box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 o,
+                                            v3 inv, float bt, float &tmin_out)
 {
 	float tmin = 0.0f, tmax = bt;
 	{
-		const float t0 = (__uint_as_float(n0.x) - o.x) * inv.x, t1 = (__uint_as_float(n1.x) - o.x) * inv.x;
+		const float t0 = (lox - o.x) * inv.x, t1 = (hix - o.x) * inv.x;
 		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
 		tmin = lo > tmin ? lo : tmin;
 		tmax = hi < tmax ? hi : tmax;
 	}
 	{
-		const float t0 = (__uint_as_float(n0.y) - o.y) * inv.y, t1 = (__uint_as_float(n1.y) - o.y) * inv.y;
+		const float t0 = (loy - o.y) * inv.y, t1 = (hiy - o.y) * inv.y;
 		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
 		tmin = lo > tmin ? lo : tmin;
 		tmax = hi < tmax ? hi : tmax;
 	}
 	{
-		const float t0 = (__uint_as_float(n0.z) - o.z) * inv.z, t1 = (__uint_as_float(n1.z) - o.z) * inv.z;
+		const float t0 = (loz - o.z) * inv.z, t1 = (hiz - o.z) * inv.z;
 		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
 		tmin = lo > tmin ? lo : tmin;
 		tmax = hi < tmax ? hi : tmax;
 	}
 	tmin_out = tmin;
 	return tmin <= tmax * 1.0000004f;
+}
+
+__device__ __forceinline__ void bvh_cswap(float &ta, uint32_t &ra, float &tb, uint32_t &rb)
+{
+	if (ta > tb) {
+		const float t = ta; ta = tb; tb = t;
+		const uint32_t r = ra; ra = rb; rb = r;
+	}
 }
 
 // kAny: the caller asks whether anything is hit (shadow rays): the BVH walk stops at its first
@@ -209,41 +218,53 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 		bt = t;
 		best = nq + sh.n_spheres + 6 * b + 2 * axis + negative;
 	}
-	// triangle meshes: the binary BVH.  Both children of an inner node are tested at once (the builder
-	// stores siblings next to each other: one 64-byte line), the walk goes on in the nearer one that is
-	// hit -- its node is already in registers -- and the farther one waits on the stack, to be tested
-	// again against the then shorter ray when it is popped.  Slab test padded as Ize 2013,
-	// Moeller-Trumbore triangles.  The oracle visits the same nodes in the same order, so the first of
-	// several equally near triangles is the same one in both.
+	// triangle meshes: the four-wide BVH.  One 128-byte node holds the boxes of its (up to four)
+	// children: they are tested together and ordered by where the ray enters them (a fixed
+	// five-comparator network), the walk goes on in the nearest -- a leaf's triangles are named by the
+	// reference itself, no node is read for it -- and the others wait on the stack with their entry
+	// distance, farthest at the bottom, to be dropped when popped if the ray has become shorter than
+	// that.  Half the dependent round trips of a binary tree: the walk is latency-bound.  The oracle
+	// visits the same nodes in the same order, so the first of several equally near triangles is the
+	// same one in both.
 	if (kGeneral >= 2 && sh.n_bvh_nodes && !(kAny && best >= 0)) {
 		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
 		const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 		const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(sh.bvh);
-		// pg_scene_set_ex has checked the tree: children follow their parent, depth <= 60, so the walk
-		// visits every node at most once and the stack (far children only) cannot overflow; the budget
-		// is a second fence
-		uint32_t stack[64];
+		// pg_scene_set_ex has checked the tree: children follow their parent, and no root-to-node path
+		// can leave more than 64 siblings waiting, so the walk opens every node at most once and the
+		// stack cannot overflow; the budget is a second fence
+		constexpr uint32_t kNone = 0xffffffffu;
+		const float kInf = __builtin_huge_valf();
+		uint32_t st_ref[64];
+		float st_t[64];
 		int sp = 0;
-		int budget = 2 * sh.n_bvh_nodes + 2; // a node is tested once as a child and at most once more when popped
-		uint4 c0 = nodes[0], c1 = nodes[1];
-		float tn;
-		bool have = bvh_box_hit(c0, c1, o, inv, bt, tn);
+		int budget = 8 * sh.n_bvh_nodes + 8;
+		uint32_t next = 0; // the root
 		while (true) {
-			while (have && !(c1.w & 0x80000000u) && budget > 0) { // inner node: test both children
-				const uint32_t left = c0.w, right = c1.w & 0x1fffffffu;
-				const uint4 l0 = nodes[2 * (size_t)left], l1 = nodes[2 * (size_t)left + 1];
-				const uint4 r0 = nodes[2 * (size_t)right], r1 = nodes[2 * (size_t)right + 1];
-				float tl, tr;
-				const bool hl = bvh_box_hit(l0, l1, o, inv, bt, tl), hr = bvh_box_hit(r0, r1, o, inv, bt, tr);
-				budget -= 2;
-				const bool right_near = hr && (!hl || tr < tl);
-				if (hl && hr) stack[sp++] = right_near ? left : right;
-				c0 = right_near ? r0 : l0;
-				c1 = right_near ? r1 : l1;
-				have = hl || hr;
+			while (!(next & 0x80000000u) && budget > 0) { // a node: test its children, go on in the nearest
+				const uint4 *N = nodes + 8 * (size_t)next;
+				const uint4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], rf = N[6];
+				uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
+				float t0, t1, t2, t3;
+#define PG_F(v) __uint_as_float(v)
+				if (!(r0 != kNone && bvh_box_hit(PG_F(lx.x), PG_F(ly.x), PG_F(lz.x), PG_F(hx.x), PG_F(hy.x), PG_F(hz.x), o, inv, bt, t0))) { r0 = kNone; t0 = kInf; }
+				if (!(r1 != kNone && bvh_box_hit(PG_F(lx.y), PG_F(ly.y), PG_F(lz.y), PG_F(hx.y), PG_F(hy.y), PG_F(hz.y), o, inv, bt, t1))) { r1 = kNone; t1 = kInf; }
+				if (!(r2 != kNone && bvh_box_hit(PG_F(lx.z), PG_F(ly.z), PG_F(lz.z), PG_F(hx.z), PG_F(hy.z), PG_F(hz.z), o, inv, bt, t2))) { r2 = kNone; t2 = kInf; }
+				if (!(r3 != kNone && bvh_box_hit(PG_F(lx.w), PG_F(ly.w), PG_F(lz.w), PG_F(hx.w), PG_F(hy.w), PG_F(hz.w), o, inv, bt, t3))) { r3 = kNone; t3 = kInf; }
+#undef PG_F
+				bvh_cswap(t0, r0, t1, r1);
+				bvh_cswap(t2, r2, t3, r3);
+				bvh_cswap(t0, r0, t2, r2);
+				bvh_cswap(t1, r1, t3, r3);
+				bvh_cswap(t1, r1, t2, r2);
+				if (r3 != kNone) { st_ref[sp] = r3; st_t[sp] = t3; ++sp; }
+				if (r2 != kNone) { st_ref[sp] = r2; st_t[sp] = t2; ++sp; }
+				if (r1 != kNone) { st_ref[sp] = r1; st_t[sp] = t1; ++sp; }
+				next = r0;
+				--budget;
 			}
-			if (have && (c1.w & 0x80000000u)) {
-				const uint32_t first = c0.w, count = c1.w & 0x7fffffffu;
+			if (next != kNone && (next & 0x80000000u)) { // a leaf
+				const uint32_t first = next & 0x0fffffffu, count = ((next >> 28) & 7u) + 1u;
 				for (uint32_t i = first; i < first + count; ++i) {
 					const float *T = sh.tris + (size_t)i * kTriStride;
 					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
@@ -262,15 +283,13 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 				}
 				if (kAny && best >= 0) break; // a shadow ray needs one occluder, not the nearest
 			}
-			have = false;
-			while (sp && !have && budget > 0) { // next node that the (now shorter) ray still reaches
-				const uint32_t idx = stack[--sp];
-				c0 = nodes[2 * (size_t)idx];
-				c1 = nodes[2 * (size_t)idx + 1];
-				have = bvh_box_hit(c0, c1, o, inv, bt, tn);
+			next = kNone;
+			while (sp && next == kNone && budget > 0) { // the nearest waiting child the (now shorter) ray still reaches
+				--sp;
+				if (st_t[sp] <= bt * 1.0000004f) next = st_ref[sp];
 				--budget;
 			}
-			if (!have) break;
+			if (next == kNone) break;
 		}
 	}
 	t_out = bt;
@@ -1423,29 +1442,36 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: box transform is not finite");
 	}
 	// triangle meshes: the kernels walk the BVH with a fixed-size stack and trust it, so check it here:
-	// children follow their parent (no cycles), leaves stay inside the triangle array, depth <= 60
+	// children follow their parent (no cycles, one parent each), leaves stay inside the triangle
+	// array, and no walk can have more than 64 siblings waiting on its stack
 	const uint64_t nt = sc->n_tris, nn = sc->n_bvh_nodes;
-	if ((nt == 0) != (nn == 0) || (nt && (!sc->tris || !sc->bvh)) || nt > 0x0fffffffull || nn > 0x1fffffffull)
+	if ((nt == 0) != (nn == 0) || (nt && (!sc->tris || !sc->bvh)) || nt > 0x0fffffffull || nn > 0x7fffffffull)
 		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangles and BVH nodes go together");
 	if (nt && !sc->materials) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: meshes need a material table");
 	if (nn) {
-		std::vector<uint8_t> depth(nn, 0);
+		std::vector<uint8_t> waiting(nn, 0); // siblings on the stack when the walk opens node i, at most
 		std::vector<uint8_t> seen(nn, 0);
 		seen[0] = 1;
 		for (uint64_t i = 0; i < nn; ++i) {
 			if (!seen[i]) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node without a parent");
 			const uint32_t *N = sc->bvh + i * kBvhStride;
-			if (N[7] & 0x80000000u) {
-				const uint64_t first = N[3], count = N[7] & 0x7fffffffu;
-				if (count == 0 || first + count > nt) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH leaf outside the triangle array");
-			} else {
-				const uint64_t left = N[3], right = N[7] & 0x1fffffffu;
-				if (left <= i || right <= i || left >= nn || right >= nn || left == right || ((N[7] >> 29) & 3u) > 2u)
-					return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH children must follow their parent");
-				if (seen[left] || seen[right]) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node with two parents");
-				if (depth[i] >= 60) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH deeper than 60 levels");
-				seen[left] = seen[right] = 1;
-				depth[left] = depth[right] = (uint8_t)(depth[i] + 1);
+			int kids = 0;
+			for (int c = 0; c < 4; ++c) kids += N[24 + c] != 0xffffffffu;
+			if (kids == 0) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node without children");
+			const int below = (int)waiting[i] + kids - 1; // its other children wait while the walk is in one of them
+			if (below > 64) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH too deep for the walk's stack");
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t ref = N[24 + c];
+				if (ref == 0xffffffffu) continue;
+				if (ref & 0x80000000u) {
+					const uint64_t first = ref & 0x0fffffffu, count = ((ref >> 28) & 7u) + 1u;
+					if (first + count > nt) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH leaf outside the triangle array");
+				} else {
+					if (ref <= i || ref >= nn) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH children must follow their parent");
+					if (seen[ref]) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node with two parents");
+					seen[ref] = 1;
+					waiting[ref] = (uint8_t)below;
+				}
 			}
 		}
 		for (uint64_t t = 0; t < nt; ++t) {

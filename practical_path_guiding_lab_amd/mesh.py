@@ -6,11 +6,13 @@ scenes/torus), with face normals.
 Layouts (include/pgsd.h):
   triangle, PG_TRI_STRIDE = 16 floats: v0 (0-2), e1 = v1 - v0 (3-5), e2 = v2 - v0 (6-8),
       unit geometric normal (9-11), material index (12), 13-15 unused
-  BVH node, PG_BVH_STRIDE = 8 x 32 bit: bmin (0-2, f32), a (3, u32), bmax (4-6, f32), b (7, u32)
-      inner node: a = left child, b = right child | split axis << 29
-      leaf:       a = first triangle, b = 0x80000000 | count
-  Node 0 is the root, children come after their parent, siblings are neighbours (right = left + 1
-  in what build_bvh makes; the kernels do not rely on it); triangles are stored in leaf order.
+  BVH node, PG_BVH_STRIDE = 32 x 32 bit (128 bytes), up to four children:
+      0-23  f32: the children's boxes, lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4] hi_z[4]
+      24-27 u32: the children: a node index | 0x80000000 + (count-1) << 28 + first triangle (a leaf
+                 of 1..8 triangles) | 0xffffffff (no child)
+      28    u32: number of children; 29-31 unused
+  Node 0 is the root (a mesh of one leaf still has it), children come after their parent;
+  triangles are stored in leaf order.
 
 Plain numpy; shared by the product and by the tests that hand the same arrays to the oracle.
 """
@@ -21,8 +23,10 @@ from typing import List, Tuple
 import numpy as np
 
 TRI_STRIDE = 16
-BVH_STRIDE = 8
+BVH_STRIDE = 32
+BVH_WIDTH = 4
 LEAF_FLAG = 0x80000000
+EMPTY_CHILD = 0xFFFFFFFF
 MAX_LEAF = 4
 
 
@@ -123,9 +127,9 @@ def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, mat
 
 
 def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
-    """BVH over triangle records (surface-area heuristic, <= MAX_LEAF triangles per leaf, depth <= 60,
-    siblings stored next to each other); returns (nodes (M,8) uint32 bit patterns, triangles in leaf
-    order); with `per_triangle` (T, k) data also that array in the same order."""
+    """Four-wide BVH over triangle records (a binary tree built with the surface-area heuristic,
+    <= MAX_LEAF triangles per leaf, then collapsed); returns (nodes (M,32) uint32 bit patterns,
+    triangles in leaf order); with `per_triangle` (T, k) data also that array in the same order."""
     tris = np.ascontiguousarray(tris, np.float32).reshape(-1, TRI_STRIDE)
     n = tris.shape[0]
     if n == 0:
@@ -160,9 +164,8 @@ def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
                 best = (float(cost[pos]), axis, srt, pos + 1)
         return best
 
-    # Children are allocated in pairs (siblings are neighbours: one 64-byte line for the walk's test
-    # of both), a node's children after the node itself.  Big nodes split by the surface-area
-    # heuristic, small ones (and very deep ones, to bound the depth) at the median of the widest axis.
+    # The binary tree first.  Big nodes split by the surface-area heuristic, small ones (and very
+    # deep ones, to bound the depth) at the median of the widest axis.
     todo = [(0, 0, n, 0)]
     while todo:
         me, first, count, depth = todo.pop()
@@ -187,12 +190,56 @@ def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
         nodes[me] = [left, (left + 1) | (axis << 29)]
         todo.append((left + 1, first + mid, count - mid, depth + 1))
         todo.append((left, first, mid, depth + 1))
-    out = np.zeros((len(nodes), BVH_STRIDE), np.uint32)
-    for i, ((a, b), (bmin, bmax)) in enumerate(zip(nodes, bounds)):
-        out[i, 0:3] = bmin.astype(np.float32).view(np.uint32)
-        out[i, 3] = a
-        out[i, 4:7] = bmax.astype(np.float32).view(np.uint32)
-        out[i, 7] = b
+    # Collapse to four children per node: a node adopts the children of its (by surface area) biggest
+    # inner child until it has four -- half the dependent steps of a walk.  Leaves are referenced
+    # straight from their parent.  Nodes are numbered in the order they are first reached, so children
+    # come after their parent.
+    def is_leaf(b):
+        return bool(nodes[b][1] & LEAF_FLAG)
+
+    def area(b):
+        return float(half_area(bounds[b][0].astype(np.float64), bounds[b][1].astype(np.float64)))
+
+    wide: List[List[int]] = []  # per wide node: the binary nodes that are its children
+    ids = {0: 0}
+    queue = [0]
+    if is_leaf(0):
+        wide.append([0])  # a mesh of <= MAX_LEAF triangles: one node with one leaf child
+        queue = []
+    while queue:
+        b = queue.pop()
+        kids = [nodes[b][0], nodes[b][1] & 0x1FFFFFFF]
+        while len(kids) < BVH_WIDTH:
+            inner = [k for k in kids if not is_leaf(k)]
+            if not inner:
+                break
+            big = max(inner, key=area)
+            at = kids.index(big)
+            kids[at:at + 1] = [nodes[big][0], nodes[big][1] & 0x1FFFFFFF]
+        me = ids[b]
+        while len(wide) <= me:
+            wide.append([])
+        wide[me] = kids
+        for k in reversed(kids):  # (a stack: the first child's subtree is numbered first)
+            if not is_leaf(k):
+                ids[k] = len(ids)
+                queue.append(k)
+    # ids were handed out when a node was pushed, so every child id exceeds its parent's
+    out = np.zeros((len(wide), BVH_STRIDE), np.uint32)
+    inf = np.float32(np.inf)
+    for i, kids in enumerate(wide):
+        box = np.empty((6, BVH_WIDTH), np.float32)
+        box[0:3], box[3:6] = inf, -inf
+        out[i, 24:28] = EMPTY_CHILD
+        for k, b in enumerate(kids):
+            box[0:3, k], box[3:6, k] = bounds[b][0], bounds[b][1]
+            if is_leaf(b):
+                first, count = nodes[b][0], nodes[b][1] & 0x7FFFFFFF
+                out[i, 24 + k] = LEAF_FLAG | ((count - 1) << 28) | first
+            else:
+                out[i, 24 + k] = ids[b]
+        out[i, 0:24] = box.reshape(-1).view(np.uint32)
+        out[i, 28] = len(kids)
     if per_triangle is None:
         return out, np.ascontiguousarray(tris[order])
     return out, np.ascontiguousarray(tris[order]), np.ascontiguousarray(np.asarray(per_triangle)[order])

@@ -55,7 +55,7 @@ class Scene:
     materials: Optional[np.ndarray] = None  # (M, 12); None: quad i is diffuse with quads[i, 16:19]
     boxes: np.ndarray = field(default_factory=lambda: np.zeros((0, BOX_STRIDE), np.float32))        # (B, 32)
     tris: np.ndarray = field(default_factory=lambda: np.zeros((0, 16), np.float32))                 # (T, 16), in BVH leaf order
-    bvh: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.uint32))                    # (M, 8) nodes, mesh.py
+    bvh: np.ndarray = field(default_factory=lambda: np.zeros((0, 32), np.uint32))                   # (M, 32) four-wide nodes, mesh.py
     dir_lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.float32))            # (K, 8): direction, irradiance
     tri_normals: Optional[np.ndarray] = None  # (T, 9) vertex normals per triangle in `tris` order; None: face normals
 

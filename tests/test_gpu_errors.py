@@ -108,16 +108,28 @@ def test_scene_and_render_pass_misuse(ctx):
         return d
 
     assert L.pg_scene_set_ex(h, C.byref(mesh_desc(nodes, tris)), C.byref(cam)) == 0
-    inner = int(np.nonzero((nodes[:, 7] & MS.LEAF_FLAG) == 0)[0][1])
-    leaf = int(np.nonzero(nodes[:, 7] & MS.LEAF_FLAG)[0][0])
-    for what, edit in (("follow their parent", lambda nd: nd.__setitem__((inner, 3), 0)),             # a cycle back to the root
-                       ("follow their parent", lambda nd: nd.__setitem__((inner, 3), nd.shape[0])),   # child past the array
-                       ("follow their parent", lambda nd: nd.__setitem__((inner, 3), int(nd[inner, 7] & 0x1FFFFFFF))),  # left == right
-                       ("triangle array", lambda nd: nd.__setitem__((leaf, 3), tris.shape[0]))):      # leaf past the triangles
+    refs = nodes[:, 24:28]
+    is_node = (refs & MS.LEAF_FLAG) == 0
+    ni, nc = [int(x[0]) for x in np.nonzero(is_node)]                         # a reference to a node ...
+    li, lc = [int(x[0]) for x in np.nonzero(~is_node & (refs != MS.EMPTY_CHILD))]   # ... and one to a leaf
+    other = int(refs[is_node][1])
+    for what, edit in (("follow their parent", lambda nd: nd.__setitem__((ni, 24 + nc), ni)),             # a cycle
+                       ("follow their parent", lambda nd: nd.__setitem__((ni, 24 + nc), nd.shape[0])),     # child past the array
+                       ("two parents", lambda nd: nd.__setitem__((ni, 24 + nc), other)),                   # a node referenced twice
+                       ("without children", lambda nd: nd.__setitem__((ni, slice(24, 28)), MS.EMPTY_CHILD)),
+                       ("triangle array", lambda nd: nd.__setitem__((li, 24 + lc), MS.LEAF_FLAG | (3 << 28) | (tris.shape[0] - 2)))):  # leaf past the triangles
         bad = nodes.copy()
         edit(bad)
         rc = L.pg_scene_set_ex(h, C.byref(mesh_desc(bad, tris)), C.byref(cam))
-        assert rc < 0, what
+        assert rc < 0 and what in _msg(L, h), (what, _msg(L, h))
+    # a chain of nodes with three waiting siblings each would overflow the walk's 64-entry stack
+    chain = np.zeros((30, MS.BVH_STRIDE), np.uint32)
+    chain[:, 0:12] = np.float32(-1).view(np.uint32)
+    chain[:, 12:24] = np.float32(1).view(np.uint32)
+    chain[:, 24:28] = MS.LEAF_FLAG  # one-triangle leaves on triangle 0
+    chain[:-1, 24] = np.arange(1, 30)
+    assert L.pg_scene_set_ex(h, C.byref(mesh_desc(chain, tris)), C.byref(cam)) < 0 and "stack" in _msg(L, h)
+    assert L.pg_scene_set_ex(h, C.byref(mesh_desc(chain[:20], tris)), C.byref(cam)) < 0   # (its last node points past the array)
     bad_t = tris.copy()
     bad_t[3, 12] = 5
     assert L.pg_scene_set_ex(h, C.byref(mesh_desc(nodes, bad_t)), C.byref(cam)) < 0 and "triangle material" in _msg(L, h)

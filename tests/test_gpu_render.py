@@ -137,6 +137,16 @@ def test_torus_scene_bit_exact():
     _guided_lifecycle_bit_exact(torus(48, 36), True)
 
 
+@pytest.mark.parametrize("which", ["cornell-box", "veach-mis", "mixed"])
+def test_long_paths_finished_by_the_tail_launch_bit_exact(which):
+    """max_depth 12-14: beyond depth 4 the few paths left are finished by one k_bounce_tail launch
+    (every feature level has its own instantiation); radiance, records, live counts as ever."""
+    from practical_path_guiding_lab_amd import scene as S
+    sc = {"cornell-box": lambda: S.cornell_box(20, 20, 12, 9), "veach-mis": lambda: S.veach_mis(32, 18, 14, 10),
+          "mixed": lambda: mixed_scene(20, max_depth=13, rr_depth=10)}[which]()
+    _guided_lifecycle_bit_exact(sc, True)
+
+
 def _guided_lifecycle_bit_exact(sc, nee):
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene

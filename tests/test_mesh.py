@@ -73,7 +73,7 @@ def test_torus_scene_from_its_fixture_and_from_the_xml():
     the reference is mounted; the fixture's sizes either way."""
     import os
     sc = S.torus(64, 48)
-    assert sc.tris.shape == (23614, 16) and sc.tri_normals.shape == (23614, 9) and sc.bvh.shape[1] == 8
+    assert sc.tris.shape == (23614, 16) and sc.tri_normals.shape == (23614, 9) and sc.bvh.shape[1] == 32
     assert sc.rfilter == "gaussian" and sc.max_depth == 30 and sc.rr_depth == 8 and sc.dir_lights.shape == (1, 8)
     np.testing.assert_allclose(sc.dir_lights[0, :3], [-0.5, 0.5, -np.sqrt(0.5)], atol=1e-7)
     assert [int(m[0]) for m in sc.materials] == [S.MAT_DIFFUSE, S.MAT_DIFFUSE, S.MAT_ROUGHDIELECTRIC, S.MAT_CONDUCTOR]
@@ -99,26 +99,32 @@ def _check_bvh(nodes, tris):
     v0, v1, v2 = tris[:, 0:3], tris[:, 0:3] + tris[:, 3:6], tris[:, 0:3] + tris[:, 6:9]
     lo, hi = np.minimum(np.minimum(v0, v1), v2), np.maximum(np.maximum(v0, v1), v2)
 
-    def bounds(i):
-        return nodes[i, 0:3].view(np.float32), nodes[i, 4:7].view(np.float32)
+    assert nodes.shape[1] == M.BVH_STRIDE == 32
 
-    def rec(i, depth):
-        bmin, bmax = bounds(i)
-        if nodes[i, 7] & M.LEAF_FLAG:
-            first, count = int(nodes[i, 3]), int(nodes[i, 7] & 0x7FFFFFFF)
-            assert 1 <= count <= M.MAX_LEAF
-            covered[first:first + count] += 1
-            assert (lo[first:first + count] >= bmin - 1e-6).all() and (hi[first:first + count] <= bmax + 1e-6).all()
-            return depth
-        left, right, axis = int(nodes[i, 3]), int(nodes[i, 7] & 0x1FFFFFFF), int(nodes[i, 7] >> 29) & 3
-        assert i < left < n and i < right < n and axis <= 2 and not seen[left] and not seen[right]
-        seen[left] = seen[right] = True
-        for c in (left, right):
-            cmin, cmax = bounds(c)
-            assert (cmin >= bmin).all() and (cmax <= bmax).all()
-        return max(rec(left, depth + 1), rec(right, depth + 1))
+    def rec(i, depth, pmin, pmax):
+        box = nodes[i, 0:24].view(np.float32).reshape(6, 4)
+        kids = int(nodes[i, 28])
+        assert 1 <= kids <= 4 and (kids >= 2 or n == 1)
+        deepest = depth
+        for k in range(4):
+            ref = int(nodes[i, 24 + k])
+            if k >= kids:
+                assert ref == M.EMPTY_CHILD and (box[0:3, k] == np.inf).all() and (box[3:6, k] == -np.inf).all()
+                continue
+            bmin, bmax = box[0:3, k], box[3:6, k]
+            assert (bmin >= pmin).all() and (bmax <= pmax).all()          # nested in the parent's box of it
+            if ref & M.LEAF_FLAG:
+                first, count = ref & 0x0FFFFFFF, ((ref >> 28) & 7) + 1
+                assert 1 <= count <= M.MAX_LEAF
+                covered[first:first + count] += 1
+                assert (lo[first:first + count] >= bmin - 1e-6).all() and (hi[first:first + count] <= bmax + 1e-6).all()
+            else:
+                assert i < ref < n and not seen[ref]
+                seen[ref] = True
+                deepest = max(deepest, rec(ref, depth + 1, bmin, bmax))
+        return deepest
 
-    d = rec(0, 0)
+    d = rec(0, 0, np.full(3, -np.inf), np.full(3, np.inf))
     assert seen.all() and (covered == 1).all()
     return d
 
@@ -160,7 +166,7 @@ def test_oracle_mesh_matches_the_sphere_it_tessellates():
     v, f = M.icosphere(4)
     tw2 = np.eye(4); tw2[:3, 3] = [0, 1.0, 0]
     meshed = S._finish(list(floor), cam, 4, 8, ["f"], [lamp], mats, None, [M.triangles(v, f, tw2, 2)])
-    assert meshed.tris.shape == (5120, 16) and meshed.bvh.shape[0] > 2000
+    assert meshed.tris.shape == (5120, 16) and meshed.bvh.shape[0] > 300
     np.testing.assert_allclose(meshed.bbox_min, analytic.bbox_min, atol=1e-3)
     imgs = []
     for sc in (analytic, meshed):

@@ -23,12 +23,18 @@ def short(name):
     return None
 
 
-stats = glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0]
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
+stats = newest(f"{src}/trace/*/*kernel_stats.csv")[0]
 shutil.copy(stats, os.path.join(dst, "bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, "bench_under_rocprof.json"))
 
 # exact per-launch durations of the timed region from the trace (last 10 passes)
-trace = glob.glob(f"{src}/trace/*/*kernel_trace.csv")[0]
+trace = newest(f"{src}/trace/*/*kernel_trace.csv")[0]
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     k = short(r["Kernel_Name"])
@@ -49,7 +55,7 @@ PMC_STEPS = 3  # tools/profile_bench.sh runs the counter passes with --steps 3
 def agg(sub):
     """Counter values of the launches of the TIMED region only (the last PMC_STEPS passes of the run:
     nothing of these kernels runs after it), in dispatch order."""
-    fs = glob.glob(f"{src}/{sub}/*/*counter_collection.csv")
+    fs = newest(f"{src}/{sub}/*/*counter_collection.csv")
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     if fs:
         rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
