@@ -70,13 +70,18 @@ static inline v3 normalize3(v3 v) { return vdivs(v, sqrtf(dot3(v, v))); }
 /* does the ray reach the box of child c of BVH node N before bt?  *tmin = where it enters (>= 0) */
 static int bvh_box_hit(const uint32_t *N, int c, const float oo[3], const float inv[3], float bt, float *tmin_out)
 {
-	float tmin = 0.0f, tmax = bt;
+	/* the plane met first on an axis follows from the sign of the direction (of its reciprocal);
+	 * fmaxf / fminf ignore a NaN operand (0 * inf: the ray lies in a face's plane), which keeps the
+	 * test conservative */
+	float tn[3], tf[3];
 	for (int k = 0; k < 3; ++k) {
-		const float t0 = (pgo_u2f(N[4 * k + c]) - oo[k]) * inv[k], t1 = (pgo_u2f(N[12 + 4 * k + c]) - oo[k]) * inv[k];
-		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-		tmin = lo > tmin ? lo : tmin;
-		tmax = hi < tmax ? hi : tmax;
+		const float lo = pgo_u2f(N[4 * k + c]), hi = pgo_u2f(N[12 + 4 * k + c]);
+		const int neg = signbit(inv[k]) != 0;
+		tn[k] = ((neg ? hi : lo) - oo[k]) * inv[k];
+		tf[k] = ((neg ? lo : hi) - oo[k]) * inv[k];
 	}
+	const float tmin = fmaxf(fmaxf(fmaxf(tn[0], tn[1]), tn[2]), 0.0f);
+	const float tmax = fminf(fminf(fminf(tf[0], tf[1]), tf[2]), bt);
 	*tmin_out = tmin;
 	return tmin <= tmax * 1.0000004f;
 }

@@ -108,29 +108,18 @@ __device__ __forceinline__ v3 box_face_normal(const float *B, int face)
 // (cornell-box), 1 = + spheres and rough conductors (veach-mis), 2 = + triangle meshes, delta
 // lobes, one-sided BSDFs, directional lights and the running index of refraction (torus-class
 // scenes).  What a level does not need is compiled out.
-// Does the ray reach the box [lo, hi] before bt?  tmin = where it enters (>= 0).  Slab test padded as Ize 2013.
+// Does the ray reach the box [lo, hi] before bt?  tmin = where it enters (>= 0).  Slab test padded
+// as Ize 2013.  The plane a ray meets first on an axis is known from the sign of its direction
+// (neg: sign bits of d, once per ray), and fmaxf/fminf (v_max3/v_min3: a NaN operand -- 0 * inf, the
+// ray lies in a face's plane -- is ignored, which keeps the test conservative) fold the three axes.
 __device__ __forceinline__ bool bvh_box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 o,
-                                            v3 inv, float bt, float &tmin_out)
+                                            v3 inv, bool negx, bool negy, bool negz, float bt, float &tmin_out)
 {
-	float tmin = 0.0f, tmax = bt;
-	{
-		const float t0 = (lox - o.x) * inv.x, t1 = (hix - o.x) * inv.x;
-		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-		tmin = lo > tmin ? lo : tmin;
-		tmax = hi < tmax ? hi : tmax;
-	}
-	{
-		const float t0 = (loy - o.y) * inv.y, t1 = (hiy - o.y) * inv.y;
-		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-		tmin = lo > tmin ? lo : tmin;
-		tmax = hi < tmax ? hi : tmax;
-	}
-	{
-		const float t0 = (loz - o.z) * inv.z, t1 = (hiz - o.z) * inv.z;
-		const float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-		tmin = lo > tmin ? lo : tmin;
-		tmax = hi < tmax ? hi : tmax;
-	}
+	const float nx = ((negx ? hix : lox) - o.x) * inv.x, fx = ((negx ? lox : hix) - o.x) * inv.x;
+	const float ny = ((negy ? hiy : loy) - o.y) * inv.y, fy = ((negy ? loy : hiy) - o.y) * inv.y;
+	const float nz = ((negz ? hiz : loz) - o.z) * inv.z, fz = ((negz ? loz : hiz) - o.z) * inv.z;
+	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
+	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), bt);
 	tmin_out = tmin;
 	return tmin <= tmax * 1.0000004f;
 }
@@ -229,6 +218,7 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 	if (kGeneral >= 2 && sh.n_bvh_nodes && !(kAny && best >= 0)) {
 		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
 		const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+		const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
 		const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(sh.bvh);
 		// pg_scene_set_ex has checked the tree: children follow their parent, and no root-to-node path
 		// can leave more than 64 siblings waiting, so the walk opens every node at most once and the
@@ -247,10 +237,10 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 				uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
 				float t0, t1, t2, t3;
 #define PG_F(v) __uint_as_float(v)
-				if (!(r0 != kNone && bvh_box_hit(PG_F(lx.x), PG_F(ly.x), PG_F(lz.x), PG_F(hx.x), PG_F(hy.x), PG_F(hz.x), o, inv, bt, t0))) { r0 = kNone; t0 = kInf; }
-				if (!(r1 != kNone && bvh_box_hit(PG_F(lx.y), PG_F(ly.y), PG_F(lz.y), PG_F(hx.y), PG_F(hy.y), PG_F(hz.y), o, inv, bt, t1))) { r1 = kNone; t1 = kInf; }
-				if (!(r2 != kNone && bvh_box_hit(PG_F(lx.z), PG_F(ly.z), PG_F(lz.z), PG_F(hx.z), PG_F(hy.z), PG_F(hz.z), o, inv, bt, t2))) { r2 = kNone; t2 = kInf; }
-				if (!(r3 != kNone && bvh_box_hit(PG_F(lx.w), PG_F(ly.w), PG_F(lz.w), PG_F(hx.w), PG_F(hy.w), PG_F(hz.w), o, inv, bt, t3))) { r3 = kNone; t3 = kInf; }
+				if (!(r0 != kNone && bvh_box_hit(PG_F(lx.x), PG_F(ly.x), PG_F(lz.x), PG_F(hx.x), PG_F(hy.x), PG_F(hz.x), o, inv, ngx, ngy, ngz, bt, t0))) { r0 = kNone; t0 = kInf; }
+				if (!(r1 != kNone && bvh_box_hit(PG_F(lx.y), PG_F(ly.y), PG_F(lz.y), PG_F(hx.y), PG_F(hy.y), PG_F(hz.y), o, inv, ngx, ngy, ngz, bt, t1))) { r1 = kNone; t1 = kInf; }
+				if (!(r2 != kNone && bvh_box_hit(PG_F(lx.z), PG_F(ly.z), PG_F(lz.z), PG_F(hx.z), PG_F(hy.z), PG_F(hz.z), o, inv, ngx, ngy, ngz, bt, t2))) { r2 = kNone; t2 = kInf; }
+				if (!(r3 != kNone && bvh_box_hit(PG_F(lx.w), PG_F(ly.w), PG_F(lz.w), PG_F(hx.w), PG_F(hy.w), PG_F(hz.w), o, inv, ngx, ngy, ngz, bt, t3))) { r3 = kNone; t3 = kInf; }
 #undef PG_F
 				bvh_cswap(t0, r0, t1, r1);
 				bvh_cswap(t2, r2, t3, r3);
