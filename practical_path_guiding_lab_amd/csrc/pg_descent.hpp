@@ -268,38 +268,12 @@ __device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *
 	}
 }
 
-// One addIrradiancePropagate call (quadtree.py:398-441): returns the accumulator slot of the
-// leaf that (cx,cy) falls into -- rec*4+child for a leaf below a record, or ~tree when the
-// root itself is the leaf -- or false when the root cell does not contain the point.
-__device__ __forceinline__ bool quad_find_leaf_slot(const QuadRec *rec, TreeHead head, float cx,
-                                                    float cy, uint32_t &slot, bool &is_root,
-                                                    uint32_t &levels)
-{
-	levels = 0;
-	if (!(cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f)) return false; // quadtree.py:404-405
-	is_root = head.root_rec == kNoRecord;
-	if (is_root) return true;
-	uint32_t r = head.root_rec;
-	float lox = 0.0f, loy = 0.0f, h = 0.5f;
-	for (int it = 0; it < kMaxLevels; ++it) {
-		const uint4 ch = reinterpret_cast<const uint4 *>(rec + r)[1];
-		const float mx = lox + h, my = loy + h;
-		int first, last;
-		quadrant(cx, cy, mx, my, first, last);
-		++levels;
-		const uint32_t c = sel4u(last, ch.x, ch.y, ch.z, ch.w);
-		if (c == 0) { slot = r * 4u + (uint32_t)last; return true; }
-		if (last == 0 || last == 3) lox = mx;
-		if (last == 0 || last == 1) loy = my;
-		h *= 0.5f;
-		r = c;
-	}
-	return false;
-}
-
-// The same walk for the two directions of one record (path direction and emitter direction fall
-// into the same quadtree, quadtree.py:443-464), advanced in lock step so that the two dependent
-// gather chains overlap instead of running one after the other.
+// addIrradiancePropagate (quadtree.py:398-441): the accumulator slot of the leaf that (cx,cy) falls
+// into -- rec*4+child for a leaf below a record, the tree's root accumulator when the root itself
+// is the leaf -- or nothing when the root cell does not contain the point (quadtree.py:404-405).
+// The walk is done for the two directions of one record together (path direction and emitter
+// direction fall into the same quadtree, quadtree.py:443-464), advanced in lock step so that the two
+// dependent gather chains overlap instead of running one after the other.
 struct LeafCursor {
 	uint32_t r, slot, levels;
 	float lox, loy, h, cx, cy;
