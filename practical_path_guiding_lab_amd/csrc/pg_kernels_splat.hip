@@ -182,6 +182,8 @@ __device__ __forceinline__ bool process_slot(uint64_t g, uint64_t S, uint64_t nu
                                              const float *__restrict__ l_final, const pg_dense_records &r,
                                              float &radiance, float &nee_lum, float &wp)
 {
+	radiance = 0.0f; nee_lum = 0.0f; wp = 0.0f;
+	if (!active) return false; // (an unused slot, or a path that left the scene: nothing to read)
 	float in[3], nee[3];
 #pragma unroll
 	for (int ch = 0; ch < 3; ++ch) {
