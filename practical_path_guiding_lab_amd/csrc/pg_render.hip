@@ -1210,15 +1210,20 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	if (pix >= a.n_pixels) return;
 	const uint64_t N = a.n_lanes, P = a.film_pixels;
 	const uint64_t gpix = a.pixel_begin + pix; // the sums are full-film arrays
-	for (int s = 0; s < a.spp; ++s) {
-		const uint64_t lane = pix * (uint64_t)a.spp + (uint64_t)s;
-		if (valid_out) valid_out[lane] = a.hit0[lane];
-		if (sumL && sumL2)
+	const uint64_t first = pix * (uint64_t)a.spp;
+	if (valid_out)
+		for (int s = 0; s < a.spp; ++s) valid_out[first + s] = a.hit0[first + s];
+	if (sumL && sumL2) {
+		// the running sums stay in registers; the additions and their order are those of the reference
+		float s1[3], s2[3];
+		for (int c = 0; c < 3; ++c) { s1[c] = sumL[c * P + gpix]; s2[c] = sumL2[c * P + gpix]; }
+		for (int s = 0; s < a.spp; ++s)
 			for (int c = 0; c < 3; ++c) {
-				const float v = a.L[c * N + lane];
-				sumL[c * P + gpix] = sumL[c * P + gpix] + v;
-				sumL2[c * P + gpix] = sumL2[c * P + gpix] + v * v;
+				const float v = a.L[c * N + first + s];
+				s1[c] = s1[c] + v;
+				s2[c] = s2[c] + v * v;
 			}
+		for (int c = 0; c < 3; ++c) { sumL[c * P + gpix] = s1[c]; sumL2[c * P + gpix] = s2[c]; }
 	}
 }
 
