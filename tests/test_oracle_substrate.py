@@ -269,6 +269,65 @@ def test_xml_with_spheres_and_rough_conductors(tmp_path):
         S.load_xml(str(p))
 
 
+def test_xml_with_meshes_transform_operations_presets_and_a_directional_light(tmp_path):
+    """The XML features scenes/torus/scene.xml uses, on files made here: $defaults, lookat, scale /
+    translate / rotate in document order, `serialized` (by shape_index) and `obj` meshes, one-sided
+    diffuse, conductor and index-of-refraction presets, dielectric / roughdielectric, a directional
+    emitter, the default (gaussian) film filter."""
+    from test_mesh import _write_serialized
+    from practical_path_guiding_lab_amd import mesh as M
+    v, f = M.icosphere(1)
+    _write_serialized(str(tmp_path / "m.serialized"), [(v * 9, f, None, False, False), (v, f, v, False, False)], 3)
+    (tmp_path / "t.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    xml = """<scene version="3.0.0">
+      <default name="resx" value="32" /><default name="resy" value="24" /><default name="max_depth" value="30" />
+      <integrator type="path_guiding_integrator"><integer name="max_depth" value="$max_depth" /><integer name="rr_depth" value="8" /></integrator>
+      <sensor type="perspective"><float name="fov" value="34.6222"/><string name="fov_axis" value="x"/>
+        <transform name="to_world"><lookat target="0, 0, 0" origin="0, -8, 3" up="0, 0, 1"/></transform>
+        <film type="hdrfilm"><integer name="width" value="$resx" /><integer name="height" value="$resy" /></film></sensor>
+      <bsdf type="diffuse" id="donut"><rgb name="reflectance" value=".8,.8,.4"/></bsdf>
+      <bsdf type="conductor" id="metal"><string name="material" value="Al"/></bsdf>
+      <bsdf type="roughdielectric" id="glass"><string name="int_ior" value="acrylic glass"/><string name="ext_ior" value="air"/><float name="alpha" value="0.01"/></bsdf>
+      <bsdf type="dielectric" id="smooth"><float name="int_ior" value="1.5"/><float name="ext_ior" value="1"/></bsdf>
+      <shape type="serialized"><string name="filename" value="m.serialized"/><integer name="shape_index" value="1"/>
+        <transform name="to_world"><scale x=".5" y="2"/><translate x="10"/><rotate z="1" angle="90"/></transform><ref id="donut"/></shape>
+      <shape type="serialized"><string name="filename" value="m.serialized"/><integer name="shape_index" value="1"/>
+        <boolean name="face_normals" value="true"/><ref id="glass"/></shape>
+      <shape type="obj"><string name="filename" value="t.obj"/><ref id="metal"/></shape>
+      <shape type="obj"><string name="filename" value="t.obj"/><transform name="to_world"><translate z="2"/></transform><ref id="smooth"/></shape>
+      <emitter type="directional"><transform name="to_world"><rotate y="1" angle="180"/><rotate y="1" angle="45"/><rotate z="1" angle="-45"/></transform>
+        <rgb name="irradiance" value="2, 2, 1.8"/></emitter>
+    </scene>"""
+    p = tmp_path / "s.xml"
+    p.write_text(xml)
+    sc = S.load_xml(str(p))
+    assert (sc.camera.width, sc.camera.height, sc.max_depth, sc.rr_depth, sc.rfilter) == (32, 24, 30, 8, "gaussian")
+    np.testing.assert_allclose(sc.camera.origin, [0, -8, 3])
+    np.testing.assert_allclose(sc.camera.axis_z, np.array([0, 8, -3]) / np.sqrt(73), atol=1e-6)   # looks at the target
+    np.testing.assert_allclose(sc.camera.axis_x, [-1, 0, 0], atol=1e-6)                             # left = up x dir
+    assert [int(m[0]) for m in sc.materials] == [S.MAT_DIFFUSE, S.MAT_CONDUCTOR, S.MAT_ROUGHDIELECTRIC, S.MAT_DIELECTRIC]
+    assert (sc.materials[:, 11] == 1).all()                                                         # nothing wrapped in twosided
+    np.testing.assert_allclose(sc.materials[1, 5:8], S.CONDUCTOR_PRESETS["Al"][0], rtol=1e-6)
+    np.testing.assert_allclose(sc.materials[2, 4:6], [0.01, 1.49 / 1.000277], rtol=1e-6)
+    assert abs(sc.materials[3, 5] - 1.5) < 1e-6
+    np.testing.assert_allclose(sc.dir_lights[0], [-0.5, 0.5, -np.sqrt(0.5), 2, 2, 1.8, 0, 0], atol=1e-6)
+    assert sc.tris.shape[0] == 80 + 80 + 1 + 1 and sc.tri_normals is not None
+    # scale, then translate, then rotate about z by 90 degrees: (x, y, z) -> (-(2 y), 0.5 x + 10, z)
+    first = sc.tris[sc.tris[:, 12] == 0]
+    pts = np.concatenate([first[:, 0:3], first[:, 0:3] + first[:, 3:6], first[:, 0:3] + first[:, 6:9]])
+    np.testing.assert_allclose([pts[:, 0].min(), pts[:, 0].max()], [-2 * v[:, 1].max(), -2 * v[:, 1].min()], atol=1e-5)
+    np.testing.assert_allclose([pts[:, 1].min(), pts[:, 1].max()], [10 + 0.5 * v[:, 0].min(), 10 + 0.5 * v[:, 0].max()], atol=1e-5)
+    # face_normals: the second copy carries its face normal three times, the first its vertex normals
+    second = sc.tris[:, 12] == 2
+    assert np.array_equal(sc.tri_normals[second], np.tile(sc.tris[second, 9:12], (1, 3)))
+    assert not np.array_equal(sc.tri_normals[sc.tris[:, 12] == 0], np.tile(first[:, 9:12], (1, 3)))
+    for bad, what in ((xml.replace('value="Al"', 'value="Unobtainium"'), "conductor preset"), (xml.replace("acrylic glass", "ice"), "preset"),
+                      (xml.replace('<rotate z="1" angle="90"/>', '<shear/>'), "transform"), (xml.replace('value="x"/>', 'value="y"/>'), "fov_axis")):
+        p.write_text(bad)
+        with pytest.raises(ValueError, match=what):
+            S.load_xml(str(p))
+
+
 # ---- delta lobes and the directional emitter (scenes/torus: `conductor`, `dielectric`, `directional`) ----
 def _look_at(o, target, fov, res=4):
     o, target = np.asarray(o, float), np.asarray(target, float)
