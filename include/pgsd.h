@@ -233,7 +233,8 @@ int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t
 #define PG_SPHERE_STRIDE 12
 /* material: 0 type (0 diffuse; 1 roughconductor, beckmann, sample_visible; 2 smooth conductor;
  *   3 smooth dielectric; 4 roughdielectric, beckmann, sample_visible)  1-3 reflectance |
- *   specular_reflectance  4 alpha  5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
+ *   specular_reflectance  4 alpha (> 0: beckmann; < 0: ggx of roughness -alpha)
+ *   5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
  *   11 one-sided flag (0 = wrapped in `twosided`) */
 #define PG_MATERIAL_STRIDE 12
 /* box (Mitsuba's `cube`: [-1,1]^3 under an affine to_world), intersected as three slabs in its local

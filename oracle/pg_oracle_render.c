@@ -423,8 +423,8 @@ static void sample_emitter(const pgo_scene *sc, const int *em, int n_em, v3 p, v
 	}
 }
 
-/* Mitsuba warp::square_to_cosine_hemisphere (concentric disk + z = safe_sqrt(1 - r^2)) */
-static inline v3 square_to_cosine_hemisphere(float u, float v)
+/* Mitsuba warp::square_to_uniform_disk_concentric */
+static inline void square_to_disk(float u, float v, float *px, float *py)
 {
 	float x = 2.0f * u - 1.0f, y = 2.0f * v - 1.0f;
 	int is_zero = (x == 0.0f) && (y == 0.0f);
@@ -435,30 +435,47 @@ static inline v3 square_to_cosine_hemisphere(float u, float v)
 	if (is_zero) phi = 0.0f;
 	float s, c;
 	pgo_sincos(phi, &s, &c);
-	float px = r * c, py = r * s;
+	*px = r * c;
+	*py = r * s;
+}
+
+/* Mitsuba warp::square_to_cosine_hemisphere (concentric disk + z = safe_sqrt(1 - r^2)) */
+static inline v3 square_to_cosine_hemisphere(float u, float v)
+{
+	float px, py;
+	square_to_disk(u, v, &px, &py);
 	float zz = 1.0f - (px * px + py * py);
 	float z = zz > 0.0f ? sqrtf(zz) : 0.0f;
 	if (z == 0.0f) z = 1e-10f;
 	return V(px, py, z);
 }
 
-/* ---- roughconductor (Beckmann, isotropic, sample_visible) after Mitsuba 3's microfacet.h /
- * roughconductor.cpp; every function below works in the local frame with cos(theta_i) > 0 ---- */
+/* ---- roughconductor (isotropic, sample_visible) after Mitsuba 3's microfacet.h /
+ * roughconductor.cpp; every function below works in the local frame with cos(theta_i) > 0.
+ * The sign of `alpha` names the distribution: > 0 Beckmann, < 0 GGX of roughness -alpha ---- */
 static float rc_D(v3 m, float alpha) /* MicrofacetDistribution::eval */
 {
 	const float ct = m.z, ct2 = ct * ct;
-	const float ax = m.x / alpha, ay = m.y / alpha;
-	const float result = pgo_exp(-((ax * ax + ay * ay) / ct2)) / (((PI_F * alpha) * alpha) * (ct2 * ct2));
+	const float a = fabsf(alpha);
+	const float ax = m.x / a, ay = m.y / a;
+	float result;
+	if (alpha < 0.0f) {
+		const float t = (ax * ax + ay * ay) + ct2;
+		result = 1.0f / (((PI_F * a) * a) * (t * t));
+	} else {
+		result = pgo_exp(-((ax * ax + ay * ay) / ct2)) / (((PI_F * a) * a) * (ct2 * ct2));
+	}
 	return result * ct > 1e-20f ? result : 0.0f; /* "prevent potential numerical issues in other stages" */
 }
 
-static float rc_G1(v3 v, v3 m, float alpha) /* smith_g1: rational approximation for Beckmann */
+static float rc_G1(v3 v, v3 m, float alpha) /* smith_g1: exact for GGX, the rational approximation for Beckmann */
 {
 	const float ax = alpha * v.x, ay = alpha * v.y;
 	const float xy = ax * ax + ay * ay;
 	const float a = 1.0f / sqrtf(xy / (v.z * v.z));
 	const float a2 = a * a;
 	float result = a >= 1.6f ? 1.0f : (3.535f * a + 2.181f * a2) / ((1.0f + 2.276f * a) + 2.577f * a2);
+	if (alpha < 0.0f) result = 2.0f / (1.0f + sqrtf(1.0f + xy / (v.z * v.z)));
 	if (xy == 0.0f) result = 1.0f;                 /* perpendicular incidence */
 	if (dot3(v, m) * v.z <= 0.0f) result = 0.0f;    /* the back of a microfacet is not seen from the front */
 	return result;
@@ -506,9 +523,26 @@ static void rc_sample_visible_11(float cos_i, float u1, float u2, float *sx, flo
 	*sy = pgo_erfinv(2.0f * u2 - 1.0f);
 }
 
-/* MicrofacetDistribution::sample (visible normals): microfacet normal and its density */
-static v3 rc_sample_m(v3 wi, float alpha, float u1, float u2, float *pdf)
+/* sample_visible_11 for GGX: a point of the unit disk, its half towards the viewer compressed by
+ * (1 + cos theta_i)/2, projected onto the hemisphere around the viewing direction, as slopes */
+static void ggx_sample_visible_11(float cos_i, float u1, float u2, float *sx, float *sy)
 {
+	float px, py;
+	square_to_disk(u1, u2, &px, &py);
+	const float s = 0.5f * (1.0f + cos_i);
+	const float h = safe_sqrtf(1.0f - px * px);
+	py = h * (1.0f - s) + py * s;
+	const float z = safe_sqrtf(1.0f - (px * px + py * py));
+	const float sin_i = safe_sqrtf(1.0f - cos_i * cos_i);
+	const float norm = 1.0f / (sin_i * py + cos_i * z);
+	*sx = (cos_i * py - sin_i * z) * norm;
+	*sy = px * norm;
+}
+
+/* MicrofacetDistribution::sample (visible normals): microfacet normal and its density */
+static v3 rc_sample_m(v3 wi, float signed_alpha, float u1, float u2, float *pdf)
+{
+	const float alpha = fabsf(signed_alpha);
 	const v3 wip = normalize3(V(alpha * wi.x, alpha * wi.y, wi.z));
 	const float s2 = wip.x * wip.x + wip.y * wip.y; /* Frame::sincos_phi */
 	float cos_phi = 1.0f, sin_phi = 0.0f;
@@ -519,11 +553,12 @@ static v3 rc_sample_m(v3 wi, float alpha, float u1, float u2, float *pdf)
 		sin_phi = sin_phi < -1.0f ? -1.0f : (sin_phi > 1.0f ? 1.0f : sin_phi);
 	}
 	float sx, sy;
-	rc_sample_visible_11(wip.z, u1, u2, &sx, &sy);
+	if (signed_alpha < 0.0f) ggx_sample_visible_11(wip.z, u1, u2, &sx, &sy);
+	else rc_sample_visible_11(wip.z, u1, u2, &sx, &sy);
 	const float rx = (cos_phi * sx - sin_phi * sy) * alpha;
 	const float ry = (sin_phi * sx + cos_phi * sy) * alpha;
 	const v3 m = normalize3(V(-rx, -ry, 1.0f));
-	*pdf = ((rc_D(m, alpha) * rc_G1(wi, m, alpha)) * fabsf(dot3(wi, m))) / wi.z;
+	*pdf = ((rc_D(m, signed_alpha) * rc_G1(wi, m, signed_alpha)) * fabsf(dot3(wi, m))) / wi.z;
 	return m;
 }
 

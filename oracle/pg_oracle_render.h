@@ -33,7 +33,8 @@ extern "C" {
 #define PGO_SPHERE_STRIDE 12
 /* one material: 0 type (0 diffuse, 1 roughconductor/beckmann/sample_visible, 2 smooth conductor,
  *  3 smooth dielectric, 4 roughdielectric/beckmann/sample_visible)  1-3 reflectance |
- *  specular_reflectance  4 alpha  5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
+ *  specular_reflectance  4 alpha (> 0: beckmann; < 0: ggx of roughness -alpha)
+ *  5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
  *  11 one-sided flag (0 = wrapped in `twosided`; dielectrics never are) */
 #define PGO_MATERIAL_STRIDE 12
 

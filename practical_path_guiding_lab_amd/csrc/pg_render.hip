@@ -409,8 +409,8 @@ __device__ __forceinline__ float emitter_hit_pdf(const Shapes &sh, int prim, v3 
 	return pdf * inv_count;
 }
 
-// Mitsuba warp::square_to_cosine_hemisphere (concentric disk)
-__device__ __forceinline__ v3 square_to_cosine_hemisphere(float u, float v)
+// Mitsuba warp::square_to_uniform_disk_concentric
+__device__ __forceinline__ void square_to_disk(float u, float v, float &px, float &py)
 {
 	const float x = 2.0f * u - 1.0f, y = 2.0f * v - 1.0f;
 	const bool is_zero = (x == 0.0f) && (y == 0.0f);
@@ -421,7 +421,15 @@ __device__ __forceinline__ v3 square_to_cosine_hemisphere(float u, float v)
 	if (is_zero) phi = 0.0f;
 	float s, c;
 	sincos_f32(phi, s, c);
-	const float px = r * c, py = r * s;
+	px = r * c;
+	py = r * s;
+}
+
+// Mitsuba warp::square_to_cosine_hemisphere (concentric disk)
+__device__ __forceinline__ v3 square_to_cosine_hemisphere(float u, float v)
+{
+	float px, py;
+	square_to_disk(u, v, px, py);
 	const float zz = 1.0f - (px * px + py * py);
 	float z = zz > 0.0f ? __builtin_sqrtf(zz) : 0.0f;
 	if (z == 0.0f) z = 1e-10f;
@@ -431,21 +439,30 @@ __device__ __forceinline__ v3 square_to_cosine_hemisphere(float u, float v)
 // ---- roughconductor (Beckmann, isotropic, sample_visible) after Mitsuba 3's microfacet.h /
 // roughconductor.cpp; local frame, cos(theta_i) > 0.  Not inlined: the diffuse-only kernel never
 // references them, and the general kernel calls them from two places each.
+// The sign of `alpha` names the distribution: > 0 Beckmann, < 0 GGX of roughness -alpha.
 __device__ __noinline__ float rc_D(v3 m, float alpha) // MicrofacetDistribution::eval
 {
 	const float ct = m.z, ct2 = ct * ct;
-	const float ax = m.x / alpha, ay = m.y / alpha;
-	const float result = exp_f32(-((ax * ax + ay * ay) / ct2)) / (((kPiF * alpha) * alpha) * (ct2 * ct2));
+	const float a = fabs_(alpha);
+	const float ax = m.x / a, ay = m.y / a;
+	float result;
+	if (alpha < 0.0f) {
+		const float t = (ax * ax + ay * ay) + ct2;
+		result = 1.0f / (((kPiF * a) * a) * (t * t));
+	} else {
+		result = exp_f32(-((ax * ax + ay * ay) / ct2)) / (((kPiF * a) * a) * (ct2 * ct2));
+	}
 	return result * ct > 1e-20f ? result : 0.0f;
 }
 
-__device__ __forceinline__ float rc_G1(v3 v, v3 m, float alpha) // smith_g1, rational approximation
+__device__ __forceinline__ float rc_G1(v3 v, v3 m, float alpha) // smith_g1: exact for GGX, rational approximation for Beckmann
 {
 	const float ax = alpha * v.x, ay = alpha * v.y;
 	const float xy = ax * ax + ay * ay;
 	const float a = 1.0f / __builtin_sqrtf(xy / (v.z * v.z));
 	const float a2 = a * a;
 	float result = a >= 1.6f ? 1.0f : (3.535f * a + 2.181f * a2) / ((1.0f + 2.276f * a) + 2.577f * a2);
+	if (alpha < 0.0f) result = 2.0f / (1.0f + __builtin_sqrtf(1.0f + xy / (v.z * v.z)));
 	if (xy == 0.0f) result = 1.0f;
 	if (dot3(v, m) * v.z <= 0.0f) result = 0.0f;
 	return result;
@@ -492,9 +509,26 @@ __device__ __noinline__ void rc_sample_visible_11(float cos_i, float u1, float u
 	sy = erfinv_call(2.0f * u2 - 1.0f);
 }
 
-// MicrofacetDistribution::sample (visible normals): microfacet normal and its density
-__device__ __forceinline__ v3 rc_sample_m(v3 wi, float alpha, float u1, float u2, float &pdf)
+// sample_visible_11 for GGX: a point of the unit disk, its half towards the viewer compressed by
+// (1 + cos theta_i)/2, projected onto the hemisphere around the viewing direction, as slopes
+__device__ __noinline__ void ggx_sample_visible_11(float cos_i, float u1, float u2, float &sx, float &sy)
 {
+	float px, py;
+	square_to_disk(u1, u2, px, py);
+	const float s = 0.5f * (1.0f + cos_i);
+	const float h = safe_sqrtf(1.0f - px * px);
+	py = h * (1.0f - s) + py * s;
+	const float z = safe_sqrtf(1.0f - (px * px + py * py));
+	const float sin_i = safe_sqrtf(1.0f - cos_i * cos_i);
+	const float norm = 1.0f / (sin_i * py + cos_i * z);
+	sx = (cos_i * py - sin_i * z) * norm;
+	sy = px * norm;
+}
+
+// MicrofacetDistribution::sample (visible normals): microfacet normal and its density
+__device__ __forceinline__ v3 rc_sample_m(v3 wi, float signed_alpha, float u1, float u2, float &pdf)
+{
+	const float alpha = fabs_(signed_alpha);
 	const v3 wip = normalize3(V(alpha * wi.x, alpha * wi.y, wi.z));
 	const float s2 = wip.x * wip.x + wip.y * wip.y; // Frame::sincos_phi
 	float cos_phi = 1.0f, sin_phi = 0.0f;
@@ -505,11 +539,12 @@ __device__ __forceinline__ v3 rc_sample_m(v3 wi, float alpha, float u1, float u2
 		sin_phi = sin_phi < -1.0f ? -1.0f : (sin_phi > 1.0f ? 1.0f : sin_phi);
 	}
 	float sx, sy;
-	rc_sample_visible_11(wip.z, u1, u2, sx, sy);
+	if (signed_alpha < 0.0f) ggx_sample_visible_11(wip.z, u1, u2, sx, sy);
+	else rc_sample_visible_11(wip.z, u1, u2, sx, sy);
 	const float rx = (cos_phi * sx - sin_phi * sy) * alpha;
 	const float ry = (sin_phi * sx + cos_phi * sy) * alpha;
 	const v3 m = normalize3(V(-rx, -ry, 1.0f));
-	pdf = ((rc_D(m, alpha) * rc_G1(wi, m, alpha)) * fabs_(dot3(wi, m))) / wi.z;
+	pdf = ((rc_D(m, signed_alpha) * rc_G1(wi, m, signed_alpha)) * fabs_(dot3(wi, m))) / wi.z;
 	return m;
 }
 
@@ -1405,8 +1440,9 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
 		if (type == 1.0f && general < 1) general = 1;                                  // rough conductor
 		if (type >= 2.0f || mats[m * kMaterialStride + 11] != 0.0f) general = 2;       // transmission, delta lobes, one-sided BSDFs
-		if ((type == 1.0f || type == 4.0f) && !(mats[m * kMaterialStride + 4] > 0.0f))
-			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: microfacet alpha must be > 0");
+		const float alpha = mats[m * kMaterialStride + 4]; // > 0: Beckmann, < 0: GGX of roughness -alpha
+		if ((type == 1.0f || type == 4.0f) && !(fabsf(alpha) > 0.0f && fabsf(alpha) < 3.0e38f))
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: microfacet alpha must be finite and not 0");
 		if ((type == 3.0f || type == 4.0f) && !(mats[m * kMaterialStride + 5] > 0.0f))
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: dielectric index ratio must be > 0");
 	}

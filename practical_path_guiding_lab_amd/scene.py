@@ -153,13 +153,22 @@ def dielectric_material(int_ior: float, ext_ior: float = 1.000277) -> np.ndarray
     return m
 
 
-def roughdielectric_material(alpha, int_ior: float, ext_ior: float = 1.000277) -> np.ndarray:
-    """Mitsuba `roughdielectric`, beckmann distribution, isotropic alpha, sample_visible: a rough
+def _signed_alpha(alpha, distribution: str) -> np.float32:
+    """The material row names the microfacet distribution by the sign of alpha: > 0 beckmann, < 0 ggx."""
+    if distribution not in ("beckmann", "ggx"):
+        raise ValueError(f"unsupported microfacet distribution {distribution}")
+    if not float(alpha) > 0.0:
+        raise ValueError("alpha must be > 0")
+    return np.float32(alpha) if distribution == "beckmann" else -np.float32(alpha)
+
+
+def roughdielectric_material(alpha, int_ior: float, ext_ior: float = 1.000277, distribution: str = "beckmann") -> np.ndarray:
+    """Mitsuba `roughdielectric`, beckmann or ggx distribution, isotropic alpha, sample_visible: a rough
     interface that reflects and refracts (scenes/torus/scene.xml `glass`); never twosided."""
     m = np.zeros(MATERIAL_STRIDE, np.float32)
     m[0] = MAT_ROUGHDIELECTRIC
     m[1:4] = 1.0
-    m[4] = np.float32(alpha)
+    m[4] = _signed_alpha(alpha, distribution)
     m[5] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
     m[11] = 1.0
     return m
@@ -174,12 +183,12 @@ def directional_light(direction, irradiance) -> np.ndarray:
     return out
 
 
-def roughconductor_material(alpha, eta, k, specular_reflectance=(1.0, 1.0, 1.0)) -> np.ndarray:
-    """Mitsuba `roughconductor`, beckmann distribution, isotropic alpha, sample_visible (its default)."""
+def roughconductor_material(alpha, eta, k, specular_reflectance=(1.0, 1.0, 1.0), distribution: str = "beckmann") -> np.ndarray:
+    """Mitsuba `roughconductor`, beckmann or ggx distribution, isotropic alpha, sample_visible (its default)."""
     m = np.zeros(MATERIAL_STRIDE, np.float32)
     m[0] = MAT_ROUGHCONDUCTOR
     m[1:4] = _f32(specular_reflectance)
-    m[4] = np.float32(alpha)
+    m[4] = _signed_alpha(alpha, distribution)
     m[5:8] = _f32(eta)
     m[8:11] = _f32(k)
     return m
@@ -448,11 +457,10 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             return named["eta"], named["k"]
 
         def alpha():
+            """(alpha, distribution); Mitsuba's default distribution is beckmann"""
             dist = node.find("string[@name='distribution']")
-            if dist is not None and dist.get("value") != "beckmann":
-                raise ValueError(f"{kind}: only the beckmann distribution is built")
             a = node.find("float[@name='alpha']")
-            return float(val(a.get("value"))) if a is not None else 0.1
+            return (float(val(a.get("value"))) if a is not None else 0.1), (dist.get("value") if dist is not None else "beckmann")
 
         if kind == "diffuse":
             materials.append(diffuse_material(named.get("reflectance", (0.5, 0.5, 0.5)), twosided))
@@ -460,14 +468,16 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             if not twosided:
                 raise ValueError("roughconductor: only the twosided form is built")
             e, k = eta_k()
-            materials.append(roughconductor_material(alpha(), e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0))))
+            a, dist = alpha()
+            materials.append(roughconductor_material(a, e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0)), dist))
         elif kind == "conductor":
             e, k = eta_k()
             materials.append(conductor_material(e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0)), twosided))
         elif kind == "dielectric":
             materials.append(dielectric_material(ior(node, "int_ior", IOR_PRESETS["bk7"]), ior(node, "ext_ior", IOR_PRESETS["air"])))
         elif kind == "roughdielectric":
-            materials.append(roughdielectric_material(alpha(), ior(node, "int_ior", IOR_PRESETS["bk7"]), ior(node, "ext_ior", IOR_PRESETS["air"])))
+            a, dist = alpha()
+            materials.append(roughdielectric_material(a, ior(node, "int_ior", IOR_PRESETS["bk7"]), ior(node, "ext_ior", IOR_PRESETS["air"]), dist))
         else:
             raise ValueError(f"unsupported bsdf type {kind}")
         return len(materials) - 1

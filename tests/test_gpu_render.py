@@ -116,6 +116,9 @@ def mixed_scene(res, max_depth=6, rr_depth=3):
     mats.append(S.roughdielectric_material(0.1, 1.49, 1.000277))                                           # frosted glass (scenes/torus)
     spheres.append(S.sphere((1.0, 0.4, 3.2), 0.4, 8))
     tris.append(MS.triangles(v, f, M(0.35, 0, 0, -1.6, 0, 0.35, 0, 0.36, 0, 0, 0.35, 3.0, 0, 0, 0, 1), 8, v))  # and a smooth-shaded frosted mesh
+    mats += [S.roughconductor_material(0.15, *S.CONDUCTOR_PRESETS["Al"], distribution="ggx"),             # the GGX forms (scenes/veach-ajar)
+             S.roughdielectric_material(0.2, 1.5, 1.0, "ggx")]
+    spheres += [S.sphere((-2.6, 0.3, 2.4), 0.3, 9), S.sphere((2.9, 0.3, 3.3), 0.3, 10)]
     lights = [S.directional_light((0.4, -1.0, -0.3), (1.5, 1.4, 1.2))]
     cam = S.make_camera(M(-1, 0, 0, 0, 0, 0.94, -0.342, 3.0, 0, -0.342, -0.94, 7.5, 0, 0, 0, 1), 40.0, res, res)
     return S._finish(quads, cam, max_depth, rr_depth, ["q"] * len(quads), spheres, mats, boxes, tris, lights)

@@ -19,9 +19,11 @@ def _hemi_grid(n):
     return np.stack([s * np.cos(p), s * np.sin(p), c], axis=-1).reshape(-1, 3).astype(np.float32), (1.0 / n) * (np.pi / n)
 
 
-@pytest.mark.parametrize("alpha,theta", [(0.25, 0.3), (0.25, 1.3), (0.1, 1.0)])
-def test_rough_conductor_sampling_matches_its_pdf_and_eval(alpha, theta):
-    m = S.roughconductor_material(alpha, ETA, K, (0.3, 0.3, 0.3))
+@pytest.mark.parametrize("alpha,theta,dist", [(0.25, 0.3, "beckmann"), (0.25, 1.3, "beckmann"), (0.1, 1.0, "beckmann"),
+                                              (0.25, 0.3, "ggx"), (0.25, 1.3, "ggx"), (0.1, 1.0, "ggx")])
+def test_rough_conductor_sampling_matches_its_pdf_and_eval(alpha, theta, dist):
+    m = S.roughconductor_material(alpha, ETA, K, (0.3, 0.3, 0.3), dist)
+    assert (m[4] < 0) == (dist == "ggx")
     wi = np.array([np.sin(theta) * np.cos(0.7), np.sin(theta) * np.sin(0.7), np.cos(theta)], np.float32)
     rng = np.random.default_rng(5)
     n, hits, mean = 6000, 0, np.zeros(3)
@@ -51,12 +53,14 @@ def test_rough_conductor_sampling_matches_its_pdf_and_eval(alpha, theta):
     assert po.bsdf_eval_pdf(m, wi, grid[0] * flip)[1] == 0.0
 
 
-@pytest.mark.parametrize("alpha,theta,side", [(0.3, 0.4, 1), (0.3, 1.2, 1), (0.3, 0.4, -1), (0.3, 1.0, -1), (0.05, 0.8, 1)])
-def test_rough_dielectric_sampling_matches_its_pdf_and_eval(alpha, theta, side):
+@pytest.mark.parametrize("alpha,theta,side,dist", [(0.3, 0.4, 1, "beckmann"), (0.3, 1.2, 1, "beckmann"), (0.3, 0.4, -1, "beckmann"),
+                                                   (0.3, 1.0, -1, "beckmann"), (0.05, 0.8, 1, "beckmann"),
+                                                   (0.3, 0.4, 1, "ggx"), (0.3, 1.2, 1, "ggx"), (0.3, 1.0, -1, "ggx")])
+def test_rough_dielectric_sampling_matches_its_pdf_and_eval(alpha, theta, side, dist):
     """`roughdielectric` (the torus scene's glass): the sampled direction's pdf and value are those
     eval_pdf gives for it, on either side of the interface and for both lobes; the pdf integrates
     to the fraction of valid samples; without the eta^2 radiance scale no energy is created."""
-    m = S.roughdielectric_material(alpha, 1.49, 1.000277)
+    m = S.roughdielectric_material(alpha, 1.49, 1.000277, dist)
     eta_m = float(m[5])
     wi = np.array([np.sin(theta) * np.cos(0.7), np.sin(theta) * np.sin(0.7), side * np.cos(theta)], np.float32)
     rng = np.random.default_rng(7)
@@ -76,7 +80,7 @@ def test_rough_dielectric_sampling_matches_its_pdf_and_eval(alpha, theta, side):
             assert np.abs(val - w * pdf).max() <= 3e-4 * np.abs(val).max()
             albedo += w[0] if refl else w[0] * eta * eta      # undo the radiance scale eta_ti^2 = 1 / eta^2
             assert w[0] * (1.0 if refl else eta * eta) <= 1.0 + 1e-4   # G1's rational fit peaks at 1.00005
-    assert albedo / n <= 1.0 and albedo / n > 0.8
+    assert albedo / n <= 1.0 and albedo / n > 0.7        # single scattering loses the masked part (ggx: heavier tails)
     # total internal reflection from inside at 1.0 rad (critical angle 0.74): mostly reflection
     if side < 0 and theta > 0.9:
         assert n_refl > 0.75 * hits
@@ -264,8 +268,10 @@ def test_xml_with_spheres_and_rough_conductors(tmp_path):
     np.testing.assert_allclose(lamp[:4], [0, 6.5, 0, 0.5])
     assert lamp[4] == 2 and lamp[5] == 1 and abs(lamp[6] - 30.3964) < 1e-4
     assert sc.bbox_max[1] >= 7.0  # the lamp is inside the scene's bounding box
+    p.write_text(xml.replace("beckmann", "ggx"))
+    assert abs(S.load_xml(str(p)).materials[1][4] + 0.05) < 1e-7      # ggx: the row carries -alpha
     with pytest.raises(ValueError):
-        p.write_text(xml.replace("beckmann", "ggx"))
+        p.write_text(xml.replace("beckmann", "phong"))
         S.load_xml(str(p))
 
 
