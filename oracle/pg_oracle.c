@@ -1074,7 +1074,7 @@ void pgo_quantize_v(size_t n, const float *w, uint64_t *lo, int64_t *hi)
 void pgo_acc_to_float_v(size_t n, const uint64_t *lo, const int64_t *hi, float *out)
 {
 	for (size_t i = 0; i < n; ++i) {
-		i128 a = ((i128)hi[i] << 64) | (i128)(u128)lo[i];
+		i128 a = (i128)(((u128)(uint64_t)hi[i] << 64) | (u128)lo[i]); /* (shifting a negative value is undefined) */
 		out[i] = acc_to_float(a);
 	}
 }
