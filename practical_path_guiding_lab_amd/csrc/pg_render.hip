@@ -1128,11 +1128,15 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 // next list with one atomic per workgroup (order inside a workgroup is kept, so neighbouring
 // pixels stay neighbours; the order of workgroups is free -- every lane's result depends on its
 // own state only).
-#ifdef PG_BOUNCE_WAVES // occupancy experiments: make EXTRA=-DPG_BOUNCE_WAVES=5
-#define PG_BOUNCE_ATTR __attribute__((amdgpu_waves_per_eu(PG_BOUNCE_WAVES, PG_BOUNCE_WAVES)))
-#else
-#define PG_BOUNCE_ATTR
+// Waves per SIMD the register allocator aims at.  Levels 0 and 1 are left to the compiler (4 waves
+// at 112-124 VGPRs; 5 or 6 measured no faster).  Level 2 would get 3 waves at 153 VGPRs; held to
+// 5 (about 100 registers, the rest spilled) it is 10 % faster on the torus scene: 2 -> 15.1, 3 ->
+// 11.5, 4 -> 10.9, 5 -> 10.4 ms per pass (make EXTRA=-DPG_BOUNCE_WAVES_L2=n to try others).
+#ifndef PG_BOUNCE_WAVES_L2
+#define PG_BOUNCE_WAVES_L2 5
 #endif
+#define PG_BOUNCE_ATTR(level) \
+	__attribute__((amdgpu_waves_per_eu((level) >= 2 ? PG_BOUNCE_WAVES_L2 : 1, (level) >= 2 ? PG_BOUNCE_WAVES_L2 : 8)))
 
 // The tail of a long path (max_depth 30 in scenes/torus): a launch cannot be shorter than the slowest
 // single path's bounce (0.1-0.3 ms when that is two BVH walks inside a glass case), so a few
@@ -1161,7 +1165,7 @@ __device__ __forceinline__ bool tail_took_over(const RenderArgs &a, int bounce)
 }
 
 template <bool kFirst, int kGeneral>
-__global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR(kGeneral) void k_bounce(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
 	__shared__ uint32_t s_wave[kRBlock / 64];
@@ -1207,7 +1211,7 @@ __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR void k_bounce(RenderArgs a)
 // bounce are added to live_count[] as the per-bounce launches would have, so the splat finds
 // N + sum(live_count) entries and pg_render_live_counts reports the same numbers either way.
 template <int kGeneral>
-__global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR(kGeneral) void k_bounce_tail(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;

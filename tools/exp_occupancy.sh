@@ -14,8 +14,8 @@ EOF
 done
 for w in 5 6; do
 	touch practical_path_guiding_lab_amd/csrc/pg_render.hip
-	make -s -C practical_path_guiding_lab_amd/csrc EXTRA=-DPG_BOUNCE_WAVES=$w > $OUT/make_w$w.log 2>&1
-	python bench.py --cpu-res 0 --steps 10 > $OUT/w$w.json
+	make -s -C practical_path_guiding_lab_amd/csrc EXTRA=-DPG_BOUNCE_WAVES_L2=$w > $OUT/make_w$w.log 2>&1   # level-2 kernels only
+	python bench.py --scene torus --cpu-res 0 --steps 10 > $OUT/w$w.json
 	python - <<EOF
 import json
 d = json.load(open("$OUT/w$w.json"))
