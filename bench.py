@@ -243,7 +243,7 @@ def run_render(args):
             "veach-mis": "built-in scene (scenes/veach-mis/scene.xml parameters: 3 sphere lamps, 4 Beckmann rough-conductor "
                          "plates, diffuse floor and wall)",
             "torus": "built-in scene (scenes/torus/scene.xml parameters; its five meshes, 23614 triangles, from "
-                     "tests/golden/torus_meshes.npz behind a BVH: diffuse donut in a frosted-glass case, aluminium "
+                     "the package data torus_meshes.npz behind a BVH: diffuse donut in a frosted-glass case, aluminium "
                      "brackets, directional light)"}[args.scene]
     roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 5),

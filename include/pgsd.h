@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGSD_ABI_VERSION 1
+#define PGSD_ABI_VERSION 2
 
 typedef struct pg_context pg_context;
 
@@ -235,8 +235,15 @@ int pg_export_accumulators(pg_context *ctx, const pg_tree_sizes *sizes, uint64_t
  *   3 smooth dielectric; 4 roughdielectric, beckmann, sample_visible)  1-3 reflectance |
  *   specular_reflectance  4 alpha (> 0: beckmann; < 0: ggx of roughness -alpha)
  *   5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
- *   11 one-sided flag (0 = wrapped in `twosided`) */
-#define PG_MATERIAL_STRIDE 12
+ *   11 one-sided flag (0 = wrapped in `twosided`)
+ *   12 texture index + 1 (0: none): on triangles with texture coordinates the texture replaces
+ *      words 1-3 (scenes/veach-ajar/scene.xml:29-80: `bitmap` reflectances, a `checkerboard`
+ *      specular_reflectance)  13-15 unused */
+#define PG_MATERIAL_STRIDE 16
+/* texture, 16 32-bit words: 0 kind (1 `bitmap`, bilinear, repeat; 2 `checkerboard`)  1 width  2 height
+ *   3 index of its first texel in `texels`  4-6 color0  7-9 color1 (checkerboard; f32 bit patterns)
+ *   10-11 to_uv scale  12-13 to_uv offset (f32 bit patterns)  14-15 unused */
+#define PG_TEXTURE_STRIDE 16
 /* box (Mitsuba's `cube`: [-1,1]^3 under an affine to_world), intersected as three slabs in its local
  * frame instead of six quads: 0-8 rows of A = (linear part of to_world)^-1, 9-11 centre c
  * (local = A (p - c)), 12-20 outward unit normals of the +x, +y, +z faces (the normalised rows
@@ -290,6 +297,16 @@ typedef struct pg_scene_desc {
 	 * normals).  The shading frame follows the interpolated normal, ray offsets the geometric one
 	 * (Mitsuba's si.sh_frame.n and si.n). */
 	const float *tri_normals;
+	/* optional texture coordinates, 6 floats per triangle (uv0 uv1 uv2) in the order of `tris`, with v
+	 * already flipped as Mitsuba's obj loader does (row 0 of a bitmap is v = 0); the texture table; the
+	 * texels of all bitmaps (8-bit sRGB packed R | G << 8 | B << 16) and the 256 linear values they are
+	 * looked up in (8-bit sRGB -> linear, as Mitsuba converts a JPG texel).  All HOST arrays. */
+	const float *tri_uvs;
+	uint64_t n_textures;
+	const uint32_t *textures; /* PG_TEXTURE_STRIDE words each */
+	uint64_t n_texels;
+	const uint32_t *texels;
+	const float *srgb_lut;    /* 256 floats */
 } pg_scene_desc;
 #define PG_DIRLIGHT_STRIDE 8
 #define PG_TRI_STRIDE 16
@@ -343,6 +360,11 @@ int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, flo
 typedef struct pg_kernel_timing {
 	double bounce_ms, splat_ms, generate_ms, finish_ms, compact_ms;
 	uint64_t bounce_launches, splat_launches, passes;
+	/* mesh scenes run a bounce as five kernels (ray casting, shading before and after the SD-tree
+	 * queries, shadow rays, the SD-tree queries): their shares of bounce_ms; bounce_launches then counts
+	 * bounces.  shade_ms = both shading kernels; tail_ms = the launch that finishes the last paths. */
+	double trace_ms, shade_ms, shadow_ms, guide_ms, tail_ms;
+	uint64_t trace_launches, guide_launches;
 } pg_kernel_timing;
 int pg_enable_kernel_timing(pg_context *ctx, int32_t on);
 int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset);

@@ -7,8 +7,25 @@
 #include "pg_oracle_render.h"
 
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "pgo_math.h"
+
+static int g_threads = 1; /* lanes are traced by this many threads (pgo_set_threads) */
+
+int pgo_set_threads(int n)
+{
+#ifdef _OPENMP
+	if (n <= 0) n = omp_get_num_procs();
+	g_threads = n;
+#else
+	(void)n;
+	g_threads = 1;
+#endif
+	return g_threads;
+}
 
 /* scalar hooks exported by pg_oracle.c */
 uint32_t pgo_i_quadtree_of(const pgo_tree *t, const float p[3], int active);
@@ -225,7 +242,7 @@ static v3 box_face_normal(const float *B, int face)
 }
 
 /* ---- surface description at a hit ---- */
-typedef struct { int type; v3 refl; float alpha; v3 eta, k; int one_sided; } material;
+typedef struct { int type; v3 refl; float alpha; v3 eta, k; int one_sided; int tex; } material;
 typedef struct { v3 p, n, ng; int is_em; v3 radiance; material m; } surface; /* n: shading normal, ng: geometric */
 
 static material load_material(const float *M)
@@ -237,7 +254,50 @@ static material load_material(const float *M)
 	m.eta = ld3(M + 5);
 	m.k = ld3(M + 8);
 	m.one_sided = M[11] != 0.0f;
+	m.tex = (int)M[12];
 	return m;
+}
+
+/* `bitmap` (bilinear, repeat wrap) and `checkerboard` textures after Mitsuba 3's bitmap.cpp /
+ * checkerboard.cpp: uv' = to_uv(uv) (scale and offset); checkerboard: color0 where frac(u') > .5 and
+ * frac(v') > .5 agree, else color1; bitmap: texel centres at (i + .5) / size, the four neighbours
+ * looked up in the sRGB table and blended in linear light, rows first */
+static v3 texture_eval(const pgo_scene *sc, int index, float u, float v)
+{
+	const uint32_t *T = sc->textures + (size_t)index * PGO_TEXTURE_STRIDE;
+	const float uu = pgo_u2f(T[10]) * u + pgo_u2f(T[12]);
+	const float vv = pgo_u2f(T[11]) * v + pgo_u2f(T[13]);
+	if (T[0] == 2u) {
+		const float fu = uu - floorf(uu), fv = vv - floorf(vv);
+		const int mx = fu > 0.5f, my = fv > 0.5f;
+		return mx == my ? V(pgo_u2f(T[4]), pgo_u2f(T[5]), pgo_u2f(T[6])) : V(pgo_u2f(T[7]), pgo_u2f(T[8]), pgo_u2f(T[9]));
+	}
+	const int32_t W = (int32_t)T[1], H = (int32_t)T[2];
+	float x = uu * (float)W - 0.5f, y = vv * (float)H - 0.5f;
+	if (!(fabsf(x) < 1e9f)) x = 0.0f; /* NaN or far outside what an int holds */
+	if (!(fabsf(y) < 1e9f)) y = 0.0f;
+	const float fx = floorf(x), fy = floorf(y);
+	const float wx1 = x - fx, wy1 = y - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+	const int32_t ix = (int32_t)fx, iy = (int32_t)fy;
+	const int32_t ix0 = ((ix % W) + W) % W, ix1 = (((ix + 1) % W) + W) % W;
+	const int32_t iy0 = ((iy % H) + H) % H, iy1 = (((iy + 1) % H) + H) % H;
+	const uint32_t *tx = sc->texels + T[3];
+	const uint32_t t00 = tx[(size_t)iy0 * W + ix0], t10 = tx[(size_t)iy0 * W + ix1];
+	const uint32_t t01 = tx[(size_t)iy1 * W + ix0], t11 = tx[(size_t)iy1 * W + ix1];
+	const float *lut = sc->srgb_lut;
+	float out[3];
+	for (int c = 0; c < 3; ++c) {
+		const float c00 = lut[(t00 >> (8 * c)) & 255u], c10 = lut[(t10 >> (8 * c)) & 255u];
+		const float c01 = lut[(t01 >> (8 * c)) & 255u], c11 = lut[(t11 >> (8 * c)) & 255u];
+		out[c] = (c00 * wx0 + c10 * wx1) * wy0 + (c01 * wx0 + c11 * wx1) * wy1;
+	}
+	return V(out[0], out[1], out[2]);
+}
+
+void pgo_texture_eval(const pgo_scene *sc, int index, float u, float v, float rgb[3])
+{
+	const v3 r = texture_eval(sc, index, u, v);
+	rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
 }
 
 static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
@@ -258,7 +318,10 @@ static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
 		const float *T = sc->tris + ti * PGO_TRI_STRIDE;
 		s.p = vadd(o, vscale(d, t));
 		s.n = ld3(T + 9); /* face normal */
-		if (sc->tri_normals) { /* interpolated vertex normals: the barycentrics of the hit, by the intersection's own formulas */
+		mi = (int)T[12];
+		s.m = load_material(sc->materials + (size_t)mi * PGO_MATERIAL_STRIDE);
+		const int textured = s.m.tex > 0 && sc->tri_uvs;
+		if (sc->tri_normals || textured) { /* the barycentrics of the hit, by the intersection's own formulas */
 			const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
 			const v3 pp = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
 			const float inv_det = 1.0f / dot3(e1, pp);
@@ -266,18 +329,24 @@ static surface surface_at(const pgo_scene *sc, int prim, v3 o, v3 d, float t)
 			const float u = dot3(sv, pp) * inv_det;
 			const v3 qq = V(sv.y * e1.z - sv.z * e1.y, sv.z * e1.x - sv.x * e1.z, sv.x * e1.y - sv.y * e1.x);
 			const float v = dot3(d, qq) * inv_det;
-			const float *Nn = sc->tri_normals + ti * 9;
-			const v3 ns = vadd(vadd(vscale(ld3(Nn), (1.0f - u) - v), vscale(ld3(Nn + 3), u)), vscale(ld3(Nn + 6), v));
-			const float l2 = dot3(ns, ns);
-			if (l2 > 0.0f) {
-				s.ng = s.n;
-				s.n = vdivs(ns, sqrtf(l2));
-				mi = (int)T[12];
-				s.m = load_material(sc->materials + (size_t)mi * PGO_MATERIAL_STRIDE);
-				return s;
+			const float b0 = (1.0f - u) - v;
+			if (sc->tri_normals) { /* interpolated vertex normals */
+				const float *Nn = sc->tri_normals + ti * 9;
+				const v3 ns = vadd(vadd(vscale(ld3(Nn), b0), vscale(ld3(Nn + 3), u)), vscale(ld3(Nn + 6), v));
+				const float l2 = dot3(ns, ns);
+				if (l2 > 0.0f) {
+					s.ng = s.n;
+					s.n = vdivs(ns, sqrtf(l2));
+				}
+			}
+			if (textured) { /* interpolated texture coordinates, then the texture in place of the reflectance */
+				const float *U = sc->tri_uvs + ti * 6;
+				const float tu = (U[0] * b0 + U[2] * u) + U[4] * v;
+				const float tv = (U[1] * b0 + U[3] * u) + U[5] * v;
+				s.m.refl = texture_eval(sc, s.m.tex - 1, tu, tv);
 			}
 		}
-		mi = (int)T[12];
+		return s;
 	} else if ((size_t)prim >= sc->n_quads + sc->n_spheres) {
 		const size_t f = (size_t)prim - sc->n_quads - sc->n_spheres;
 		const float *B = sc->boxes + (f / 6) * PGO_BOX_STRIDE;
@@ -835,6 +904,11 @@ void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_sc
 		r_tr = calloc(3 * S, 4); r_nee = calloc(3 * S, 4); r_dnee = calloc(2 * S, 4); r_wp = calloc(S, 4);
 	}
 	const float aspect_tan_y = cam->tan_half_fov_x / ((float)W / (float)H);
+	/* lanes are independent (every lane has its own sampler stream, record slots and outputs): the
+	 * loop may run on several threads without changing a bit of the result */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+#endif
 	for (size_t lane = 0; lane < N; ++lane) {
 		pgo_pcg32 rng;
 		pgo_pcg32_seed(&rng, prm->seed, (uint32_t)lane);

@@ -35,8 +35,14 @@ extern "C" {
  *  3 smooth dielectric, 4 roughdielectric/beckmann/sample_visible)  1-3 reflectance |
  *  specular_reflectance  4 alpha (> 0: beckmann; < 0: ggx of roughness -alpha)
  *  5-7 eta (dielectrics: 5 = int_ior / ext_ior)  8-10 k
- *  11 one-sided flag (0 = wrapped in `twosided`; dielectrics never are) */
-#define PGO_MATERIAL_STRIDE 12
+ *  11 one-sided flag (0 = wrapped in `twosided`; dielectrics never are)
+ *  12 texture index + 1 that replaces words 1-3 on triangles with texture coordinates (0: none)
+ *  13-15 pad */
+#define PGO_MATERIAL_STRIDE 16
+/* one texture, 16 32-bit words: 0 kind (1 `bitmap`: bilinear, repeat; 2 `checkerboard`)  1 width
+ *  2 height  3 index of its first texel in `texels` (u32)  4-6 color0  7-9 color1 (checkerboard)
+ *  10-11 to_uv scale  12-13 to_uv offset (f32 bit patterns)  14-15 pad */
+#define PGO_TEXTURE_STRIDE 16
 
 /* one box (Mitsuba's `cube` shape, [-1,1]^3 under an affine to_world), intersected as three slabs
  * in its local frame instead of six quads:
@@ -76,6 +82,15 @@ typedef struct pgo_scene {
 	 * normals: the shading frame then follows the interpolated normal, ray offsets keep using the
 	 * geometric one (Mitsuba's si.sh_frame.n vs si.n) */
 	const float *tri_normals;
+	/* optional texture coordinates of the triangles (6 floats each: uv0 uv1 uv2, same order as
+	 * `tris`; v already flipped as Mitsuba's obj loader does), the texture table, the RGBA8 sRGB
+	 * texels of all bitmaps (R in the low byte, row 0 at v = 0) and the 256-entry 8-bit sRGB ->
+	 * linear table the texels are looked up in */
+	const float *tri_uvs;
+	size_t n_textures;
+	const uint32_t *textures; /* PGO_TEXTURE_STRIDE words each */
+	const uint32_t *texels;
+	const float *srgb_lut;    /* 256 floats */
 } pgo_scene;
 #define PGO_DIRLIGHT_STRIDE 8
 #define PGO_TRI_STRIDE 16
@@ -107,6 +122,13 @@ void pgo_render_pass(const pgo_tree *prev, pgo_tree *current, size_t n_quads, co
 void pgo_render_pass_scene(const pgo_tree *prev, pgo_tree *current, const pgo_scene *scene,
                            const pgo_camera *cam, const pgo_render_params *prm, float *L_out,
                            uint8_t *valid_out, float *sumL, float *sumL2);
+
+/* Texture `index` of the scene at (u, v): the reflectance a textured material takes there. */
+void pgo_texture_eval(const pgo_scene *scene, int index, float u, float v, float rgb[3]);
+
+/* Threads the lane loop of pgo_render_pass_scene runs on (OpenMP; results do not depend on it: lanes
+ * are independent and the splat adds integers).  0 = all cores.  Returns the number in effect. */
+int pgo_set_threads(int n);
 
 /* BSDF of material `m` (PGO_MATERIAL_STRIDE floats) in the local frame, for unit tests:
  * eval_pdf -> value (incl. cos theta_o) and pdf; sample -> wo, pdf, weight = value/pdf. */

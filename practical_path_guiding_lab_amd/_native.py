@@ -77,7 +77,8 @@ class pg_scene_desc(C.Structure):
                 ("n_materials", C.c_uint64), ("materials", C.c_void_p), ("n_boxes", C.c_uint64), ("boxes", C.c_void_p),
                 ("n_tris", C.c_uint64), ("tris", C.c_void_p), ("n_bvh_nodes", C.c_uint64), ("bvh", C.c_void_p),
                 ("n_dir_lights", C.c_uint64), ("dir_lights", C.c_void_p), ("bsphere", C.c_float * 4),
-                ("tri_normals", C.c_void_p)]
+                ("tri_normals", C.c_void_p), ("tri_uvs", C.c_void_p), ("n_textures", C.c_uint64), ("textures", C.c_void_p),
+                ("n_texels", C.c_uint64), ("texels", C.c_void_p), ("srgb_lut", C.c_void_p)]
 
 
 class pg_pass_params(C.Structure):
@@ -89,7 +90,9 @@ class pg_kernel_timing(C.Structure):
     _fields_ = [("bounce_ms", C.c_double), ("splat_ms", C.c_double), ("generate_ms", C.c_double),
                 ("finish_ms", C.c_double), ("compact_ms", C.c_double), ("bounce_launches", C.c_uint64),
                 ("splat_launches", C.c_uint64),
-                ("passes", C.c_uint64)]
+                ("passes", C.c_uint64),
+                ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double), ("guide_ms", C.c_double),
+                ("tail_ms", C.c_double), ("trace_launches", C.c_uint64), ("guide_launches", C.c_uint64)]
 
 
 class pg_depth_counters(C.Structure):

@@ -16,879 +16,10 @@
 //
 // Arithmetic mirrors oracle/pg_oracle_render.c operation by operation (fp32, no contraction), so
 // radiance, records and therefore the refined trees are bit-identical to the CPU restatement.
-#include "pg_context.hpp"
-#include "pg_descent.hpp"
-#include "pg_kernels.hpp"
+#include "pg_render_dev.hpp"
 
 namespace pg {
 
-constexpr int kRBlock = 256;
-constexpr float kInvPiF = 0.31830988618379067154f;
-constexpr float kRayEps = 1e-4f;
-constexpr float kShadowEps = 1e-3f;
-constexpr int kQuadStride = 24;
-
-struct v3 {
-	float x, y, z;
-};
-__device__ __forceinline__ v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
-__device__ __forceinline__ v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ v3 vdiv(v3 a, v3 b) { return V(a.x / b.x, a.y / b.y, a.z / b.z); }
-__device__ __forceinline__ float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ v3 ld3(const float *p) { return V(p[0], p[1], p[2]); }
-__device__ __forceinline__ float max3(v3 a) { const float m = a.x > a.y ? a.x : a.y; return m > a.z ? m : a.z; }
-__device__ __forceinline__ float fabs_(float v) { return __builtin_fabsf(v); }
-
-// path_guiding_integrator.py:16-24
-__device__ __forceinline__ float mis_weight(float a, float b)
-{
-	const float a2 = a * a;
-	float r = a > 0.0f ? a2 / (b * b + a2) : 0.0f;
-	if (r != r) r = 0.0f;
-	return r;
-}
-
-struct Frame {
-	v3 s, t, n;
-};
-// Mitsuba coordinate_system(n) (Duff et al. 2017)
-__device__ __forceinline__ Frame make_frame(v3 n)
-{
-	const float sign = (__float_as_uint(n.z) >> 31) ? -1.0f : 1.0f;
-	const float a = -1.0f / (sign + n.z);
-	const float b = (n.x * n.y) * a;
-	Frame f;
-	f.n = n;
-	f.s = V(1.0f + (sign * (n.x * n.x)) * a, sign * b, -sign * n.x);
-	f.t = V(b, sign + (n.y * n.y) * a, -n.y);
-	return f;
-}
-__device__ __forceinline__ v3 to_local(const Frame &f, v3 v) { return V(dot3(v, f.s), dot3(v, f.t), dot3(v, f.n)); }
-__device__ __forceinline__ v3 to_world(const Frame &f, v3 v)
-{
-	return vadd(vadd(vscale(f.s, v.x), vscale(f.t, v.y)), vscale(f.n, v.z));
-}
-
-constexpr float kPiF = 3.14159265358979323846f;
-constexpr float kInvTwoPiF = 0.15915494309189533577f;
-constexpr float kInvSqrtPiF = 0.56418958354775628695f;
-constexpr float kSphereEps = 8.94069671630859375e-05f; // Mitsuba's math::RayEpsilon<float> = 1500 * 2^-24
-constexpr int kSphereStride = 12;                       // PG_SPHERE_STRIDE
-constexpr int kMaterialStride = 12;                     // PG_MATERIAL_STRIDE
-
-__device__ __forceinline__ float safe_sqrtf(float v) { return __builtin_sqrtf(v > 0.0f ? v : 0.0f); }
-__device__ __forceinline__ v3 normalize3(v3 v) { return vdivs(v, __builtin_sqrtf(dot3(v, v))); }
-
-constexpr int kBoxStride = 32; // PG_BOX_STRIDE
-
-// The shapes of a scene: quads, then spheres, then box faces (shape number = quad index,
-// n_quads + sphere index, or n_quads + n_spheres + 6 box + 2 axis + (outward normal negative))
-// ... then the triangles of the meshes, in BVH leaf order (general scenes only)
-constexpr int kTriStride = 16; // PG_TRI_STRIDE
-constexpr int kBvhStride = 32; // PG_BVH_STRIDE
-struct Shapes {
-	const float *quads, *spheres, *boxes, *tris;
-	const float *tri_normals; // 9 per triangle, or nullptr (face normals)
-	const uint32_t *bvh;
-	int n_quads, n_spheres, n_boxes, n_bvh_nodes;
-};
-
-__device__ __forceinline__ v3 box_face_normal(const float *B, int face)
-{
-	const v3 n = ld3(B + 12 + 3 * (face >> 1));
-	return (face & 1) ? V(-n.x, -n.y, -n.z) : n;
-}
-
-// closest hit over all shapes, 0 < t < tmax (scene.ray_intersect / ray_test).  kGeneral is the
-// feature level the kernel is compiled for: 0 = quads and boxes with twosided diffuse BSDFs
-// (cornell-box), 1 = + spheres and rough conductors (veach-mis), 2 = + triangle meshes, delta
-// lobes, one-sided BSDFs, directional lights and the running index of refraction (torus-class
-// scenes).  What a level does not need is compiled out.
-// Does the ray reach the box [lo, hi] before bt?  tmin = where it enters (>= 0).  Slab test padded
-// as Ize 2013.  The plane a ray meets first on an axis is known from the sign of its direction
-// (neg: sign bits of d, once per ray), and fmaxf/fminf (v_max3/v_min3: a NaN operand -- 0 * inf, the
-// ray lies in a face's plane -- is ignored, which keeps the test conservative) fold the three axes.
-__device__ __forceinline__ bool bvh_box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 o,
-                                            v3 inv, bool negx, bool negy, bool negz, float bt, float &tmin_out)
-{
-	const float nx = ((negx ? hix : lox) - o.x) * inv.x, fx = ((negx ? lox : hix) - o.x) * inv.x;
-	const float ny = ((negy ? hiy : loy) - o.y) * inv.y, fy = ((negy ? loy : hiy) - o.y) * inv.y;
-	const float nz = ((negz ? hiz : loz) - o.z) * inv.z, fz = ((negz ? loz : hiz) - o.z) * inv.z;
-	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
-	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), bt);
-	tmin_out = tmin;
-	return tmin <= tmax * 1.0000004f;
-}
-
-__device__ __forceinline__ void bvh_cswap(float &ta, uint32_t &ra, float &tb, uint32_t &rb)
-{
-	if (ta > tb) {
-		const float t = ta; ta = tb; tb = t;
-		const uint32_t r = ra; ra = rb; rb = r;
-	}
-}
-
-// kAny: the caller asks whether anything is hit (shadow rays): the BVH walk stops at its first
-// triangle.  The answer is that of the closest-hit walk, which visits the same nodes until then.
-template <int kGeneral, bool kAny = false>
-__device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out)
-{
-	const int nq = sh.n_quads;
-	const float *__restrict__ quads = sh.quads;
-	int best = -1;
-	float bt = tmax;
-	for (int q = 0; q < nq; ++q) {
-		const float *Q = quads + q * kQuadStride;
-		const v3 n = ld3(Q + 9);
-		const float denom = dot3(n, d);
-		if (denom == 0.0f) continue;
-		const float num = dot3(n, vsub(ld3(Q), o));
-		// IEEE division keeps the sign: when the signs differ t is not > 0 and the (correctly rounded,
-		// hence long) division can be skipped without changing any result
-		if ((__float_as_uint(num) ^ __float_as_uint(denom)) >> 31) continue;
-		const float t = num / denom;
-		if (!(t > 0.0f && t < bt)) continue;
-		const v3 w = vsub(vadd(o, vscale(d, t)), ld3(Q));
-		const float u = dot3(w, ld3(Q + 3)) * Q[12];
-		const float v = dot3(w, ld3(Q + 6)) * Q[13];
-		if (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) { bt = t; best = q; }
-	}
-	if (kGeneral) { // spheres: the quadratic in double precision, as Mitsuba's Sphere::ray_intersect_preliminary
-		for (int s = 0; s < sh.n_spheres; ++s) {
-			const float *S = sh.spheres + s * kSphereStride;
-			const double ox = (double)o.x - (double)S[0], oy = (double)o.y - (double)S[1], oz = (double)o.z - (double)S[2];
-			const double dx = (double)d.x, dy = (double)d.y, dz = (double)d.z, r = (double)S[3];
-			const double A = (dx * dx + dy * dy) + dz * dz;
-			const double B = 2.0 * ((ox * dx + oy * dy) + oz * dz);
-			const double C = ((ox * ox + oy * oy) + oz * oz) - r * r;
-			const double disc = B * B - (4.0 * A) * C;
-			if (!(disc >= 0.0) || A == 0.0) continue;
-			const double root = __builtin_sqrt(disc);
-			const double temp = -0.5 * (B + (B < 0.0 ? -root : root)); // the cancellation-free root first
-			double x0 = temp / A, x1 = temp != 0.0 ? C / temp : x0;
-			if (x0 > x1) { const double tt = x0; x0 = x1; x1 = tt; }
-			const float t = (float)(x0 > 0.0 ? x0 : x1);
-			if (t > 0.0f && t < bt) { bt = t; best = nq + s; }
-		}
-	}
-	// boxes (Mitsuba `cube` shapes): three slabs in the box's local frame, one reciprocal per axis,
-	// instead of six quad tests (t is the same in both frames: the map is linear)
-	for (int b = 0; b < sh.n_boxes; ++b) {
-		const float *B = sh.boxes + b * kBoxStride;
-		const v3 oc = vsub(o, ld3(B + 9));
-		const float ol[3] = {dot3(ld3(B), oc), dot3(ld3(B + 3), oc), dot3(ld3(B + 6), oc)};
-		const float dl[3] = {dot3(ld3(B), d), dot3(ld3(B + 3), d), dot3(ld3(B + 6), d)};
-		float tn = -__builtin_huge_valf(), tf = __builtin_huge_valf();
-		int an = 0, af = 0;
-		bool miss = false;
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			if (dl[k] == 0.0f) { // parallel to this slab: inside it or never
-				if (!(ol[k] >= -1.0f && ol[k] <= 1.0f)) miss = true;
-				continue;
-			}
-			const float inv = 1.0f / dl[k];
-			const float t1 = (-1.0f - ol[k]) * inv, t2 = (1.0f - ol[k]) * inv;
-			const float lo = dl[k] > 0.0f ? t1 : t2, hi = dl[k] > 0.0f ? t2 : t1;
-			if (lo > tn) { tn = lo; an = k; }
-			if (hi < tf) { tf = hi; af = k; }
-		}
-		if (miss || !(tn <= tf)) continue;
-		const bool entering = tn > 0.0f;
-		const float t = entering ? tn : tf;
-		if (!(t > 0.0f && t < bt)) continue;
-		const int axis = entering ? an : af;
-		const float da = axis == 0 ? dl[0] : (axis == 1 ? dl[1] : dl[2]);
-		const int negative = entering ? (da > 0.0f) : (da < 0.0f);
-		bt = t;
-		best = nq + sh.n_spheres + 6 * b + 2 * axis + negative;
-	}
-	// triangle meshes: the four-wide BVH.  One 128-byte node holds the boxes of its (up to four)
-	// children: they are tested together and ordered by where the ray enters them (a fixed
-	// five-comparator network), the walk goes on in the nearest -- a leaf's triangles are named by the
-	// reference itself, no node is read for it -- and the others wait on the stack with their entry
-	// distance, farthest at the bottom, to be dropped when popped if the ray has become shorter than
-	// that.  Half the dependent round trips of a binary tree: the walk is latency-bound.  The oracle
-	// visits the same nodes in the same order, so the first of several equally near triangles is the
-	// same one in both.
-	if (kGeneral >= 2 && sh.n_bvh_nodes && !(kAny && best >= 0)) {
-		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
-		const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-		const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
-		const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(sh.bvh);
-		// pg_scene_set_ex has checked the tree: children follow their parent, and no root-to-node path
-		// can leave more than 64 siblings waiting, so the walk opens every node at most once and the
-		// stack cannot overflow; the budget is a second fence
-		constexpr uint32_t kNone = 0xffffffffu;
-		const float kInf = __builtin_huge_valf();
-		uint32_t st_ref[64];
-		float st_t[64];
-		int sp = 0;
-		int budget = 8 * sh.n_bvh_nodes + 8;
-		uint32_t next = 0; // the root
-		while (true) {
-			while (!(next & 0x80000000u) && budget > 0) { // a node: test its children, go on in the nearest
-				const uint4 *N = nodes + 8 * (size_t)next;
-				const uint4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], rf = N[6];
-				uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
-				float t0, t1, t2, t3;
-#define PG_F(v) __uint_as_float(v)
-				if (!(r0 != kNone && bvh_box_hit(PG_F(lx.x), PG_F(ly.x), PG_F(lz.x), PG_F(hx.x), PG_F(hy.x), PG_F(hz.x), o, inv, ngx, ngy, ngz, bt, t0))) { r0 = kNone; t0 = kInf; }
-				if (!(r1 != kNone && bvh_box_hit(PG_F(lx.y), PG_F(ly.y), PG_F(lz.y), PG_F(hx.y), PG_F(hy.y), PG_F(hz.y), o, inv, ngx, ngy, ngz, bt, t1))) { r1 = kNone; t1 = kInf; }
-				if (!(r2 != kNone && bvh_box_hit(PG_F(lx.z), PG_F(ly.z), PG_F(lz.z), PG_F(hx.z), PG_F(hy.z), PG_F(hz.z), o, inv, ngx, ngy, ngz, bt, t2))) { r2 = kNone; t2 = kInf; }
-				if (!(r3 != kNone && bvh_box_hit(PG_F(lx.w), PG_F(ly.w), PG_F(lz.w), PG_F(hx.w), PG_F(hy.w), PG_F(hz.w), o, inv, ngx, ngy, ngz, bt, t3))) { r3 = kNone; t3 = kInf; }
-#undef PG_F
-				bvh_cswap(t0, r0, t1, r1);
-				bvh_cswap(t2, r2, t3, r3);
-				bvh_cswap(t0, r0, t2, r2);
-				bvh_cswap(t1, r1, t3, r3);
-				bvh_cswap(t1, r1, t2, r2);
-				if (r3 != kNone) { st_ref[sp] = r3; st_t[sp] = t3; ++sp; }
-				if (r2 != kNone) { st_ref[sp] = r2; st_t[sp] = t2; ++sp; }
-				if (r1 != kNone) { st_ref[sp] = r1; st_t[sp] = t1; ++sp; }
-				next = r0;
-				--budget;
-			}
-			if (next != kNone && (next & 0x80000000u)) { // a leaf
-				const uint32_t first = next & 0x0fffffffu, count = ((next >> 28) & 7u) + 1u;
-				for (uint32_t i = first; i < first + count; ++i) {
-					const float *T = sh.tris + (size_t)i * kTriStride;
-					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
-					const v3 p = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
-					const float det = dot3(e1, p);
-					if (det == 0.0f) continue;
-					const float inv_det = 1.0f / det;
-					const v3 s = vsub(o, ld3(T));
-					const float u = dot3(s, p) * inv_det;
-					if (!(u >= 0.0f && u <= 1.0f)) continue;
-					const v3 q = V(s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x);
-					const float v = dot3(d, q) * inv_det;
-					if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-					const float t = dot3(e2, q) * inv_det;
-					if (t > 0.0f && t < bt) { bt = t; best = tri_base + (int)i; }
-				}
-				if (kAny && best >= 0) break; // a shadow ray needs one occluder, not the nearest
-			}
-			next = kNone;
-			while (sp && next == kNone && budget > 0) { // the nearest waiting child the (now shorter) ray still reaches
-				--sp;
-				if (st_t[sp] <= bt * 1.0000004f) next = st_ref[sp];
-				--budget;
-			}
-			if (next == kNone) break;
-		}
-	}
-	t_out = bt;
-	return best;
-}
-
-// ---- surface description at a hit ----
-struct Material {
-	int type;        // 0 diffuse, 1 roughconductor (Beckmann, visible normals), 2 smooth conductor, 3 smooth dielectric, 4 roughdielectric
-	v3 refl;         // reflectance | specular_reflectance
-	const float *M;  // the material row: alpha, eta, k are read where the BSDF needs them
-	bool one_sided;  // not wrapped in `twosided` (row word 11)
-};
-struct Surface {
-	v3 p, n, radiance; // n: the normal of the shading frame
-	v3 ng;             // geometric normal (ray offsets); differs from n on smooth-shaded triangles only
-	bool is_em;
-	Material m;
-};
-
-template <int kGeneral>
-__device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mats, int prim, v3 o, v3 d, float t)
-{
-	Surface s;
-	const float *M;
-	if (kGeneral >= 2 && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes) { // a mesh triangle (face normals)
-		const size_t ti = (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes);
-		const float *T = sh.tris + ti * kTriStride;
-		s.p = vadd(o, vscale(d, t));
-		s.n = ld3(T + 9);
-		s.ng = s.n;
-		if (sh.tri_normals) { // interpolated vertex normals: the barycentrics of the hit, by the intersection's own formulas
-			const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
-			const v3 pp = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
-			const float inv_det = 1.0f / dot3(e1, pp);
-			const v3 sv = vsub(o, ld3(T));
-			const float u = dot3(sv, pp) * inv_det;
-			const v3 qq = V(sv.y * e1.z - sv.z * e1.y, sv.z * e1.x - sv.x * e1.z, sv.x * e1.y - sv.y * e1.x);
-			const float v = dot3(d, qq) * inv_det;
-			const float *Nn = sh.tri_normals + ti * 9;
-			const v3 ns = vadd(vadd(vscale(ld3(Nn), (1.0f - u) - v), vscale(ld3(Nn + 3), u)), vscale(ld3(Nn + 6), v));
-			const float l2 = dot3(ns, ns);
-			if (l2 > 0.0f) s.n = vdivs(ns, __builtin_sqrtf(l2));
-		}
-		s.is_em = false;
-		s.radiance = V(0, 0, 0);
-		M = mats + (int)T[12] * kMaterialStride;
-	} else if (prim >= sh.n_quads + sh.n_spheres) { // a box face
-		const int f = prim - sh.n_quads - sh.n_spheres;
-		const float *B = sh.boxes + (f / 6) * kBoxStride;
-		s.p = vadd(o, vscale(d, t));
-		s.n = box_face_normal(B, f % 6);
-		s.ng = s.n;
-		s.is_em = false;
-		s.radiance = V(0, 0, 0);
-		M = mats + (int)B[21] * kMaterialStride;
-	} else if (!kGeneral || prim < sh.n_quads) {
-		const float *Q = sh.quads + prim * kQuadStride;
-		s.p = vadd(o, vscale(d, t));
-		s.n = ld3(Q + 9);
-		s.ng = s.n;
-		s.is_em = Q[15] != 0.0f;
-		s.radiance = ld3(Q + 19);
-		if (!kGeneral) { // all-diffuse quad scene: the reflectance sits in the quad itself (pg_scene_set keeps it there)
-			s.m.type = 0;
-			s.m.refl = ld3(Q + 16);
-			s.m.M = nullptr;
-			s.m.one_sided = false;
-			return s;
-		}
-		M = mats + (int)Q[22] * kMaterialStride;
-	} else {
-		const float *S = sh.spheres + (prim - sh.n_quads) * kSphereStride;
-		const v3 c = ld3(S);
-		// sphere.h: n = normalize(ray(t) - c), p = c + n r; the normal is then taken again from the
-		// re-projected point so that it is a function of p alone (the next bounce recomputes it)
-		const v3 n0 = normalize3(vsub(vadd(o, vscale(d, t)), c));
-		s.p = vadd(c, vscale(n0, S[3]));
-		s.n = normalize3(vsub(s.p, c));
-		s.ng = s.n;
-		s.is_em = S[5] != 0.0f;
-		s.radiance = ld3(S + 6);
-		M = mats + (int)S[4] * kMaterialStride;
-	}
-	s.m.type = kGeneral ? (int)M[0] : 0; // a scene with anything but twosided diffuse runs the general kernels
-	s.m.one_sided = kGeneral >= 2 && M[11] != 0.0f;
-	s.m.refl = ld3(M + 1);
-	s.m.M = M;
-	return s;
-}
-
-// normal of shape `prim` at the surface point p (quads: constant; spheres: as surface_at defines it)
-template <int kGeneral>
-__device__ __forceinline__ v3 normal_at(const Shapes &sh, int prim, v3 p)
-{
-	if (kGeneral >= 2 && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes)
-		return ld3(sh.tris + (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes) * kTriStride + 9);
-	if (prim >= sh.n_quads + sh.n_spheres) {
-		const int f = prim - sh.n_quads - sh.n_spheres;
-		return box_face_normal(sh.boxes + (f / 6) * kBoxStride, f % 6);
-	}
-	if (!kGeneral || prim < sh.n_quads) return ld3(sh.quads + prim * kQuadStride + 9);
-	return normalize3(vsub(p, ld3(sh.spheres + (prim - sh.n_quads) * kSphereStride)));
-}
-
-// scene.pdf_emitter_direction(prev, ds) for a hit on emitter shape `prim` at p (normal n) seen from
-// `ref`, times the 1/count of the uniform emitter choice
-template <int kGeneral>
-__device__ __forceinline__ float emitter_hit_pdf(const Shapes &sh, int prim, v3 ref, v3 p, v3 n, float inv_count)
-{
-	const v3 dd = vsub(p, ref);
-	const float d2 = dot3(dd, dd), dist = __builtin_sqrtf(d2);
-	const v3 dn = vdivs(dd, dist);
-	const float dp = dot3(dn, n);
-	if (!(dp < 0.0f)) return 0.0f;
-	float pdf;
-	if (!kGeneral || prim < sh.n_quads) {
-		pdf = d2 / (fabs_(dp) * sh.quads[prim * kQuadStride + 14]);
-	} else { // Sphere::pdf_direction
-		const float *S = sh.spheres + (prim - sh.n_quads) * kSphereStride;
-		const v3 cv = vsub(ld3(S), ref);
-		const float sin_alpha = S[3] / __builtin_sqrtf(dot3(cv, cv));
-		const float cos_alpha = safe_sqrtf(1.0f - sin_alpha * sin_alpha);
-		if (sin_alpha < 0.99999994f) pdf = kInvTwoPiF / (1.0f - cos_alpha);
-		else pdf = (d2 / fabs_(dp)) / ((4.0f * kPiF) * (S[3] * S[3]));
-	}
-	return pdf * inv_count;
-}
-
-// Mitsuba warp::square_to_uniform_disk_concentric
-__device__ __forceinline__ void square_to_disk(float u, float v, float &px, float &py)
-{
-	const float x = 2.0f * u - 1.0f, y = 2.0f * v - 1.0f;
-	const bool is_zero = (x == 0.0f) && (y == 0.0f);
-	const bool q13 = fabs_(x) < fabs_(y);
-	const float r = q13 ? y : x, rp = q13 ? x : y;
-	float phi = (0.25f * 3.14159265358979323846f) * (rp / r);
-	if (q13) phi = (0.5f * 3.14159265358979323846f) - phi;
-	if (is_zero) phi = 0.0f;
-	float s, c;
-	sincos_f32(phi, s, c);
-	px = r * c;
-	py = r * s;
-}
-
-// Mitsuba warp::square_to_cosine_hemisphere (concentric disk)
-__device__ __forceinline__ v3 square_to_cosine_hemisphere(float u, float v)
-{
-	float px, py;
-	square_to_disk(u, v, px, py);
-	const float zz = 1.0f - (px * px + py * py);
-	float z = zz > 0.0f ? __builtin_sqrtf(zz) : 0.0f;
-	if (z == 0.0f) z = 1e-10f;
-	return V(px, py, z);
-}
-
-// ---- roughconductor (Beckmann, isotropic, sample_visible) after Mitsuba 3's microfacet.h /
-// roughconductor.cpp; local frame, cos(theta_i) > 0.  Not inlined: the diffuse-only kernel never
-// references them, and the general kernel calls them from two places each.
-// The sign of `alpha` names the distribution: > 0 Beckmann, < 0 GGX of roughness -alpha.
-__device__ __noinline__ float rc_D(v3 m, float alpha) // MicrofacetDistribution::eval
-{
-	const float ct = m.z, ct2 = ct * ct;
-	const float a = fabs_(alpha);
-	const float ax = m.x / a, ay = m.y / a;
-	float result;
-	if (alpha < 0.0f) {
-		const float t = (ax * ax + ay * ay) + ct2;
-		result = 1.0f / (((kPiF * a) * a) * (t * t));
-	} else {
-		result = exp_f32(-((ax * ax + ay * ay) / ct2)) / (((kPiF * a) * a) * (ct2 * ct2));
-	}
-	return result * ct > 1e-20f ? result : 0.0f;
-}
-
-__device__ __forceinline__ float rc_G1(v3 v, v3 m, float alpha) // smith_g1: exact for GGX, rational approximation for Beckmann
-{
-	const float ax = alpha * v.x, ay = alpha * v.y;
-	const float xy = ax * ax + ay * ay;
-	const float a = 1.0f / __builtin_sqrtf(xy / (v.z * v.z));
-	const float a2 = a * a;
-	float result = a >= 1.6f ? 1.0f : (3.535f * a + 2.181f * a2) / ((1.0f + 2.276f * a) + 2.577f * a2);
-	if (alpha < 0.0f) result = 2.0f / (1.0f + __builtin_sqrtf(1.0f + xy / (v.z * v.z)));
-	if (xy == 0.0f) result = 1.0f;
-	if (dot3(v, m) * v.z <= 0.0f) result = 0.0f;
-	return result;
-}
-
-__device__ __forceinline__ float fresnel_conductor(float cos_i, float eta_r, float eta_i)
-{
-	const float c2 = cos_i * cos_i, s2 = 1.0f - c2, s4 = s2 * s2;
-	const float temp_1 = (eta_r * eta_r - eta_i * eta_i) - s2;
-	const float a2pb2 = safe_sqrtf(temp_1 * temp_1 + ((4.0f * eta_i) * eta_i) * (eta_r * eta_r));
-	const float a = safe_sqrtf(0.5f * (a2pb2 + temp_1));
-	const float term_1 = a2pb2 + c2, term_2 = (2.0f * cos_i) * a;
-	const float r_s = (term_1 - term_2) / (term_1 + term_2);
-	const float term_3 = a2pb2 * c2 + s4, term_4 = term_2 * s2;
-	const float r_p = r_s * ((term_3 - term_4) / (term_3 + term_4));
-	return 0.5f * (r_s + r_p);
-}
-
-__device__ __forceinline__ v3 rc_fresnel(const float *M, float cos_i)
-{
-	return V(fresnel_conductor(cos_i, M[5], M[8]), fresnel_conductor(cos_i, M[6], M[9]), fresnel_conductor(cos_i, M[7], M[10]));
-}
-
-__device__ __noinline__ float erfinv_call(float x) { return erfinv_f32(x); }
-
-// sample_visible_11: slopes of the visible Beckmann normals for alpha = 1
-__device__ __noinline__ void rc_sample_visible_11(float cos_i, float u1, float u2, float &sx, float &sy)
-{
-	const float tan_i = safe_sqrtf(1.0f - cos_i * cos_i) / cos_i;
-	const float cot_i = 1.0f / tan_i;
-	const float maxval = erf_f32(cot_i);
-	u1 = u1 < 1.0f - 1e-6f ? u1 : 1.0f - 1e-6f; u1 = u1 > 1e-6f ? u1 : 1e-6f;
-	u2 = u2 < 1.0f - 1e-6f ? u2 : 1.0f - 1e-6f; u2 = u2 > 1e-6f ? u2 : 1e-6f;
-	float x = maxval - (maxval + 1.0f) * erf_f32(__builtin_sqrtf(-log_f32(u1)));
-	const float tail = tan_i == 0.0f ? 0.0f : (kInvSqrtPiF * tan_i) * exp_f32(-(cot_i * cot_i));
-	u1 = u1 * ((1.0f + maxval) + tail);
-	for (int i = 0; i < 3; ++i) {
-		const float slope = erfinv_call(x);
-		const float value = ((1.0f + x) + (kInvSqrtPiF * tan_i) * exp_f32(-(slope * slope))) - u1;
-		const float derivative = 1.0f - slope * tan_i;
-		x = x - value / derivative;
-	}
-	sx = erfinv_call(x);
-	sy = erfinv_call(2.0f * u2 - 1.0f);
-}
-
-// sample_visible_11 for GGX: a point of the unit disk, its half towards the viewer compressed by
-// (1 + cos theta_i)/2, projected onto the hemisphere around the viewing direction, as slopes
-__device__ __noinline__ void ggx_sample_visible_11(float cos_i, float u1, float u2, float &sx, float &sy)
-{
-	float px, py;
-	square_to_disk(u1, u2, px, py);
-	const float s = 0.5f * (1.0f + cos_i);
-	const float h = safe_sqrtf(1.0f - px * px);
-	py = h * (1.0f - s) + py * s;
-	const float z = safe_sqrtf(1.0f - (px * px + py * py));
-	const float sin_i = safe_sqrtf(1.0f - cos_i * cos_i);
-	const float norm = 1.0f / (sin_i * py + cos_i * z);
-	sx = (cos_i * py - sin_i * z) * norm;
-	sy = px * norm;
-}
-
-// MicrofacetDistribution::sample (visible normals): microfacet normal and its density
-__device__ __forceinline__ v3 rc_sample_m(v3 wi, float signed_alpha, float u1, float u2, float &pdf)
-{
-	const float alpha = fabs_(signed_alpha);
-	const v3 wip = normalize3(V(alpha * wi.x, alpha * wi.y, wi.z));
-	const float s2 = wip.x * wip.x + wip.y * wip.y; // Frame::sincos_phi
-	float cos_phi = 1.0f, sin_phi = 0.0f;
-	if (fabs_(s2) > 4.0f * 5.9604644775390625e-08f) {
-		const float inv = 1.0f / __builtin_sqrtf(s2);
-		cos_phi = wip.x * inv; sin_phi = wip.y * inv;
-		cos_phi = cos_phi < -1.0f ? -1.0f : (cos_phi > 1.0f ? 1.0f : cos_phi);
-		sin_phi = sin_phi < -1.0f ? -1.0f : (sin_phi > 1.0f ? 1.0f : sin_phi);
-	}
-	float sx, sy;
-	if (signed_alpha < 0.0f) ggx_sample_visible_11(wip.z, u1, u2, sx, sy);
-	else rc_sample_visible_11(wip.z, u1, u2, sx, sy);
-	const float rx = (cos_phi * sx - sin_phi * sy) * alpha;
-	const float ry = (sin_phi * sx + cos_phi * sy) * alpha;
-	const v3 m = normalize3(V(-rx, -ry, 1.0f));
-	pdf = ((rc_D(m, signed_alpha) * rc_G1(wi, m, signed_alpha)) * fabs_(dot3(wi, m))) / wi.z;
-	return m;
-}
-
-__device__ __forceinline__ void rc_eval_pdf(const Material &mt, v3 wi, v3 wo, v3 &value, float &pdf) // wi.z > 0
-{
-	value = V(0, 0, 0);
-	pdf = 0.0f;
-	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
-	const float alpha = mt.M[4];
-	const v3 H = normalize3(vadd(wo, wi));
-	const float D = rc_D(H, alpha);
-	if (D == 0.0f) return;
-	const float g_i = rc_G1(wi, H, alpha);
-	const float res = (D * (g_i * rc_G1(wo, H, alpha))) / (4.0f * wi.z);
-	const v3 F = rc_fresnel(mt.M, dot3(wi, H));
-	value = vmul(F, vscale(mt.refl, res));
-	if (dot3(wi, H) > 0.0f && dot3(wo, H) > 0.0f) pdf = (D * g_i) / (4.0f * wi.z);
-}
-
-__device__ __forceinline__ void rc_sample(const Material &mt, v3 wi, float u1, float u2, v3 &wo, float &pdf, v3 &weight) // wi.z > 0
-{
-	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0);
-	const float alpha = mt.M[4];
-	float pdf_m;
-	const v3 m = rc_sample_m(wi, alpha, u1, u2, pdf_m);
-	const float wim = dot3(wi, m);
-	const v3 o = vsub(vscale(m, 2.0f * wim), wi); // reflect(wi, m)
-	if (!(pdf_m != 0.0f && o.z > 0.0f)) return;
-	const float p = pdf_m / (4.0f * dot3(o, m));
-	const v3 F = rc_fresnel(mt.M, wim);
-	wo = o;
-	pdf = p;
-	weight = vmul(F, vscale(mt.refl, rc_G1(o, m, alpha)));
-}
-
-// Mitsuba fresnel(cos_theta_i, eta): unpolarised reflectance of a dielectric interface, the signed
-// cosine of the transmitted direction, the relative index along / against the ray
-__device__ __forceinline__ float fresnel_dielectric(float cos_i, float eta, float &cos_t, float &eta_it, float &eta_ti)
-{
-	const bool outside = cos_i >= 0.0f;
-	const float rcp_eta = 1.0f / eta;
-	eta_it = outside ? eta : rcp_eta;
-	eta_ti = outside ? rcp_eta : eta;
-	const float cos_t_sqr = 1.0f - ((1.0f - cos_i * cos_i) * (eta_ti * eta_ti));
-	const float ci = fabs_(cos_i), ct = safe_sqrtf(cos_t_sqr);
-	const float a_s = (eta_it * ct - ci) / (eta_it * ct + ci);
-	const float a_p = (eta_it * ci - ct) / (eta_it * ci + ct);
-	float r = 0.5f * (a_s * a_s + a_p * a_p);
-	if (eta == 1.0f) r = 0.0f;
-	else if (ci == 0.0f) r = 1.0f;
-	cos_t = cos_i >= 0.0f ? -ct : ct;
-	return r;
-}
-
-// ---- roughdielectric (Beckmann, isotropic, sample_visible) after Mitsuba 3's roughdielectric.cpp:
-// reflection and transmission through a rough interface, radiance transport; wi on either side,
-// M[4] = alpha, M[5] = int_ior / ext_ior.  Out of line: only scenes with such a material get here.
-__device__ __forceinline__ v3 vflip_if(v3 v, bool c) { return c ? V(-v.x, -v.y, -v.z) : v; }
-
-__device__ __noinline__ void rd_eval_pdf(const float *M, v3 wi, v3 wo, v3 &value, float &pdf)
-{
-	value = V(0, 0, 0);
-	pdf = 0.0f;
-	const float alpha = M[4], eta_m = M[5];
-	const float ci = wi.z, co = wo.z;
-	if (ci == 0.0f) return;
-	const bool reflect = ci * co > 0.0f;
-	const float eta = ci > 0.0f ? eta_m : 1.0f / eta_m, inv_eta = ci > 0.0f ? 1.0f / eta_m : eta_m;
-	v3 m = normalize3(vadd(wi, vscale(wo, reflect ? 1.0f : eta)));
-	m = vflip_if(m, m.z < 0.0f); // into the hemisphere of the macro-surface normal
-	const float D = rc_D(m, alpha);
-	float cos_t, eta_it, eta_ti;
-	const float wim = dot3(wi, m), wom = dot3(wo, m);
-	const float F = fresnel_dielectric(wim, eta_m, cos_t, eta_it, eta_ti);
-	const float G = rc_G1(wi, m, alpha) * rc_G1(wo, m, alpha);
-	const float denom = wim + eta * wom;
-	float val;
-	if (reflect) val = ((F * D) * G) / (4.0f * fabs_(ci));
-	else val = fabs_(((((((inv_eta * inv_eta) * (1.0f - F)) * D) * G) * (eta * eta)) * (wim * wom)) / (ci * (denom * denom)));
-	if (!(val == val)) val = 0.0f;
-	value = V(val, val, val);
-	if (!(wim * ci > 0.0f && wom * co > 0.0f)) return; // the micro- and macro-surface must agree on the sides
-	const float dwh_dwo = reflect ? 1.0f / (4.0f * wom) : ((eta * eta) * wom) / (denom * denom);
-	const v3 wiu = vflip_if(wi, ci < 0.0f);
-	float prob = ((D * rc_G1(wiu, m, alpha)) * fabs_(dot3(wiu, m))) / wiu.z;
-	prob = prob * (reflect ? F : 1.0f - F);
-	float p = prob * fabs_(dwh_dwo);
-	if (!(p == p)) p = 0.0f;
-	pdf = p;
-}
-
-__device__ __noinline__ void rd_sample(const float *M, v3 wi, float u1, float u, float v, v3 &wo, float &pdf, v3 &weight, float &eta_out)
-{
-	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta_out = 0.0f;
-	const float alpha = M[4], eta_m = M[5];
-	const float ci = wi.z;
-	if (ci == 0.0f) return;
-	float pdf_m;
-	const v3 m = rc_sample_m(vflip_if(wi, ci < 0.0f), alpha, u, v, pdf_m);
-	if (!(pdf_m != 0.0f)) return;
-	float cos_t, eta_it, eta_ti;
-	const float wim = dot3(wi, m);
-	const float F = fresnel_dielectric(wim, eta_m, cos_t, eta_it, eta_ti);
-	const bool reflect = u1 <= F;
-	float p = pdf_m * (reflect ? F : 1.0f - F);
-	v3 o;
-	float w = 1.0f, dwh_dwo, e;
-	if (reflect) {
-		o = vsub(vscale(m, 2.0f * wim), wi);
-		dwh_dwo = 1.0f / (4.0f * dot3(o, m));
-		e = 1.0f;
-	} else {
-		o = vsub(vscale(m, wim * eta_ti + cos_t), vscale(wi, eta_ti)); // refract(wi, m, cos_theta_t, eta_ti)
-		w = eta_ti * eta_ti;
-		const float om = dot3(o, m), denom = wim + eta_it * om;
-		dwh_dwo = ((eta_it * eta_it) * om) / (denom * denom);
-		e = eta_it;
-	}
-	eta_out = e;
-	w = w * rc_G1(o, m, alpha);
-	p = p * fabs_(dwh_dwo);
-	if (!(p == p) || !(w == w)) return;
-	wo = o;
-	pdf = p;
-	weight = V(w, w, w);
-}
-
-// BSDFFlags.Smooth (:210): does the material have a non-delta lobe?
-__device__ __forceinline__ bool material_is_smooth(const Material &mt) { return mt.type != 2 && mt.type != 3; }
-
-// bsdf.eval_pdf (twosided unless the material says otherwise): value includes cos(theta_o)
-template <int kGeneral>
-__device__ __forceinline__ void bsdf_eval_pdf(const Material &mt, v3 wi, v3 wo, bool active, v3 &value, float &pdf)
-{
-	value = V(0, 0, 0);
-	pdf = 0.0f;
-	if (!active) return;
-	if (kGeneral >= 2 && (mt.type == 2 || mt.type == 3)) return; // smooth conductor / dielectric: delta lobes only
-	if (kGeneral >= 2 && mt.type == 4) {
-		rd_eval_pdf(mt.M, wi, wo, value, pdf);
-		return;
-	}
-	if (wi.z < 0.0f && !(kGeneral >= 2 && mt.one_sided)) { wi.z = -wi.z; wo.z = -wo.z; }
-	if (kGeneral && mt.type == 1) {
-		rc_eval_pdf(mt, wi, wo, value, pdf);
-		return;
-	}
-	const v3 refl = mt.refl;
-	if (!(wi.z > 0.0f && wo.z > 0.0f)) return;
-	value = vscale(vscale(refl, kInvPiF), wo.z);
-	pdf = kInvPiF * wo.z;
-}
-
-// bsdf.sample(ctx, si, u1, (u, v)): wo (local), pdf, weight = value / pdf, the relative index along
-// wo, and whether a delta lobe was sampled (BSDFFlags.Delta, :282)
-template <int kGeneral>
-__device__ __forceinline__ void bsdf_sample(const Material &mt, v3 wi, float u1, float u, float v, bool active, v3 &wo,
-                                            float &pdf, v3 &weight, float &eta, bool &delta)
-{
-	wo = V(0, 0, 0); pdf = 0.0f; weight = V(0, 0, 0); eta = 0.0f; delta = false;
-	if (!active) return;
-	if (kGeneral >= 2 && mt.type == 3) { // smooth dielectric (dielectric.cpp), radiance transport
-		float cos_t, eta_it, eta_ti;
-		const float r_i = fresnel_dielectric(wi.z, mt.M[5], cos_t, eta_it, eta_ti);
-		const bool reflect = u1 <= r_i;
-		const float sc = eta_ti * eta_ti;
-		delta = true;
-		pdf = reflect ? r_i : 1.0f - r_i;
-		wo = reflect ? V(-wi.x, -wi.y, wi.z) : V(-eta_ti * wi.x, -eta_ti * wi.y, cos_t);
-		eta = reflect ? 1.0f : eta_it;
-		weight = reflect ? V(1, 1, 1) : V(sc, sc, sc);
-		return;
-	}
-	if (kGeneral >= 2 && mt.type == 4) {
-		rd_sample(mt.M, wi, u1, u, v, wo, pdf, weight, eta);
-		return;
-	}
-	const bool flip = wi.z < 0.0f && !(kGeneral >= 2 && mt.one_sided);
-	const float cos_i = flip ? -wi.z : wi.z;
-	if (!(cos_i > 0.0f)) return;
-	if (kGeneral >= 2 && mt.type == 2) { // smooth conductor (conductor.cpp): the mirror direction, weighted by Fresnel
-		delta = true;
-		pdf = 1.0f;
-		eta = 1.0f;
-		wo = V(-wi.x, -wi.y, wi.z);
-		weight = vmul(rc_fresnel(mt.M, cos_i), mt.refl);
-		return;
-	}
-	if (kGeneral && mt.type == 1) {
-		v3 o;
-		rc_sample(mt, V(wi.x, wi.y, cos_i), u, v, o, pdf, weight);
-		eta = 1.0f;
-		if (flip) o.z = -o.z;
-		wo = o;
-		return;
-	}
-	const v3 refl = mt.refl;
-	v3 w = square_to_cosine_hemisphere(u, v);
-	const float p = kInvPiF * w.z;
-	eta = 1.0f;
-	pdf = p;
-	if (p > 0.0f) weight = refl;
-	if (flip) w.z = -w.z;
-	wo = w;
-}
-
-// scene.sample_emitter_direction(si, (e1, e2), test_visibility=True): uniform choice of one emitter
-// (e1 is reused after the choice), then a point on it; returns ds.d, ds.pdf and radiance / pdf
-// (zero when occluded, facing away, or from inside a sphere)
-// Directional emitters of a scene (scenes/torus/scene.xml) and the bounding sphere their samples sit on
-struct DirLights {
-	const float *lights; // 8 floats each: 0-2 unit direction the light travels in, 3-5 irradiance
-	float bsphere[4];    // centre, radius
-};
-
-template <int kGeneral>
-__device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights &dls, const int32_t *__restrict__ emitters,
-                                               int n_em, v3 p, v3 n, float e1, float e2, v3 &ds_d, float &ds_pdf,
-                                               v3 &em_weight, bool &ds_delta)
-{
-	ds_d = V(0, 0, 0);
-	ds_pdf = 0.0f;
-	em_weight = V(0, 0, 0);
-	ds_delta = false;
-	if (n_em <= 0) return;
-	const float count = (float)n_em, inv_count = 1.0f / count;
-	uint32_t idx = (uint32_t)(e1 * count);
-	if (idx > (uint32_t)(n_em - 1)) idx = (uint32_t)(n_em - 1);
-	e1 = e1 * count - (float)idx;
-	const int prim = emitters[idx];
-	if (kGeneral >= 2 && prim < 0) { // directional.cpp sample_direction: a point two radii up the light's direction, pdf 1, delta
-		const float *Dl = dls.lights + (size_t)(-1 - prim) * 8;
-		const v3 dl = ld3(Dl);
-		const v3 cd = vsub(p, V(dls.bsphere[0], dls.bsphere[1], dls.bsphere[2]));
-		const float dc = __builtin_sqrtf(dot3(cd, cd));
-		const float dist = 2.0f * (dls.bsphere[3] > dc ? dls.bsphere[3] : dc);
-		const v3 pl = vsub(p, vscale(dl, dist));
-		ds_d = V(-dl.x, -dl.y, -dl.z);
-		ds_delta = true;
-		ds_pdf = 1.0f * inv_count;
-		float mag = (1.0f + max3(V(fabs_(p.x), fabs_(p.y), fabs_(p.z)))) * kRayEps;
-		if (dot3(n, ds_d) < 0.0f) mag = -mag;
-		const v3 so = vadd(p, vscale(n, mag));
-		const v3 sd = vsub(pl, so);
-		const float sdist = __builtin_sqrtf(dot3(sd, sd));
-		float th;
-		const bool occ = intersect<kGeneral, true>(sh, so, vdivs(sd, sdist), sdist * (1.0f - kShadowEps), th) >= 0;
-		if (!occ) em_weight = vscale(ld3(Dl + 3), count);
-		return;
-	}
-	v3 pl, ln, radiance;
-	float pdf_cone = 0.0f, area = 1.0f;
-	const bool is_sphere = kGeneral && prim >= sh.n_quads;
-	if (!is_sphere) {
-		const float *E = sh.quads + prim * kQuadStride;
-		pl = vadd(vadd(ld3(E), vscale(ld3(E + 3), e1)), vscale(ld3(E + 6), e2));
-		ln = ld3(E + 9);
-		radiance = ld3(E + 19);
-		area = E[14];
-	} else { // Sphere::sample_direction, reference point outside
-		const float *S = sh.spheres + (prim - sh.n_quads) * kSphereStride;
-		const v3 c = ld3(S);
-		const float r = S[3];
-		const v3 dc_v = vsub(c, p);
-		const float dc_2 = dot3(dc_v, dc_v);
-		const float radius_adj = r * (1.0f - kSphereEps);
-		if (!(dc_2 > radius_adj * radius_adj)) return;
-		const float inv_dc = 1.0f / __builtin_sqrtf(dc_2);
-		const float sin_max = r * inv_dc, sin_max2 = sin_max * sin_max, inv_sin_max = 1.0f / sin_max;
-		const float cos_max = safe_sqrtf(1.0f - sin_max2);
-		float sin_theta_2;
-		if (sin_max2 > 0.00068523f) { // sin^2(1.5 deg)
-			const float tt = 1.0f + (cos_max - 1.0f) * e1;
-			sin_theta_2 = 1.0f - tt * tt;
-		} else sin_theta_2 = sin_max2 * e1; // small-angle Taylor expansion
-		const float cos_theta = safe_sqrtf(1.0f - sin_theta_2);
-		const float cos_alpha = sin_theta_2 * inv_sin_max +
-		                        cos_theta * safe_sqrtf(1.0f - sin_theta_2 * (inv_sin_max * inv_sin_max));
-		const float sin_alpha = safe_sqrtf(1.0f - cos_alpha * cos_alpha);
-		float sin_phi, cos_phi;
-		sincos_f32(e2 * (2.0f * kPiF), sin_phi, cos_phi);
-		const Frame fr = make_frame(vscale(dc_v, -inv_dc));
-		const v3 dl = to_world(fr, V(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha));
-		pl = vadd(c, vscale(dl, r));
-		ln = dl;
-		radiance = ld3(S + 6);
-		pdf_cone = kInvTwoPiF / (1.0f - cos_max);
-	}
-	const v3 dir0 = vsub(pl, p);
-	// si.spawn_ray_to(pl): offset origin, then aim at the light point
-	float mag = (1.0f + max3(V(fabs_(p.x), fabs_(p.y), fabs_(p.z)))) * kRayEps;
-	if (dot3(n, dir0) < 0.0f) mag = -mag;
-	const v3 so = vadd(p, vscale(n, mag));
-	const float d2 = dot3(dir0, dir0), dist = __builtin_sqrtf(d2);
-	ds_d = vdivs(dir0, dist);
-	const float dp = dot3(ds_d, ln);
-	float pdf = 0.0f;
-	if (dp < 0.0f) pdf = is_sphere ? (dist == 0.0f ? 0.0f : pdf_cone) : d2 / (fabs_(dp) * area);
-	if (!(pdf == pdf) || pdf == __builtin_huge_valf()) pdf = 0.0f;
-	ds_pdf = pdf * inv_count;
-	if (pdf > 0.0f) {
-		const v3 sd = vsub(pl, so);
-		const float sdist = __builtin_sqrtf(dot3(sd, sd));
-		const v3 sdn = vdivs(sd, sdist);
-		float th;
-#ifdef PG_ABLATE_SHADOW // timing experiment only: no shadow rays
-		const bool occ = false; (void)th; (void)sdn;
-#else
-		const bool occ = intersect<kGeneral, true>(sh, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
-#endif
-		if (!occ) em_weight = vscale(vdivs(radiance, pdf), count);
-	}
-}
-
-struct RenderArgs {
-	TreeView tree;
-	Shapes shapes;
-	const float *mats;          // material table (general scenes)
-	const int32_t *emitters;    // the emitters: shape numbers of flagged quads, then flagged spheres, then -1-k for directional light k
-	int n_emitters;
-	DirLights dir_lights;
-	float *ior;                 // general scenes: running product of the relative indices along the path (:357)
-	pg_camera cam;
-	uint64_t n_lanes, n_pixels;      // of this pass (tile)
-	uint64_t pixel_begin, film_pixels; // first pixel of the tile, pixels of the whole film
-	int spp, max_depth, rr_depth, guided, record, store_nee;
-	float frac;
-	uint32_t seed;
-	DepthCounters *dc;
-	int bounce, last;          // index of this launch = path depth of every live lane; last launch of the pass
-	const uint32_t *order_in;  // live-ray list written by the previous bounce (unused by the first)
-	uint32_t *order_out;       // live-ray list for the next bounce
-	uint32_t *live_count;      // [max_depth + 1]: live_count[b] = lanes alive after bounce b; [max_depth]: see k_bounce_tail (zeroed per pass)
-	// per-lane state (planar), 57 B in and out per live lane and bounce.  The ray origin is not
-	// state: it is the previous vertex pushed off its quad (:352 spawn_ray), recomputed from prev_p
-	// and the quad id; depth is the launch index; ior stays 1 (every BSDF of the substrate has eta 1)
-	float *ray_d, *thr, *L, *prev_p, *prev_pdf;
-	uint32_t *prev_quad; // shape number of the previous vertex
-	uint8_t *hit0; // the first bounce hit something (the `valid` flag, :400)
-	uint64_t *rng_state, *rng_inc;
-	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth
-	uint32_t *ray_of;
-	float *r_pos, *r_dir, *r_bsdf, *r_tb, *r_tr, *r_nee, *r_dnee, *r_wp;
-};
 
 // One loop iteration of :179-381 for one live lane; returns whether the path continues.
 // kFirst: the camera ray is generated here (mi.render's sensor.sample_ray_differential: one 2-D
@@ -905,8 +36,9 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	Pcg32 rng;
 	v3 ray_o, ray_d, thr, L, prev_p;
 	float prev_bsdf_pdf;
-	bool prev_delta = kFirst; // general scenes: bit 31 of the stored shape number (a delta lobe was sampled)
-	float ior = 1.0f;         // general scenes: a.ior
+	const bool prev_delta = kFirst; // no delta lobes in these scenes (feature levels 0 and 1): only the camera "vertex" counts as one
+	const float ior = 1.0f;         // every BSDF of these scenes has eta 1: the running product stays exactly 1
+	static_assert(kGeneral < 2, "mesh scenes run the split pipeline of pg_render_wave.hip");
 	if (kFirst) {
 		// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
 		// the full-frame pass would, whatever the number of ranks
@@ -936,11 +68,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		prev_bsdf_pdf = a.prev_pdf[lane];
 		// :352 spawn_ray of the previous vertex: the same three operations that produced the origin
 		const uint32_t pq = a.prev_quad[lane];
-		if (kGeneral >= 2) {
-			prev_delta = (pq >> 31) != 0u;
-			ior = a.ior[lane];
-		}
-		const v3 pn = normal_at<kGeneral>(sh, (int)(pq & 0x7fffffffu), prev_p);
+		const v3 pn = normal_at<kGeneral>(sh, (int)pq, prev_p);
 		float mag = (1.0f + max3(V(fabs_(prev_p.x), fabs_(prev_p.y), fabs_(prev_p.z)))) * kRayEps;
 		if (dot3(pn, ray_d) < 0.0f) mag = -mag;
 		ray_o = vadd(prev_p, vscale(pn, mag));
@@ -968,7 +96,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const v3 Le = vmul(vscale(thr, mis), em_radiance);
 	// ---- :207-220 emitter sampling ----
 	bool active_next = (depth + 1 < (uint32_t)D) && valid;
-	bool active_em = active_next && (kGeneral < 2 || material_is_smooth(mt)); // :210 BSDFFlags.Smooth
+	bool active_em = active_next; // :210 BSDFFlags.Smooth: every BSDF of these scenes has a non-delta lobe
 	const float e1 = rng.next_f32(), e2 = rng.next_f32(); // :214, unmasked
 	v3 ds_d = V(0, 0, 0), em_weight = V(0, 0, 0);
 	float ds_pdf = 0.0f;
@@ -1008,14 +136,13 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
 	if (!a.guided) surface_pdf_em = bsdf_pdf_em;
-	const float mis_em = (kGeneral >= 2 && ds_delta) ? 1.0f : mis_weight(ds_pdf, surface_pdf_em); // :253
+	const float mis_em = mis_weight(ds_pdf, surface_pdf_em); // :253 (no delta emitters in these scenes)
 	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em), em_weight);
 	L = vadd(L, vadd(Le, Lr_dir)); // :261
 	// ---- :272-311 next direction ----
 	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
 	if (active_next) { // next_1d (lobe choice: only the dielectric reads it), next_2d
-		if (kGeneral >= 2) s1 = rng.next_f32();
-		else rng.skip();
+		rng.skip(); // (the lobe choice: only dielectrics read it)
 		s2x = rng.next_f32();
 		s2y = rng.next_f32();
 	}
@@ -1097,7 +224,6 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	// ---- :352-381 advance ----
 	// ior (:357): without a dielectric every sampled direction has eta = 1, the running product stays
 	// exactly 1 and is not carried; general scenes carry it
-	if (kGeneral >= 2) ior = ior * eta;
 	thr = vmul(thr, bsdf_weight);
 	const float tmax = max3(thr);
 	active_next = active_next && (tmax != 0.0f);
@@ -1117,8 +243,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
 		a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
 		a.prev_pdf[lane] = woPdf;
-		a.prev_quad[lane] = (uint32_t)q | ((kGeneral >= 2 && delta) ? 0x80000000u : 0u);
-		if (kGeneral >= 2) a.ior[lane] = ior;
+		a.prev_quad[lane] = (uint32_t)q;
 	}
 	return active_next;
 }
@@ -1128,44 +253,10 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 // next list with one atomic per workgroup (order inside a workgroup is kept, so neighbouring
 // pixels stay neighbours; the order of workgroups is free -- every lane's result depends on its
 // own state only).
-// Waves per SIMD the register allocator aims at.  Levels 0 and 1 are left to the compiler (4 waves
-// at 112-124 VGPRs; 5 or 6 measured no faster).  Level 2 would get 3 waves at 153 VGPRs; held to
-// 5 (about 100 registers, the rest spilled) it is 10 % faster on the torus scene: 2 -> 15.1, 3 ->
-// 11.5, 4 -> 10.9, 5 -> 10.4 ms per pass (make EXTRA=-DPG_BOUNCE_WAVES_L2=n to try others).
-#ifndef PG_BOUNCE_WAVES_L2
-#define PG_BOUNCE_WAVES_L2 5
-#endif
-#define PG_BOUNCE_ATTR(level) \
-	__attribute__((amdgpu_waves_per_eu((level) >= 2 ? PG_BOUNCE_WAVES_L2 : 1, (level) >= 2 ? PG_BOUNCE_WAVES_L2 : 8)))
-
-// The tail of a long path (max_depth 30 in scenes/torus): a launch cannot be shorter than the slowest
-// single path's bounce (0.1-0.3 ms when that is two BVH walks inside a glass case), so a few
-// thousand survivors would cost that floor once per bounce.  At fixed checkpoints the host also
-// launches k_bounce_tail: when no more than kTailPaths paths are alive it takes all of them over
-// and every lane follows its own path to its end in this one launch; the per-bounce launches after
-// it find that out from the same counts and retire.
-#ifndef PG_TAIL_PATHS
-#define PG_TAIL_PATHS (128u * 1024u) // torus (tools/exp_tail.sh): 32 Ki -> 12.9, 128 Ki -> 12.4, 512 Ki -> 13.2, 2 Mi -> 13.2 ms per pass
-#endif
-constexpr uint32_t kTailPaths = PG_TAIL_PATHS;
-__host__ __device__ constexpr bool tail_checkpoint(int bounce, int max_depth)
-{
-	return max_depth > 8 && bounce >= 4 && bounce + 1 < max_depth &&
-	       (bounce < 8 || (bounce < 16 && bounce % 2 == 0) || bounce % 4 == 0);
-}
-// Did a tail launch at a checkpoint <= bounce take the paths over?  live_count[c-1] is final when
-// checkpoint c is launched, and the first checkpoint that fires decides: the entries a tail launch
-// adds to afterwards are never looked at before one that already said yes.
-__device__ __forceinline__ bool tail_took_over(const RenderArgs &a, int bounce)
-{
-	if (a.max_depth <= 8) return false;
-	for (int c = 4; c <= bounce; ++c)
-		if (tail_checkpoint(c, a.max_depth) && a.live_count[c - 1] <= kTailPaths) return true;
-	return false;
-}
-
+// (Scenes with triangle meshes do not come here: pg_render_wave.hip splits their bounce into a
+// ray-casting, a shading and an SD-tree kernel.)
 template <bool kFirst, int kGeneral>
-__global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR(kGeneral) void k_bounce(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
 	__shared__ uint32_t s_wave[kRBlock / 64];
@@ -1211,7 +302,7 @@ __global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR(kGeneral) void k_bounce(Ren
 // bounce are added to live_count[] as the per-bounce launches would have, so the splat finds
 // N + sum(live_count) entries and pg_render_live_counts reports the same numbers either way.
 template <int kGeneral>
-__global__ __launch_bounds__(kRBlock) PG_BOUNCE_ATTR(kGeneral) void k_bounce_tail(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 {
 	__shared__ uint4 s_kd[kLdsKdNodes];
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
@@ -1340,8 +431,13 @@ using namespace pg;
 
 // library-owned renderer state
 struct pg_render_state {
-	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior, tri_normals;
-	bool have_tri_normals = false;
+	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior, tri_normals, tri_uvs, srgb_lut;
+	DevBuf<uint32_t> textures, texels;
+	bool have_tri_normals = false, have_tri_uvs = false;
+	// mesh scenes: ray origins, the per-bounce workspace and the BVH stacks' overflow strips (pg_render_wave.hip)
+	DevBuf<float> ray_o;
+	DevBuf<uint32_t> ws;
+	DevBuf<uint2> bvh_ovf;
 	float bsphere[4] = {0, 0, 0, 0};
 	DevBuf<uint32_t> bvh;
 	DevBuf<int32_t> emitters;
@@ -1360,7 +456,7 @@ struct pg_render_state {
 	bool timing_on = false;
 	struct Ev { int kind; hipEvent_t a, b; };
 	std::vector<Ev> events;
-	pg_kernel_timing acc = {0, 0, 0, 0, 0, 0, 0, 0};
+	pg_kernel_timing acc = {};
 };
 
 namespace {
@@ -1410,6 +506,8 @@ int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const 
 	d.n_dir_lights = 0; d.dir_lights = nullptr;
 	d.bsphere[0] = d.bsphere[1] = d.bsphere[2] = d.bsphere[3] = 0.0f;
 	d.tri_normals = nullptr;
+	d.tri_uvs = nullptr;
+	d.n_textures = 0; d.textures = nullptr; d.texels = nullptr; d.n_texels = 0; d.srgb_lut = nullptr;
 	return pg_scene_set_ex(ctx, &d, cam);
 }
 
@@ -1437,27 +535,44 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 		}
 	}
 	const uint64_t n_mats = mats.size() / kMaterialStride;
-	int general = ns > 0 ? 1 : 0; // feature level, see intersect()
+	const uint64_t n_tex = sc->n_textures;
+	if (n_tex > 65536 || (n_tex && (!sc->textures || !sc->srgb_lut))) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: textures need their table and the sRGB lookup table");
+	for (uint64_t t = 0; t < n_tex; ++t) { // a texture's texels must lie inside the texel array
+		const uint32_t *T = sc->textures + t * kTextureStride;
+		if (T[0] == 1u) {
+			if (T[1] == 0u || T[2] == 0u || T[1] > 65536u || T[2] > 65536u || !sc->texels || (uint64_t)T[3] + (uint64_t)T[1] * T[2] > sc->n_texels)
+				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: bitmap texture outside the texel array");
+		} else if (T[0] != 2u) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown texture kind");
+	}
 	for (uint64_t m = 0; m < n_mats; ++m) {
 		const float type = mats[m * kMaterialStride];
 		if (type != 0.0f && type != 1.0f && type != 2.0f && type != 3.0f && type != 4.0f)
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: unknown material type");
-		if (type == 1.0f && general < 1) general = 1;                                  // rough conductor
-		if (type >= 2.0f || mats[m * kMaterialStride + 11] != 0.0f) general = 2;       // transmission, delta lobes, one-sided BSDFs
 		const float alpha = mats[m * kMaterialStride + 4]; // > 0: Beckmann, < 0: GGX of roughness -alpha
 		if ((type == 1.0f || type == 4.0f) && !(fabsf(alpha) > 0.0f && fabsf(alpha) < 3.0e38f))
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: microfacet alpha must be finite and not 0");
 		if ((type == 3.0f || type == 4.0f) && !(mats[m * kMaterialStride + 5] > 0.0f))
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: dielectric index ratio must be > 0");
+		const float tex = mats[m * kMaterialStride + 12];
+		if (!(tex >= 0.0f && tex <= (float)n_tex) || tex != (float)(uint64_t)tex)
+			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: material texture index out of range");
 	}
+	// feature level of the kernels (see intersect()): decided by the materials the shapes USE
+	int general = ns > 0 ? 1 : 0;
+	auto use_material = [&](uint64_t m) {
+		const float type = mats[m * kMaterialStride];
+		if (type == 1.0f && general < 1) general = 1;                              // rough conductor
+		if (type >= 2.0f || mats[m * kMaterialStride + 11] != 0.0f) general = 3;   // transmission, delta lobes, one-sided BSDFs
+	};
 	const uint64_t nd = sc->n_dir_lights;
 	if (nd > 64 || (nd && !sc->dir_lights)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: at most 64 directional lights");
 	if (nd && !(sc->bsphere[3] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: directional lights need the scene's bounding sphere");
-	if (nd) general = 2;
+	if (nd) general = 3;
 	for (uint64_t q = 0; q < nq; ++q) {
 		const float mi = quads[q * kQuadStride + 22];
 		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: quad material index out of range");
+		use_material((uint64_t)mi);
 		const float *M = &mats[(uint64_t)mi * kMaterialStride];
 		if (M[0] == 0.0f)
 			for (int c = 0; c < 3; ++c) quads[q * kQuadStride + 16 + c] = M[1 + c];
@@ -1466,19 +581,21 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 		const float mi = sc->spheres[s * kSphereStride + 4];
 		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: sphere material index out of range");
+		use_material((uint64_t)mi);
 		if (!(sc->spheres[s * kSphereStride + 3] > 0.0f)) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: sphere radius must be > 0");
 	}
 	for (uint64_t b = 0; b < nb; ++b) {
 		const float mi = sc->boxes[b * kBoxStride + 21];
 		if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
 			return fail(ctx, PG_ERR_INVALID, "pg_scene_set: box material index out of range");
+		use_material((uint64_t)mi);
 		for (int k = 0; k < 21; ++k)
 			if (!(sc->boxes[b * kBoxStride + k] == sc->boxes[b * kBoxStride + k]) || fabsf(sc->boxes[b * kBoxStride + k]) > 3.0e38f)
 				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: box transform is not finite");
 	}
 	// triangle meshes: the kernels walk the BVH with a fixed-size stack and trust it, so check it here:
 	// children follow their parent (no cycles, one parent each), leaves stay inside the triangle
-	// array, and no walk can have more than 64 siblings waiting on its stack
+	// array, and no walk can have more than kLdsStack + kOvfStack siblings waiting on its stack
 	const uint64_t nt = sc->n_tris, nn = sc->n_bvh_nodes;
 	if ((nt == 0) != (nn == 0) || (nt && (!sc->tris || !sc->bvh)) || nt > 0x0fffffffull || nn > 0x7fffffffull)
 		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangles and BVH nodes go together");
@@ -1494,7 +611,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			for (int c = 0; c < 4; ++c) kids += N[24 + c] != 0xffffffffu;
 			if (kids == 0) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node without children");
 			const int below = (int)waiting[i] + kids - 1; // its other children wait while the walk is in one of them
-			if (below > 64) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH too deep for the walk's stack");
+			if (below > kLdsStack + kOvfStack) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH too deep for the walk's stack (32 waiting siblings)");
 			for (int c = 0; c < 4; ++c) {
 				const uint32_t ref = N[24 + c];
 				if (ref == 0xffffffffu) continue;
@@ -1513,9 +630,11 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			const float mi = sc->tris[t * kTriStride + 12];
 			if (!(mi >= 0.0f && mi < (float)n_mats) || mi != (float)(uint64_t)mi)
 				return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangle material index out of range");
+			use_material((uint64_t)mi);
 		}
-		general = 2;
+		if (general < 2) general = 2;
 	}
+	// (a textured material on anything but a triangle with texture coordinates keeps its plain colour)
 	std::vector<int32_t> em;
 	for (uint64_t q = 0; q < nq; ++q)
 		if (quads[q * kQuadStride + 15] != 0.0f) em.push_back((int32_t)q);
@@ -1540,6 +659,17 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	if (r->have_tri_normals) {
 		PG_HIP(ctx, r->tri_normals.ensure(nt * 9));
 		PG_HIP(ctx, hipMemcpy(r->tri_normals.p, sc->tri_normals, nt * 9 * sizeof(float), hipMemcpyHostToDevice));
+	}
+	r->have_tri_uvs = nt && sc->tri_uvs && n_tex;
+	if (r->have_tri_uvs) {
+		PG_HIP(ctx, r->tri_uvs.ensure(nt * 6));
+		PG_HIP(ctx, hipMemcpy(r->tri_uvs.p, sc->tri_uvs, nt * 6 * sizeof(float), hipMemcpyHostToDevice));
+		PG_HIP(ctx, r->textures.ensure(n_tex * kTextureStride));
+		PG_HIP(ctx, hipMemcpy(r->textures.p, sc->textures, n_tex * kTextureStride * sizeof(uint32_t), hipMemcpyHostToDevice));
+		PG_HIP(ctx, r->texels.ensure(sc->n_texels ? sc->n_texels : 1));
+		if (sc->n_texels) PG_HIP(ctx, hipMemcpy(r->texels.p, sc->texels, sc->n_texels * sizeof(uint32_t), hipMemcpyHostToDevice));
+		PG_HIP(ctx, r->srgb_lut.ensure(256));
+		PG_HIP(ctx, hipMemcpy(r->srgb_lut.p, sc->srgb_lut, 256 * sizeof(float), hipMemcpyHostToDevice));
 	}
 	if (nq) PG_HIP(ctx, hipMemcpy(r->quads.p, quads.data(), quads.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (ns) PG_HIP(ctx, hipMemcpy(r->spheres.p, sc->spheres, ns * kSphereStride * sizeof(float), hipMemcpyHostToDevice));
@@ -1579,7 +709,15 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
 	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
 	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
-	if (r->general >= 2) PG_HIP(ctx, r->ior.ensure(N));
+	const bool wave = r->general >= 2; // mesh scenes: the split pipeline
+	if (r->general >= 3) PG_HIP(ctx, r->ior.ensure(N));
+	if (wave) {
+		PG_HIP(ctx, r->ray_o.ensure(3 * N));
+		PG_HIP(ctx, r->ws.ensure((size_t)wave_workspace_planes() * N));
+		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
+	}
+	if (sumL && film > ctx->num_rays)
+		return fail(ctx, PG_ERR_INVALID, "pg_render_pass: sumL/sumL2 are sized by pg_setup's num_rays, which is smaller than the film");
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
 	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D + 1));
 	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, ((size_t)D + 1) * sizeof(uint32_t), s)); // [D]: entries handed out by k_bounce_tail
@@ -1595,6 +733,13 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.boxes = r->boxes.p;
 	a.shapes.tris = r->tris.p;
 	a.shapes.tri_normals = r->have_tri_normals ? r->tri_normals.p : nullptr;
+	a.shapes.tri_uvs = r->have_tri_uvs ? r->tri_uvs.p : nullptr;
+	a.shapes.textures = r->textures.p;
+	a.shapes.texels = r->texels.p;
+	a.shapes.srgb_lut = r->srgb_lut.p;
+	a.ray_o = r->ray_o.p;
+	a.ws = r->ws.p;
+	a.bvh_ovf = r->bvh_ovf.p;
 	a.shapes.bvh = r->bvh.p;
 	a.shapes.n_bvh_nodes = r->n_bvh_nodes;
 	a.shapes.n_quads = r->n_quads;
@@ -1631,19 +776,26 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		a.last = it + 1 == D ? 1 : 0;
 		a.order_in = r->order[it & 1].p;
 		a.order_out = r->order[(it + 1) & 1].p;
+		if (wave) { // pg_render_wave.hip: five kernels per bounce, each timed on its own (kinds 5-9; 10 = tail)
+			if (tail_checkpoint(it, D)) {
+				Timed t(r, s, 10);
+				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), s);
+			}
+			for (int stage = 0; stage < 5; ++stage) {
+				Timed t(r, s, 5 + stage);
+				launch_wave_stage(stage, r->general, it == 0, a, grid.x, s);
+			}
+			continue;
+		}
 		Timed t(r, s, 1);
 		if (tail_checkpoint(it, D)) { // finishes every path in one launch once few are left (see k_bounce_tail)
 			const dim3 tgrid((unsigned)((kTailPaths + kRBlock - 1) / kRBlock));
-			if (r->general >= 2) hipLaunchKernelGGL((k_bounce_tail<2>), tgrid, dim3(kRBlock), 0, s, a);
-			else if (r->general == 1) hipLaunchKernelGGL((k_bounce_tail<1>), tgrid, dim3(kRBlock), 0, s, a);
+			if (r->general == 1) hipLaunchKernelGGL((k_bounce_tail<1>), tgrid, dim3(kRBlock), 0, s, a);
 			else hipLaunchKernelGGL((k_bounce_tail<0>), tgrid, dim3(kRBlock), 0, s, a);
 		}
 		// every launch is sized for the whole wavefront: the live count is only known on the device,
 		// and workgroups past it retire on their first instruction
-		if (r->general >= 2) {
-			if (it == 0) hipLaunchKernelGGL((k_bounce<true, 2>), grid, dim3(kRBlock), 0, s, a);
-			else hipLaunchKernelGGL((k_bounce<false, 2>), grid, dim3(kRBlock), 0, s, a);
-		} else if (r->general == 1) {
+		if (r->general == 1) {
 			if (it == 0) hipLaunchKernelGGL((k_bounce<true, 1>), grid, dim3(kRBlock), 0, s, a);
 			else hipLaunchKernelGGL((k_bounce<false, 1>), grid, dim3(kRBlock), 0, s, a);
 		} else {
@@ -1739,6 +891,12 @@ int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
 		switch (e.kind) {
 		case 0: r->acc.generate_ms += ms; break;
 		case 1: r->acc.bounce_ms += ms; ++r->acc.bounce_launches; break;
+		case 5: r->acc.trace_ms += ms; r->acc.bounce_ms += ms; ++r->acc.trace_launches; ++r->acc.bounce_launches; break;
+		case 6: r->acc.shade_ms += ms; r->acc.bounce_ms += ms; break;
+		case 7: r->acc.shadow_ms += ms; r->acc.bounce_ms += ms; break;
+		case 8: r->acc.guide_ms += ms; r->acc.bounce_ms += ms; ++r->acc.guide_launches; break;
+		case 9: r->acc.shade_ms += ms; r->acc.bounce_ms += ms; break;
+		case 10: r->acc.tail_ms += ms; r->acc.bounce_ms += ms; break;
 		case 2: r->acc.splat_ms += ms; ++r->acc.splat_launches; break;
 		case 4: r->acc.compact_ms += ms; break;
 		default: r->acc.finish_ms += ms; break;
@@ -1748,7 +906,7 @@ int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
 	}
 	r->events.clear();
 	*out = r->acc;
-	if (reset) r->acc = pg_kernel_timing{0, 0, 0, 0, 0, 0, 0, 0};
+	if (reset) r->acc = pg_kernel_timing{};
 	return PG_OK;
 }
 

@@ -1,0 +1,651 @@
+// pg_render_wave.hip -- the bounce of PathGuidingIntegrator.sample() (src/path_guiding_integrator.py:
+// 179-381) for scenes with triangle meshes (scenes/veach-ajar, scenes/torus), as a wavefront pipeline
+// of five small kernels per bounce instead of one big one:
+//
+//   k_wave_trace    :185   scene.ray_intersect: closest hit of every live ray (BVH walk, stack in LDS);
+//                          the first launch also makes the camera rays
+//   k_wave_shade_a  :189-220, 272-297   surface and textures at the hit, emitted radiance and its MIS
+//                          weight, one emitter sample (a shadow ray to trace), the BSDF towards it, the
+//                          BSDF sample, the lane's class (delta | bsdf | bsdf-mis | sdtree-mis)
+//   k_wave_shadow   :213   test_visibility: any-hit walk of the shadow rays
+//   k_wave_guide    :244, 301, 307   the three SD-tree calls of the bounce and nothing else: one KD
+//                          descent, the pdf of the emitter direction, sample-or-pdf of the continuation
+//                          direction, the canonical coordinates the record needs -- the kernel the
+//                          HBM roofline of the hot path is measured on
+//   k_wave_shade_b  :247-261, 302-381   mixture pdfs and MIS weights, radiance, the path-vertex record,
+//                          throughput, Russian roulette, the next ray; survivors are appended to the
+//                          next live list (one atomic per workgroup)
+//
+// Why split: the fused kernel of this scene class needed 153 vector registers (three waves per SIMD)
+// and kept its 64-entry BVH stack in scratch memory; a walk is a chain of dependent loads that wants
+// many waves to hide them, the shading wants registers.  Between the kernels a lane's intermediate
+// results travel through `ws`, planes indexed by the lane's position in the live list, so every
+// load and store of them is coalesced; what a path carries from bounce to bounce stays in the
+// per-lane state arrays.  The stages are device functions (stage_a, stage_guide, stage_b): the split
+// kernels load their inputs, call one, store its outputs; k_wave_tail calls all of them in sequence for
+// the last few thousand paths of a long pass (see tail_checkpoint).  Arithmetic and sampler draw order
+// are those of oracle/pg_oracle_render.c, operation by operation.
+#define PG_RENDER_INLINE_ALL
+#include "pg_render_dev.hpp"
+
+namespace pg {
+
+// ---- the workspace: planes of n_lanes 32-bit words ----
+enum : int {
+	WS_HIT_PRIM = 0, WS_HIT_T, WS_HIT_U, WS_HIT_V,
+	WS_P, WS_N = WS_P + 3, WS_NG = WS_N + 3, WS_WI = WS_NG + 3,
+	WS_FLAGS = WS_WI + 3, WS_MAT,
+	WS_REFL, WS_LE = WS_REFL + 3,
+	WS_DS_D = WS_LE + 3, WS_DS_PDF = WS_DS_D + 3, WS_EM_W, WS_BV_EM = WS_EM_W + 3, WS_BP_EM = WS_BV_EM + 3,
+	WS_SH_O, WS_SH_D = WS_SH_O + 3, WS_SH_T = WS_SH_D + 3,
+	WS_WO, WS_BSDF_PDF = WS_WO + 3, WS_BSDF_W, WS_ETA = WS_BSDF_W + 3,
+	WS_RNG_LO, WS_RNG_HI,
+	WS_OCC,
+	WS_NEE_C, WS_WO_C = WS_NEE_C + 2, WS_PDF_NEE = WS_WO_C + 2, WS_PDF_TREE,
+	WS_COUNT
+};
+
+// lane classes and switches a bounce decides in stage_a
+enum : uint32_t {
+	F_VALID = 1u,        // the ray hit something (:185)
+	F_ACTIVE_NEXT = 2u,  // depth + 1 < max_depth and valid (:208)
+	F_ACTIVE_EM = 4u,    // emitter sampling happened and ds.pdf != 0 (:210, 216)
+	F_NEED_SHADOW = 8u,  // em_weight holds the unoccluded value: trace the shadow ray
+	F_DS_DELTA = 16u,    // the emitter sample came from a delta light
+	F_DELTA = 32u,       // the BSDF sample is a delta lobe (:282)
+	F_DO_MIS = 64u,      // bsdf-mis or sdtree-mis lane (:283)
+	F_SMP_TREE = 128u,   // sdtree-mis: the direction comes from the SD-tree (:297)
+	F_BSDF_MIS = 256u,   // bsdf-mis: BSDF direction, SD-tree pdf (:293)
+};
+
+struct HitRec {
+	int prim;
+	float t, u, v;
+};
+
+struct StageA {
+	v3 p, n, ng, wi, refl, Le, ds_d, em_w, bv_em, sh_o, sh_d, wo, bsdf_w;
+	float ds_pdf, bp_em, sh_tmax, bsdf_pdf, eta;
+	int mat;
+	uint32_t flags;
+};
+
+struct GuideOut {
+	float nee_cx, nee_cy, wo_cx, wo_cy, pdf_nee, pdf_tree;
+	v3 wo;
+};
+
+__device__ __forceinline__ Material material_of(const RenderArgs &a, int mat, v3 refl, int level)
+{
+	Material m;
+	const float *M = a.mats + (size_t)mat * kMaterialStride;
+	m.type = (int)M[0];
+	m.refl = refl;
+	m.M = M;
+	m.one_sided = level >= 3 && M[11] != 0.0f;
+	return m;
+}
+
+// ---- :185-220, 272-297 ----
+template <int kLevel>
+__device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_o, v3 ray_d, v3 thr, v3 prev_p,
+                                        float prev_bsdf_pdf, bool prev_delta, const HitRec &h, uint32_t depth, StageA &o)
+{
+	const Shapes &sh = a.shapes;
+	const int D = a.max_depth;
+	const float f = a.frac;
+	const bool valid = h.prim >= 0;
+	Surface sf;
+	sf.p = V(0, 0, 0); sf.n = V(0, 0, 1); sf.ng = V(0, 0, 1); sf.radiance = V(0, 0, 0); sf.is_em = false;
+	sf.m.type = 0; sf.m.refl = V(0, 0, 0); sf.m.M = a.mats; sf.m.one_sided = false;
+	if (valid) sf = surface_at<kLevel>(sh, a.mats, h.prim, ray_o, ray_d, h.t, h.u, h.v);
+	const v3 p = sf.p, n = sf.n;
+	const Material &mt = sf.m;
+	const Frame fr = make_frame(n);
+	const v3 wi = to_local(fr, V(-ray_d.x, -ray_d.y, -ray_d.z));
+	const bool is_em = valid && sf.is_em;
+	const float inv_em_count = 1.0f / (float)a.n_emitters; // only used when an emitter was hit
+	// ---- :189-200 direct emission ----
+	const v3 em_radiance = (is_em && wi.z > 0.0f) ? sf.radiance : V(0, 0, 0);
+	float emitter_pdf = 0.0f;
+	if (is_em && !prev_delta) emitter_pdf = emitter_hit_pdf<kLevel>(sh, h.prim, prev_p, p, n, inv_em_count);
+	const float mis = mis_weight(prev_bsdf_pdf, emitter_pdf);
+	o.Le = vmul(vscale(thr, mis), em_radiance);
+	// ---- :207-220 emitter sampling ----
+	const bool active_next = (depth + 1 < (uint32_t)D) && valid;
+	bool active_em = active_next && (kLevel < 3 || material_is_smooth(mt)); // :210 BSDFFlags.Smooth
+	const float e1 = rng.next_f32(), e2 = rng.next_f32(); // :214, unmasked
+	bool ds_delta = false, need_shadow = false;
+	o.ds_d = V(0, 0, 0); o.em_w = V(0, 0, 0); o.ds_pdf = 0.0f;
+	o.sh_o = V(0, 0, 0); o.sh_d = V(0, 0, 1); o.sh_tmax = 0.0f;
+	if (active_em)
+		sample_emitter_ray<kLevel>(sh, a.dir_lights, a.emitters, a.n_emitters, p, sf.ng, e1, e2, o.ds_d, o.ds_pdf, o.em_w,
+		                           ds_delta, need_shadow, o.sh_o, o.sh_d, o.sh_tmax);
+	active_em = active_em && (o.ds_pdf != 0.0f); // :216
+	const v3 wo_em = to_local(fr, o.ds_d);
+	bsdf_eval_pdf<kLevel>(mt, wi, wo_em, active_em, o.bv_em, o.bp_em);
+	// ---- :272-297 next direction ----
+	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
+	if (active_next) { // next_1d (lobe choice: only the dielectrics read it), next_2d
+		if (kLevel >= 3) s1 = rng.next_f32();
+		else rng.skip();
+		s2x = rng.next_f32();
+		s2y = rng.next_f32();
+	}
+	v3 wo_local;
+	bool delta;
+	bsdf_sample<kLevel>(mt, wi, s1, s2x, s2y, active_next, wo_local, o.bsdf_pdf, o.bsdf_w, o.eta, delta);
+	o.wo = to_world(fr, wo_local);
+	const bool do_mis = active_next && !delta && a.guided; // :283
+	bool pick_tree = false;
+	if (active_next) pick_tree = rng.next_f32() > f; // :286
+	const bool smp_tree = pick_tree && do_mis;
+	const bool bsdf_mis = do_mis && !smp_tree;
+	o.p = p; o.n = n; o.ng = sf.ng; o.wi = wi; o.refl = mt.refl;
+	o.mat = valid ? (int)((mt.M - a.mats) / kMaterialStride) : 0;
+	o.flags = (valid ? F_VALID : 0u) | (active_next ? F_ACTIVE_NEXT : 0u) | (active_em ? F_ACTIVE_EM : 0u) |
+	          (need_shadow ? F_NEED_SHADOW : 0u) | (ds_delta ? F_DS_DELTA : 0u) | (delta ? F_DELTA : 0u) |
+	          (do_mis ? F_DO_MIS : 0u) | (smp_tree ? F_SMP_TREE : 0u) | (bsdf_mis ? F_BSDF_MIS : 0u);
+}
+
+// ---- :244, 301, 307: the SD-tree calls of a bounce (one KD descent) and the canonical coordinates of
+// the two directions (dirToCanonical feeds the pdf queries and the record, :327, 338) ----
+__device__ __forceinline__ bool guide_has_work(const RenderArgs &a, uint32_t flags)
+{
+	const bool do_record = a.record && (flags & F_VALID);
+	return do_record || ((flags & F_ACTIVE_EM) && a.guided) || (flags & (F_SMP_TREE | F_BSDF_MIS));
+}
+
+__device__ __forceinline__ void stage_guide(const RenderArgs &a, const uint4 *s_kd, Pcg32 &rng, v3 p, v3 ds_d, v3 wo_in,
+                                            uint32_t flags, GuideOut &g)
+{
+	const bool active_sd_em = (flags & F_ACTIVE_EM) && a.guided;
+	const bool do_record = a.record && (flags & F_VALID);
+	const bool smp_tree = (flags & F_SMP_TREE) != 0u, bsdf_mis = (flags & F_BSDF_MIS) != 0u;
+	TreeHead head = {kNoRecord, 0.0f};
+	uint32_t tree_id = 0;
+	bool tree_known = false;
+	uint32_t lv;
+	unsigned c_kd = 0, c_kdq = 0, c_q = 0, c_qq = 0; // descent statistics for the byte model
+	g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f;
+	g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
+	g.wo = wo_in;
+	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, g.nee_cx, g.nee_cy);
+	if (active_sd_em) {
+		KdNode leaf;
+		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		c_kd += lv; ++c_kdq;
+		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
+		head.root_rec = hv.x;
+		head.root_irr = __uint_as_float(hv.y);
+		tree_known = true;
+		tree_id = leaf.tree;
+		g.pdf_nee = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, g.nee_cx, g.nee_cy, lv);
+		c_q += lv; ++c_qq;
+	}
+	if ((smp_tree || bsdf_mis) && !tree_known) {
+		KdNode leaf;
+		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		c_kd += lv; ++c_kdq;
+		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
+		head.root_rec = hv.x;
+		head.root_irr = __uint_as_float(hv.y);
+		tree_id = leaf.tree;
+	}
+	if (smp_tree) { // :301
+		float dx, dy, dz;
+		quad_sample(a.tree.rec, a.tree.jump, tree_id, head, rng, dx, dy, dz, g.pdf_tree, lv);
+		c_q += lv; ++c_qq;
+		g.wo = V(dx, dy, dz);
+	}
+	if (bsdf_mis || do_record) dir_to_canonical(g.wo.x, g.wo.y, g.wo.z, g.wo_cx, g.wo_cy);
+	if (bsdf_mis) { // :307
+		g.pdf_tree = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, g.wo_cx, g.wo_cy, lv);
+		c_q += lv; ++c_qq;
+	}
+	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
+		atomicAdd(&a.dc->kd_levels, (unsigned long long)c_kd);
+		atomicAdd(&a.dc->kd_queries, (unsigned long long)c_kdq);
+		atomicAdd(&a.dc->quad_levels, (unsigned long long)c_q);
+		atomicAdd(&a.dc->quad_queries, (unsigned long long)c_qq);
+	}
+}
+
+// ---- :247-261, 302-381; returns whether the path continues, with its state for the next bounce in
+// thr, L, ior, ray_o, ray_d, prev_pdf, delta_out ----
+template <int kLevel>
+__device__ __forceinline__ bool stage_b(const RenderArgs &a, Pcg32 &rng, v3 &thr, v3 &L, float &ior, const StageA &A,
+                                        const GuideOut &g, bool occluded, uint64_t lane, uint64_t rec_slot, uint32_t depth,
+                                        v3 &ray_o, v3 &ray_d, float &prev_pdf, bool &delta_out)
+{
+	const uint64_t N = a.n_lanes;
+	const int D = a.max_depth;
+	const float f = a.frac;
+	const bool valid = (A.flags & F_VALID) != 0u;
+	bool active_next = (A.flags & F_ACTIVE_NEXT) != 0u;
+	const bool ds_delta = (A.flags & F_DS_DELTA) != 0u, delta = (A.flags & F_DELTA) != 0u;
+	const bool do_mis = (A.flags & F_DO_MIS) != 0u, smp_tree = (A.flags & F_SMP_TREE) != 0u;
+	const v3 em_weight = occluded ? V(0, 0, 0) : A.em_w;
+	// ---- :223-256 NEE MIS against the mixture pdf ----
+	const float pdf_diffuse = 1.0f; // :222-241
+	const float sdtree_pdf_em = g.pdf_nee;
+	float surface_pdf_em = f * A.bp_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
+	if (!a.guided) surface_pdf_em = A.bp_em;
+	const float mis_em = (kLevel >= 3 && ds_delta) ? 1.0f : mis_weight(A.ds_pdf, surface_pdf_em); // :253
+	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), A.bv_em), em_weight);
+	L = vadd(L, vadd(A.Le, Lr_dir)); // :261
+	// ---- :302-311 ----
+	v3 bsdf_weight = A.bsdf_w;
+	float bsdf_pdf = A.bsdf_pdf;
+	v3 bsdf_value = vscale(bsdf_weight, bsdf_pdf);
+	float woPdf = bsdf_pdf;
+	const v3 wo_world = g.wo;
+	if (smp_tree) { // :302-304
+		const Frame fr = make_frame(A.n);
+		const v3 wo_local = to_local(fr, wo_world);
+		const Material mt = material_of(a, A.mat, A.refl, kLevel);
+		bsdf_eval_pdf<kLevel>(mt, A.wi, wo_local, true, bsdf_value, bsdf_pdf);
+	}
+	if (do_mis) { // :310-311
+		woPdf = f * bsdf_pdf + (1.0f - f) * g.pdf_tree;
+		bsdf_weight = vdivs(bsdf_value, woPdf);
+		// deliberate deviation: 0/0 when a zero-energy tree proposes a direction below
+		// the surface; the reference's throughput turns NaN there, here the path simply ends
+		if (!(woPdf > 0.0f)) bsdf_weight = V(0, 0, 0);
+	}
+	// ---- :318-346 record (a list in visiting order, see pg_render.hip) ----
+	const bool do_record = a.record && valid;
+	if (a.record) a.ray_of[rec_slot] = valid ? (uint32_t)lane : 0xffffffffu;
+	if (do_record) {
+		const uint64_t S = N * (uint64_t)D;
+		const uint64_t s = rec_slot;
+		const v3 p = A.p;
+		a.r_pos[s] = p.x; a.r_pos[S + s] = p.y; a.r_pos[2 * S + s] = p.z;
+		a.r_dir[s] = g.wo_cx; a.r_dir[S + s] = g.wo_cy;
+		a.r_bsdf[s] = bsdf_weight.x; a.r_bsdf[S + s] = bsdf_weight.y; a.r_bsdf[2 * S + s] = bsdf_weight.z;
+		a.r_tb[s] = thr.x; a.r_tb[S + s] = thr.y; a.r_tb[2 * S + s] = thr.z;
+		a.r_tr[s] = L.x; a.r_tr[S + s] = L.y; a.r_tr[2 * S + s] = L.z;
+		if (a.store_nee) {
+			const v3 rn = vdiv(Lr_dir, thr);
+			a.r_nee[s] = rn.x; a.r_nee[S + s] = rn.y; a.r_nee[2 * S + s] = rn.z;
+			a.r_dnee[s] = g.nee_cx; a.r_dnee[S + s] = g.nee_cy;
+		} else {
+			a.r_nee[s] = 0.0f; a.r_nee[S + s] = 0.0f; a.r_nee[2 * S + s] = 0.0f;
+			a.r_dnee[s] = 0.0f; a.r_dnee[S + s] = 0.0f;
+		}
+		a.r_wp[s] = woPdf;
+	}
+	// ---- :352-381 advance ----
+	if (kLevel >= 3) ior = ior * A.eta; // :357 (the BSDF sample's eta also when the direction came from the tree)
+	thr = vmul(thr, bsdf_weight);
+	const float tmax = max3(thr);
+	active_next = active_next && (tmax != 0.0f);
+	float rr_prob = tmax * (ior * ior);
+	if (!(rr_prob < 0.95f)) rr_prob = 0.95f;
+	const bool rr_active = depth >= (uint32_t)a.rr_depth;
+	const float rr = rng.next_f32(); // :377, unmasked
+	const bool rr_continue = rr < rr_prob;
+	active_next = active_next && (!rr_active || rr_continue);
+	// :352 spawn_ray: the vertex pushed off the surface along the geometric normal, towards wo
+	float mag = (1.0f + max3(V(fabs_(A.p.x), fabs_(A.p.y), fabs_(A.p.z)))) * kRayEps;
+	if (dot3(A.ng, wo_world) < 0.0f) mag = -mag;
+	ray_o = vadd(A.p, vscale(A.ng, mag));
+	ray_d = wo_world;
+	prev_pdf = woPdf;
+	delta_out = delta;
+	return active_next;
+}
+
+// ---- lane state and workspace access ----
+__device__ __forceinline__ v3 ldp(const float *b, uint64_t N, uint64_t i) { return V(b[i], b[N + i], b[2 * N + i]); }
+__device__ __forceinline__ void stp(float *b, uint64_t N, uint64_t i, v3 v) { b[i] = v.x; b[N + i] = v.y; b[2 * N + i] = v.z; }
+__device__ __forceinline__ float wsf(const RenderArgs &a, int plane, uint64_t i) { return __uint_as_float(a.ws[(uint64_t)plane * a.n_lanes + i]); }
+__device__ __forceinline__ uint32_t wsu(const RenderArgs &a, int plane, uint64_t i) { return a.ws[(uint64_t)plane * a.n_lanes + i]; }
+__device__ __forceinline__ v3 ws3(const RenderArgs &a, int plane, uint64_t i) { return V(wsf(a, plane, i), wsf(a, plane + 1, i), wsf(a, plane + 2, i)); }
+__device__ __forceinline__ void wsput(const RenderArgs &a, int plane, uint64_t i, float v) { a.ws[(uint64_t)plane * a.n_lanes + i] = __float_as_uint(v); }
+__device__ __forceinline__ void wsputu(const RenderArgs &a, int plane, uint64_t i, uint32_t v) { a.ws[(uint64_t)plane * a.n_lanes + i] = v; }
+__device__ __forceinline__ void wsput3(const RenderArgs &a, int plane, uint64_t i, v3 v)
+{
+	wsput(a, plane, i, v.x); wsput(a, plane + 1, i, v.y); wsput(a, plane + 2, i, v.z);
+}
+
+// the camera ray of a lane (mi.render's sensor.sample_ray_differential: one 2-D jitter draw per sample)
+__device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, Pcg32 &rng, v3 &ray_o, v3 &ray_d)
+{
+	// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples the
+	// full-frame pass would, whatever the number of ranks
+	rng = pcg32_seed(a.seed, (uint32_t)(a.pixel_begin * (uint64_t)a.spp + lane));
+	const uint64_t pixel = a.pixel_begin + lane / (uint64_t)a.spp;
+	const int W = a.cam.width, H = a.cam.height;
+	const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
+	const float jx = rng.next_f32(), jy = rng.next_f32();
+	const float tan_y = a.cam.tan_half_fov_x / ((float)W / (float)H);
+	const float cx = (1.0f - 2.0f * ((px + jx) / (float)W)) * a.cam.tan_half_fov_x;
+	const float cy = (1.0f - 2.0f * ((py + jy) / (float)H)) * tan_y;
+	const float len = __builtin_sqrtf((cx * cx + cy * cy) + 1.0f);
+	const v3 dc = V(cx / len, cy / len, 1.0f / len);
+	ray_d = vadd(vadd(vscale(ld3(a.cam.axis_x), dc.x), vscale(ld3(a.cam.axis_y), dc.y)), vscale(ld3(a.cam.axis_z), dc.z));
+	ray_o = ld3(a.cam.origin);
+}
+
+// which live-list entry does this thread serve, if any: false for a whole workgroup past the list or
+// when a tail launch is finishing the paths (both uniform over the workgroup)
+template <bool kFirst>
+__device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, bool &alive, uint64_t &lane)
+{
+	tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
+	if ((uint64_t)blockIdx.x * kRBlock >= live) return false;
+	if (!kFirst && tail_took_over(a, a.bounce)) return false;
+	alive = tid < live;
+	lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
+	return true;
+}
+
+// ---- :185 ----
+template <int kLevel, bool kFirst>
+__global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
+{
+	__shared__ uint2 s_stack[kLdsStack][kRBlock];
+	uint64_t tid, lane;
+	bool alive;
+	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
+	if (!alive) return;
+	const uint64_t N = a.n_lanes;
+	v3 ray_o, ray_d;
+	if (kFirst) {
+		Pcg32 rng;
+		camera_ray(a, lane, rng, ray_o, ray_d);
+		a.rng_state[lane] = rng.state;
+		a.rng_inc[lane] = rng.inc;
+		stp(a.ray_o, N, lane, ray_o);
+		stp(a.ray_d, N, lane, ray_d);
+	} else {
+		ray_o = ldp(a.ray_o, N, lane);
+		ray_d = ldp(a.ray_d, N, lane);
+	}
+	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
+	HitRec h;
+	h.u = 0.0f; h.v = 0.0f;
+	h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
+	wsputu(a, WS_HIT_PRIM, tid, (uint32_t)h.prim);
+	wsput(a, WS_HIT_T, tid, h.t);
+	wsput(a, WS_HIT_U, tid, h.u);
+	wsput(a, WS_HIT_V, tid, h.v);
+}
+
+// ---- :189-220, 272-297 ----
+template <int kLevel, bool kFirst>
+__global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
+{
+	uint64_t tid, lane;
+	bool alive;
+	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
+	if (!alive) return;
+	const uint64_t N = a.n_lanes;
+	Pcg32 rng;
+	rng.state = a.rng_state[lane];
+	rng.inc = a.rng_inc[lane];
+	const v3 ray_o = ldp(a.ray_o, N, lane), ray_d = ldp(a.ray_d, N, lane);
+	v3 thr = V(1, 1, 1), prev_p = V(0, 0, 0);
+	float prev_pdf = 1.0f;
+	bool prev_delta = true;
+	if (!kFirst) {
+		thr = ldp(a.thr, N, lane);
+		prev_p = ldp(a.prev_p, N, lane);
+		prev_pdf = a.prev_pdf[lane];
+		prev_delta = (a.prev_quad[lane] >> 31) != 0u;
+	}
+	HitRec h;
+	h.prim = (int)wsu(a, WS_HIT_PRIM, tid);
+	h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
+	StageA A;
+	stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
+	wsput3(a, WS_P, tid, A.p); wsput3(a, WS_N, tid, A.n); wsput3(a, WS_NG, tid, A.ng); wsput3(a, WS_WI, tid, A.wi);
+	wsputu(a, WS_FLAGS, tid, A.flags); wsputu(a, WS_MAT, tid, (uint32_t)A.mat);
+	wsput3(a, WS_REFL, tid, A.refl); wsput3(a, WS_LE, tid, A.Le);
+	wsput3(a, WS_DS_D, tid, A.ds_d); wsput(a, WS_DS_PDF, tid, A.ds_pdf); wsput3(a, WS_EM_W, tid, A.em_w);
+	wsput3(a, WS_BV_EM, tid, A.bv_em); wsput(a, WS_BP_EM, tid, A.bp_em);
+	if (A.flags & F_NEED_SHADOW) {
+		wsput3(a, WS_SH_O, tid, A.sh_o); wsput3(a, WS_SH_D, tid, A.sh_d); wsput(a, WS_SH_T, tid, A.sh_tmax);
+	}
+	wsput3(a, WS_WO, tid, A.wo); wsput(a, WS_BSDF_PDF, tid, A.bsdf_pdf); wsput3(a, WS_BSDF_W, tid, A.bsdf_w);
+	wsput(a, WS_ETA, tid, A.eta);
+	wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
+}
+
+// ---- :213 test_visibility ----
+template <int kLevel>
+__global__ __launch_bounds__(kRBlock) void k_wave_shadow(RenderArgs a)
+{
+	__shared__ uint2 s_stack[kLdsStack][kRBlock];
+	uint64_t tid, lane;
+	bool alive;
+	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive, lane)) return; }
+	else if (!wave_entry<false>(a, tid, alive, lane)) return;
+	if (!alive) return;
+	if (!(wsu(a, WS_FLAGS, tid) & F_NEED_SHADOW)) return;
+	const v3 so = ws3(a, WS_SH_O, tid), sd = ws3(a, WS_SH_D, tid);
+	const float tmax = wsf(a, WS_SH_T, tid);
+	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
+	float th, bu, bv;
+	const bool occ = intersect<kLevel, true>(a.shapes, so, sd, tmax, th, stk, bu, bv) >= 0;
+	wsputu(a, WS_OCC, tid, occ ? 1u : 0u);
+}
+
+// ---- :244, 301, 307 ----
+__global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
+{
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	uint64_t tid, lane;
+	bool alive;
+	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive, lane)) return; }
+	else if (!wave_entry<false>(a, tid, alive, lane)) return;
+	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	if (!alive) return;
+	const uint32_t flags = wsu(a, WS_FLAGS, tid);
+	if (!guide_has_work(a, flags)) return;
+	Pcg32 rng;
+	rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
+	rng.inc = a.rng_inc[lane];
+	GuideOut g;
+	stage_guide(a, s_kd, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), ws3(a, WS_WO, tid), flags, g);
+	wsput(a, WS_NEE_C, tid, g.nee_cx); wsput(a, WS_NEE_C + 1, tid, g.nee_cy);
+	wsput(a, WS_WO_C, tid, g.wo_cx); wsput(a, WS_WO_C + 1, tid, g.wo_cy);
+	wsput(a, WS_PDF_NEE, tid, g.pdf_nee); wsput(a, WS_PDF_TREE, tid, g.pdf_tree);
+	if (flags & F_SMP_TREE) {
+		wsput3(a, WS_WO, tid, g.wo);
+		wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
+	}
+}
+
+// ---- :247-261, 302-381 ----
+template <int kLevel, bool kFirst>
+__global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
+{
+	__shared__ uint32_t s_wave[kRBlock / 64];
+	__shared__ uint32_t s_base;
+	uint64_t tid, lane;
+	bool alive;
+	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
+	const uint64_t N = a.n_lanes;
+	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
+	uint64_t rec_base = 0;
+	if (!kFirst) {
+		rec_base = a.n_lanes;
+		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+	}
+	bool cont = false;
+	if (alive) {
+		StageA A;
+		A.flags = wsu(a, WS_FLAGS, tid);
+		A.p = ws3(a, WS_P, tid); A.n = ws3(a, WS_N, tid); A.ng = ws3(a, WS_NG, tid); A.wi = ws3(a, WS_WI, tid);
+		A.mat = (int)wsu(a, WS_MAT, tid);
+		A.refl = ws3(a, WS_REFL, tid); A.Le = ws3(a, WS_LE, tid);
+		A.ds_d = ws3(a, WS_DS_D, tid); A.ds_pdf = wsf(a, WS_DS_PDF, tid); A.em_w = ws3(a, WS_EM_W, tid);
+		A.bv_em = ws3(a, WS_BV_EM, tid); A.bp_em = wsf(a, WS_BP_EM, tid);
+		A.wo = ws3(a, WS_WO, tid); A.bsdf_pdf = wsf(a, WS_BSDF_PDF, tid); A.bsdf_w = ws3(a, WS_BSDF_W, tid);
+		A.eta = wsf(a, WS_ETA, tid);
+		GuideOut g;
+		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
+		g.wo = A.wo; // (k_wave_guide has overwritten WS_WO for sdtree-mis lanes)
+		if (guide_has_work(a, A.flags)) {
+			g.nee_cx = wsf(a, WS_NEE_C, tid); g.nee_cy = wsf(a, WS_NEE_C + 1, tid);
+			g.wo_cx = wsf(a, WS_WO_C, tid); g.wo_cy = wsf(a, WS_WO_C + 1, tid);
+			g.pdf_nee = wsf(a, WS_PDF_NEE, tid); g.pdf_tree = wsf(a, WS_PDF_TREE, tid);
+		}
+		const bool occluded = (A.flags & F_NEED_SHADOW) && wsu(a, WS_OCC, tid) != 0u;
+		Pcg32 rng;
+		rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
+		rng.inc = a.rng_inc[lane];
+		v3 thr = V(1, 1, 1), L = V(0, 0, 0);
+		float ior = 1.0f;
+		if (!kFirst) {
+			thr = ldp(a.thr, N, lane);
+			L = ldp(a.L, N, lane);
+			if (kLevel >= 3) ior = a.ior[lane];
+		}
+		v3 ray_o, ray_d;
+		float prev_pdf;
+		bool delta;
+		cont = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, rec_base + tid, (uint32_t)a.bounce, ray_o, ray_d,
+		                       prev_pdf, delta);
+		// ---- state for the next bounce; a path that ends here leaves only its radiance ----
+		stp(a.L, N, lane, L);
+		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
+		if (cont) {
+			a.rng_state[lane] = rng.state;
+			stp(a.ray_o, N, lane, ray_o);
+			stp(a.ray_d, N, lane, ray_d);
+			stp(a.thr, N, lane, thr);
+			stp(a.prev_p, N, lane, A.p);
+			a.prev_pdf[lane] = prev_pdf;
+			a.prev_quad[lane] = delta ? 0x80000000u : 0u;
+			if (kLevel >= 3) a.ior[lane] = ior;
+		}
+	}
+	if (a.last) return; // nothing survives the last bounce
+	const unsigned long long ballot = __ballot(cont);
+	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	if (wl == 0) s_wave[wv] = (uint32_t)__popcll(ballot);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
+		s_base = tot ? atomicAdd(&a.live_count[a.bounce], tot) : 0u;
+	}
+	__syncthreads();
+	if (cont) {
+		uint32_t off = s_base + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
+		for (unsigned w = 0; w < wv; ++w) off += s_wave[w];
+		a.order_out[off] = (uint32_t)lane;
+	}
+}
+
+// See tail_checkpoint (pg_render_dev.hpp): launched before the launches of bounce a.bounce with a grid
+// for kTailPaths lanes.  When no more paths than that are alive every lane follows its own path to
+// its end here, all stages in sequence with their intermediate results in registers; the state still
+// goes through the per-lane arrays only at the start.  Record entries of the later bounces are handed
+// out wave by wave behind the entries of bounce a.bounce (a.live_count[max_depth] counts them), and
+// the survivors of every bounce are added to live_count[] as the per-bounce launches would have.
+template <int kLevel>
+__global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
+{
+	__shared__ uint4 s_kd[kLdsKdNodes];
+	__shared__ uint2 s_stack[kLdsStack][kRBlock];
+	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	const uint64_t live = (uint64_t)a.live_count[a.bounce - 1];
+	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
+	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
+	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	bool alive = tid < live;
+	const uint64_t N = a.n_lanes;
+	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
+	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce
+	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+	const uint64_t tail_base = rec_base + live; // behind the entries of bounce a.bounce
+	uint64_t slot = rec_base + tid;
+	const unsigned wl = threadIdx.x & 63u;
+	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
+	Pcg32 rng;
+	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(0, 0, 0), L = V(0, 0, 0), prev_p = V(0, 0, 0);
+	float prev_pdf = 1.0f, ior = 1.0f;
+	bool prev_delta = false;
+	rng.state = 0; rng.inc = 1;
+	if (alive) {
+		rng.state = a.rng_state[lane];
+		rng.inc = a.rng_inc[lane];
+		ray_o = ldp(a.ray_o, N, lane); ray_d = ldp(a.ray_d, N, lane);
+		thr = ldp(a.thr, N, lane); L = ldp(a.L, N, lane); prev_p = ldp(a.prev_p, N, lane);
+		prev_pdf = a.prev_pdf[lane];
+		prev_delta = (a.prev_quad[lane] >> 31) != 0u;
+		if (kLevel >= 3) ior = a.ior[lane];
+	}
+	for (int depth = a.bounce; depth < a.max_depth; ++depth) {
+		if (alive) {
+			HitRec h;
+			h.u = 0.0f; h.v = 0.0f;
+			h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
+			StageA A;
+			stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)depth, A);
+			bool occluded = false;
+			if (A.flags & F_NEED_SHADOW) {
+				float th, bu, bv;
+				occluded = intersect<kLevel, true>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
+			}
+			GuideOut g;
+			g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
+			g.wo = A.wo;
+			if (guide_has_work(a, A.flags)) stage_guide(a, s_kd, rng, A.p, A.ds_d, A.wo, A.flags, g);
+			bool delta;
+			alive = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, slot, (uint32_t)depth, ray_o, ray_d, prev_pdf, delta);
+			prev_p = A.p;
+			prev_delta = delta;
+			stp(a.L, N, lane, L);
+		}
+		const unsigned long long ballot = __ballot(alive);
+		if (ballot == 0ull) break; // (nothing survives the last bounce)
+		const uint32_t n = (uint32_t)__popcll(ballot);
+		uint32_t off = 0;
+		if (wl == (unsigned)__builtin_ctzll(ballot)) {
+			atomicAdd(&a.live_count[depth], n);
+			off = atomicAdd(&a.live_count[a.max_depth], n);
+		}
+		off = __shfl(off, __builtin_ctzll(ballot), 64);
+		slot = tail_base + off + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
+	}
+}
+
+// ---- launcher: one stage of one bounce (pg_render_pass wraps each in its timing events) ----
+template <int kLevel>
+static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 grid, hipStream_t s)
+{
+	const dim3 block(kRBlock);
+	switch (stage) {
+	case 0:
+		if (first) hipLaunchKernelGGL((k_wave_trace<kLevel, true>), grid, block, 0, s, a);
+		else hipLaunchKernelGGL((k_wave_trace<kLevel, false>), grid, block, 0, s, a);
+		break;
+	case 1:
+		if (first) hipLaunchKernelGGL((k_wave_shade_a<kLevel, true>), grid, block, 0, s, a);
+		else hipLaunchKernelGGL((k_wave_shade_a<kLevel, false>), grid, block, 0, s, a);
+		break;
+	case 2: hipLaunchKernelGGL((k_wave_shadow<kLevel>), grid, block, 0, s, a); break;
+	case 3: hipLaunchKernelGGL(k_wave_guide, grid, block, 0, s, a); break;
+	case 4:
+		if (first) hipLaunchKernelGGL((k_wave_shade_b<kLevel, true>), grid, block, 0, s, a);
+		else hipLaunchKernelGGL((k_wave_shade_b<kLevel, false>), grid, block, 0, s, a);
+		break;
+	default: hipLaunchKernelGGL((k_wave_tail<kLevel>), grid, block, 0, s, a); break;
+	}
+}
+
+void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, hipStream_t s)
+{
+	if (level >= 3) launch_stage_level<3>(stage, first, a, dim3(grid_blocks), s);
+	else launch_stage_level<2>(stage, first, a, dim3(grid_blocks), s);
+}
+
+int wave_workspace_planes() { return WS_COUNT; }
+
+} // namespace pg

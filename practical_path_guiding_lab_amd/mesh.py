@@ -30,10 +30,23 @@ EMPTY_CHILD = 0xFFFFFFFF
 MAX_LEAF = 4
 
 
-def read_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
-    """Vertices (V,3) float64 and triangles (F,3) int (polygons are fanned); only `v` and `f` are read."""
+def read_obj(path: str, attributes: bool = False):
+    """Vertices (V,3) float64 and triangles (F,3) int (polygons are fanned).  attributes=True also
+    returns the per-corner texture coordinates (F,3,2) and normals (F,3,3) of `v/vt/vn` faces (None
+    where the file has none for some face): (v, f, uv, n).  Texture coordinates are returned as the
+    file holds them; Mitsuba's `obj` plugin flips v (flip_tex_coords, its default) -- see triangles()."""
     verts: List[List[float]] = []
+    tex: List[List[float]] = []
+    nrm: List[List[float]] = []
     faces: List[List[int]] = []
+    fuv: List[List[int]] = []
+    fnr: List[List[int]] = []
+    has_uv = has_n = True
+
+    def resolve(tok: str, count: int) -> int:
+        i = int(tok)
+        return i - 1 if i > 0 else count + i
+
     with open(path) as f:
         for line in f:
             s = line.split()
@@ -41,12 +54,28 @@ def read_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
                 continue
             if s[0] == "v":
                 verts.append([float(s[1]), float(s[2]), float(s[3])])
+            elif s[0] == "vt":
+                tex.append([float(s[1]), float(s[2]) if len(s) > 2 else 0.0])
+            elif s[0] == "vn":
+                nrm.append([float(s[1]), float(s[2]), float(s[3])])
             elif s[0] == "f":
-                idx = [int(tok.split("/")[0]) for tok in s[1:]]
-                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                parts = [tok.split("/") for tok in s[1:]]
+                idx = [resolve(p[0], len(verts)) for p in parts]
+                ti = [resolve(p[1], len(tex)) if len(p) > 1 and p[1] else -1 for p in parts]
+                ni = [resolve(p[2], len(nrm)) if len(p) > 2 and p[2] else -1 for p in parts]
                 for k in range(1, len(idx) - 1):
                     faces.append([idx[0], idx[k], idx[k + 1]])
-    return np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int64).reshape(-1, 3)
+                    fuv.append([ti[0], ti[k], ti[k + 1]])
+                    fnr.append([ni[0], ni[k], ni[k + 1]])
+                has_uv = has_uv and min(ti) >= 0
+                has_n = has_n and min(ni) >= 0
+    v = np.asarray(verts, np.float64).reshape(-1, 3)
+    fa = np.asarray(faces, np.int64).reshape(-1, 3)
+    if not attributes:
+        return v, fa
+    uv = np.asarray(tex, np.float64).reshape(-1, 2)[np.asarray(fuv, np.int64).reshape(-1, 3)] if has_uv and tex and faces else None
+    n = np.asarray(nrm, np.float64).reshape(-1, 3)[np.asarray(fnr, np.int64).reshape(-1, 3)] if has_n and nrm and faces else None
+    return v, fa, uv, n
 
 
 def read_serialized(path: str, shape_index: int):
@@ -102,10 +131,14 @@ def read_serialized(path: str, shape_index: int):
 
 
 def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, material_index: int,
-              vertex_normals: np.ndarray = None):
-    """(F,16) triangle records in world space; degenerate triangles are dropped.  With per-vertex
-    normals (V,3) it returns (records, (F,9) world-space unit vertex normals per triangle)."""
+              vertex_normals: np.ndarray = None, uvs: np.ndarray = None, flip_tex_coords: bool = True):
+    """(F,16) triangle records in world space; degenerate triangles are dropped.
+    vertex_normals: (V,3) per vertex or (F,3,3) per face corner; uvs: (V,2) or (F,3,2) likewise.
+    Without either it returns the records; with normals only (records, (F,9) world-space unit
+    normals); with texture coordinates (records, normals or None, (F,6) uv0 uv1 uv2).
+    flip_tex_coords: v -> 1 - v, the default of Mitsuba's `obj` plugin (image row 0 is then v = 0)."""
     m = np.asarray(to_world, np.float64)
+    faces = np.asarray(faces, np.int64)
     v = np.asarray(vertices, np.float64) @ m[:3, :3].T + m[:3, 3]
     v = v.astype(np.float32)  # the kernels see fp32 vertices: derive everything from those
     a, b, c = v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]]
@@ -117,13 +150,24 @@ def triangles(vertices: np.ndarray, faces: np.ndarray, to_world: np.ndarray, mat
     out[:, 0:3], out[:, 3:6], out[:, 6:9] = a[keep], e1[keep], e2[keep]
     out[:, 9:12] = (n[keep] / ln[keep, None]).astype(np.float32)
     out[:, 12] = np.float32(material_index)
-    if vertex_normals is None:
+    if vertex_normals is None and uvs is None:
         return out
-    nw = np.asarray(vertex_normals, np.float64) @ np.linalg.inv(m[:3, :3])  # normals transform by the inverse transpose
-    nl = np.linalg.norm(nw, axis=1)
-    nw = np.where(nl[:, None] > 0, nw / np.maximum(nl[:, None], 1e-300), 0.0)
-    fn = np.concatenate([nw[faces[:, 0]], nw[faces[:, 1]], nw[faces[:, 2]]], axis=1)[keep].astype(np.float32)
-    return out, fn
+    fn = None
+    if vertex_normals is not None:
+        vn = np.asarray(vertex_normals, np.float64)
+        nw = vn.reshape(-1, 3) @ np.linalg.inv(m[:3, :3])  # normals transform by the inverse transpose
+        nl = np.linalg.norm(nw, axis=1)
+        nw = np.where(nl[:, None] > 0, nw / np.maximum(nl[:, None], 1e-300), 0.0)
+        corner = nw.reshape(-1, 3, 3) if vn.ndim == 3 else nw[faces]     # (F,3,3)
+        fn = corner.reshape(-1, 9)[keep].astype(np.float32)
+    if uvs is None:
+        return out, fn
+    uv = np.asarray(uvs, np.float64)
+    corner = (uv if uv.ndim == 3 else uv[faces]).astype(np.float32)      # (F,3,2)
+    if flip_tex_coords:
+        corner = corner.copy()
+        corner[:, :, 1] = np.float32(1.0) - corner[:, :, 1]
+    return out, fn, corner.reshape(-1, 6)[keep].astype(np.float32)
 
 
 def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):

@@ -85,6 +85,18 @@ class WavefrontScene:
         if tn is not None:
             assert tn.shape == (t.shape[0], 9)
             d.tri_normals = tn.ctypes.data
+        tu = None if self.scene.tri_uvs is None else np.ascontiguousarray(self.scene.tri_uvs, np.float32)
+        tex = np.ascontiguousarray(self.scene.textures, np.uint32)
+        txl = np.ascontiguousarray(self.scene.texels, np.uint32)
+        lut = np.ascontiguousarray(self.scene.srgb_lut, np.float32)
+        if tu is not None:
+            assert tu.shape == (t.shape[0], 6)
+            d.tri_uvs = tu.ctypes.data
+        if tex.shape[0]:
+            assert tex.shape[1] == 16 and lut.shape == (256,)
+            d.n_textures, d.textures = tex.shape[0], tex.ctypes.data
+            d.n_texels, d.texels = txl.shape[0], (txl.ctypes.data if txl.size else None)
+            d.srgb_lut = lut.ctypes.data
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 

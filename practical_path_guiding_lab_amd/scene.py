@@ -22,7 +22,10 @@ import numpy as np
 
 QUAD_STRIDE = 24  # floats per quad, layout documented in include/pgsd.h (pg_scene_desc)
 SPHERE_STRIDE = 12    # centre 0-2, radius 3, material 4, emitter flag 5, radiance 6-8
-MATERIAL_STRIDE = 12  # type 0, reflectance 1-3, alpha 4, eta 5-7, k 8-10
+MATERIAL_STRIDE = 16  # type 0, reflectance 1-3, alpha 4, eta 5-7, k 8-10, one-sided 11, texture index + 1 (0: none) 12
+TEXTURE_STRIDE = 16   # 32-bit words: kind 0 (1 bitmap, 2 checkerboard), width 1, height 2, first texel 3 (u32);
+                      # color0 4-6, color1 7-9, to_uv scale 10-11 and offset 12-13 (f32 bit patterns)
+TEX_BITMAP, TEX_CHECKERBOARD = 1, 2
 BOX_STRIDE = 32       # rows of the inverse linear map 0-8, centre 9-11, +x/+y/+z face normals 12-20, material 21
 MAT_DIFFUSE, MAT_ROUGHCONDUCTOR, MAT_CONDUCTOR, MAT_DIELECTRIC, MAT_ROUGHDIELECTRIC = 0, 1, 2, 3, 4
 # RGB indices of refraction Mitsuba's `material` presets resolve to in an RGB variant
@@ -58,6 +61,11 @@ class Scene:
     bvh: np.ndarray = field(default_factory=lambda: np.zeros((0, 32), np.uint32))                   # (M, 32) four-wide nodes, mesh.py
     dir_lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.float32))            # (K, 8): direction, irradiance
     tri_normals: Optional[np.ndarray] = None  # (T, 9) vertex normals per triangle in `tris` order; None: face normals
+    tri_uvs: Optional[np.ndarray] = None      # (T, 6) texture coordinates uv0 uv1 uv2 per triangle in `tris` order
+    textures: np.ndarray = field(default_factory=lambda: np.zeros((0, TEXTURE_STRIDE), np.uint32))  # (NT, 16) descriptors
+    texels: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))  # RGBA8 sRGB texels of all bitmaps (R in the low byte)
+    srgb_lut: np.ndarray = field(default_factory=lambda: srgb_to_linear_lut())  # (256,) 8-bit sRGB -> linear fp32
+    skipped: List[str] = field(default_factory=list)  # shapes of the scene file left out (mesh file missing)
 
     def bounding_sphere(self) -> np.ndarray:
         """Mitsuba's scene.bbox().bounding_sphere(): centre and radius (x, y, z, r), fp32."""
@@ -69,6 +77,85 @@ class Scene:
 
 def _f32(v):
     return np.asarray(v, dtype=np.float32)
+
+
+def srgb_to_linear_lut() -> np.ndarray:
+    """The 256 linear values of 8-bit sRGB (what `mi.Bitmap.convert(..., srgb_gamma=False)` makes of a
+    JPG/PNG texel), computed once in double and rounded to fp32: part of the scene data, so that the
+    product and the oracle look the same numbers up."""
+    c = np.arange(256, dtype=np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4).astype(np.float32)
+
+
+def bitmap_texture(image: np.ndarray, to_uv=(1.0, 1.0, 0.0, 0.0)) -> dict:
+    """Mitsuba `bitmap` texture (bilinear, repeat) over an 8-bit sRGB image (H, W, 3); row 0 is v = 0
+    (Mitsuba's obj loader has already flipped v).  to_uv: (scale u, scale v, offset u, offset v)."""
+    img = np.ascontiguousarray(image, np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3 or img.shape[0] == 0 or img.shape[1] == 0:
+        raise ValueError("bitmap_texture: need an (H, W, 3) uint8 image")
+    return {"kind": TEX_BITMAP, "image": img, "to_uv": tuple(float(x) for x in to_uv)}
+
+
+def checkerboard_texture(color0=(0.4, 0.4, 0.4), color1=(0.2, 0.2, 0.2), to_uv=(1.0, 1.0, 0.0, 0.0)) -> dict:
+    """Mitsuba `checkerboard` texture: color0 where frac(u) > .5 and frac(v) > .5 agree, else color1."""
+    return {"kind": TEX_CHECKERBOARD, "color0": tuple(color0), "color1": tuple(color1), "to_uv": tuple(float(x) for x in to_uv)}
+
+
+def pack_textures(textures: List[dict]) -> Tuple[np.ndarray, np.ndarray]:
+    """(descriptors (NT, 16) uint32, texels uint32 RGBA8) of a list of texture dicts."""
+    desc = np.zeros((len(textures), TEXTURE_STRIDE), np.uint32)
+    chunks, first = [], 0
+    for i, t in enumerate(textures):
+        f = np.zeros(10, np.float32)
+        desc[i, 0] = t["kind"]
+        if t["kind"] == TEX_BITMAP:
+            img = t["image"]
+            h, w = img.shape[:2]
+            desc[i, 1], desc[i, 2], desc[i, 3] = w, h, first
+            rgba = img[:, :, 0].astype(np.uint32) | (img[:, :, 1].astype(np.uint32) << 8) | (img[:, :, 2].astype(np.uint32) << 16)
+            chunks.append(rgba.reshape(-1))
+            first += w * h
+        else:
+            f[0:3], f[3:6] = _f32(t["color0"]), _f32(t["color1"])
+        f[6:10] = _f32(t["to_uv"])
+        desc[i, 4:14] = f.view(np.uint32)
+    if first >= 2 ** 31:
+        raise ValueError("more than 2^31 texels")
+    texels = np.concatenate(chunks).astype(np.uint32) if chunks else np.zeros(0, np.uint32)
+    return desc, texels
+
+
+def texture_eval(sc: "Scene", index: int, u, v) -> np.ndarray:
+    """Reference evaluation of texture `index` at (u, v) in numpy, the arithmetic of the kernels
+    (fp32, every operation rounded): used by tests."""
+    d = sc.textures[index]
+    f = d[4:14].view(np.float32)
+    u, v = np.float32(u), np.float32(v)
+    uu = np.float32(np.float32(f[6] * u) + f[8])
+    vv = np.float32(np.float32(f[7] * v) + f[9])
+    if int(d[0]) == TEX_CHECKERBOARD:
+        fu, fv = np.float32(uu - np.floor(uu)), np.float32(vv - np.floor(vv))
+        return f[0:3].copy() if (fu > 0.5) == (fv > 0.5) else f[3:6].copy()
+    w, h, first = int(d[1]), int(d[2]), int(d[3])
+    x = np.float32(np.float32(uu * np.float32(w)) - np.float32(0.5))
+    y = np.float32(np.float32(vv * np.float32(h)) - np.float32(0.5))
+    if not abs(x) < 1e9:
+        x = np.float32(0)
+    if not abs(y) < 1e9:
+        y = np.float32(0)
+    fx, fy = np.floor(x), np.floor(y)
+    wx1, wy1 = np.float32(x - fx), np.float32(y - fy)
+    wx0, wy0 = np.float32(np.float32(1) - wx1), np.float32(np.float32(1) - wy1)
+    ix0, iy0 = int(fx) % w, int(fy) % h
+    ix1, iy1 = (int(fx) + 1) % w, (int(fy) + 1) % h
+
+    def texel(ix, iy):
+        t = int(sc.texels[first + iy * w + ix])
+        return np.array([sc.srgb_lut[t & 255], sc.srgb_lut[(t >> 8) & 255], sc.srgb_lut[(t >> 16) & 255]], np.float32)
+
+    top = (texel(ix0, iy0) * wx0 + texel(ix1, iy0) * wx1).astype(np.float32)
+    bot = (texel(ix0, iy1) * wx0 + texel(ix1, iy1) * wx1).astype(np.float32)
+    return (top * wy0 + bot * wy1).astype(np.float32)
 
 
 def _quad(o, e1, e2, refl, radiance=None) -> np.ndarray:
@@ -124,11 +211,13 @@ def cube(to_world: np.ndarray, refl) -> List[np.ndarray]:
     return out
 
 
-def diffuse_material(reflectance, twosided: bool = True) -> np.ndarray:
+def diffuse_material(reflectance, twosided: bool = True, texture: Optional[int] = None) -> np.ndarray:
+    """texture: index into the scene's texture list that replaces `reflectance` on meshes with uvs."""
     m = np.zeros(MATERIAL_STRIDE, np.float32)
     m[0] = MAT_DIFFUSE
     m[1:4] = _f32(reflectance)
     m[11] = 0.0 if twosided else 1.0
+    m[12] = 0.0 if texture is None else np.float32(texture + 1)
     return m
 
 
@@ -183,14 +272,17 @@ def directional_light(direction, irradiance) -> np.ndarray:
     return out
 
 
-def roughconductor_material(alpha, eta, k, specular_reflectance=(1.0, 1.0, 1.0), distribution: str = "beckmann") -> np.ndarray:
-    """Mitsuba `roughconductor`, beckmann or ggx distribution, isotropic alpha, sample_visible (its default)."""
+def roughconductor_material(alpha, eta, k, specular_reflectance=(1.0, 1.0, 1.0), distribution: str = "beckmann",
+                            texture: Optional[int] = None) -> np.ndarray:
+    """Mitsuba `roughconductor`, beckmann or ggx distribution, isotropic alpha, sample_visible (its default).
+    texture: index of the texture that replaces `specular_reflectance` on meshes with uvs."""
     m = np.zeros(MATERIAL_STRIDE, np.float32)
     m[0] = MAT_ROUGHCONDUCTOR
     m[1:4] = _f32(specular_reflectance)
     m[4] = _signed_alpha(alpha, distribution)
     m[5:8] = _f32(eta)
     m[8:11] = _f32(k)
+    m[12] = 0.0 if texture is None else np.float32(texture + 1)
     return m
 
 
@@ -223,7 +315,7 @@ def box(to_world: np.ndarray, material_index: int) -> np.ndarray:
 
 
 def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int, names, spheres=None, materials=None,
-            boxes=None, tris=None, dir_lights=None) -> Scene:
+            boxes=None, tris=None, dir_lights=None, textures=None) -> Scene:
     q = np.stack(quads).astype(np.float32) if quads else np.zeros((0, QUAD_STRIDE), np.float32)
     corners = [q[:, 0:3], q[:, 0:3] + q[:, 3:6], q[:, 0:3] + q[:, 6:9], q[:, 0:3] + q[:, 3:6] + q[:, 6:9]]
     s = np.stack(spheres).astype(np.float32) if spheres else np.zeros((0, SPHERE_STRIDE), np.float32)
@@ -234,9 +326,11 @@ def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int,
         for sy in (-1, 1):
             for sz in (-1, 1):
                 corners.append(bx[:, 9:12] + sx * bx[:, 22:25] + sy * bx[:, 25:28] + sz * bx[:, 28:31])
-    # meshes: arrays of triangle records, or (records, vertex normals) pairs from mesh.triangles
-    recs = [t[0] if isinstance(t, tuple) else t for t in (tris or [])]
-    smooth = any(isinstance(t, tuple) for t in (tris or []))
+    # meshes: arrays of triangle records, or (records, vertex normals[, uvs]) tuples from mesh.triangles
+    parts = [t if isinstance(t, tuple) else (t,) for t in (tris or [])]
+    recs = [t[0] for t in parts]
+    smooth = any(len(t) > 1 and t[1] is not None for t in parts)
+    mapped = any(len(t) > 2 and t[2] is not None for t in parts)
     tr = np.concatenate(recs).astype(np.float32) if recs else np.zeros((0, 16), np.float32)
     if tr.shape[0]:
         corners += [tr[:, 0:3], tr[:, 0:3] + tr[:, 3:6], tr[:, 0:3] + tr[:, 6:9]]
@@ -244,9 +338,20 @@ def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int,
     sc = Scene(q, cam, max_depth, rr_depth, corners.min(axis=0).astype(np.float32), corners.max(axis=0).astype(np.float32), names)
     if tr.shape[0]:
         from .mesh import build_bvh
+        cols = []
         if smooth:  # flat-shaded meshes among smooth ones carry their face normal three times
-            nrm = np.concatenate([t[1] if isinstance(t, tuple) else np.tile(t[:, 9:12], (1, 3)) for t in tris]).astype(np.float32)
-            sc.bvh, sc.tris, sc.tri_normals = build_bvh(tr, nrm)
+            cols.append(np.concatenate([t[1] if len(t) > 1 and t[1] is not None else np.tile(t[0][:, 9:12], (1, 3))
+                                        for t in parts]).astype(np.float32))
+        if mapped:  # meshes without texture coordinates among mapped ones: uv = 0
+            cols.append(np.concatenate([t[2] if len(t) > 2 and t[2] is not None else np.zeros((t[0].shape[0], 6), np.float32)
+                                        for t in parts]).astype(np.float32))
+        if cols:
+            sc.bvh, sc.tris, per = build_bvh(tr, np.concatenate(cols, axis=1))
+            at = 0
+            if smooth:
+                sc.tri_normals, at = np.ascontiguousarray(per[:, 0:9]), 9
+            if mapped:
+                sc.tri_uvs = np.ascontiguousarray(per[:, at:at + 6])
         else:
             sc.bvh, sc.tris = build_bvh(tr)
     sc.spheres = s
@@ -254,6 +359,17 @@ def _finish(quads: List[np.ndarray], cam: Camera, max_depth: int, rr_depth: int,
     if dir_lights:
         sc.dir_lights = np.stack(dir_lights).astype(np.float32)
     sc.materials = np.stack(materials).astype(np.float32) if materials else None
+    if textures:
+        sc.textures, sc.texels = pack_textures(textures)
+    if sc.materials is not None:
+        tex = sc.materials[:, 12]
+        if (tex < 0).any() or (tex > sc.textures.shape[0]).any() or (tex != np.floor(tex)).any():
+            raise ValueError("material texture index out of range")
+        used = set(int(v) for v in sc.quads[:, 22]) | set(int(v) for v in s[:, 4]) | set(int(v) for v in bx[:, 21])
+        if any(sc.materials[i, 12] != 0 for i in used if 0 <= i < sc.materials.shape[0]):
+            raise ValueError("textured materials are built for meshes with texture coordinates only")
+        if (tex != 0).any() and tr.shape[0] and sc.tri_uvs is None and (sc.materials[sc.tris[:, 12].astype(int), 12] != 0).any():
+            raise ValueError("a textured material is used by a mesh without texture coordinates")
     return sc
 
 
@@ -356,15 +472,15 @@ def rotation(axis, angle_deg: float) -> np.ndarray:
 
 def _torus_mesh_file() -> str:
     import os
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "torus_meshes.npz")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "torus_meshes.npz")
 
 
 def torus(width: int = 1024, height: int = 768, max_depth: int = 30, rr_depth: int = 8, meshes: Optional[str] = None) -> Scene:
     """The torus scene of the reference (scenes/torus/scene.xml): a one-sided diffuse donut inside a
     frosted acrylic-glass case (roughdielectric, alpha 0.01) held by two aluminium brackets (smooth
     conductor) on a diffuse floor, lit by one directional light, gaussian film filter, z up.
-    `meshes`: the five meshes of meshes.serialized as arrays (tests/golden/torus_meshes.npz, made by
-    tests/golden/make_torus_fixture.py)."""
+    `meshes`: the five meshes of meshes.serialized as arrays (data/torus_meshes.npz of this package,
+    made by tests/golden/make_torus_fixture.py)."""
     from .mesh import triangles
     data = np.load(meshes or _torus_mesh_file())
     mats = [diffuse_material((0.725, 0.71, 0.68), twosided=False), diffuse_material((0.8, 0.8, 0.4), twosided=False),
@@ -383,14 +499,90 @@ def torus(width: int = 1024, height: int = 768, max_depth: int = 30, rr_depth: i
     return sc
 
 
-def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None, boxes: bool = True) -> Scene:
+def _data_file(name: str) -> str:
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name)
+
+
+# Pixels of the 1280x720 film that show the three teapots of scenes/veach-ajar (Mesh000.obj /
+# Mesh009.obj are missing from the reference mount), their shadows and caustics on the table top:
+# (x0, y0, x1, y1), half-open; comparisons with the reference's ground truth leave them out.
+VEACH_AJAR_TEAPOT_RECT = (270, 370, 850, 590)
+
+
+def veach_ajar_mask(width: int, height: int) -> np.ndarray:
+    """(height, width) bool: True where a veach-ajar image can be compared with TungstenRender.exr."""
+    x0, y0, x1, y1 = VEACH_AJAR_TEAPOT_RECT
+    m = np.ones((height, width), bool)
+    m[int(np.floor(y0 * height / 720.0)):int(np.ceil(y1 * height / 720.0)),
+      int(np.floor(x0 * width / 1280.0)):int(np.ceil(x1 * width / 1280.0))] = False
+    return m
+
+
+def veach_ajar(width: int = 1280, height: int = 720, max_depth: int = 13, rr_depth: int = 8, data: Optional[str] = None) -> Scene:
+    """The veach-ajar scene of the reference (scenes/veach-ajar/scene.xml): a room lit through a door
+    left ajar -- one rectangle emitter of radiance 1000 behind the door, diffuse walls, a textured
+    door, table top and landscape picture (`bitmap` textures), a GGX rough-conductor floor whose
+    specular reflectance is a `checkerboard`, GGX hinges, a Beckmann door handle (the one smooth-shaded
+    mesh), fov 60, tent filter.  Built from its numeric parameters and the package's data file
+    (data/veach_ajar.npz, made by tests/golden/make_ajar_fixture.py: the 15 OBJ meshes present in the
+    reference mount and the three textures at reduced resolution).  The six teapot shapes
+    (scene.xml:252-293) are left out -- their two mesh files are missing from the reference mount --
+    and named in `Scene.skipped`; their three materials stay in the table (unused)."""
+    from .mesh import triangles
+    d = np.load(data or _data_file("veach_ajar.npz"))
+    al_eta, al_k = (1.65746, 0.880369, 0.521229), (9.22387, 6.26952, 4.837)
+    textures = [bitmap_texture(d["tex_landscape"]), bitmap_texture(d["tex_table"]), bitmap_texture(d["tex_cherry"]),
+                checkerboard_texture((0.8, 0.8, 0.8), (0.2, 0.2, 0.2), (20.0, 80.0, 0.0, 0.0))]
+    mats = [diffuse_material((0.5, 0.5, 0.5), texture=0),                                     # 0 LandscapeBSDF
+            diffuse_material((0.5, 0.5, 0.5), texture=1),                                     # 1 TableBSDF
+            roughconductor_material(0.25, al_eta, al_k, (1, 1, 1), "beckmann"),               # 2 DoorHandleBSDF
+            diffuse_material((0.5, 0.5, 0.5), texture=2),                                     # 3 DoorBSDF
+            diffuse_material((0.8, 0.8, 0.8)),                                                # 4 DiffuseBSDF
+            roughconductor_material(0.1, al_eta, al_k, (1, 1, 1), "ggx", texture=3),          # 5 FloorBSDF
+            diffuse_material((0.247059, 0.168627, 0.0901961)),                                # 6 DoorFrameBSDF
+            diffuse_material((0.258824, 0.207843, 0.145098)),                                 # 7 PictureFrameBSDF
+            roughconductor_material(0.1, al_eta, al_k, (1, 1, 1), "ggx"),                     # 8 HingeBSDF
+            diffuse_material((0.0, 0.0, 0.0)),                                                # 9 LightBSDF
+            roughconductor_material(0.15, al_eta, al_k, (1, 1, 1), "ggx"),                    # 10 Pot2BSDF (teapot, unused)
+            dielectric_material(1.5, 1.0),                                                    # 11 MaterialBSDF (teapot, unused)
+            diffuse_material((0.8, 0.8, 0.8))]                                                # 12 Pot3BSDF (teapot, unused)
+    floor_tw = np.eye(4)
+    floor_tw[0, 0], floor_tw[0, 3] = 1.8, 2.3
+    eye = np.eye(4)
+    shapes = [("Landscape", "Mesh008", eye, 0), ("PictureFrame", "Mesh013", eye, 7), ("Floor", "Mesh011", floor_tw, 5),
+              ("DoorHandle", "Mesh015", eye, 2), ("Hinge_0001", "Mesh016", eye, 8), ("Hinge_0002", "Mesh012", eye, 8),
+              ("Hinge_0003", "Mesh010", eye, 8), ("Door", "Mesh006", eye, 3), ("DoorFrame", "Mesh005", eye, 6),
+              ("Diffuse_0001", "Mesh007", eye, 4), ("Diffuse_0002", "Mesh003", eye, 4), ("Diffuse_0003", "Mesh002", eye, 4),
+              ("Diffuse_0004", "Mesh001", eye, 4), ("Table", "Mesh004", eye, 1), ("Diffuse_0005", "Mesh014", floor_tw, 4)]
+    tris = []
+    for _, mesh, tw, mi in shapes:
+        n = d[mesh + "_n"] if (mesh + "_n") in d.files else None  # only the door handle is smooth-shaded
+        tris.append(triangles(d[mesh + "_v"], d[mesh + "_f"].astype(np.int64), tw, mi, n, d[mesh + "_uv"]))
+    light = rectangle(_mat("0.730445 0 0 -4.4391 0 -1.32136 -1.42138e-007 1.50656 0 1.42138e-007 -1.93037 -4.44377 0 0 0 1"),
+                      (0.0, 0.0, 0.0), (1000.0, 1000.0, 1000.0))
+    for q in light:
+        q[22] = 9.0
+    cam = make_camera(_mat("-0.137283 -0.0319925 -0.990015 4.05402 2.71355e-008 0.999478 -0.0322983 1.61647 "
+                           "0.990532 -0.00443408 -0.137213 -2.30652 0 0 0 1"), 60.0, width, height)
+    sc = _finish(light, cam, max_depth, rr_depth, ["Light"], None, mats, None, tris, None, textures)
+    sc.rfilter = "tent"
+    sc.skipped = ["Pot2_0001", "Pot2_0002", "Pot3_0001", "Pot3_0002", "Material_0001", "Material_0002"]
+    return sc
+
+
+def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None, boxes: bool = True,
+             skip_missing_meshes: bool = False) -> Scene:
     """Mitsuba 3 XML subset: <default>, perspective sensor (fov, to_world, film size, rfilter); diffuse,
-    roughconductor / roughdielectric (beckmann), conductor and dielectric bsdfs (by id or inline;
-    `twosided` wrappers honoured, a bare BSDF is one-sided as in Mitsuba); rectangle / cube shapes,
-    spheres by centre and radius, `serialized` and `obj` meshes; area emitters on rectangles and
-    spheres, `directional` emitters; transforms from matrix / lookat / scale / translate / rotate.
-    Anything else raises ValueError.  boxes: `cube` shapes become box primitives (else six quads
-    each)."""
+    roughconductor / roughdielectric (beckmann, ggx), conductor and dielectric bsdfs (by id or inline;
+    `twosided` wrappers honoured, a bare BSDF is one-sided as in Mitsuba), `bitmap` (bilinear, repeat;
+    decoded with PIL) and `checkerboard` textures for a diffuse reflectance or a rough conductor's
+    specular reflectance; rectangle / cube shapes, spheres by centre and radius, `serialized` and `obj`
+    meshes (with their texture coordinates and, unless face_normals is set, their normals); area
+    emitters on rectangles and spheres, `directional` emitters; transforms from matrix / lookat /
+    scale / translate / rotate.  Anything else raises ValueError.  boxes: `cube` shapes become box
+    primitives (else six quads each).  skip_missing_meshes: a mesh whose file does not exist is left
+    out and named in Scene.skipped (scenes/veach-ajar in the reference mount) instead of raising."""
     import os
     root = ET.parse(path).getroot()
     base = os.path.dirname(os.path.abspath(path))
@@ -430,6 +622,34 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
         return m
 
     materials: List[np.ndarray] = []
+    textures: List[dict] = []
+
+    def texture(node) -> int:
+        """Index of the texture for a <texture> element."""
+        kind = node.get("type")
+        tu = node.find("transform[@name='to_uv']")
+        to_uv = (1.0, 1.0, 0.0, 0.0)
+        if tu is not None:
+            m = transform(tu)
+            if abs(m[0, 1]) > 1e-12 or abs(m[1, 0]) > 1e-12:
+                raise ValueError("to_uv: only scale and translate are built")
+            to_uv = (m[0, 0], m[1, 1], m[0, 3], m[1, 3])  # (a 3-D transform element read as the 2-D one: z is unused)
+        if kind == "bitmap":
+            ft = node.find("string[@name='filter_type']")
+            if ft is not None and ft.get("value") != "bilinear":
+                raise ValueError("bitmap: only filter_type bilinear is built")
+            wm = node.find("string[@name='wrap_mode']")
+            if wm is not None and wm.get("value") != "repeat":
+                raise ValueError("bitmap: only wrap_mode repeat is built")
+            from PIL import Image
+            img = np.asarray(Image.open(os.path.join(base, node.find("string[@name='filename']").get("value"))).convert("RGB"))
+            textures.append(bitmap_texture(img, to_uv))
+        elif kind == "checkerboard":
+            cols = {r.get("name"): rgb(r) for r in node.findall("rgb")}
+            textures.append(checkerboard_texture(cols.get("color0", (0.4, 0.4, 0.4)), cols.get("color1", (0.2, 0.2, 0.2)), to_uv))
+        else:
+            raise ValueError(f"unsupported texture type {kind}")
+        return len(textures) - 1
 
     def ior(node, name: str, default: float) -> float:
         s, f = node.find(f"string[@name='{name}']"), node.find(f"float[@name='{name}']")
@@ -445,6 +665,9 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             return material(node.find("bsdf"), True)
         kind = node.get("type")
         named = {r.get("name"): rgb(r) for r in node.findall("rgb")}
+        tex = {t.get("name"): t for t in node.findall("texture")}
+        if any(k not in ("reflectance", "specular_reflectance") for k in tex) or (tex and kind not in ("diffuse", "roughconductor")):
+            raise ValueError(f"{kind}: textures are built for a diffuse reflectance and a rough conductor's specular_reflectance")
 
         def eta_k():
             preset = node.find("string[@name='material']")
@@ -463,13 +686,15 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             return (float(val(a.get("value"))) if a is not None else 0.1), (dist.get("value") if dist is not None else "beckmann")
 
         if kind == "diffuse":
-            materials.append(diffuse_material(named.get("reflectance", (0.5, 0.5, 0.5)), twosided))
+            materials.append(diffuse_material(named.get("reflectance", (0.5, 0.5, 0.5)), twosided,
+                                              texture(tex["reflectance"]) if "reflectance" in tex else None))
         elif kind == "roughconductor":
             if not twosided:
                 raise ValueError("roughconductor: only the twosided form is built")
             e, k = eta_k()
             a, dist = alpha()
-            materials.append(roughconductor_material(a, e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0)), dist))
+            materials.append(roughconductor_material(a, e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0)), dist,
+                                                     texture(tex["specular_reflectance"]) if "specular_reflectance" in tex else None))
         elif kind == "conductor":
             e, k = eta_k()
             materials.append(conductor_material(e, k, named.get("specular_reflectance", (1.0, 1.0, 1.0)), twosided))
@@ -496,7 +721,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     fw = int(val(film.find("integer[@name='width']").get("value")))
     fh = int(val(film.find("integer[@name='height']").get("value")))
     cam = make_camera(transform(sensor.find("transform")), fov, width or fw, height or fh)
-    quads, names, spheres, bxs, tris = [], [], [], [], []
+    quads, names, spheres, bxs, tris, skipped = [], [], [], [], [], []
     for sh in root.findall("shape"):
         kind = sh.get("type")
         ref = sh.find("ref")
@@ -519,16 +744,20 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
                 raise ValueError("emitting meshes are not supported")
             from .mesh import read_obj, read_serialized, triangles
             fname = os.path.join(base, sh.find("string[@name='filename']").get("value"))
+            if skip_missing_meshes and not os.path.exists(fname):
+                skipped.append(sh.get("id", fname))
+                continue
+            uv = None
             if kind == "obj":
-                v, f = read_obj(fname)
-                nrm = None
+                v, f, uv, nrm = read_obj(fname, attributes=True)
             else:
                 si = sh.find("integer[@name='shape_index']")
                 v, f, nrm = read_serialized(fname, int(val(si.get("value"))) if si is not None else 0)
             fn = sh.find("boolean[@name='face_normals']")
             if fn is not None and fn.get("value") == "true":
                 nrm = None
-            tris.append(triangles(v, f, m, mi, nrm))
+            flip = sh.find("boolean[@name='flip_tex_coords']")
+            tris.append(triangles(v, f, m, mi, nrm, uv, flip is None or flip.get("value") == "true"))
             continue
         if kind == "rectangle":
             qs = rectangle(m, refl, rad)
@@ -553,7 +782,9 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
         direction = vec(d, 0.0) if d is not None else transform(em.find("transform"))[:3, 2]
         irr = em.find("rgb[@name='irradiance']")
         lights.append(directional_light(direction, rgb(irr) if irr is not None else (1.0, 1.0, 1.0)))
-    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials, bxs, tris, lights)
+    sc = _finish(quads, cam, props.get("max_depth", 30), props.get("rr_depth", 8), names, spheres, materials, bxs, tris, lights,
+                 textures)
+    sc.skipped = skipped
     rf = film.find("rfilter")
     sc.rfilter = rf.get("type") if rf is not None else "gaussian"  # hdrfilm's default
     if sc.rfilter not in ("tent", "box", "gaussian"):

@@ -1,4 +1,4 @@
-"""Makes tests/golden/torus_meshes.npz: the five meshes scenes/torus/scene.xml refers to
+"""Makes practical_path_guiding_lab_amd/data/torus_meshes.npz: the five meshes scenes/torus/scene.xml refers to
 (`meshes.serialized`, shape_index 1..5), read with practical_path_guiding_lab_amd.mesh.read_serialized
 and stored as plain arrays (float32 positions and normals exactly as in the file, integer faces), so
 that the torus scene can be built where the reference's files are absent (the GPU box).
@@ -26,7 +26,7 @@ def main():
         out[f"{name}_n"] = n.astype(np.float32)
         out[f"{name}_f"] = f.astype(np.uint16 if v.shape[0] <= 65536 else np.uint32)
         print(name, v.shape[0], "vertices", f.shape[0], "faces")
-    dst = os.path.join(os.path.dirname(__file__), "torus_meshes.npz")
+    dst = os.path.join(os.path.dirname(__file__), "..", "..", "practical_path_guiding_lab_amd", "data", "torus_meshes.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes")
 

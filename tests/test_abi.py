@@ -30,7 +30,7 @@ def test_header_symbols_are_exported(native):
 
 def test_abi_version_and_loud_failure_without_gpu(native):
     L = native.lib()
-    assert L.pg_abi_version() == 1
+    assert L.pg_abi_version() == 2
     import torch
 
     if torch.cuda.is_available():

@@ -69,7 +69,7 @@ def test_read_serialized_meshes(tmp_path, version):
 
 
 def test_torus_scene_from_its_fixture_and_from_the_xml():
-    """scene.torus() (meshes from tests/golden/torus_meshes.npz) against the scene file itself where
+    """scene.torus() (meshes from the package data torus_meshes.npz) against the scene file itself where
     the reference is mounted; the fixture's sizes either way."""
     import os
     sc = S.torus(64, 48)
