@@ -1,19 +1,31 @@
 #!/usr/bin/env python
-"""bench.py -- guided Msamples/s of the MI355X-native path-guiding integrator.
+"""bench.py -- guided Msamples/s (+ image MSE vs ground truth) of the MI355X-native path-guiding integrator.
 
-Workload (BASELINE.json configs[1]): cornell-box 512x512, max_depth 8, guided iterations with the
-2^(k+2) spp schedule.  The SD-tree is first trained by really rendering iterations 0..train_iters-1
-(untimed); a *step* is then one guided pass of the next iteration: every pixel x spp_per_pass camera
-paths through pg_render_pass (camera rays, max_depth bounces with NEE and BSDF/SD-tree one-sample
-MIS, record store) followed by record post-processing and the splat into sdTree_current -- i.e.
-PathGuidingIntegrator.sample() of the reference, whole.  Everything is resident in HBM.
+Default workload = the one BASELINE.json's metric is quoted on: veach-ajar 1920x1080, the scene
+file's max_depth 13, the 2^(k+2) spp schedule (scenes/veach-ajar/scene.xml, main.py:170).  Phases:
 
-value     = camera paths per second over all ranks (Msamples/s), wall clock over K steps.
-roofline  = dominant kernel of the timed region (HIP events recorded by the library on the launch
-            stream): its SD-tree algorithmic bytes per launch / mean launch time vs
-            the 8 TB/s HBM peak.
-cpu_baseline = the CPU oracle ("port") rendering a guided pass of the same scene and tree at
-            1/4 of the pixels on one host core.
+  train   iterations 0 .. train_iters-1 are really rendered (4, 8, 16 ... spp; accumulators summed
+          over the ranks and the SD-tree refined after each) and timed per iteration ->
+          `value_full_schedule`: guided paths (iterations >= 2) per second INCLUDING exchange + refine.
+  steps   a *step* is one guided pass of iteration train_iters over the whole film (spp_per_pass
+          samples per pixel): camera rays, max_depth bounces with NEE and BSDF/SD-tree one-sample MIS,
+          the record list, then record post-processing and the splat into sdTree_current --
+          PathGuidingIntegrator.sample() of the reference, whole.  `value` = paths per second over
+          K steps, wall clock between barriers, max over ranks.  Everything is resident in HBM.
+  N > 1   the film is sharded: rank r traces bands of 4 rows dealt round-robin (pg_pass_params
+          stripes), no data-path collective inside a step; one int64 all-reduce of the accumulators
+          per iteration (RCCL).  The film is fixed, so `scaling` is "strong".  `--shard passes` is the
+          weak-scaling form (every rank traces the whole film with its own seeds).
+  mse     MSE of the last trained iteration's image against the reference's ground truth
+          (path_guiding_integrator.py:503-517; teapot pixels masked, both images box-filtered to
+          640x360), and -- at N = 1 -- the same schedule on a 320x180 film on the device and on the
+          CPU oracle: equal spp, equal seeds, the two MSEs must be equal (`mse_equal`).
+  cpu_baseline   the CPU oracle ("port") timed on the guided passes of that 320x180 run, all host cores.
+
+roofline = the SD-tree kernel of the timed region (k_wave_guide for mesh scenes, the fused k_bounce
+otherwise): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
+counted by an instrumented pass) per launch / mean launch time (HIP events recorded by the library on
+the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a step with its share.
 
 `--synthetic` runs the renderer-free hot-path workload instead (seeded synthetic surface points).
 Launch:  python bench.py [--gpus 1]
@@ -30,38 +42,50 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+SCENES = {  # film width, aspect (w, h), max_depth of the BASELINE config
+    "veach-ajar": (1920, (16, 9), 13), "cornell-box": (512, (1, 1), 8), "veach-mis": (1280, (16, 9), 3),
+    "torus": (1920, (16, 9), 32),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="cornell-box", choices=["cornell-box", "veach-mis", "torus"],
-                    help="cornell-box 512x512 max_depth 8 (BASELINE configs[1], the default), veach-mis 1280x720 "
-                         "max_depth 3 (configs[2]) or torus 1024x768 max_depth 30 (configs[4])")
-    ap.add_argument("--res", type=int, default=None, help="film width (cornell-box: square film; veach-mis: 16:9; torus: 4:3)")
-    ap.add_argument("--depth", type=int, default=None, help="max_depth (default: 8 / 3 / 30)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="veach-ajar", choices=sorted(SCENES),
+                    help="veach-ajar 1920x1080 max_depth 13 (BASELINE configs[3], the metric's scene; default), cornell-box "
+                         "512x512 max_depth 8 (configs[1]), veach-mis 1280x720 max_depth 3 (configs[2]), torus 1920x1080 "
+                         "max_depth 32 (configs[4])")
+    ap.add_argument("--res", type=int, default=None, help="film width (height follows the scene's aspect)")
+    ap.add_argument("--depth", type=int, default=None, help="max_depth")
     ap.add_argument("--spp-per-pass", type=int, default=8, help="samples per pixel traced by one pass")
-    ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered (untimed) to train the SD-tree")
-    ap.add_argument("--cpu-res", type=int, default=256, help="film size of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered to train the SD-tree (the configs say 8/10/12)")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"], help="N > 1: strong scaling by tiles (default) or weak by passes")
+    ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
+    w, _, d = SCENES[args.scene]
     if args.res is None:
-        args.res = {"cornell-box": 512, "veach-mis": 1280, "torus": 1024}[args.scene]
+        args.res = 512 if args.synthetic else w
     if args.depth is None:
-        args.depth = {"cornell-box": 8, "veach-mis": 3, "torus": 30}[args.scene]
+        args.depth = 8 if args.synthetic else d
     return args
 
 
-def make_scene(args, width):
+def make_scene(name, width, depth):
     from practical_path_guiding_lab_amd import scene as S
 
-    if args.scene == "veach-mis":
-        return S.veach_mis(width, width * 9 // 16, args.depth, 8)
-    if args.scene == "torus":
-        return S.torus(width, width * 3 // 4, args.depth, 8)
-    return S.cornell_box(width, width, args.depth, 8)
+    aw, ah = SCENES[name][1]
+    height = width * ah // aw
+    if name == "veach-mis":
+        return S.veach_mis(width, height, depth, 8)
+    if name == "torus":
+        return S.torus(width, height, depth, 8)
+    if name == "veach-ajar":
+        return S.veach_ajar(width, height, depth, 8)
+    return S.cornell_box(width, height, depth, 8)
 
 
 def traffic_for(kernel, key):
@@ -126,55 +150,119 @@ def timed_steps(step, steps, warmup, world):
     return elapsed
 
 
+def masked_mse(img, gt, mask):
+    """path_guiding_integrator.py:503-517 on (H, W, 3) arrays, over the pixels of `mask`."""
+    import numpy as np
+    d2 = (img.astype(np.float64) - gt.astype(np.float64)) ** 2
+    lum = np.minimum(0.212671 * d2[..., 0] + 0.715160 * d2[..., 1] + 0.072169 * d2[..., 2], 1e4)
+    return float(lum[mask].mean())
+
+
+def gt_fixture(name, width, height):
+    """(ground truth (h, w, 3) float32, mask (h, w) bool, factor) at the largest committed size that
+    divides the film, or None: the reference's TungstenRender.exr box-downsampled (tests/golden/)."""
+    import numpy as np
+    from practical_path_guiding_lab_amd import scene as S
+    files = {"veach-ajar": [(640, 360), (320, 180)], "cornell-box": [(256, 256)], "veach-mis": [(320, 180)]}.get(name, [])
+    stem = {"veach-ajar": "veach_ajar_gt_%dx%d_f16.npy", "cornell-box": "cornell_gt_%d_f16.npy", "veach-mis": "veach_mis_gt_%dx%d_f16.npy"}
+    for gw, gh in files:
+        if width % gw or height % gh or width // gw != height // gh:
+            continue
+        fn = stem[name] % ((gw, gh) if name != "cornell-box" else (gw,))
+        path = os.path.join(ROOT, "tests", "golden", fn)
+        if not os.path.exists(path):
+            continue
+        gt = np.load(path).astype(np.float32)
+        mask = S.veach_ajar_mask(gw, gh) if name == "veach-ajar" else np.ones((gh, gw), bool)
+        return gt, mask, width // gw
+    return None
+
+
+def image_mse(sumL, spp, width, height, name):
+    """MSE vs the ground-truth fixture of the per-pixel mean image sumL/spp ((3, H*W) array)."""
+    import numpy as np
+    fx = gt_fixture(name, width, height)
+    if fx is None:
+        return None, None
+    gt, mask, f = fx
+    img = (np.asarray(sumL, dtype=np.float64) / float(spp)).T.reshape(height, width, 3)
+    if f > 1:
+        img = img.reshape(height // f, f, width // f, f, 3).mean(axis=(1, 3))
+    note = (f"mean image box-filtered {f}x{f} to {gt.shape[1]}x{gt.shape[0]} vs TungstenRender.exr box-filtered to the same size"
+            + ("; the teapot rectangle (their meshes are missing from the reference mount) is masked" if name == "veach-ajar" else ""))
+    return masked_mse(img, gt, mask), note
+
+
 # ------------------------------------------------------------------------------------------------
 def run_render(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from practical_path_guiding_lab_amd import scene as S
-    from practical_path_guiding_lab_amd import workload as W
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
-    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators, shard
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators, all_reduce_sums
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
     world, rank, local_rank = init_dist(args)
-    # Sharding: the passes of an iteration are independent (main.py:208-218: pass p uses seed
-    # initial_seed + cumm_spp), so N ranks trace N consecutive passes of the same film concurrently,
-    # each into its own accumulators, and sum them (int64 all-reduce) before the refine.  Weak
-    # scaling: every GPU traces the full res x res film per step.
-    sc = make_scene(args, args.res)
+    sc = make_scene(args.scene, args.res, args.depth)
+    W, H = sc.camera.width, sc.camera.height
     integ = PathGuidingIntegrator({"max_depth": args.depth, "rr_depth": 8}, device=local_rank)
     tree = integ.sdTree
-    npix = sc.camera.width * sc.camera.height
+    npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
     ws = WavefrontScene(sc)
-    my_pixels = npix
+    tiles = world > 1 and args.shard == "tiles"
+    if tiles:
+        ws.set_shard(rank, world, 4)
+    my_pixels = int(ws.local_pixels().shape[0])
     reduce_fn = (lambda acc: all_reduce_accumulators(acc)) if world > 1 else None
 
     # ---- train: really render iterations 0..train_iters-1 (2^(k+2) spp each, main.py:170) ----
-    torch.cuda.synchronize()
-    t_train = time.perf_counter()
+    per_iter = []
     cumm = 0
     for k in range(args.train_iters):
         integ.setIteration(k, False)
+        integ.resetVarianceCounter()  # main.py:161-163: the image of an iteration holds its own samples only
         iter_spp = 2 ** (k + 2)
-        chunk = max(1, min(args.spp_per_pass, iter_spp // world))
-        for i in range(iter_spp // chunk):
-            if i % world == rank:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if tiles or world == 1:
+            chunk = max(1, min(args.spp_per_pass, iter_spp))
+            for i in range(iter_spp // chunk):
                 integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk))
-        cumm += iter_spp
+        else:  # passes: the passes of an iteration are independent (main.py:208-218), ranks take them in turn
+            chunk = max(1, min(args.spp_per_pass, iter_spp // world))
+            for i in range(iter_spp // chunk):
+                if i % world == rank:
+                    integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         integ.refineAndPrepareSDTreeForNextIteration(reduce_fn)
-    torch.cuda.synchronize()
-    t_train = time.perf_counter() - t_train
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        cumm += iter_spp
+        per_iter.append({"iteration": k, "spp": iter_spp, "render_ms": round(1e3 * (t1 - t0), 2),
+                         "exchange_refine_ms": round(1e3 * (t2 - t1), 2)})
+    last_spp = 2 ** (args.train_iters + 1)
+    sums = all_reduce_sums(integ.sumL, integ.sumL2) if world > 1 else (integ.sumL, integ.sumL2)
+    mse_train, mse_note = (None, None)
+    if rank == 0:
+        mse_train, mse_note = image_mse(sums[0].cpu().numpy(), last_spp, W, H, args.scene)
+    guided = [p for p in per_iter if p["iteration"] >= 2]
+    t_guided = sum(p["render_ms"] + p["exchange_refine_ms"] for p in guided) * 1e-3
+    full_schedule = (npix * sum(p["spp"] for p in guided) / t_guided / 1e6) if guided and t_guided > 0 else None
     stats = tree.stats()
     k = args.train_iters
     integ.setIteration(k, False)
 
-    seed = [cumm + rank * args.spp_per_pass]
+    seed = [cumm + (0 if tiles else rank * args.spp_per_pass)]
 
     def step():
         integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0]))
-        seed[0] += args.spp_per_pass * world
+        seed[0] += args.spp_per_pass * (1 if tiles else world)
 
     # one instrumented pass for the byte model (depth counters add atomics: not timed)
     tree.enableDepthCounters(True)
@@ -187,7 +275,6 @@ def run_render(args):
     live = tree.renderLiveCounts(args.depth)  # paths alive after each bounce of that pass
 
     tree.enableKernelTiming(True)
-    tree.readKernelTiming(reset=True)
     for _ in range(args.warmup):
         step()
     tree.readKernelTiming(reset=True)
@@ -210,91 +297,155 @@ def run_render(args):
             dist.destroy_process_group()
         return None
 
-    paths_per_step = npix * args.spp_per_pass * world  # all ranks
+    paths_per_step = npix * args.spp_per_pass * (1 if (tiles or world == 1) else world)  # all ranks
     value = paths_per_step * args.steps / elapsed / 1e6
     # instrumented pass -> algorithmic bytes per pass on this rank
-    # bounce: 16 B per KD level + 20 B per quadtree level; splat: per record 16*D_kd + 4 + 48 + 12 per quadtree level
-    # the splat's depths are not separated from the bounce's by the counters, so it is priced with the
-    # tree's mean depths over the records actually kept (counted from sdTree_current's leaf counters)
-    paths_bytes = 16.0 * dc.kd_levels + 20.0 * dc.quad_levels          # all bounces of one pass
+    # SD-tree queries: 16 B per KD level + 20 B per quadtree level; splat: per record 16*D_kd + 4 + 48 + 12 per quadtree
+    # level and descent, priced with the measured mean depths over the records actually kept
+    tree_bytes = 16.0 * dc.kd_levels + 20.0 * dc.quad_levels          # all bounces of one pass
     d_kd = dc.kd_levels / max(dc.kd_queries, 1)
     d_q = dc.quad_levels / max(dc.quad_queries, 1)
-    splat_bytes = records_per_pass * (16.0 * d_kd + 4.0 + 48.0 + 12.0 * 2.0 * d_q)  # B_rec with the measured mean depths
-    n_b, n_s = max(kt.bounce_launches, 1), max(kt.splat_launches, 1)
-    paths_us = 1e3 * kt.bounce_ms / n_b
-    splat_us = 1e3 * kt.splat_ms / n_s
+    splat_bytes = records_per_pass * (16.0 * d_kd + 4.0 + 48.0 + 12.0 * 2.0 * d_q)
     passes = max(kt.passes, 1)
-    per_pass = n_b / passes  # bounce launches per pass (= max_depth)
-    kern = {
-        "k_bounce": {"launches": int(kt.bounce_launches), "avg_us": round(paths_us, 2),
-                     "alg_bytes_per_launch": round(paths_bytes / per_pass),
-                     "alg_GBps": round(paths_bytes / per_pass / (paths_us * 1e-6) / 1e9, 2) if paths_us else 0.0},
-        "k_process_and_splat": {"launches": int(kt.splat_launches), "avg_us": round(splat_us, 2),
-                                "records_per_launch": int(records_per_pass), "alg_bytes_per_launch": round(splat_bytes),
-                                "alg_GBps": round(splat_bytes / (splat_us * 1e-6) / 1e9, 2) if splat_us else 0.0},
-        "k_finish": {"avg_us": round(1e3 * kt.finish_ms / passes, 2)},
-    }
-    dom = "k_bounce" if kt.bounce_ms >= kt.splat_ms else "k_process_and_splat"
-    cfg_key = f"render res={args.res} depth={args.depth} spp={args.spp_per_pass}"
-    if args.scene != "cornell-box":
-        cfg_key = f"{args.scene} " + cfg_key
-    film = f"{sc.camera.width}x{sc.camera.height}"
+    wave = kt.guide_launches > 0
+    step_ms = 1e3 * elapsed / args.steps
+
+    def kern(ms, launches, alg_bytes_per_pass=None):
+        per_pass = launches / passes
+        d = {"launches": int(launches), "avg_us": round(1e3 * ms / max(launches, 1), 2), "ms_per_step": round(ms / passes, 3),
+             "share_of_step": round(ms / passes / step_ms, 3)}
+        if alg_bytes_per_pass is not None and ms > 0:
+            d["alg_bytes_per_launch"] = round(alg_bytes_per_pass / max(per_pass, 1))
+            d["alg_GBps"] = round(alg_bytes_per_pass * passes / (ms * 1e-3) / 1e9, 2)
+        return d
+
+    kernels = {}
+    if wave:
+        nb = kt.bounce_launches  # bounces
+        kernels["k_wave_guide"] = kern(kt.guide_ms, kt.guide_launches, tree_bytes)
+        kernels["k_wave_trace"] = kern(kt.trace_ms, kt.trace_launches)
+        kernels["k_wave_shadow"] = kern(kt.shadow_ms, nb)
+        kernels["k_wave_shade_a+b"] = kern(kt.shade_ms, 2 * nb)
+        kernels["k_wave_tail"] = kern(kt.tail_ms, max(kt.passes, 1))
+        dom = "k_wave_guide"
+    else:
+        kernels["k_bounce"] = kern(kt.bounce_ms, kt.bounce_launches, tree_bytes)
+        dom = "k_bounce"
+    kernels["k_process_and_splat"] = kern(kt.splat_ms, kt.splat_launches, splat_bytes)
+    kernels["k_process_and_splat"]["records_per_launch"] = int(records_per_pass)
+    kernels["k_finish"] = kern(kt.finish_ms, passes)
+    slowest = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+    cfg_key = f"{args.scene} res={args.res} depth={args.depth} spp={args.spp_per_pass}"
+    film = f"{W}x{H}"
     what = {"cornell-box": "built-in scene (Mitsuba cornell-box parameters), no textures",
             "veach-mis": "built-in scene (scenes/veach-mis/scene.xml parameters: 3 sphere lamps, 4 Beckmann rough-conductor "
                          "plates, diffuse floor and wall)",
-            "torus": "built-in scene (scenes/torus/scene.xml parameters; its five meshes, 23614 triangles, from "
-                     "the package data torus_meshes.npz behind a BVH: diffuse donut in a frosted-glass case, aluminium "
-                     "brackets, directional light)"}[args.scene]
-    roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 5),
-            "traffic": traffic_for(dom, cfg_key),
-            "note": "k_bounce is one whole bounce of the wavefront (ray casting, NEE incl. shadow ray, shading, SD-tree "
-                    "queries, record store, state load/store); its algorithmic bytes count only the SD-tree descents "
-                    "(16 B/KD level, 20 B/quadtree level, SURVEY 8d). k_process_and_splat is bound by scattered "
-                    "atomics, not HBM (DESIGN.md 5)"}
-    cpu = cpu_baseline_render(args, tree, sc) if (args.cpu_res > 0 and world == 1) else None
+            "torus": "built-in scene (scenes/torus/scene.xml parameters; its five meshes, 23614 triangles, from the package "
+                     "data torus_meshes.npz behind a BVH: diffuse donut in a frosted-glass case, aluminium brackets, "
+                     "directional light)",
+            "veach-ajar": "built-in scene (scenes/veach-ajar/scene.xml parameters; its 15 OBJ meshes present in the reference "
+                          "mount, 4482 triangles with texture coordinates, and its three bitmap textures at reduced "
+                          "resolution from the package data veach_ajar.npz; checkerboard GGX floor, Beckmann door handle; "
+                          "the six teapot shapes are absent: their mesh files are missing from the reference mount)"}[args.scene]
+    traffic = traffic_for(dom, cfg_key)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "slowest_kernel_of_step": slowest,
+            "note": ("k_wave_guide holds the SD-tree calls of a bounce and nothing else (KD descent, NEE pdf, sample-or-pdf, the "
+                     "canonical coordinates of the record): the hot path of SURVEY 8; its algorithmic bytes are 16 B per KD "
+                     "level + 20 B per quadtree level over the levels an instrumented pass counted. The renderer substrate around "
+                     "it (ray casting k_wave_trace / k_wave_shadow, shading) is row f-1; `kernels` gives every kernel's share. "
+                     if wave else
+                     "k_bounce is one whole bounce of the wavefront (ray casting, NEE incl. shadow ray, shading, SD-tree "
+                     "queries, record store, state load/store); its algorithmic bytes count only the SD-tree descents "
+                     "(16 B/KD level, 20 B/quadtree level, SURVEY 8d). ")
+                    + "k_process_and_splat is bound by scattered atomics, not HBM (DESIGN.md 5). `traffic` is not measured in "
+                      "this run: it is the PMC figure of the same configuration committed in profiles/pmc_traffic.json "
+                      "(null: none committed)."}
+    cpu = None
+    mse_small = mse_small_cpu = None
+    if args.cpu and world == 1:
+        cpu, mse_small, mse_small_cpu = cpu_leg(args)
     out = {
         "metric": f"Msamples/s guided, {args.scene} {film} max_depth {args.depth}", "value": round(value, 3), "unit": "Msamples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.scene} {film} per GPU, max_depth {args.depth}, guided iteration "
-                               f"{k} (SD-tree trained by rendering iterations 0-{k - 1}), {args.spp_per_pass} spp per pass; "
-                               "full PathGuidingIntegrator.sample(): camera rays, NEE, BSDF/SD-tree MIS, record store, "
-                               "post-process + splat; " + what,
-                   "pixels_per_gpu": my_pixels, "spp_per_pass": args.spp_per_pass,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
+        "higher_is_better": True, "scaling": "strong" if (tiles or world == 1) else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "value_full_schedule": None if full_schedule is None else round(full_schedule, 3),
+        "mse_vs_gt": mse_train, "mse_vs_gt_small": mse_small, "mse_vs_gt_cpu": mse_small_cpu,
+        "mse_equal": None if mse_small is None else bool(mse_small == mse_small_cpu),
+        "config": {"workload": f"{args.scene} {film} (the whole film per step"
+                               + (", sharded by interleaved 4-row bands over the ranks" if tiles else (", per GPU" if world > 1 else ""))
+                               + f"), max_depth {args.depth}, guided iteration {k} (SD-tree trained by rendering iterations 0-{k - 1}, "
+                               f"{cumm} spp), {args.spp_per_pass} spp per pass; full PathGuidingIntegrator.sample(): camera rays, NEE, "
+                               "BSDF/SD-tree MIS, record list, post-process + splat; " + what,
+                   "pixels_this_rank": my_pixels, "spp_per_pass": args.spp_per_pass,
                    "paths_per_step": paths_per_step, "kd_nodes": stats.n_kd_nodes, "kd_leaves": stats.n_kd_leaves,
                    "quad_records": stats.n_quad_records, "mean_kd_leaf_depth": round(stats.mean_kd_leaf_depth, 3),
                    "mean_quad_leaf_depth": round(stats.mean_quad_leaf_depth, 3),
                    "guided_tree_queries_per_pass": int(dc.quad_queries), "paths_alive_after_bounce": live,
-                   "measured_D_kd": round(dc.kd_levels / max(dc.kd_queries, 1), 3),
-                   "measured_D_quad": round(dc.quad_levels / max(dc.quad_queries, 1), 3)},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
-        "extra": {"train_s": round(t_train, 3), "trained_spp": cumm, "allreduce_ms": round(1e3 * t_allreduce, 3),
-                  "refine_ms": round(1e3 * t_refine, 3)},
+                   "measured_D_kd": round(d_kd, 3), "measured_D_quad": round(d_q, 3)},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        "schedule": {"note": "value_full_schedule = film pixels x spp of the trained iterations >= 2 / their wall time incl. "
+                             "accumulator exchange and refine (main.py:159,394); mse_vs_gt = the last trained iteration's "
+                             f"image ({last_spp} spp) vs the ground truth" + (": " + mse_note if mse_note else ""),
+                     "iterations": per_iter, "trained_spp": cumm},
+        "extra": {"allreduce_ms": round(1e3 * t_allreduce, 3), "refine_ms": round(1e3 * t_refine, 3)},
     }
     if world > 1:
         dist.destroy_process_group()
     return out
 
 
-def cpu_baseline_render(args, tree, sc_full):
-    """The CPU oracle renders one guided pass of the same scene with the same trained tree."""
+def cpu_leg(args, iters=4, width=320):
+    """The same 4-iteration schedule (4+8+16+32 spp, the last two guided) of the same scene on a
+    320-pixel-wide film, on the device and on the CPU oracle with all host cores: same seeds, so the
+    images -- and their MSEs against the ground truth -- must be identical; the oracle's guided
+    passes are the timed cpu_baseline sample."""
+    import numpy as np
     from oracle import pg_oracle as po
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
     po.build()
+    cores = po.set_threads(0)
+    sc = make_scene(args.scene, width, args.depth)
+    W, H = sc.camera.width, sc.camera.height
+    npix = W * H
+    bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
+    g = PathGuidingIntegrator({"max_depth": args.depth, "rr_depth": 8})
+    g.setup(npix, bmin, bmax, 20, 20, True, 0.5)
+    ws = WavefrontScene(sc)
     pair = po.OracleSDTreePair()
-    pair.prev.load(tree.export())
-    pair.current.copy_from(pair.prev)
-    pair.current.reset()
-    sc = make_scene(args, args.cpu_res)
-    spp = args.spp_per_pass
-    t0 = time.perf_counter()
-    po.render_pass(pair, sc, sc.camera, args.depth, 8, args.train_iters, False, 12345, spp, True, 0.5)
-    dt = time.perf_counter() - t0
-    n = sc.camera.width * sc.camera.height * spp
-    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"one guided pass of the same scene and SD-tree at {sc.camera.width}x{sc.camera.height} x {spp} spp "
-                      f"({n} paths), single-threaded C oracle, {dt:.1f} s"}
+    pair.setup(bmin, bmax, 20, 20, True)
+    o_sumL, o_sumL2 = np.zeros((3, npix), np.float32), np.zeros((3, npix), np.float32)
+    cumm, t_guided, n_guided = 0, 0.0, 0
+    for k in range(iters):
+        spp = 2 ** (k + 2)
+        g.setIteration(k, False)
+        g.resetVarianceCounter()
+        o_sumL[:] = 0
+        o_sumL2[:] = 0
+        g.sample(ws, IndependentSampler(spp, cumm))
+        t0 = time.perf_counter()
+        po.render_pass(pair, sc, sc.camera, args.depth, 8, k, False, cumm, spp, True, 0.5, o_sumL, o_sumL2)
+        dt = time.perf_counter() - t0
+        if k >= 2:
+            t_guided += dt
+            n_guided += npix * spp
+        cumm += spp
+        if k + 1 < iters:
+            g.refineAndPrepareSDTreeForNextIteration()
+            pair.refine_and_prepare(k)
+    last = 2 ** (iters + 1)
+    g_sum = g.sumL.cpu().numpy()
+    same = bool((g_sum.view(np.uint32) == o_sumL.view(np.uint32)).all())
+    mse_g, _ = image_mse(g_sum, last, W, H, args.scene)
+    mse_c, _ = image_mse(o_sumL, last, W, H, args.scene)
+    cpu = {"value": round(n_guided / t_guided / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "images_bit_identical_to_device": same,
+           "sample": f"the guided passes (iterations 2-3, 16 + 32 spp) of a 4-iteration schedule of the same scene on a {W}x{H} "
+                     f"film ({n_guided} paths), C oracle with OpenMP over the lanes on {cores} threads, {t_guided:.1f} s"}
+    return cpu, mse_g, mse_c
 
 
 # ------------------------------------------------------------------------------------------------

@@ -323,6 +323,12 @@ typedef struct pg_pass_params {
 	 * streams are keyed by the global lane id, so the union of tiles equals the full-frame pass.
 	 * L_out / valid_out hold only the tile's lanes; sumL / sumL2 are full-film arrays. */
 	uint64_t pixel_begin, pixel_count;
+	/* Interleaved sharding (load balance across GPUs): with stripe_count > 1 the call traces the rows r
+	 * of the film with (r / stripe_rows) % stripe_count == stripe_index -- bands of stripe_rows rows dealt
+	 * round-robin -- in ascending order; pixel_begin must be 0 and pixel_count the number of pixels of
+	 * those rows (or 0).  The tile-local pixel i of L_out / valid_out is column i % width of the
+	 * (i / width)-th owned row.  stripe_count 0 or 1: the contiguous range above. */
+	uint32_t stripe_rows, stripe_index, stripe_count, reserved2;
 } pg_pass_params;
 
 /* One call of PathGuidingIntegrator.sample() for all width*height*spp lanes

@@ -42,8 +42,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	if (kFirst) {
 		// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
 		// the full-frame pass would, whatever the number of ranks
-		rng = pcg32_seed(a.seed, (uint32_t)(a.pixel_begin * (uint64_t)a.spp + lane));
-		const uint64_t pixel = a.pixel_begin + lane / (uint64_t)a.spp;
+		const uint64_t pixel = global_pixel(a, lane / (uint64_t)a.spp);
+		rng = pcg32_seed(a.seed, (uint32_t)(pixel * (uint64_t)a.spp + lane % (uint64_t)a.spp));
 		const int W = a.cam.width, H = a.cam.height;
 		const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
 		const float jx = rng.next_f32(), jy = rng.next_f32();
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	const uint64_t pix = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	if (pix >= a.n_pixels) return;
 	const uint64_t N = a.n_lanes, P = a.film_pixels;
-	const uint64_t gpix = a.pixel_begin + pix; // the sums are full-film arrays
+	const uint64_t gpix = global_pixel(a, pix); // the sums are full-film arrays
 	const uint64_t first = pix * (uint64_t)a.spp;
 	if (valid_out)
 		for (int s = 0; s < a.spp; ++s) valid_out[first + s] = a.hit0[first + s];
@@ -699,7 +699,17 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	const uint64_t film = (uint64_t)r->cam.width * (uint64_t)r->cam.height;
 	if (prm->pixel_begin > film || prm->pixel_count > film - prm->pixel_begin)
 		return fail(ctx, PG_ERR_INVALID, "pg_render_pass: pixel range outside the film");
-	const uint64_t P = prm->pixel_count ? prm->pixel_count : film - prm->pixel_begin; // 0 = to the end
+	uint64_t P = prm->pixel_count ? prm->pixel_count : film - prm->pixel_begin; // 0 = to the end
+	if (prm->stripe_count > 1) { // bands of stripe_rows rows dealt round-robin: this rank's rows
+		if (prm->stripe_rows == 0 || prm->stripe_index >= prm->stripe_count || prm->pixel_begin != 0)
+			return fail(ctx, PG_ERR_INVALID, "pg_render_pass: bad stripe parameters");
+		uint64_t rows = 0;
+		for (uint64_t row = 0; row < (uint64_t)r->cam.height; ++row)
+			rows += (row / prm->stripe_rows) % prm->stripe_count == prm->stripe_index;
+		if (prm->pixel_count && prm->pixel_count != rows * (uint64_t)r->cam.width)
+			return fail(ctx, PG_ERR_INVALID, "pg_render_pass: pixel_count does not match the stripes of this rank");
+		P = rows * (uint64_t)r->cam.width;
+	}
 	if (P == 0) return PG_OK;
 	const uint64_t N = P * (uint64_t)prm->spp;
 	const int D = ctx->max_depth;
@@ -755,6 +765,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.n_lanes = N;
 	a.n_pixels = P;
 	a.pixel_begin = prm->pixel_begin;
+	a.stripe_rows = prm->stripe_rows; a.stripe_index = prm->stripe_index; a.stripe_count = prm->stripe_count;
 	a.film_pixels = film;
 	a.spp = prm->spp;
 	a.max_depth = D;

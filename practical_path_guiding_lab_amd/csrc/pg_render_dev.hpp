@@ -1050,6 +1050,7 @@ struct RenderArgs {
 	pg_camera cam;
 	uint64_t n_lanes, n_pixels;      // of this pass (tile)
 	uint64_t pixel_begin, film_pixels; // first pixel of the tile, pixels of the whole film
+	uint32_t stripe_rows, stripe_index, stripe_count; // interleaved sharding (pg_pass_params); count <= 1: the contiguous tile
 	int spp, max_depth, rr_depth, guided, record, store_nee;
 	float frac;
 	uint32_t seed;
@@ -1104,6 +1105,16 @@ __device__ __forceinline__ bool tail_took_over(const RenderArgs &a, int bounce)
 	return false;
 }
 
+
+// film pixel of the tile-local pixel i (pg_pass_params: a contiguous range, or bands of rows dealt round-robin)
+__device__ __forceinline__ uint64_t global_pixel(const RenderArgs &a, uint64_t i)
+{
+	if (a.stripe_count <= 1u) return a.pixel_begin + i;
+	const uint64_t W = (uint64_t)a.cam.width, row = i / W, col = i % W;
+	const uint64_t grow = (row / a.stripe_rows) * ((uint64_t)a.stripe_rows * a.stripe_count) +
+	                      (uint64_t)a.stripe_index * a.stripe_rows + row % a.stripe_rows;
+	return grow * W + col;
+}
 
 // pg_render_wave.hip: one stage (0 trace, 1 shade_a, 2 shadow, 3 guide, 4 shade_b, 5 tail) of one bounce of
 // the split pipeline, feature level 2 or 3; the number of 32-bit planes of its workspace

@@ -314,8 +314,8 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, P
 {
 	// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples the
 	// full-frame pass would, whatever the number of ranks
-	rng = pcg32_seed(a.seed, (uint32_t)(a.pixel_begin * (uint64_t)a.spp + lane));
-	const uint64_t pixel = a.pixel_begin + lane / (uint64_t)a.spp;
+	const uint64_t pixel = global_pixel(a, lane / (uint64_t)a.spp);
+	rng = pcg32_seed(a.seed, (uint32_t)(pixel * (uint64_t)a.spp + lane % (uint64_t)a.spp));
 	const int W = a.cam.width, H = a.cam.height;
 	const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
 	const float jx = rng.next_f32(), jy = rng.next_f32();

@@ -91,9 +91,26 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                       stable_variance_spp_threshold: int = 256, train_stop_cumm_spp: int = 1000,
                       record_in_iteration: bool = False, out_dir: Optional[str] = None,
                       all_reduce: Optional[Callable[[torch.Tensor], None]] = None,
-                      log: Callable[[str], None] = print) -> Dict:
-    """Runs the whole training + rendering schedule; returns the final image, logs and timings."""
+                      log: Callable[[str], None] = print, shard=None) -> Dict:
+    """Runs the whole training + rendering schedule; returns the final image, logs and timings.
+
+    Multi-GPU (one process per GPU, torch.distributed initialised): shard = (rank, world[, stripe_rows
+    [, group]]) makes this rank trace its interleaved bands of the film only (WavefrontScene.set_shard);
+    the SD-tree accumulators are summed over the ranks before every refine (exact integers, so every
+    rank refines the same tree), every pass's lanes are gathered before the film is developed, and
+    variance / MSE / the stop decision are taken on the whole film's sums -- every rank ends with the
+    image, the tree and the logs a single rank produces."""
     w, h = scene.film_size
+    gather = sums_of = None
+    if shard is not None and shard[1] > 1:
+        from .parallel import LaneGather, all_reduce_accumulators, all_reduce_sums
+        rank, world = shard[0], shard[1]
+        group = shard[3] if len(shard) > 3 else None
+        scene.set_shard(rank, world, shard[2] if len(shard) > 2 else 4)
+        gather = LaneGather(group)
+        sums_of = lambda: all_reduce_sums(integrator.sumL, integrator.sumL2, group)  # noqa: E731
+        if all_reduce is None:
+            all_reduce = lambda acc: all_reduce_accumulators(acc, group)  # noqa: E731
     bmin, bmax = scene.bbox()
     eps = np.float32(1e-4)  # main.py:55-59
     integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
@@ -135,7 +152,7 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         log(f"Iteration {k}: SPP {iter_spp}, cumm_SPP {cumm_spp}, remaining {budget_spp - cumm_spp}, final {is_final}")
         for p in range(n_pass):
             cur = min(spp_per_pass, iter_spp - done)
-            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp)  # main.py:218
+            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp, gather=gather)  # main.py:218
             wimg = img * float(cur / iter_spp)
             curr_iter_image = wimg if curr_iter_image is None else curr_iter_image + wimg
             if is_final:
@@ -145,12 +162,13 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
             cumm_spp += cur
             if record_in_iteration:
                 el = time.perf_counter() - t_iter + cumm_time
-                rec["variance_inIter"].append(el, image_spp, cumm_spp, k, variance=integrator.computeVariance(image_spp))
+                sums = sums_of() if sums_of else None
+                rec["variance_inIter"].append(el, image_spp, cumm_spp, k, variance=integrator.computeVariance(image_spp, sums=sums))
                 if ground_truth is not None:
                     rec["variance_groundTruth_inIter"].append(el, image_spp, cumm_spp, k,
-                                                              variance=integrator.computeVariance(image_spp, ground_truth))
+                                                              variance=integrator.computeVariance(image_spp, ground_truth, sums))
                     rec["mse_groundTruth_inIter"].append(el, image_spp, cumm_spp, k,
-                                                         mse=integrator.computeMSE(image_spp, ground_truth))
+                                                         mse=integrator.computeMSE(image_spp, ground_truth, sums))
             if is_final and cumm_spp in possible and prev_iter_image is not None and out_dir:
                 cur_cnt = cumm_spp - cumm_spp_prev
                 blend = (curr_iter_acc / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
@@ -164,9 +182,10 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
             image = (curr_iter_image * iter_spp + prev_iter_image * (image_spp - iter_spp)) / image_spp  # main.py:287-288
         else:
             image = curr_iter_image
-        variance = integrator.computeVariance(image_spp)
-        variance_gt = integrator.computeVariance(image_spp, ground_truth) if ground_truth is not None else 0.0
-        mse_gt = integrator.computeMSE(image_spp, ground_truth) if ground_truth is not None else 0.0
+        sums = sums_of() if sums_of else None
+        variance = integrator.computeVariance(image_spp, sums=sums)
+        variance_gt = integrator.computeVariance(image_spp, ground_truth, sums) if ground_truth is not None else 0.0
+        mse_gt = integrator.computeMSE(image_spp, ground_truth, sums) if ground_truth is not None else 0.0
         el = time.perf_counter() - t_iter + cumm_time
         rec["variance_endIter"].append(el, image_spp, cumm_spp, k, variance=variance)
         rec["variance_groundTruth_endIter"].append(el, image_spp, cumm_spp, k, variance=variance_gt)

@@ -91,19 +91,23 @@ class PathGuidingIntegrator:
             self.sumL2 += (Lr * Lr).sum(dim=2)
 
     # ---- metrics (:503-550) ---------------------------------------------------------------------
-    def computeMSE(self, spp: float, groundTruth: torch.Tensor) -> float:
-        L = self.sumL / spp
+    # `sums`: whole-film (sumL, sumL2) of a tile-sharded render (parallel.all_reduce_sums) instead of
+    # this rank's own arrays
+    def computeMSE(self, spp: float, groundTruth: torch.Tensor, sums=None) -> float:
+        sumL = self.sumL if sums is None else sums[0]
+        L = sumL / spp
         mse = (L - groundTruth) ** 2
         mse = torch.clamp(luminance(mse), max=10000.0)
         return float(mse.mean().item())
 
-    def computeVariance(self, spp: float, groundTruth: Optional[torch.Tensor] = None) -> float:
+    def computeVariance(self, spp: float, groundTruth: Optional[torch.Tensor] = None, sums=None) -> float:
+        sumL, sumL2 = (self.sumL, self.sumL2) if sums is None else sums
         if groundTruth is not None:
-            variance = (self.sumL2 / spp) - (groundTruth * groundTruth)
+            variance = (sumL2 / spp) - (groundTruth * groundTruth)
             variance = torch.clamp(luminance(variance), max=10000.0)
             return float(variance.mean().item()) / spp
-        L = self.sumL / spp
-        L2 = self.sumL2 / spp
+        L = sumL / spp
+        L2 = sumL2 / spp
         variance = torch.clamp(luminance(L2 - L * L), max=10000.0)
         v = float(variance.mean().item())
         if spp > 1:

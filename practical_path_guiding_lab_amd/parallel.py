@@ -44,6 +44,43 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     return acc
 
 
+def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks of any tensor; CUDA tensors go through the host under gloo."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1 or t.numel() == 0:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_reduce_sums(sumL: torch.Tensor, sumL2: torch.Tensor, group=None):
+    """Whole-film copies of the per-pixel sums of a tile-sharded render: every rank holds its own
+    pixels and zeros elsewhere (tiles are disjoint), so the sum over ranks is exact and identical on
+    every rank -- variance, MSE and the stop-training decision (main.py:334-377) then agree."""
+    return _all_reduce_sum(sumL.clone(), group), _all_reduce_sum(sumL2.clone(), group)
+
+
+class LaneGather:
+    """Collects the lanes every rank traced for its tile into full-frame lane order (lane = pixel *
+    spp + s), for the film reconstruction that needs a pixel's neighbours (render.render)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, L: torch.Tensor, scene, spp: int) -> torch.Tensor:
+        w, h = scene.film_size
+        npix = w * h
+        pix = torch.from_numpy(scene.local_pixels()).to(L.device)
+        lanes = (pix[:, None] * spp + torch.arange(spp, device=L.device)[None, :]).reshape(-1)
+        full = torch.zeros((3, npix * spp), dtype=L.dtype, device=L.device)
+        full[:, lanes] = L
+        return _all_reduce_sum(full, self.group)  # disjoint tiles: x + 0 is exact
+
+
 def max_over_ranks(seconds: float, device=None, group: Optional[dist.ProcessGroup] = None) -> float:
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return seconds

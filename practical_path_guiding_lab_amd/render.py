@@ -102,6 +102,37 @@ class WavefrontScene:
 
     # image tile of this rank (multi-GPU): (first pixel, pixel count) in row-major order; None = whole film
     pixel_range = None
+    # or: bands of `rows` rows dealt round-robin over `count` ranks, this rank being `index`
+    # (pg_pass_params.stripe_*): (rows, index, count); None = pixel_range decides
+    stripe = None
+
+    def set_shard(self, rank: int, world: int, stripe_rows: int = 4) -> None:
+        """This rank's share of the film for `world` ranks: interleaved bands of stripe_rows rows
+        (stripe_rows = 0: one contiguous range of pixels).  world = 1 clears the sharding."""
+        self.pixel_range = self.stripe = None
+        if world <= 1:
+            return
+        if stripe_rows > 0:
+            self.stripe = (int(stripe_rows), int(rank), int(world))
+        else:
+            from .parallel import shard
+            w, h = self.film_size
+            self.pixel_range = shard(w * h, rank, world)
+
+    def local_pixels(self) -> np.ndarray:
+        """Film pixel (row-major index) of every tile-local pixel of this rank, in tile order."""
+        w, h = self.film_size
+        if self.stripe is not None:
+            rows, index, count = self.stripe
+            r = np.arange(h, dtype=np.int64)
+            own = r[(r // rows) % count == index]
+            return (own[:, None] * w + np.arange(w, dtype=np.int64)[None, :]).reshape(-1)
+        begin, count = self.pixel_range if self.pixel_range is not None else (0, w * h)
+        return np.arange(begin, begin + count, dtype=np.int64)
+
+    @property
+    def sharded(self) -> bool:
+        return self.stripe is not None or self.pixel_range is not None
 
     def trace_pass(self, integrator, sampler: IndependentSampler, accumulate: bool = True):
         """One device pass over this rank's tile; returns (L (3,N) float32 cuda, valid (N,) uint8 cuda, spp)."""
@@ -109,13 +140,23 @@ class WavefrontScene:
         self._upload(tree)
         cam = self.scene.camera
         spp = sampler.sample_count()
-        begin, count = self.pixel_range if self.pixel_range is not None else (0, cam.width * cam.height)
+        if self.stripe is not None:
+            begin, count = 0, int(self.local_pixels().shape[0])
+            stripe = self.stripe
+        else:
+            begin, count = self.pixel_range if self.pixel_range is not None else (0, cam.width * cam.height)
+            stripe = (0, 0, 0)
         n = count * spp
         L = torch.empty((3, n), dtype=torch.float32, device=tree.device)
         valid = torch.empty(n, dtype=torch.uint8, device=tree.device)
         if n == 0:
             return L, valid, spp
-        p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth), 0, begin, count)
+        p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth), 0, begin, count,
+                             stripe[0], stripe[1], stripe[2], 0)
+        if accumulate and tuple(integrator.sumL.shape) != (3, cam.width * cam.height):
+            # k_finish indexes the sums by film pixel: setup(numRays) must have been given the film size
+            raise ValueError(f"integrator.setup(numRays={integrator.sumL.shape[1]}) does not match the film "
+                             f"{cam.width}x{cam.height}: call setup again for this scene")
         sl = integrator.sumL.data_ptr() if accumulate else None
         sl2 = integrator.sumL2.data_ptr() if accumulate else None
         N.check(tree._h, tree._lib.pg_render_pass(tree._h, C.byref(p), L.data_ptr(), valid.data_ptr(), sl, sl2,
@@ -123,15 +164,24 @@ class WavefrontScene:
         return L, valid, spp
 
 
-def render(scene: WavefrontScene, integrator, spp: int, seed: int) -> torch.Tensor:
+def render(scene: WavefrontScene, integrator, spp: int, seed: int, gather=None) -> torch.Tensor:
     """mi.render(scene, spp=spp, seed=seed) (main.py:218): one pass, returns the (H, W, 3) image the
-    film develops: with the scene's `tent` reconstruction filter (pg_film_tent) or the per-pixel
-    mean (`box`).  The integrator's own sums (computeMSE/computeVariance) are raw per-pixel sums
-    either way, as in the reference (:400-429)."""
+    film develops: with the scene's `tent` / `gaussian` reconstruction filter (pg_film) or the
+    per-pixel mean (`box`).  The integrator's own sums (computeMSE/computeVariance) are raw per-pixel
+    sums either way, as in the reference (:400-429).
+
+    A sharded scene (set_shard) traces this rank's tile only; `gather` (parallel.LaneGather) then
+    collects every rank's lanes into the full-frame lane order before the film is developed, so every
+    rank returns the same image a single rank would.  Without `gather` a sharded scene returns its
+    tile as (pixels, 1, 3) per-pixel means."""
     sampler = IndependentSampler(spp, seed)
     L, _, _ = integrator.sample(scene, sampler)
     w, h = scene.film_size
-    if scene.scene.rfilter in ("tent", "gaussian") and scene.pixel_range is None:
+    if scene.sharded:
+        if gather is None:
+            return L.reshape(3, -1, spp).mean(dim=2).T.reshape(-1, 1, 3).contiguous()
+        L = gather(L, scene, spp)
+    if scene.scene.rfilter in ("tent", "gaussian"):
         tree = integrator.sdTree
         img = torch.empty((3, h * w), dtype=torch.float32, device=tree.device)
         N.check(tree._h, tree._lib.pg_film(tree._h, ("tent", "gaussian").index(scene.scene.rfilter),
