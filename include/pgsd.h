@@ -183,6 +183,25 @@ int pg_refine_and_swap(pg_context *ctx, void *stream);
  * all-reduce (ncclInt64, ncclSum) before pg_refine_and_swap. */
 int pg_accumulators(pg_context *ctx, int64_t **d_buffer, uint64_t *count);
 
+/* The exchange itself for hosts that do not bring their own collective library: one RCCL
+ * all-reduce (ncclAllReduce, ncclInt64, ncclSum, in place) of that buffer over the ranks, asynchronous
+ * on `stream`; call it on every rank after the iteration's last pass and before pg_refine_and_swap --
+ * exact integer sums, so every rank then refines the same tree.  RCCL is loaded at run
+ * time (the copy the process already holds, else librccl.so.1 from the library path, else
+ * $PGSD_RCCL_LIBRARY); nothing of it is touched before the first pg_comm_* call.
+ *   pg_comm_unique_id : ncclGetUniqueId into h_id_out[PG_COMM_ID_BYTES] (rank 0 calls it and hands the
+ *                       bytes to the other ranks by whatever channel the host has)
+ *   pg_comm_init      : ncclCommInitRank on the context's device; collective over the n_ranks callers
+ *   pg_comm_attach    : use a communicator the host already owns (an ncclComm_t of the same RCCL
+ *                       library; it stays the host's: pg_comm_destroy / pg_destroy do not destroy it)
+ * There is no reference counterpart (single process, single GPU: SURVEY 8e). */
+#define PG_COMM_ID_BYTES 128
+int pg_comm_unique_id(pg_context *ctx, uint8_t *h_id_out);
+int pg_comm_init(pg_context *ctx, int32_t n_ranks, int32_t rank, const uint8_t *h_id);
+int pg_comm_attach(pg_context *ctx, void *nccl_comm, int32_t n_ranks);
+int pg_comm_destroy(pg_context *ctx);
+int pg_allreduce(pg_context *ctx, void *stream);
+
 /* ---- import / export in the reference's schema (kdtree.py:539-602) -------------------- */
 
 typedef struct pg_tree_sizes {

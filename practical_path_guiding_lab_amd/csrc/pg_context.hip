@@ -131,6 +131,7 @@ int pg_destroy(pg_context *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->dc) (void)hipFree(ctx->dc);
 	destroy_render_state(ctx);
+	destroy_comm(ctx);
 	delete ctx;
 	return PG_OK;
 }
@@ -319,7 +320,16 @@ int pg_process_and_splat(pg_context *ctx, uint64_t num_rays, int32_t max_depth, 
 int pg_refine_and_swap(pg_context *ctx, void *stream)
 {
 	PG_READY(ctx);
-	return refine_and_swap(ctx, (hipStream_t)stream);
+	const int rc = refine_and_swap(ctx, (hipStream_t)stream);
+	if (rc != PG_OK) {
+		// The refine changes the KD nodes in place before the new quadtree forest, heads and counts are
+		// committed: a failure in between (out of memory, a limit) leaves links that point past the old
+		// arrays.  Nothing may walk such a tree: the context goes back to "not set up" -- every later
+		// query, splat or pass is refused until pg_setup or pg_import gives it a whole tree again.
+		ctx->configured = false;
+		ctx->err += " (the SD-tree is no longer valid: call pg_setup or pg_import)";
+	}
+	return rc;
 }
 
 int pg_accumulators(pg_context *ctx, int64_t **d_buffer, uint64_t *count)

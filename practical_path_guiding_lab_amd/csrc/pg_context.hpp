@@ -98,6 +98,9 @@ struct pg_context {
 	pg::Forest f;
 	pg::DepthCounters *dc = nullptr; // device
 	bool dc_on = false;
+	void *comm = nullptr;            // ncclComm_t of the multi-GPU exchange (pg_comm.hip)
+	bool comm_owned = false;         // made by pg_comm_init (destroyed with the context) or attached by the caller
+	int comm_ranks = 0;
 
 	pg::TreeView view() const
 	{
@@ -120,6 +123,8 @@ int refine_and_swap(pg_context *ctx, hipStream_t s);
 int rebuild_jump(pg_context *ctx, hipStream_t s); // after every change of the quadtree records or heads
 // pg_render.hip
 void destroy_render_state(pg_context *ctx);
+// pg_comm.hip
+void destroy_comm(pg_context *ctx);
 // helpers shared by pg_context.hip / pg_refine.hip
 int fail(pg_context *ctx, int code, const std::string &msg);
 int hip_fail(pg_context *ctx, hipError_t e, const char *what);

@@ -44,6 +44,34 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     return acc
 
 
+def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
+    """Gives `tree` (an SDTree) its own RCCL communicator over the ranks of `group` (pg_comm_init): rank
+    0's ncclUniqueId travels through torch.distributed, then every rank joins.  Afterwards
+    tree.allReduce() is the exchange -- one ncclAllReduce issued by libpgsd.so itself, the form a host
+    without PyTorch would use.  Returns False (and leaves the tree untouched) when the ranks do not each
+    have a GPU of their own (RCCL refuses two ranks on one device) or RCCL cannot be loaded."""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world > torch.cuda.device_count():
+        return False
+    ident = [None]
+    err = None
+    if rank == 0:
+        try:
+            ident[0] = tree.commUniqueId()
+        except Exception as e:  # RCCL missing: tell the others instead of leaving them waiting
+            err = e
+    dist.broadcast_object_list(ident, src=0, group=group)
+    if ident[0] is None:
+        if err is not None and rank == 0:
+            import warnings
+            warnings.warn(f"libpgsd RCCL communicator not available: {err}")
+        return False
+    tree.commInit(world, rank, ident[0])
+    return True
+
+
 def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over ranks of any tensor; CUDA tensors go through the host under gloo."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1 or t.numel() == 0:

@@ -269,6 +269,27 @@ class SDTree:
         self._ck(self._lib.pg_accumulators(self._h, C.byref(p), C.byref(n)))
         return _wrap_device_i64(p.value, n.value, self.device)
 
+    # ---- the library's own exchange (pg_comm_*, pg_allreduce: RCCL bound at run time) ----------
+    def commUniqueId(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._ck(self._lib.pg_comm_unique_id(self._h, buf))
+        return bytes(buf)
+
+    def commInit(self, n_ranks: int, rank: int, unique_id: bytes) -> None:
+        """ncclCommInitRank on this tree's device: collective over the n_ranks callers."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id: 128 bytes from commUniqueId() of rank 0")
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self._lib.pg_comm_init(self._h, int(n_ranks), int(rank), buf))
+
+    def commDestroy(self) -> None:
+        self._ck(self._lib.pg_comm_destroy(self._h))
+
+    def allReduce(self) -> None:
+        """In-place sum of sdTree_current's accumulators over the ranks (pg_allreduce), asynchronous on
+        the current stream; call before refineAndPrepare on every rank."""
+        self._ck(self._lib.pg_allreduce(self._h, _stream_ptr()))
+
     # ---- import / export in the reference's npz schema (kdtree.py:539-602) -----------------
     def sizes(self) -> N.pg_tree_sizes:
         s = N.pg_tree_sizes()

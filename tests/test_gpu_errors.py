@@ -122,7 +122,7 @@ def test_scene_and_render_pass_misuse(ctx):
         edit(bad)
         rc = L.pg_scene_set_ex(h, C.byref(mesh_desc(bad, tris)), C.byref(cam))
         assert rc < 0 and what in _msg(L, h), (what, _msg(L, h))
-    # a chain of nodes with three waiting siblings each would overflow the walk's 64-entry stack
+    # a chain of nodes with three waiting siblings each would overflow the walk's 32-entry stack (8 in LDS + 24 in the workspace)
     chain = np.zeros((30, MS.BVH_STRIDE), np.uint32)
     chain[:, 0:12] = np.float32(-1).view(np.uint32)
     chain[:, 12:24] = np.float32(1).view(np.uint32)
@@ -145,6 +145,32 @@ def test_scene_and_render_pass_misuse(ctx):
     assert L.pg_render_pass(h, C.byref(prm), None, None, None, None, None) < 0
     assert L.pg_film_tent(h, 1, 0, Lout.data_ptr(), Lout.data_ptr(), None) < 0
     assert L.pg_math_eval(h, 9, 4, Lout.data_ptr(), Lout.data_ptr(), None) < 0
+    # stripes (interleaved sharding): rows per band, rank index, and the pixel count must be consistent
+    for bad in (N.pg_pass_params(1, 1, 8, 0, 0, 0, 0, 0, 2, 0), N.pg_pass_params(1, 1, 8, 0, 0, 0, 2, 2, 2, 0),
+                N.pg_pass_params(1, 1, 8, 0, 8, 0, 2, 0, 2, 0), N.pg_pass_params(1, 1, 8, 0, 0, 24, 2, 0, 2, 0)):
+        assert L.pg_render_pass(h, C.byref(bad), Lout.data_ptr(), None, None, None, None) < 0 and "stripe" in _msg(L, h)
+    assert L.pg_render_pass(h, C.byref(N.pg_pass_params(1, 1, 8, 0, 0, 32, 2, 1, 2, 0)), Lout.data_ptr(), None, None, None, None) == 0
+    # the per-pixel sums are film-sized arrays: a context set up for fewer rays than the film has pixels must
+    # not be handed sums (k_finish would write past what setup(numRays) made the caller allocate)
+    assert L.pg_setup(h, lo, hi, 32, 4, 20, 20, 1, 0.5) == 0
+    s2 = torch.zeros((3, 64), device="cuda")
+    assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, s1.data_ptr(), s2.data_ptr(), None) < 0 and "num_rays" in _msg(L, h)
+    assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, None, None, None) == 0   # without sums it is fine
+    assert L.pg_setup(h, lo, hi, 64, 4, 20, 20, 1, 0.5) == 0
+    assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, s1.data_ptr(), s2.data_ptr(), None) == 0
+    # textures: a material naming a texture that is not there, a bitmap reaching past the texel array
+    tm = np.stack([S.diffuse_material((0.5, 0.5, 0.5), texture=0), S.diffuse_material((0.1, 0.1, 0.1))])
+    tex, texels = S.pack_textures([S.bitmap_texture(np.zeros((4, 4, 3), np.uint8))])
+    lut = S.srgb_to_linear_lut()
+    uvs = np.zeros((tris.shape[0], 6), np.float32)
+    d = mesh_desc(nodes, tris, tm)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "texture index" in _msg(L, h)
+    d.tri_uvs, d.n_textures, d.textures, d.n_texels, d.texels, d.srgb_lut = (uvs.ctypes.data, 1, tex.ctypes.data, 15, texels.ctypes.data,
+                                                                              lut.ctypes.data)
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) < 0 and "texel array" in _msg(L, h)
+    d.n_texels = 16
+    assert L.pg_scene_set_ex(h, C.byref(d), C.byref(cam)) == 0
+    assert L.pg_scene_set(h, q.shape[0], q.ctypes.data, C.byref(cam)) == 0
     # and the good call still works afterwards
     assert L.pg_render_pass(h, C.byref(prm), Lout.data_ptr(), None, None, None, None) == 0
     torch.cuda.synchronize()

@@ -1,11 +1,14 @@
 #!/bin/bash
 # Dev experiment (GPU box, repo root): where does k_bounce's time go?  Rebuilds the library with
 # timing-only ablations (results are wrong on purpose) and prints the bench's kernel times.
+# whatever happens, leave the DEFAULT build behind: variant objects are newer than the sources, so a later
+# `make` (or __graft_entry__.build()) would otherwise keep shipping the experiment
+trap 'touch practical_path_guiding_lab_amd/csrc/*.hip; make -s -C practical_path_guiding_lab_amd/csrc -j8' EXIT
 set -e
 OUT=gpurun_out/exp_ablate
 mkdir -p $OUT
 run() {
-	python bench.py --cpu-res 0 --steps 10 > $OUT/$1.json
+	python bench.py --cpu 0 --steps 10 > $OUT/$1.json
 	python - <<EOF
 import json
 d = json.load(open("$OUT/$1.json"))

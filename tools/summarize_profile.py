@@ -13,7 +13,9 @@ import sys
 src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 BOUNCES = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # k_bounce launches per pass = max_depth
 os.makedirs(dst, exist_ok=True)
-KERNELS = ("k_bounce", "k_process_and_splat", "k_finish")
+KERNELS = ("k_wave_trace", "k_wave_shade_a", "k_wave_shadow", "k_wave_guide", "k_wave_shade_b", "k_wave_tail", "k_bounce",
+           "k_process_and_splat", "k_finish")
+PER_BOUNCE = ("k_bounce", "k_wave_trace", "k_wave_shade_a", "k_wave_shadow", "k_wave_guide", "k_wave_shade_b")
 
 
 def short(name):
@@ -43,7 +45,9 @@ for r in csv.DictReader(open(trace)):
 trace_summary = {}
 for k, v in dur.items():
     v.sort()
-    per_pass = {"k_bounce": BOUNCES}.get(k, 1)
+    per_pass = BOUNCES if k in PER_BOUNCE else 1
+    if k == "k_wave_tail":
+        per_pass = sum(1 for b in range(BOUNCES) if BOUNCES > 8 and b >= 4 and b + 1 < BOUNCES and (b < 8 or (b < 16 and b % 2 == 0) or b % 4 == 0))
     last = [d for _, d in v[-10 * per_pass:]]
     trace_summary[k] = {"launches_in_timed_region": len(last), "avg_us": round(sum(last) / len(last) / 1e3, 2),
                         "min_us": round(min(last) / 1e3, 2), "max_us": round(max(last) / 1e3, 2)}
@@ -64,7 +68,9 @@ def agg(sub):
             if k:
                 d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k in d:
-            per_pass = {"k_bounce": BOUNCES}.get(k, 1)
+            per_pass = BOUNCES if k in PER_BOUNCE else 1
+            if k == "k_wave_tail":
+                per_pass = sum(1 for b in range(BOUNCES) if BOUNCES > 8 and b >= 4 and b + 1 < BOUNCES and (b < 8 or (b < 16 and b % 2 == 0) or b % 4 == 0))
             for c in d[k]:
                 d[k][c] = d[k][c][-PMC_STEPS * per_pass:]
     return d
@@ -72,13 +78,13 @@ def agg(sub):
 
 f, w, l2, sq = agg("pmc_fetch"), agg("pmc_write"), agg("pmc_l2"), agg("pmc_sq")
 out = {"config": cfg,
-       "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu-res 0`; means per launch over "
+       "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu 0 --train-iters 4`; means per launch over "
                "the launches of the timed region (the last 3 passes). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024 applies the gfx950 x2 FETCH correction of MI355X_MICROARCH.md section HBM "
                "(calibrated for wide coalesced reads only: an upper bound here).",
        "kernels": {}, "trace": trace_summary}
 for k in KERNELS:
-    if k not in f:
+    if k not in f or not f[k]["FETCH_SIZE"] or not w[k]["WRITE_SIZE"]:
         continue
     m = lambda d, c: (sum(d[k][c]) / len(d[k][c])) if d[k][c] else None
     fs, ws = m(f, "FETCH_SIZE"), m(w, "WRITE_SIZE")
