@@ -3,7 +3,8 @@
 (takkasila/practical_path_guiding_lab main.py): same schedule and outputs, MI355X-native engine.
 
     python main.py                                  # built-in cornell-box, 252 spp budget
-    python main.py --scene /path/to/scene.xml       # Mitsuba 3 XML (quad/diffuse/area-light subset)
+    python main.py --scene veach-ajar               # the metric's scene (also: veach-mis, torus)
+    python main.py --scene /path/to/scene.xml       # Mitsuba 3 XML of the supported subset
 """
 import argparse
 import os
@@ -16,7 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="cornell-box",
-                    help="built-in scene (cornell-box, veach-mis, torus) or a Mitsuba 3 scene XML of the supported subset")
+                    help="built-in scene (cornell-box, veach-mis, veach-ajar, torus) or a Mitsuba 3 scene XML of the supported subset")
     ap.add_argument("--width", type=int, default=None, help="film width (default: 512 / 1280 / 1024 / the XML's)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--max-depth", type=int, default=None)
@@ -40,8 +41,12 @@ def main():
         sc = S.veach_mis(args.width or 1280, args.height or 720)
     elif args.scene == "torus":
         sc = S.torus(args.width or 1024, args.height or 768)
+    elif args.scene == "veach-ajar":
+        sc = S.veach_ajar(args.width or 1280, args.height or 720)
     else:
-        sc = S.load_xml(args.scene, args.width, args.height)
+        sc = S.load_xml(args.scene, args.width, args.height, skip_missing_meshes=True)
+        if sc.skipped:
+            print("shapes left out (mesh file missing):", ", ".join(sc.skipped))
     if args.out == "debug/cornell-box" and args.scene != "cornell-box":
         args.out = "debug/" + os.path.splitext(os.path.basename(os.path.dirname(args.scene) or args.scene))[0]
     if args.max_depth is not None:

@@ -1,11 +1,13 @@
-"""Parity at BASELINE.json's full size (configs[1]: cornell-box 512x512, max_depth 8; a pass of
-8 spp is 2.1 M paths and up to 16.8 M path vertices), where the CPU oracle is too slow to be the
-checker: size-independent properties of the domain instead.
+"""Parity at BASELINE.json's full sizes -- configs[1] cornell-box 512x512 max_depth 8, configs[2]
+veach-mis 1280x720 max_depth 3, configs[3] veach-ajar 1920x1080 max_depth 13, configs[4] torus
+1920x1080 max_depth 32: the sizes bench.py measures, millions of paths per pass -- where the CPU
+oracle is too slow to be the checker: size-independent properties of the domain instead.
 
   * reproducibility: two independent runs give bit-identical radiance, accumulators and trees
     although the order in which workgroups append live paths, records and atomics is free;
-  * tile invariance: a pass rendered as three ragged tiles (one of them a single pixel) equals the
-    full-frame pass, lane for lane and accumulator for accumulator (what the multi-GPU shard relies on);
+  * tile invariance: a pass rendered as three ragged tiles (one of them a single pixel), or as the
+    interleaved 4-row bands of three ranks, equals the full-frame pass, lane for lane and accumulator
+    for accumulator (what the multi-GPU shard relies on);
   * flux and count conservation (the reference's self-test properties, quadtree.py:1208-1218,
     kdtree.py:769-772): every inner accumulator is exactly the sum of its children's;
   * KDTree.sample returns pdfQuadTree of the direction it returns (kdtree.py:483-484), the pdf
@@ -18,27 +20,93 @@ pytestmark = pytest.mark.gpu
 
 RES, DEPTH, SPP = 512, 8, 8
 NPIX = RES * RES
+# name -> (scene constructor arguments, spp per pass): the film sizes and depths of BASELINE.json's configs
+CONFIGS = {"cornell-box": ((512, 512, 8, 8), 8), "veach-mis": ((1280, 720, 3, 8), 8), "veach-ajar": ((1920, 1080, 13, 8), 4),
+           "torus": ((1920, 1080, 32, 8), 4)}
 
 
-def _trained():
+def _trained(name="cornell-box"):
     """Renders iterations 0..2 of main.py's schedule (4, 8, 16 spp) and refines after each."""
+    from practical_path_guiding_lab_amd import scene as S
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
-    from practical_path_guiding_lab_amd.scene import cornell_box
 
-    sc = cornell_box(RES, RES, DEPTH, 8)
-    g = PathGuidingIntegrator({"max_depth": DEPTH, "rr_depth": 8})
-    g.setup(NPIX, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
+    (w, h, depth, rr), spp = CONFIGS[name]
+    sc = {"cornell-box": S.cornell_box, "veach-mis": S.veach_mis, "veach-ajar": S.veach_ajar, "torus": S.torus}[name](w, h, depth, rr)
+    g = PathGuidingIntegrator({"max_depth": depth, "rr_depth": rr})
+    g.setup(w * h, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
     ws = WavefrontScene(sc)
     cumm = 0
     for k in range(3):
         g.setIteration(k, False)
         iter_spp = 2 ** (k + 2)
-        for p in range(0, iter_spp, SPP):
-            g.sample(ws, IndependentSampler(min(SPP, iter_spp), 4000 + cumm + p))
+        for p in range(0, iter_spp, spp):
+            g.sample(ws, IndependentSampler(min(spp, iter_spp), 4000 + cumm + p))
         cumm += iter_spp
         g.refineAndPrepareSDTreeForNextIteration()
     return g, ws
+
+
+@pytest.mark.parametrize("name", ["veach-mis", "veach-ajar", "torus"])
+def test_other_bench_configs_reproducible_tile_invariant_and_conserving(name):
+    """The three properties of the cornell-box tests below at the other bench sizes: veach-mis 1280x720
+    (level-1 fused kernels), veach-ajar 1920x1080 max_depth 13 and torus 1920x1080 max_depth 32 (the
+    split pipeline, levels 2 and 3, 8.3 M paths per pass, the tail launch at the end of the long paths)."""
+    import torch
+    from practical_path_guiding_lab_amd.render import IndependentSampler
+
+    (w, h, depth, _), spp = CONFIGS[name]
+    npix = w * h
+    ga, wsa = _trained(name)
+    gb, wsb = _trained(name)
+    ta = ga.sdTree.export()
+    _same_tree(ta, gb.sdTree.export())
+    assert ta["kdtree_depth"].shape[0] > 100 and ta["quadtree_depth"].shape[0] > 10000
+    assert torch.equal(ga.sumL.view(torch.int32), gb.sumL.view(torch.int32))
+    del ta
+    ga.setIteration(3, False)
+    gb.setIteration(3, False)
+    La, va, _ = ga.sample(wsa, IndependentSampler(spp, 999))
+    assert La.shape == (3, npix * spp) and bool(torch.isfinite(La).all()) and float(La.mean()) > 0
+    # (a) three ragged contiguous tiles, (b) then on a fresh accumulator state the bands of three ranks
+    for begin, count in [(0, 700_001), (700_001, 1), (700_002, npix - 700_002)]:
+        wsb.pixel_range = (begin, count)
+        Lb, vb, _ = gb.sample(wsb, IndependentSampler(spp, 999))
+        assert torch.equal(Lb.view(torch.int32), La[:, begin * spp:(begin + count) * spp].contiguous().view(torch.int32))
+        assert torch.equal(vb, va[begin * spp:(begin + count) * spp])
+    wsb.pixel_range = None
+    assert torch.equal(ga.sdTree.accumulators(), gb.sdTree.accumulators())
+    assert torch.equal(ga.sumL.view(torch.int32), gb.sumL.view(torch.int32))
+    acc_one = ga.sdTree.accumulators().clone()
+    for r in range(3):
+        wsb.set_shard(r, 3, 4)
+        px = torch.from_numpy(wsb.local_pixels()).cuda()
+        lanes = (px[:, None] * spp + torch.arange(spp, device="cuda")[None, :]).reshape(-1)
+        Lb, vb, _ = gb.sample(wsb, IndependentSampler(spp, 999))
+        assert torch.equal(Lb.view(torch.int32), La[:, lanes].contiguous().view(torch.int32))
+        assert torch.equal(vb, va[lanes])
+    wsb.set_shard(0, 1)
+    # the same pass splatted twice: integer accumulators are exactly twice those of one pass
+    assert torch.equal(gb.sdTree.accumulators(), 2 * acc_one)
+    live = ga.sdTree.renderLiveCounts(depth)
+    assert npix * spp > live[0] > live[1] > 0 and live[-1] == 0
+    # conservation (quadtree.py:1208-1218, kdtree.py:769-772) on the accumulators of that pass
+    t = ga.sdTree.export()
+    kd, lo, hi = ga.sdTree.exportAccumulators()
+    inner = ~t["kdtree_isLeaf"]
+    np.testing.assert_array_equal(kd[inner], kd[t["kdtree_child_left_index"][inner]] + kd[t["kdtree_child_right_index"][inner]])
+    assert kd[0] == kd[t["kdtree_isLeaf"]].sum() and kd[0] > 1_000_000
+    qi = np.nonzero(~t["quadtree_isLeaf"])[0]
+    # 128-bit sums as (hi, lo) pairs of Python-free numpy arithmetic: lo wraps modulo 2^64, the carries go to hi
+    ch = [t["quadtree_child_%d_index" % c][qi] for c in (1, 2, 3, 4)]
+    lo_sum = np.zeros(qi.shape[0], np.uint64)
+    hi_sum = np.zeros(qi.shape[0], np.int64)
+    for c in ch:
+        nxt = lo_sum + lo[c]
+        hi_sum += hi[c] + (nxt < lo_sum).astype(np.int64)
+        lo_sum = nxt
+    np.testing.assert_array_equal(lo_sum, lo[qi])
+    np.testing.assert_array_equal(hi_sum, hi[qi])
 
 
 def _same_tree(a, b):

@@ -204,6 +204,21 @@ def test_long_paths_finished_by_the_tail_launch_bit_exact(which):
     _guided_lifecycle_bit_exact(sc, True)
 
 
+@pytest.mark.parametrize("which", ["torus 160x120", "veach-ajar 160x90", "mixed 96", "mixed 64 depth 13", "veach-mis 160x90 depth 14",
+                                   "cornell-box 96 depth 12"])
+def test_lifecycle_parity_at_larger_sizes(which):
+    """The guided-lifecycle parity of the tests above (radiance, pixel sums, accumulators and refined trees
+    bit for bit against the CPU oracle) at the largest sizes the oracle finishes in seconds, for every
+    scene and feature level, including the long-path configurations that end in the tail launch."""
+    from practical_path_guiding_lab_amd import scene as S
+    po.set_threads(0)
+    sc = {"torus 160x120": lambda: S.torus(160, 120), "veach-ajar 160x90": lambda: S.veach_ajar(160, 90),
+          "mixed 96": lambda: mixed_scene(96), "mixed 64 depth 13": lambda: mixed_scene(64, max_depth=13, rr_depth=10),
+          "veach-mis 160x90 depth 14": lambda: S.veach_mis(160, 90, 14, 10),
+          "cornell-box 96 depth 12": lambda: S.cornell_box(96, 96, 12, 9)}[which]()
+    _guided_lifecycle_bit_exact(sc, True)
+
+
 def _guided_lifecycle_bit_exact(sc, nee):
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
@@ -260,7 +275,8 @@ def test_veach_mis_direct_light_matches_the_tungsten_ground_truth():
     independent renderer (Tungsten).  That image holds direct light only -- it equals this library's
     max_depth 2 render block for block, while every deeper setting is 5-50 % brighter -- so the
     comparison is made at max_depth 2: every 15x20 block without a lamp or highlight pixel agrees
-    (1.6 % at 1020 spp; the bound here is the noise of 252 spp).  Guiding is on from iteration 2."""
+    at main.py's full 1020-spp schedule (8 iterations; measured with this seed: block ratios 0.990 ... 1.037,
+    0.23 % off on average, the image mean 0.10 % off).  Guiding is on from iteration 2."""
     import os
     from practical_path_guiding_lab_amd.driver import load_ground_truth, run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
@@ -271,14 +287,16 @@ def test_veach_mis_direct_light_matches_the_tungsten_ground_truth():
     gt_path = os.path.join(os.path.dirname(__file__), "golden", "veach_mis_gt_320x180_f16.npy")
     gt = load_ground_truth(gt_path, 320, 180)
     g = PathGuidingIntegrator({"max_depth": 2, "rr_depth": 8})
-    res = run_guided_render(WavefrontScene(sc), g, 252, initial_seed=3, ground_truth=gt, training_spp_per_pass=4,
+    res = run_guided_render(WavefrontScene(sc), g, 1020, initial_seed=3, ground_truth=gt, training_spp_per_pass=4,
                             log=lambda s: None)
+    assert res["cumm_spp"] == 1020
     img = res["image"].cpu().numpy().astype(np.float64)
     assert np.isfinite(img).all()
     ratios = _block_ratios(img, np.load(gt_path).astype(np.float64), 15, 20)
     assert ratios.size >= 150
-    assert np.abs(ratios - 1).max() < 0.05, (ratios.min(), ratios.max())  # 1.6 % at 1020 spp; this is 252 spp noise
-    assert np.abs(ratios - 1).mean() < 0.01 and abs(ratios.mean() - 1) < 0.005
+    assert np.abs(ratios - 1).max() < 0.04, (ratios.min(), ratios.max())
+    assert np.abs(ratios - 1).mean() < 0.004 and abs(ratios.mean() - 1) < 0.003
+    assert np.percentile(np.abs(ratios - 1), 95) < 0.016
     # one more bounce and the image is brighter than the direct-light ground truth everywhere
     sc3 = veach_mis(320, 180, max_depth=3)
     g3 = PathGuidingIntegrator({"max_depth": 3, "rr_depth": 8})
@@ -312,8 +330,9 @@ def test_torus_matches_the_tungsten_image_where_it_converges():
 
 def test_guided_render_converges_to_the_ground_truth():
     """main.py's schedule at 256x256 against the reference's ground truth of the same scene
-    (tests/golden/cornell_gt_256_f16.npy, from scenes/cornell-box/TungstenRender.exr): the MSE
-    metric of path_guiding_integrator.py:530-550 falls as spp grows and the mean radiance agrees."""
+    (tests/golden/cornell_gt_256_f16.npy, from scenes/cornell-box/TungstenRender.exr) over the full
+    1020-spp schedule: the MSE metric of path_guiding_integrator.py:530-550 falls as spp grows and the
+    mean radiance agrees to 0.5 % (measured -0.50 %: max_depth 8 against the unbounded ground truth)."""
     import os
     from practical_path_guiding_lab_amd.driver import load_ground_truth, run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
@@ -323,14 +342,46 @@ def test_guided_render_converges_to_the_ground_truth():
     sc = cornell_box(256, 256, 8, 8)
     gt = load_ground_truth(os.path.join(os.path.dirname(__file__), "golden", "cornell_gt_256_f16.npy"), 256, 256)
     g = PathGuidingIntegrator({"max_depth": 8, "rr_depth": 8})
-    res = run_guided_render(WavefrontScene(sc), g, 252, initial_seed=0, ground_truth=gt, training_spp_per_pass=4,
+    res = run_guided_render(WavefrontScene(sc), g, 1020, initial_seed=3, ground_truth=gt, training_spp_per_pass=4,
                             log=lambda s: None)
-    assert res["cumm_spp"] == 252
+    assert res["cumm_spp"] == 1020
     mse = [r[5] for r in res["records"]["mse_groundTruth_endIter"].rows]
-    assert len(mse) == 6 and all(np.isfinite(mse))
-    assert mse[-1] < 0.25 * mse[0] and mse[-1] < 5e-3
+    assert len(mse) == 8 and all(np.isfinite(mse))
+    assert mse[-1] < 0.12 * mse[0] and mse[-1] < 4e-4
     img = res["image"].cpu().numpy()
-    assert abs(img.mean() - float(gt.mean())) < 0.015 * float(gt.mean())
+    assert -0.006 * float(gt.mean()) < img.mean() - float(gt.mean()) < 0.0
+
+
+def test_veach_ajar_agrees_with_the_tungsten_ground_truth():
+    """scenes/veach-ajar at 320x180 over main.py's full 1020-spp schedule against the reference's
+    ground truth (tests/golden/veach_ajar_gt_320x180_f16.npy from scenes/veach-ajar/TungstenRender.exr),
+    outside the rectangle of the three teapots whose meshes the reference mount lacks: the MSE metric
+    falls by two orders of magnitude over the iterations; the image mean agrees to 2.5 % and the
+    15x20 blocks to 4 % on average (measured: -1.6 % and 3.8 %; the scene is lit through the gap of a
+    door, still noisy at this sample count, and the teapots' share of the indirect light is missing)."""
+    import os
+    from practical_path_guiding_lab_amd.driver import load_ground_truth, run_guided_render
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import WavefrontScene
+    from practical_path_guiding_lab_amd.scene import veach_ajar, veach_ajar_mask
+
+    sc = veach_ajar(320, 180)
+    assert sc.max_depth == 13 and sc.rfilter == "tent" and len(sc.skipped) == 6
+    gt_path = os.path.join(os.path.dirname(__file__), "golden", "veach_ajar_gt_320x180_f16.npy")
+    gt = load_ground_truth(gt_path, 320, 180)
+    g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
+    res = run_guided_render(WavefrontScene(sc), g, 1020, initial_seed=3, ground_truth=gt, training_spp_per_pass=4,
+                            log=lambda s: None)
+    mse = [r[5] for r in res["records"]["mse_groundTruth_endIter"].rows]
+    assert len(mse) == 8 and all(np.isfinite(mse)) and mse[-1] < 0.02 * mse[0]
+    gtn = np.load(gt_path).astype(np.float64)
+    mask = veach_ajar_mask(320, 180)
+    img = np.where(mask[..., None], res["image"].cpu().numpy().astype(np.float64), gtn)  # teapot pixels drop out
+    assert np.isfinite(img).all()
+    assert abs(img[mask].mean() / gtn[mask].mean() - 1) < 0.025
+    ratios = _block_ratios(img, gtn, 15, 20)
+    assert ratios.size >= 150
+    assert abs(ratios.mean() - 1) < 0.04 and np.abs(ratios - 1).mean() < 0.05 and np.abs(ratios - 1).max() < 0.15
 
 
 def test_tent_film_matches_the_oracle_bit_for_bit():
