@@ -1,0 +1,163 @@
+"""veach-ajar on the CPU side: the OBJ attributes and textures of the host data model, the packaged
+scene against the reference's own scene file (where the reference is mounted), the oracle's texture
+arithmetic against a numpy restatement, the threaded oracle against the single-threaded one, and a
+low-sample comparison of the oracle's image with the reference's ground truth."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pg_oracle as po
+from practical_path_guiding_lab_amd import mesh as M
+from practical_path_guiding_lab_amd import scene as S
+
+REF_XML = "/root/reference/scenes/veach-ajar/scene.xml"
+
+
+def test_read_obj_attributes_and_flipped_texture_coordinates(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 0.75\nvt 0 0.75\nvn 0 0 1\nvn 0 1 0\n"
+                 "f 1/1/1 2/2/1 3/3/2 4/4/2\n")
+    v, f, uv, n = M.read_obj(str(p), attributes=True)
+    assert f.tolist() == [[0, 1, 2], [0, 2, 3]] and uv.shape == (2, 3, 2) and n.shape == (2, 3, 3)
+    assert uv[1].tolist() == [[0, 0], [1, 0.75], [0, 0.75]] and n[0, 2].tolist() == [0, 1, 0]
+    rec, fn, fuv = M.triangles(v, f, np.eye(4), 3, n, uv)
+    assert rec.shape == (2, 16) and fn.shape == (2, 9) and fuv.shape == (2, 6)
+    np.testing.assert_allclose(fuv[0], [0, 1, 1, 1, 1, 0.25])           # v -> 1 - v (Mitsuba's flip_tex_coords)
+    _, _, raw = M.triangles(v, f, np.eye(4), 3, None, uv, flip_tex_coords=False)
+    np.testing.assert_allclose(raw[0], [0, 0, 1, 0, 1, 0.75])
+    # a file without vt / vn: None; the plain form still returns (v, f)
+    q = tmp_path / "plain.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    assert M.read_obj(str(q), attributes=True)[2:] == (None, None) and len(M.read_obj(str(q))) == 2
+
+
+def test_texture_tables_and_their_evaluation():
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, (6, 9, 3)).astype(np.uint8)
+    v, f = M.icosphere(0)
+    uv = np.stack([v[:, 0] * 0.5 + 0.5, v[:, 1] * 0.5 + 0.5], axis=1)
+    mats = [S.diffuse_material((0.5, 0.5, 0.5), texture=0), S.roughconductor_material(0.2, (1, 1, 1), (2, 2, 2), texture=1, distribution="ggx")]
+    tex = [S.bitmap_texture(img, (2.0, 3.0, 0.125, -0.25)), S.checkerboard_texture((0.8, 0.7, 0.6), (0.2, 0.1, 0.0), (20.0, 80.0, 0.0, 0.0))]
+    cam = S.make_camera(np.eye(4), 40.0, 8, 8)
+    sc = S._finish([], cam, 4, 8, [], None, mats, None, [M.triangles(v, f, np.eye(4), 0, None, uv), M.triangles(v * 2, f, np.eye(4), 1)],
+                   None, tex)
+    assert sc.tri_uvs.shape == (40, 6) and sc.textures.shape == (2, 16) and sc.texels.shape == (54,) and sc.tri_normals is None
+    assert sc.textures[0, :4].tolist() == [S.TEX_BITMAP, 9, 6, 0] and sc.textures[1, 0] == S.TEX_CHECKERBOARD
+    assert sc.materials.shape[1] == S.MATERIAL_STRIDE == 16 and sc.materials[:, 12].tolist() == [1.0, 2.0]
+    assert (sc.tri_uvs[sc.tris[:, 12] == 1] == 0).all()                  # the mesh without coordinates: uv = 0
+    assert sc.srgb_lut[0] == 0 and sc.srgb_lut[255] == 1 and abs(sc.srgb_lut[128] - 0.2158605) < 1e-6
+    # the oracle's C evaluation equals the numpy restatement of the same fp32 operations, bit for bit:
+    # texel centres, the wrap-around, negative and large coordinates, a cell edge of the checkerboard
+    for u, w in [(0.0, 0.0), (0.3, 0.7), (-1.25, 2.5), (17.125, -3.0625), (0.99999, 0.5), (1e6, -1e6), (0.0125, 0.00625), (0.025, 0.0)]:
+        for t in (0, 1):
+            a, b = S.texture_eval(sc, t, u, w), po.texture_eval(sc, t, u, w)
+            assert a.view(np.uint32).tolist() == b.view(np.uint32).tolist(), (t, u, w, a, b)
+    assert po.texture_eval(sc, 1, 0.01, 0.001).tolist() == pytest.approx([0.8, 0.7, 0.6])     # both fractions below .5: color0
+    assert po.texture_eval(sc, 1, 0.03, 0.001).tolist() == pytest.approx([0.2, 0.1, 0.0])
+    # a texel centre returns the texel: u = (x + .5) / (2 W) - offset / 2 ...
+    x, y = 4, 2
+    u, w = ((x + 0.5) / 9 - 0.125) / 2.0, ((y + 0.5) / 6 + 0.25) / 3.0
+    np.testing.assert_allclose(po.texture_eval(sc, 0, u, w), sc.srgb_lut[img[y, x]], rtol=2e-5)
+    with pytest.raises(ValueError):  # a textured material on a quad has no texture coordinates to use
+        q = S.rectangle(np.eye(4), (0.5, 0.5, 0.5))
+        q[0][22] = 0
+        S._finish(q, cam, 4, 8, ["q"], None, mats, None, None, None, tex)
+    with pytest.raises(ValueError):
+        S._finish([], cam, 4, 8, [], None, [S.diffuse_material((0.5,) * 3, texture=5)], None, [M.triangles(v, f, np.eye(4), 0, None, uv)],
+                  None, tex)
+
+
+def test_veach_ajar_scene_from_its_data_and_from_the_xml():
+    sc = S.veach_ajar(64, 36)
+    assert sc.tris.shape == (4482, 16) and sc.tri_uvs.shape == (4482, 6) and sc.tri_normals.shape == (4482, 9)
+    assert sc.quads.shape[0] == 1 and sc.quads[0, 15] == 1 and sc.quads[0, 19:22].tolist() == [1000.0] * 3   # the light behind the door
+    assert sc.max_depth == 13 and sc.rr_depth == 8 and sc.rfilter == "tent" and len(sc.skipped) == 6
+    assert [int(m[0]) for m in sc.materials] == [0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 3, 0]
+    assert sc.materials[:, 12].tolist() == [1, 2, 0, 3, 0, 4, 0, 0, 0, 0, 0, 0, 0]
+    assert sc.materials[2, 4] == np.float32(0.25) and sc.materials[5, 4] == np.float32(-0.1)                 # beckmann / ggx
+    used = set(int(v) for v in sc.tris[:, 12]) | {int(sc.quads[0, 22])}
+    assert used == set(range(10))                                       # the three teapot materials are unused
+    assert sc.textures[:, 0].tolist() == [1, 1, 1, 2] and sc.textures[3, 4:14].view(np.float32).tolist() == pytest.approx(
+        [0.8, 0.8, 0.8, 0.2, 0.2, 0.2, 20, 80, 0, 0])
+    smooth = np.abs(sc.tri_normals - np.tile(sc.tris[:, 9:12], (1, 3))).max(axis=1) > 1e-3
+    assert smooth.sum() > 2000 and set(sc.tris[smooth, 12].astype(int)) == {2}                              # only the door handle
+    m = S.veach_ajar_mask(1280, 720)
+    assert m.shape == (720, 1280) and not m[480, 560] and m[100, 100] and 0.85 < m.mean() < 0.87
+    if not os.path.exists(REF_XML):
+        pytest.skip("reference not mounted")
+    with pytest.raises(FileNotFoundError):
+        S.load_xml(REF_XML, 64, 36)                                      # Mesh000.obj / Mesh009.obj are missing blobs
+    ref = S.load_xml(REF_XML, 64, 36, skip_missing_meshes=True)
+    assert ref.skipped == sc.skipped
+    for k in ("tris", "bvh", "tri_uvs", "tri_normals", "materials", "quads", "bbox_min", "bbox_max", "srgb_lut"):
+        assert np.array_equal(getattr(sc, k), getattr(ref, k)), k
+    for k in ("origin", "axis_x", "axis_y", "axis_z", "tan_half_fov_x"):
+        assert np.array_equal(getattr(sc.camera, k), getattr(ref.camera, k)), k
+    # the packaged textures are the file's at reduced resolution: same kinds and parameters, fewer texels
+    assert np.array_equal(sc.textures[:, 0], ref.textures[:, 0]) and np.array_equal(sc.textures[:, 4:], ref.textures[:, 4:])
+    assert ref.textures[:3, 1].tolist() == [1920, 2000, 1280] and sc.textures[:3, 1].tolist() == [480, 500, 640]
+    for t, (u, w) in ((0, (0.5, 0.5)), (1, (0.25, 0.75)), (2, (0.4, 0.6))):
+        np.testing.assert_allclose(S.texture_eval(sc, t, u, w), S.texture_eval(ref, t, u, w), atol=0.06)
+
+
+def _ajar_pass(threads, iters=3, w=48, h=27, spp=2):
+    po.set_threads(threads)
+    sc = S.veach_ajar(w, h)
+    pair = po.OracleSDTreePair()
+    pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
+    sumL, sumL2 = np.zeros((3, w * h), np.float32), np.zeros((3, w * h), np.float32)
+    out = []
+    for k in range(iters):
+        L, v = po.render_pass(pair, sc, sc.camera, 13, 8, k, False, 100 + k, spp << k, True, 0.5, sumL, sumL2)
+        pair.refine_and_prepare(k)
+        out.append((L, v))
+    return out, sumL, pair.prev.export()
+
+
+def test_threaded_oracle_equals_the_single_threaded_one():
+    """pgo_set_threads: the lane loop of the oracle on all cores gives the radiance, the sums and -- through
+    the records it splats -- the refined trees of the single-threaded run, bit for bit (guided passes
+    included: iteration 2 samples from the tree the first two built)."""
+    one, s1, t1 = _ajar_pass(1)
+    n = po.set_threads(0)
+    assert n >= 1
+    many, s2, t2 = _ajar_pass(0)
+    po.set_threads(1)
+    for (La, va), (Lb, vb) in zip(one, many):
+        assert np.array_equal(La.view(np.uint32), Lb.view(np.uint32)) and np.array_equal(va, vb)
+    assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+    for k in t1:
+        assert np.array_equal(np.asarray(t1[k]), np.asarray(t2[k])), k
+    assert np.isfinite(s1).all() and s1.max() > 0 and t1["kdtree_depth"].shape[0] >= 1
+
+
+def test_oracle_image_resembles_the_ground_truth():
+    """64x36, 60 spp on the CPU: far from converged (the scene is lit through the gap of a door), but the
+    landscape picture, the door and the wall already have the ground truth's colours."""
+    po.set_threads(0)
+    w, h = 64, 36
+    sc = S.veach_ajar(w, h)
+    pair = po.OracleSDTreePair()
+    pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
+    sumL, sumL2 = np.zeros((3, w * h), np.float32), np.zeros((3, w * h), np.float32)
+    cumm = 0
+    for k in range(4):
+        spp = 2 ** (k + 2)
+        po.render_pass(pair, sc, sc.camera, 13, 8, k, False, cumm, spp, True, 0.5, sumL, sumL2)
+        cumm += spp
+        pair.refine_and_prepare(k)
+    po.set_threads(1)
+    img = (sumL / cumm).T.reshape(h, w, 3).astype(np.float64)
+    gt = np.load(os.path.join(os.path.dirname(__file__), "golden", "veach_ajar_gt_320x180_f16.npy")).astype(np.float64)
+    gt = gt.reshape(h, 5, w, 5, 3).mean(axis=(1, 3))
+    assert np.isfinite(img).all()
+
+    def region(a, x0, y0, x1, y1):  # in 1280x720 coordinates
+        return a[y0 * h // 720:y1 * h // 720, x0 * w // 1280:x1 * w // 1280].reshape(-1, 3).mean(axis=0)
+
+    for name, box, tol in (("wall", (40, 60, 340, 360), 0.25), ("door", (900, 180, 1100, 540), 0.25), ("picture", (420, 170, 680, 280), 0.3)):
+        a, b = region(img, *box), region(gt, *box)
+        assert np.abs(a / b - 1).max() < tol, (name, a, b)
+    door = region(img, 900, 180, 1100, 540)
+    assert door[0] > 1.5 * door[2]                                      # cherry wood is red-brown
