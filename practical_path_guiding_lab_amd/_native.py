@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libpgsd.so")
+# PGSD_LIBRARY: another build of the same library (tools/build_variant.sh), for A/B measurements
+LIB_PATH = os.environ.get("PGSD_LIBRARY") or os.path.join(_PKG, "libpgsd.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 PG_OK = 0

@@ -164,6 +164,20 @@ __device__ __forceinline__ bool bvh_box_hit(float lox, float loy, float loz, flo
 	return tmin <= tmax * 1.0000004f;
 }
 
+// The same test with the near and far planes already picked (the walk loads the rows of a node in
+// the order the ray's signs dictate): identical arithmetic, no selects.
+__device__ __forceinline__ bool bvh_box_hit_nf(float nxp, float nyp, float nzp, float fxp, float fyp, float fzp, v3 o, v3 inv,
+                                               float bt, float &tmin_out)
+{
+	const float nx = (nxp - o.x) * inv.x, fx = (fxp - o.x) * inv.x;
+	const float ny = (nyp - o.y) * inv.y, fy = (fyp - o.y) * inv.y;
+	const float nz = (nzp - o.z) * inv.z, fz = (fzp - o.z) * inv.z;
+	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
+	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), bt);
+	tmin_out = tmin;
+	return tmin <= tmax * 1.0000004f;
+}
+
 __device__ __forceinline__ void bvh_cswap(float &ta, uint32_t &ra, float &tb, uint32_t &rb)
 {
 	if (ta > tb) {
@@ -261,6 +275,7 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
 		const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 		const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
+		const int row_nx = ngx ? 3 : 0, row_fx = ngx ? 0 : 3, row_ny = ngy ? 4 : 1, row_fy = ngy ? 1 : 4, row_nz = ngz ? 5 : 2, row_fz = ngz ? 2 : 5;
 		const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(sh.bvh);
 		// pg_scene_set_ex has checked the tree: children follow their parent, and no root-to-node path
 		// can leave more than kLdsStack + kOvfStack siblings waiting, so the walk opens every node at
@@ -272,15 +287,23 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 		uint32_t next = 0; // the root
 		while (true) {
 			while (!(next & 0x80000000u) && budget > 0) { // a node: test its children, go on in the nearest
+				// a node's rows are lo_x lo_y lo_z hi_x hi_y hi_z (four children each): the row holding the planes
+				// the ray meets first on an axis is known from the sign of its direction, so the rows are
+				// loaded as (near, far) per axis -- per-ray offsets, no per-child selects
 				const uint4 *N = nodes + 8 * (size_t)next;
-				const uint4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], rf = N[6];
+				const uint4 nx4 = N[row_nx], ny4 = N[row_ny], nz4 = N[row_nz], fx4 = N[row_fx], fy4 = N[row_fy], fz4 = N[row_fz], rf = N[6];
 				uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
 				float t0, t1, t2, t3;
 #define PG_F(v) __uint_as_float(v)
-				if (!(r0 != kNone && bvh_box_hit(PG_F(lx.x), PG_F(ly.x), PG_F(lz.x), PG_F(hx.x), PG_F(hy.x), PG_F(hz.x), o, inv, ngx, ngy, ngz, bt, t0))) { r0 = kNone; t0 = kInf; }
-				if (!(r1 != kNone && bvh_box_hit(PG_F(lx.y), PG_F(ly.y), PG_F(lz.y), PG_F(hx.y), PG_F(hy.y), PG_F(hz.y), o, inv, ngx, ngy, ngz, bt, t1))) { r1 = kNone; t1 = kInf; }
-				if (!(r2 != kNone && bvh_box_hit(PG_F(lx.z), PG_F(ly.z), PG_F(lz.z), PG_F(hx.z), PG_F(hy.z), PG_F(hz.z), o, inv, ngx, ngy, ngz, bt, t2))) { r2 = kNone; t2 = kInf; }
-				if (!(r3 != kNone && bvh_box_hit(PG_F(lx.w), PG_F(ly.w), PG_F(lz.w), PG_F(hx.w), PG_F(hy.w), PG_F(hz.w), o, inv, ngx, ngy, ngz, bt, t3))) { r3 = kNone; t3 = kInf; }
+				// (all four tests unconditionally: a test skipped for an absent child would split the row loads)
+				const bool h0 = bvh_box_hit_nf(PG_F(nx4.x), PG_F(ny4.x), PG_F(nz4.x), PG_F(fx4.x), PG_F(fy4.x), PG_F(fz4.x), o, inv, bt, t0);
+				const bool h1 = bvh_box_hit_nf(PG_F(nx4.y), PG_F(ny4.y), PG_F(nz4.y), PG_F(fx4.y), PG_F(fy4.y), PG_F(fz4.y), o, inv, bt, t1);
+				const bool h2 = bvh_box_hit_nf(PG_F(nx4.z), PG_F(ny4.z), PG_F(nz4.z), PG_F(fx4.z), PG_F(fy4.z), PG_F(fz4.z), o, inv, bt, t2);
+				const bool h3 = bvh_box_hit_nf(PG_F(nx4.w), PG_F(ny4.w), PG_F(nz4.w), PG_F(fx4.w), PG_F(fy4.w), PG_F(fz4.w), o, inv, bt, t3);
+				if (!(r0 != kNone && h0)) { r0 = kNone; t0 = kInf; }
+				if (!(r1 != kNone && h1)) { r1 = kNone; t1 = kInf; }
+				if (!(r2 != kNone && h2)) { r2 = kNone; t2 = kInf; }
+				if (!(r3 != kNone && h3)) { r3 = kNone; t3 = kInf; }
 #undef PG_F
 				bvh_cswap(t0, r0, t1, r1);
 				bvh_cswap(t2, r2, t3, r3);

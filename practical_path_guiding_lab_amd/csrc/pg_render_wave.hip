@@ -56,6 +56,8 @@ enum : uint32_t {
 	F_DO_MIS = 64u,      // bsdf-mis or sdtree-mis lane (:283)
 	F_SMP_TREE = 128u,   // sdtree-mis: the direction comes from the SD-tree (:297)
 	F_BSDF_MIS = 256u,   // bsdf-mis: BSDF direction, SD-tree pdf (:293)
+	F_NEE_LIVE = 512u,   // the emitter sample can contribute: its BSDF value is not zero (see stage_a)
+	F_HAS_LE = 1024u,    // emitted radiance reached the path here (Le has a non-zero bit)
 };
 
 struct HitRec {
@@ -124,6 +126,14 @@ __device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_
 	active_em = active_em && (o.ds_pdf != 0.0f); // :216
 	const v3 wo_em = to_local(fr, o.ds_d);
 	bsdf_eval_pdf<kLevel>(mt, wi, wo_em, active_em, o.bv_em, o.bp_em);
+	// An emitter sample whose BSDF value is zero (the light is behind the surface) contributes
+	// Lr_dir = ((thr mis_em) 0) em_weight = +0 whatever the visibility test and the SD-tree pdf of its
+	// direction say -- as long as em_weight is finite, and it is unless the light point all but touches
+	// the surface.  Such a lane needs neither the shadow ray nor the tree query: result-neutral, bit for
+	// bit (the oracle performs both and multiplies by zero).
+	const bool nee_live = active_em && !(o.bv_em.x == 0.0f && o.bv_em.y == 0.0f && o.bv_em.z == 0.0f && finite_f32(o.em_w.x) &&
+	                                     finite_f32(o.em_w.y) && finite_f32(o.em_w.z));
+	if (!nee_live) need_shadow = false;
 	// ---- :272-297 next direction ----
 	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
 	if (active_next) { // next_1d (lobe choice: only the dielectrics read it), next_2d
@@ -145,7 +155,9 @@ __device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_
 	o.mat = valid ? (int)((mt.M - a.mats) / kMaterialStride) : 0;
 	o.flags = (valid ? F_VALID : 0u) | (active_next ? F_ACTIVE_NEXT : 0u) | (active_em ? F_ACTIVE_EM : 0u) |
 	          (need_shadow ? F_NEED_SHADOW : 0u) | (ds_delta ? F_DS_DELTA : 0u) | (delta ? F_DELTA : 0u) |
-	          (do_mis ? F_DO_MIS : 0u) | (smp_tree ? F_SMP_TREE : 0u) | (bsdf_mis ? F_BSDF_MIS : 0u);
+	          (do_mis ? F_DO_MIS : 0u) | (smp_tree ? F_SMP_TREE : 0u) | (bsdf_mis ? F_BSDF_MIS : 0u) |
+	          (nee_live ? F_NEE_LIVE : 0u) |
+	          ((__float_as_uint(o.Le.x) | __float_as_uint(o.Le.y) | __float_as_uint(o.Le.z)) != 0u ? F_HAS_LE : 0u);
 }
 
 // ---- :244, 301, 307: the SD-tree calls of a bounce (one KD descent) and the canonical coordinates of
@@ -153,13 +165,13 @@ __device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_
 __device__ __forceinline__ bool guide_has_work(const RenderArgs &a, uint32_t flags)
 {
 	const bool do_record = a.record && (flags & F_VALID);
-	return do_record || ((flags & F_ACTIVE_EM) && a.guided) || (flags & (F_SMP_TREE | F_BSDF_MIS));
+	return do_record || ((flags & F_NEE_LIVE) && a.guided) || (flags & (F_SMP_TREE | F_BSDF_MIS));
 }
 
 __device__ __forceinline__ void stage_guide(const RenderArgs &a, const uint4 *s_kd, Pcg32 &rng, v3 p, v3 ds_d, v3 wo_in,
                                             uint32_t flags, GuideOut &g)
 {
-	const bool active_sd_em = (flags & F_ACTIVE_EM) && a.guided;
+	const bool active_sd_em = (flags & F_NEE_LIVE) && a.guided; // (a dead emitter sample's pdf would multiply zero: stage_a)
 	const bool do_record = a.record && (flags & F_VALID);
 	const bool smp_tree = (flags & F_SMP_TREE) != 0u, bsdf_mis = (flags & F_BSDF_MIS) != 0u;
 	TreeHead head = {kNoRecord, 0.0f};
@@ -225,15 +237,21 @@ __device__ __forceinline__ bool stage_b(const RenderArgs &a, Pcg32 &rng, v3 &thr
 	bool active_next = (A.flags & F_ACTIVE_NEXT) != 0u;
 	const bool ds_delta = (A.flags & F_DS_DELTA) != 0u, delta = (A.flags & F_DELTA) != 0u;
 	const bool do_mis = (A.flags & F_DO_MIS) != 0u, smp_tree = (A.flags & F_SMP_TREE) != 0u;
-	const v3 em_weight = occluded ? V(0, 0, 0) : A.em_w;
+	const bool nee_live = (A.flags & F_NEE_LIVE) != 0u;
+	const v3 em_weight = (occluded || !nee_live) ? V(0, 0, 0) : A.em_w;
 	// ---- :223-256 NEE MIS against the mixture pdf ----
 	const float pdf_diffuse = 1.0f; // :222-241
 	const float sdtree_pdf_em = g.pdf_nee;
-	float surface_pdf_em = f * A.bp_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
-	if (!a.guided) surface_pdf_em = A.bp_em;
-	const float mis_em = (kLevel >= 3 && ds_delta) ? 1.0f : mis_weight(A.ds_pdf, surface_pdf_em); // :253
-	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), A.bv_em), em_weight);
-	L = vadd(L, vadd(A.Le, Lr_dir)); // :261
+	// a lane without a live emitter sample: every factor stage_a computed for it is zero or multiplies
+	// zero -- the same formula on zeros gives the same +0
+	const float bp_em = nee_live ? A.bp_em : 0.0f, ds_pdf = nee_live ? A.ds_pdf : 0.0f;
+	const v3 bv_em = nee_live ? A.bv_em : V(0, 0, 0);
+	float surface_pdf_em = f * bp_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
+	if (!a.guided) surface_pdf_em = bp_em;
+	const float mis_em = (kLevel >= 3 && ds_delta && nee_live) ? 1.0f : mis_weight(ds_pdf, surface_pdf_em); // :253
+	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bv_em), em_weight);
+	const v3 Le = (A.flags & F_HAS_LE) ? A.Le : V(0, 0, 0);
+	L = vadd(L, vadd(Le, Lr_dir)); // :261
 	// ---- :302-311 ----
 	v3 bsdf_weight = A.bsdf_w;
 	float bsdf_pdf = A.bsdf_pdf;
@@ -401,11 +419,17 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 	h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
 	StageA A;
 	stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
+	// (n, wi, material and reflectance are read back only by sdtree-mis lanes, :304; storing them for those
+	// lanes only was measured no faster: a wave's partial store touches the same sectors)
 	wsput3(a, WS_P, tid, A.p); wsput3(a, WS_N, tid, A.n); wsput3(a, WS_NG, tid, A.ng); wsput3(a, WS_WI, tid, A.wi);
 	wsputu(a, WS_FLAGS, tid, A.flags); wsputu(a, WS_MAT, tid, (uint32_t)A.mat);
-	wsput3(a, WS_REFL, tid, A.refl); wsput3(a, WS_LE, tid, A.Le);
-	wsput3(a, WS_DS_D, tid, A.ds_d); wsput(a, WS_DS_PDF, tid, A.ds_pdf); wsput3(a, WS_EM_W, tid, A.em_w);
-	wsput3(a, WS_BV_EM, tid, A.bv_em); wsput(a, WS_BP_EM, tid, A.bp_em);
+	wsput3(a, WS_REFL, tid, A.refl);
+	if (A.flags & F_HAS_LE) wsput3(a, WS_LE, tid, A.Le);
+	wsput3(a, WS_DS_D, tid, A.ds_d);
+	if (A.flags & F_NEE_LIVE) { // (what k_wave_shade_b reads of an emitter sample only when it can contribute)
+		wsput(a, WS_DS_PDF, tid, A.ds_pdf); wsput3(a, WS_EM_W, tid, A.em_w);
+		wsput3(a, WS_BV_EM, tid, A.bv_em); wsput(a, WS_BP_EM, tid, A.bp_em);
+	}
 	if (A.flags & F_NEED_SHADOW) {
 		wsput3(a, WS_SH_O, tid, A.sh_o); wsput3(a, WS_SH_D, tid, A.sh_d); wsput(a, WS_SH_T, tid, A.sh_tmax);
 	}
@@ -479,11 +503,19 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 	if (alive) {
 		StageA A;
 		A.flags = wsu(a, WS_FLAGS, tid);
-		A.p = ws3(a, WS_P, tid); A.n = ws3(a, WS_N, tid); A.ng = ws3(a, WS_NG, tid); A.wi = ws3(a, WS_WI, tid);
-		A.mat = (int)wsu(a, WS_MAT, tid);
-		A.refl = ws3(a, WS_REFL, tid); A.Le = ws3(a, WS_LE, tid);
-		A.ds_d = ws3(a, WS_DS_D, tid); A.ds_pdf = wsf(a, WS_DS_PDF, tid); A.em_w = ws3(a, WS_EM_W, tid);
-		A.bv_em = ws3(a, WS_BV_EM, tid); A.bp_em = wsf(a, WS_BP_EM, tid);
+		A.p = ws3(a, WS_P, tid); A.ng = ws3(a, WS_NG, tid);
+		A.n = V(0, 0, 1); A.wi = V(0, 0, 1); A.mat = 0; A.refl = V(0, 0, 0);
+		if (A.flags & F_SMP_TREE) { // (only these lanes evaluate their BSDF again)
+			A.n = ws3(a, WS_N, tid); A.wi = ws3(a, WS_WI, tid);
+			A.mat = (int)wsu(a, WS_MAT, tid); A.refl = ws3(a, WS_REFL, tid);
+		}
+		A.Le = (A.flags & F_HAS_LE) ? ws3(a, WS_LE, tid) : V(0, 0, 0);
+		A.ds_d = V(0, 0, 0); // (stage_b does not read it: the record takes the canonical form k_wave_guide made)
+		A.ds_pdf = 0.0f; A.em_w = V(0, 0, 0); A.bv_em = V(0, 0, 0); A.bp_em = 0.0f;
+		if (A.flags & F_NEE_LIVE) {
+			A.ds_pdf = wsf(a, WS_DS_PDF, tid); A.em_w = ws3(a, WS_EM_W, tid);
+			A.bv_em = ws3(a, WS_BV_EM, tid); A.bp_em = wsf(a, WS_BP_EM, tid);
+		}
 		A.wo = ws3(a, WS_WO, tid); A.bsdf_pdf = wsf(a, WS_BSDF_PDF, tid); A.bsdf_w = ws3(a, WS_BSDF_W, tid);
 		A.eta = wsf(a, WS_ETA, tid);
 		GuideOut g;
