@@ -118,6 +118,7 @@ int pg_create(pg_context **out, int device_ordinal)
 	pg_context *ctx = new (std::nothrow) pg_context();
 	if (!ctx) return fail(nullptr, PG_ERR_NOMEM, "pg_create: out of host memory");
 	ctx->device = device_ordinal;
+	if (prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
 	e = hipMalloc((void **)&ctx->dc, sizeof(DepthCounters));
 	if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipMalloc(depth counters)"); }
 	(void)hipMemset(ctx->dc, 0, sizeof(DepthCounters));

@@ -87,6 +87,7 @@ struct pg_render_state; // pg_render.hip
 struct pg_context {
 	pg_render_state *render = nullptr;
 	int device = 0;
+	int n_cus = 256; // compute units of the device (sizes the persistent grids)
 	std::string err;
 	bool configured = false;
 	float bmin[3] = {0, 0, 0}, bmax[3] = {1, 1, 1};

@@ -438,6 +438,7 @@ struct pg_render_state {
 	DevBuf<float> ray_o;
 	DevBuf<uint32_t> ws;
 	DevBuf<uint2> bvh_ovf;
+	DevBuf<uint32_t> shadow_list;
 	float bsphere[4] = {0, 0, 0, 0};
 	DevBuf<uint32_t> bvh;
 	DevBuf<int32_t> emitters;
@@ -724,13 +725,18 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	if (wave) {
 		PG_HIP(ctx, r->ray_o.ensure(3 * N));
 		PG_HIP(ctx, r->ws.ensure((size_t)wave_workspace_planes() * N));
-		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
+		PG_HIP(ctx, r->shadow_list.ensure(N));
 	}
+	if (wave) // one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
+		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
 	if (sumL && film > ctx->num_rays)
 		return fail(ctx, PG_ERR_INVALID, "pg_render_pass: sumL/sumL2 are sized by pg_setup's num_rays, which is smaller than the film");
 	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
-	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure((uint64_t)D + 1));
-	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, ((size_t)D + 1) * sizeof(uint32_t), s)); // [D]: entries handed out by k_bounce_tail
+	// counters of a pass, zeroed together: live_count[D + 1] ([D]: entries handed out by the tail launch), then for
+	// mesh scenes cast_count[2 D] and shadow_count[D] of the persistent ray-casting kernels
+	const size_t n_counters = (size_t)D + 1 + 3 * (size_t)D;
+	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure(n_counters));
+	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, n_counters * sizeof(uint32_t), s));
 	if (record) {
 		PG_HIP(ctx, r->ray_of.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
 		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
@@ -750,6 +756,9 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.ray_o = r->ray_o.p;
 	a.ws = r->ws.p;
 	a.bvh_ovf = r->bvh_ovf.p;
+	a.cast_count = r->live_count.p + (D + 1);
+	a.shadow_count = r->live_count.p + (D + 1) + 2 * D;
+	a.shadow_list = r->shadow_list.p;
 	a.shapes.bvh = r->bvh.p;
 	a.shapes.n_bvh_nodes = r->n_bvh_nodes;
 	a.shapes.n_quads = r->n_quads;
@@ -790,11 +799,11 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		if (wave) { // pg_render_wave.hip: five kernels per bounce, each timed on its own (kinds 5-9; 10 = tail)
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
-				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), s);
+				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
 			}
 			for (int stage = 0; stage < 5; ++stage) {
 				Timed t(r, s, 5 + stage);
-				launch_wave_stage(stage, r->general, it == 0, a, grid.x, s);
+				launch_wave_stage(stage, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
 			}
 			continue;
 		}

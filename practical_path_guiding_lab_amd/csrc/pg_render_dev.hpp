@@ -186,17 +186,16 @@ __device__ __forceinline__ void bvh_cswap(float &ta, uint32_t &ra, float &tb, ui
 	}
 }
 
+// ---- ray casting ----
 // kAny: the caller asks whether anything is hit (shadow rays): the BVH walk stops at its first
 // triangle.  The answer is that of the closest-hit walk, which visits the same nodes until then.
-// stk: the walk's stack (mesh scenes only); bu, bv: barycentrics of the triangle hit (closest-hit walks).
-template <int kGeneral, bool kAny = false>
-__device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out, const BvhStack &stk,
-                                         float &bu, float &bv)
+
+// The shapes outside the BVH (quads, spheres, boxes), tested one after the other: updates bt / best.
+template <int kGeneral>
+__device__ __forceinline__ void intersect_linear(const Shapes &sh, v3 o, v3 d, float &bt, int &best)
 {
 	const int nq = sh.n_quads;
 	const float *__restrict__ quads = sh.quads;
-	int best = -1;
-	float bt = tmax;
 	for (int q = 0; q < nq; ++q) {
 		const float *Q = quads + q * kQuadStride;
 		const v3 n = ld3(Q + 9);
@@ -263,88 +262,132 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 		bt = t;
 		best = nq + sh.n_spheres + 6 * b + 2 * axis + negative;
 	}
-	// triangle meshes: the four-wide BVH.  One 128-byte node holds the boxes of its (up to four)
-	// children: they are tested together and ordered by where the ray enters them (a fixed
-	// five-comparator network), the walk goes on in the nearest -- a leaf's triangles are named by the
-	// reference itself, no node is read for it -- and the others wait on the stack with their entry
-	// distance, farthest at the bottom, to be dropped when popped if the ray has become shorter than
-	// that.  Half the dependent round trips of a binary tree: the walk is latency-bound.  The oracle
-	// visits the same nodes in the same order, so the first of several equally near triangles is the
-	// same one in both.
-	if (kGeneral >= 2 && sh.n_bvh_nodes && !(kAny && best >= 0)) {
-		const int tri_base = nq + sh.n_spheres + 6 * sh.n_boxes;
-		const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-		const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
-		const int row_nx = ngx ? 3 : 0, row_fx = ngx ? 0 : 3, row_ny = ngy ? 4 : 1, row_fy = ngy ? 1 : 4, row_nz = ngz ? 5 : 2, row_fz = ngz ? 2 : 5;
-		const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(sh.bvh);
-		// pg_scene_set_ex has checked the tree: children follow their parent, and no root-to-node path
-		// can leave more than kLdsStack + kOvfStack siblings waiting, so the walk opens every node at
-		// most once and the stack cannot overflow; the budget is a second fence
-		constexpr uint32_t kNone = 0xffffffffu;
-		const float kInf = __builtin_huge_valf();
-		int sp = 0;
-		int budget = 8 * sh.n_bvh_nodes + 8;
-		uint32_t next = 0; // the root
-		while (true) {
-			while (!(next & 0x80000000u) && budget > 0) { // a node: test its children, go on in the nearest
-				// a node's rows are lo_x lo_y lo_z hi_x hi_y hi_z (four children each): the row holding the planes
-				// the ray meets first on an axis is known from the sign of its direction, so the rows are
-				// loaded as (near, far) per axis -- per-ray offsets, no per-child selects
-				const uint4 *N = nodes + 8 * (size_t)next;
-				const uint4 nx4 = N[row_nx], ny4 = N[row_ny], nz4 = N[row_nz], fx4 = N[row_fx], fy4 = N[row_fy], fz4 = N[row_fz], rf = N[6];
-				uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
-				float t0, t1, t2, t3;
+}
+
+// The walk through the four-wide BVH as three steps on a small state, so that a ray can be walked by
+// a loop of its own (intersect) or a few steps at a time (the persistent kernels of pg_render_wave.hip,
+// which hand a lane a new ray as soon as its old one is done).  One 128-byte node holds the boxes of
+// its (up to four) children: they are tested together and ordered by where the ray enters them (a
+// fixed five-comparator network), the walk goes on in the nearest -- a leaf's triangles are named by
+// the reference itself, no node is read for it -- and the others wait on the stack with their entry
+// distance, farthest at the bottom, to be dropped when popped if the ray has become shorter than that.
+// The oracle visits the same nodes in the same order, so the first of several equally near triangles
+// is the same one in both.  pg_scene_set_ex has checked the tree: children follow their parent, and no
+// root-to-node path can leave more than kLdsStack + kOvfStack siblings waiting, so the walk opens every
+// node at most once and the stack cannot overflow; the budget is a second fence.
+constexpr uint32_t kBvhNone = 0xffffffffu;
+struct BvhWalk {
+	v3 o, d, inv;
+	int row_nx, row_fx, row_ny, row_fy, row_nz, row_fz; // which rows of a node hold the near / far planes for this ray
+	float bt, bu, bv;
+	int best, sp, budget;
+	uint32_t next; // a node, a leaf (bit 31), or kBvhNone: take the next candidate from the stack
+};
+
+__device__ __forceinline__ void bvh_begin(BvhWalk &w, const Shapes &sh, v3 o, v3 d, float bt, int best)
+{
+	w.o = o; w.d = d;
+	w.inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
+	w.row_nx = ngx ? 3 : 0; w.row_fx = ngx ? 0 : 3; w.row_ny = ngy ? 4 : 1; w.row_fy = ngy ? 1 : 4; w.row_nz = ngz ? 5 : 2; w.row_fz = ngz ? 2 : 5;
+	w.bt = bt; w.bu = 0.0f; w.bv = 0.0f;
+	w.best = best; w.sp = 0;
+	w.budget = 8 * sh.n_bvh_nodes + 8;
+	w.next = 0; // the root
+}
+
+// w.next is a node: test its children, push the farther ones, go on in the nearest
+__device__ __forceinline__ void bvh_node_step(BvhWalk &w, const Shapes &sh, const BvhStack &stk)
+{
+	const float kInf = __builtin_huge_valf();
+	// a node's rows are lo_x lo_y lo_z hi_x hi_y hi_z (four children each): the row holding the planes
+	// the ray meets first on an axis is known from the sign of its direction, so the rows are
+	// loaded as (near, far) per axis -- per-ray offsets, no per-child selects
+	const uint4 *N = reinterpret_cast<const uint4 *>(sh.bvh) + 8 * (size_t)w.next;
+	const uint4 nx4 = N[w.row_nx], ny4 = N[w.row_ny], nz4 = N[w.row_nz], fx4 = N[w.row_fx], fy4 = N[w.row_fy], fz4 = N[w.row_fz], rf = N[6];
+	uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
+	float t0, t1, t2, t3;
 #define PG_F(v) __uint_as_float(v)
-				// (all four tests unconditionally: a test skipped for an absent child would split the row loads)
-				const bool h0 = bvh_box_hit_nf(PG_F(nx4.x), PG_F(ny4.x), PG_F(nz4.x), PG_F(fx4.x), PG_F(fy4.x), PG_F(fz4.x), o, inv, bt, t0);
-				const bool h1 = bvh_box_hit_nf(PG_F(nx4.y), PG_F(ny4.y), PG_F(nz4.y), PG_F(fx4.y), PG_F(fy4.y), PG_F(fz4.y), o, inv, bt, t1);
-				const bool h2 = bvh_box_hit_nf(PG_F(nx4.z), PG_F(ny4.z), PG_F(nz4.z), PG_F(fx4.z), PG_F(fy4.z), PG_F(fz4.z), o, inv, bt, t2);
-				const bool h3 = bvh_box_hit_nf(PG_F(nx4.w), PG_F(ny4.w), PG_F(nz4.w), PG_F(fx4.w), PG_F(fy4.w), PG_F(fz4.w), o, inv, bt, t3);
-				if (!(r0 != kNone && h0)) { r0 = kNone; t0 = kInf; }
-				if (!(r1 != kNone && h1)) { r1 = kNone; t1 = kInf; }
-				if (!(r2 != kNone && h2)) { r2 = kNone; t2 = kInf; }
-				if (!(r3 != kNone && h3)) { r3 = kNone; t3 = kInf; }
+	// (all four tests unconditionally: a test skipped for an absent child would split the row loads)
+	const bool h0 = bvh_box_hit_nf(PG_F(nx4.x), PG_F(ny4.x), PG_F(nz4.x), PG_F(fx4.x), PG_F(fy4.x), PG_F(fz4.x), w.o, w.inv, w.bt, t0);
+	const bool h1 = bvh_box_hit_nf(PG_F(nx4.y), PG_F(ny4.y), PG_F(nz4.y), PG_F(fx4.y), PG_F(fy4.y), PG_F(fz4.y), w.o, w.inv, w.bt, t1);
+	const bool h2 = bvh_box_hit_nf(PG_F(nx4.z), PG_F(ny4.z), PG_F(nz4.z), PG_F(fx4.z), PG_F(fy4.z), PG_F(fz4.z), w.o, w.inv, w.bt, t2);
+	const bool h3 = bvh_box_hit_nf(PG_F(nx4.w), PG_F(ny4.w), PG_F(nz4.w), PG_F(fx4.w), PG_F(fy4.w), PG_F(fz4.w), w.o, w.inv, w.bt, t3);
 #undef PG_F
-				bvh_cswap(t0, r0, t1, r1);
-				bvh_cswap(t2, r2, t3, r3);
-				bvh_cswap(t0, r0, t2, r2);
-				bvh_cswap(t1, r1, t3, r3);
-				bvh_cswap(t1, r1, t2, r2);
-				if (r3 != kNone) { stk.push(sp, r3, t3); ++sp; }
-				if (r2 != kNone) { stk.push(sp, r2, t2); ++sp; }
-				if (r1 != kNone) { stk.push(sp, r1, t1); ++sp; }
-				next = r0;
-				--budget;
+	if (!(r0 != kBvhNone && h0)) { r0 = kBvhNone; t0 = kInf; }
+	if (!(r1 != kBvhNone && h1)) { r1 = kBvhNone; t1 = kInf; }
+	if (!(r2 != kBvhNone && h2)) { r2 = kBvhNone; t2 = kInf; }
+	if (!(r3 != kBvhNone && h3)) { r3 = kBvhNone; t3 = kInf; }
+	bvh_cswap(t0, r0, t1, r1);
+	bvh_cswap(t2, r2, t3, r3);
+	bvh_cswap(t0, r0, t2, r2);
+	bvh_cswap(t1, r1, t3, r3);
+	bvh_cswap(t1, r1, t2, r2);
+	if (r3 != kBvhNone) { stk.push(w.sp, r3, t3); ++w.sp; }
+	if (r2 != kBvhNone) { stk.push(w.sp, r2, t2); ++w.sp; }
+	if (r1 != kBvhNone) { stk.push(w.sp, r1, t1); ++w.sp; }
+	w.next = r0;
+	--w.budget;
+}
+
+// w.next is a leaf: Moeller-Trumbore on its 1..8 triangles
+__device__ __forceinline__ void bvh_leaf_step(BvhWalk &w, const Shapes &sh, int tri_base)
+{
+	const uint32_t first = w.next & 0x0fffffffu, count = ((w.next >> 28) & 7u) + 1u;
+	const v3 o = w.o, d = w.d;
+	for (uint32_t i = first; i < first + count; ++i) {
+		const float *T = sh.tris + (size_t)i * kTriStride;
+		const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
+		const v3 p = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
+		const float det = dot3(e1, p);
+		if (det == 0.0f) continue;
+		const float inv_det = 1.0f / det;
+		const v3 s = vsub(o, ld3(T));
+		const float u = dot3(s, p) * inv_det;
+		if (!(u >= 0.0f && u <= 1.0f)) continue;
+		const v3 q = V(s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x);
+		const float v = dot3(d, q) * inv_det;
+		if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+		const float t = dot3(e2, q) * inv_det;
+		if (t > 0.0f && t < w.bt) { w.bt = t; w.best = tri_base + (int)i; w.bu = u; w.bv = v; }
+	}
+}
+
+// the nearest waiting child the (now shorter) ray still reaches, or kBvhNone: the walk is over
+__device__ __forceinline__ void bvh_pop(BvhWalk &w, const BvhStack &stk)
+{
+	w.next = kBvhNone;
+	while (w.sp && w.next == kBvhNone && w.budget > 0) {
+		--w.sp;
+		const uint2 e = stk.at(w.sp);
+		if (__uint_as_float(e.y) <= w.bt * 1.0000004f) w.next = e.x;
+		--w.budget;
+	}
+}
+
+// stk: the walk's stack (mesh scenes only); bu, bv: barycentrics of the triangle hit (closest-hit walks).
+template <int kGeneral, bool kAny = false>
+__device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out, const BvhStack &stk,
+                                         float &bu, float &bv)
+{
+	int best = -1;
+	float bt = tmax;
+	intersect_linear<kGeneral>(sh, o, d, bt, best);
+	if (kGeneral >= 2 && sh.n_bvh_nodes && !(kAny && best >= 0)) {
+		const int tri_base = sh.n_quads + sh.n_spheres + 6 * sh.n_boxes;
+		BvhWalk w;
+		bvh_begin(w, sh, o, d, bt, best);
+		while (true) {
+			while (!(w.next & 0x80000000u) && w.budget > 0) bvh_node_step(w, sh, stk);
+			if (w.next != kBvhNone && (w.next & 0x80000000u)) {
+				bvh_leaf_step(w, sh, tri_base);
+				if (kAny && w.best >= 0) break; // a shadow ray needs one occluder, not the nearest
 			}
-			if (next != kNone && (next & 0x80000000u)) { // a leaf
-				const uint32_t first = next & 0x0fffffffu, count = ((next >> 28) & 7u) + 1u;
-				for (uint32_t i = first; i < first + count; ++i) {
-					const float *T = sh.tris + (size_t)i * kTriStride;
-					const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
-					const v3 p = V(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
-					const float det = dot3(e1, p);
-					if (det == 0.0f) continue;
-					const float inv_det = 1.0f / det;
-					const v3 s = vsub(o, ld3(T));
-					const float u = dot3(s, p) * inv_det;
-					if (!(u >= 0.0f && u <= 1.0f)) continue;
-					const v3 q = V(s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x);
-					const float v = dot3(d, q) * inv_det;
-					if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-					const float t = dot3(e2, q) * inv_det;
-					if (t > 0.0f && t < bt) { bt = t; best = tri_base + (int)i; bu = u; bv = v; }
-				}
-				if (kAny && best >= 0) break; // a shadow ray needs one occluder, not the nearest
-			}
-			next = kNone;
-			while (sp && next == kNone && budget > 0) { // the nearest waiting child the (now shorter) ray still reaches
-				--sp;
-				const uint2 e = stk.at(sp);
-				if (__uint_as_float(e.y) <= bt * 1.0000004f) next = e.x;
-				--budget;
-			}
-			if (next == kNone) break;
+			bvh_pop(w, stk);
+			if (w.next == kBvhNone) break;
 		}
+		bt = w.bt; best = w.best;
+		if (w.best >= tri_base) { bu = w.bu; bv = w.bv; }
 	}
 	t_out = bt;
 	return best;
@@ -1099,6 +1142,11 @@ struct RenderArgs {
 	float *ray_o;
 	uint32_t *ws;
 	uint2 *bvh_ovf;
+	// the ray-casting kernels are persistent: a lane whose ray is done takes the next one of the launch's
+	// list.  cast_count[2 b] / [2 b + 1]: rays of bounce b's closest-hit / shadow launch handed out beyond
+	// the first one per thread; shadow_count[b] and shadow_list: the shadow rays of bounce b (list
+	// positions, appended by k_wave_shade_a).  All zeroed per pass.
+	uint32_t *cast_count, *shadow_count, *shadow_list;
 };
 
 
@@ -1141,7 +1189,9 @@ __device__ __forceinline__ uint64_t global_pixel(const RenderArgs &a, uint64_t i
 
 // pg_render_wave.hip: one stage (0 trace, 1 shade_a, 2 shadow, 3 guide, 4 shade_b, 5 tail) of one bounce of
 // the split pipeline, feature level 2 or 3; the number of 32-bit planes of its workspace
-void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, hipStream_t s);
+// n_cus: compute units of the device (the two ray-casting stages are persistent kernels sized by it)
+void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, unsigned n_cus, hipStream_t s);
+constexpr int kCastBlocksPerCU = 8; // upper bound of the resident 256-thread workgroups of a ray-casting kernel per compute unit
 int wave_workspace_planes();
 
 } // namespace pg

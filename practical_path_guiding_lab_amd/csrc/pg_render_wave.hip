@@ -7,7 +7,8 @@
 //   k_wave_shade_a  :189-220, 272-297   surface and textures at the hit, emitted radiance and its MIS
 //                          weight, one emitter sample (a shadow ray to trace), the BSDF towards it, the
 //                          BSDF sample, the lane's class (delta | bsdf | bsdf-mis | sdtree-mis)
-//   k_wave_shadow   :213   test_visibility: any-hit walk of the shadow rays
+//   k_wave_cast     :213   test_visibility: any-hit walk of the shadow rays, a persistent kernel (a lane whose
+//                          ray is done takes the next one: shadow rays end after very different numbers of steps)
 //   k_wave_guide    :244, 301, 307   the three SD-tree calls of the bounce and nothing else: one KD
 //                          descent, the pdf of the emitter direction, sample-or-pdf of the continuation
 //                          direction, the canonical coordinates the record needs -- the kernel the
@@ -360,7 +361,9 @@ __device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, b
 	return true;
 }
 
-// ---- :185 ----
+// ---- :185 scene.ray_intersect: one ray per lane.  (The persistent form below was measured too: the walks of
+// closest-hit rays are all about equally long, handing idle lanes new rays gains nothing after the second
+// bounce and loses a factor of two on the coherent camera rays.) ----
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 {
@@ -390,6 +393,136 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	wsput(a, WS_HIT_T, tid, h.t);
 	wsput(a, WS_HIT_U, tid, h.u);
 	wsput(a, WS_HIT_V, tid, h.v);
+}
+
+// ---- :213 test_visibility (and :185, see above) ----
+// One kernel for both kinds of ray, persistent: the grid is a fixed number of workgroups per compute
+// unit, and a lane whose ray is done does not wait for the slowest ray of its wave -- as soon as
+// kRefillIdle lanes of a wave are idle they take the next rays of the launch's list.  The list is dealt
+// out in chunks of kCastChunk rays, chunk c to wave c mod (number of waves): no atomic counter (one
+// counter word serialises at about 11 ns per atomic -- a counter bumped per refill cost more than the
+// walks, and big chunks per atomic left the waves unevenly loaded at the end), and with some fifty
+// chunks per wave the rays' costs even out.  Incoherent rays take very different numbers of
+// steps: measured on veach-ajar, the one-ray-per-lane form kept 23 % of the lanes of a wave busy in
+// the closest-hit launches after the first bounce and 14 % in the shadow launches.  Every ray still
+// takes exactly the steps intersect() takes for it, in the same order.
+//   kAny = false: the rays are the live list's (or the camera rays, kFirst); the hit goes to WS_HIT_*
+//   kAny = true:  the rays are the entries of the live list flagged F_NEED_SHADOW; WS_OCC receives 0 / 1
+constexpr int kRefillIdle = 16;
+constexpr uint32_t kCastChunk = 128;
+template <int kLevel, bool kFirst, bool kAny>
+__global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
+{
+	__shared__ uint2 s_stack[kLdsStack][kRBlock];
+	if (!kFirst && tail_took_over(a, a.bounce)) return; // a tail launch is finishing these paths
+	const uint32_t total = kFirst ? (uint32_t)a.n_lanes : a.live_count[a.bounce - 1];
+	const uint32_t gtid = blockIdx.x * kRBlock + threadIdx.x, n_static = gridDim.x * kRBlock;
+	if (blockIdx.x * kRBlock >= total) return; // (uniform) not even a first ray for this workgroup
+	const unsigned wl = threadIdx.x & 63u;
+	const uint64_t N = a.n_lanes;
+	const Shapes &sh = a.shapes;
+	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + (size_t)gtid * kOvfStack);
+	const int tri_base = sh.n_quads + sh.n_spheres + 6 * sh.n_boxes;
+	BvhWalk w;
+	w.next = kBvhNone; w.sp = 0; w.budget = 0; w.best = -1; w.bt = 0.0f; w.bu = 0.0f; w.bv = 0.0f;
+	bool has = false, first_round = true;
+	bool exhausted = n_static >= total; // no rays beyond the first round
+	uint32_t pool_next = 0, pool_end = 0; // (wave-uniform) the rays of this wave's current chunk not dealt out yet
+	const uint32_t n_waves = n_static / 64u;
+	uint64_t chunk = gtid / 64u; // this wave's next chunk of the list beyond the first round
+	uint32_t my = 0; // the ray this lane is walking: position in the live list
+	for (;;) {
+		// ---- idle lanes take new rays ----
+		const unsigned long long idle = __ballot(!has);
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if (first_round || (!exhausted && n_idle >= (uint32_t)kRefillIdle)) {
+			uint32_t idx = 0xffffffffu;
+			if (first_round) idx = gtid;
+			else {
+				if (pool_next == pool_end) { // this wave's next chunk of the list
+					const uint64_t begin = (uint64_t)n_static + chunk * kCastChunk;
+					chunk += n_waves;
+					if (begin >= (uint64_t)total) exhausted = true;
+					else {
+						pool_next = (uint32_t)begin;
+						pool_end = begin + kCastChunk < (uint64_t)total ? (uint32_t)(begin + kCastChunk) : total;
+					}
+				}
+				const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << wl) - 1ull));
+				const uint32_t take = n_idle < pool_end - pool_next ? n_idle : pool_end - pool_next;
+				if (rank < take) idx = pool_next + rank;
+				pool_next += take;
+			}
+			first_round = false;
+			if (!has && idx < total) {
+				v3 ray_o, ray_d;
+				float tmax = __builtin_huge_valf();
+				bool wanted = true;
+				if (kAny) { // the shadow rays are the flagged entries of the live list
+					my = idx;
+					wanted = (wsu(a, WS_FLAGS, my) & F_NEED_SHADOW) != 0u;
+					if (wanted) {
+						ray_o = ws3(a, WS_SH_O, my); ray_d = ws3(a, WS_SH_D, my);
+						tmax = wsf(a, WS_SH_T, my);
+					}
+				} else {
+					my = idx;
+					const uint64_t lane = kFirst ? (uint64_t)idx : (uint64_t)a.order_in[idx];
+					if (kFirst) {
+						Pcg32 rng;
+						camera_ray(a, lane, rng, ray_o, ray_d);
+						a.rng_state[lane] = rng.state;
+						a.rng_inc[lane] = rng.inc;
+						stp(a.ray_o, N, lane, ray_o);
+						stp(a.ray_d, N, lane, ray_d);
+					} else {
+						ray_o = ldp(a.ray_o, N, lane);
+						ray_d = ldp(a.ray_d, N, lane);
+					}
+				}
+				if (wanted) {
+					int best = -1;
+					float bt = tmax;
+					intersect_linear<kLevel>(sh, ray_o, ray_d, bt, best);
+					bvh_begin(w, sh, ray_o, ray_d, bt, best);
+					has = true;
+					if (!sh.n_bvh_nodes || (kAny && best >= 0)) { // nothing to walk: the round below finds the stack empty
+						w.budget = 0;
+						w.next = kBvhNone;
+					}
+				}
+			}
+		}
+		if (__ballot(has) == 0ull) {
+			if (exhausted) break;
+			continue; // (every lane idle and rays left: the refill above has just run or runs now)
+		}
+		// ---- one round of every lane's walk, the loop body of intersect(): down through nodes to a leaf
+		// (the wave stays in the node loop until all its lanes have left it: the lanes of a wave are in
+		// the same phase most of the time), the leaf's triangles, the next candidate from the stack ----
+		if (has) {
+			bool done = false;
+			while (!(w.next & 0x80000000u) && w.budget > 0) bvh_node_step(w, sh, stk);
+			if (w.next != kBvhNone && (w.next & 0x80000000u)) {
+				bvh_leaf_step(w, sh, tri_base);
+				if (kAny && w.best >= 0) done = true; // a shadow ray needs one occluder, not the nearest
+			}
+			if (!done) {
+				bvh_pop(w, stk);
+				if (w.next == kBvhNone) done = true;
+			}
+			if (done) {
+				if (kAny) wsputu(a, WS_OCC, my, w.best >= 0 ? 1u : 0u);
+				else {
+					wsputu(a, WS_HIT_PRIM, my, (uint32_t)w.best);
+					wsput(a, WS_HIT_T, my, w.bt);
+					wsput(a, WS_HIT_U, my, w.bu);
+					wsput(a, WS_HIT_V, my, w.bv);
+				}
+				has = false;
+			}
+		}
+	}
 }
 
 // ---- :189-220, 272-297 ----
@@ -436,25 +569,6 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 	wsput3(a, WS_WO, tid, A.wo); wsput(a, WS_BSDF_PDF, tid, A.bsdf_pdf); wsput3(a, WS_BSDF_W, tid, A.bsdf_w);
 	wsput(a, WS_ETA, tid, A.eta);
 	wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
-}
-
-// ---- :213 test_visibility ----
-template <int kLevel>
-__global__ __launch_bounds__(kRBlock) void k_wave_shadow(RenderArgs a)
-{
-	__shared__ uint2 s_stack[kLdsStack][kRBlock];
-	uint64_t tid, lane;
-	bool alive;
-	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive, lane)) return; }
-	else if (!wave_entry<false>(a, tid, alive, lane)) return;
-	if (!alive) return;
-	if (!(wsu(a, WS_FLAGS, tid) & F_NEED_SHADOW)) return;
-	const v3 so = ws3(a, WS_SH_O, tid), sd = ws3(a, WS_SH_D, tid);
-	const float tmax = wsf(a, WS_SH_T, tid);
-	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
-	float th, bu, bv;
-	const bool occ = intersect<kLevel, true>(a.shapes, so, sd, tmax, th, stk, bu, bv) >= 0;
-	wsputu(a, WS_OCC, tid, occ ? 1u : 0u);
 }
 
 // ---- :244, 301, 307 ----
@@ -648,11 +762,28 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	}
 }
 
+// The grid of a persistent kernel: as many workgroups as the device holds at once (the occupancy the
+// register count of this instantiation allows, asked of the runtime once), never more than the rays need.
+template <class K>
+static dim3 persistent_grid(K kernel, unsigned &cached_per_cu, unsigned n_cus, uint64_t n_rays)
+{
+	if (cached_per_cu == 0) {
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kRBlock, 0) != hipSuccess || nb < 1) nb = 4;
+		cached_per_cu = (unsigned)nb;
+	}
+	uint64_t blocks = (uint64_t)cached_per_cu * n_cus;
+	const uint64_t need = (n_rays + kRBlock - 1) / kRBlock;
+	if (blocks > need) blocks = need;
+	return dim3((unsigned)(blocks ? blocks : 1));
+}
+
 // ---- launcher: one stage of one bounce (pg_render_pass wraps each in its timing events) ----
 template <int kLevel>
-static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 grid, hipStream_t s)
+static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 grid, unsigned n_cus, hipStream_t s)
 {
 	const dim3 block(kRBlock);
+	static unsigned occ[4] = {0, 0, 0, 0}; // resident workgroups per CU of the four ray-casting instantiations of this level
 	switch (stage) {
 	case 0:
 		if (first) hipLaunchKernelGGL((k_wave_trace<kLevel, true>), grid, block, 0, s, a);
@@ -662,7 +793,10 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		if (first) hipLaunchKernelGGL((k_wave_shade_a<kLevel, true>), grid, block, 0, s, a);
 		else hipLaunchKernelGGL((k_wave_shade_a<kLevel, false>), grid, block, 0, s, a);
 		break;
-	case 2: hipLaunchKernelGGL((k_wave_shadow<kLevel>), grid, block, 0, s, a); break;
+	case 2:
+		if (first) hipLaunchKernelGGL((k_wave_cast<kLevel, true, true>), persistent_grid(k_wave_cast<kLevel, true, true>, occ[2], n_cus, a.n_lanes), block, 0, s, a);
+		else hipLaunchKernelGGL((k_wave_cast<kLevel, false, true>), persistent_grid(k_wave_cast<kLevel, false, true>, occ[3], n_cus, a.n_lanes), block, 0, s, a);
+		break;
 	case 3: hipLaunchKernelGGL(k_wave_guide, grid, block, 0, s, a); break;
 	case 4:
 		if (first) hipLaunchKernelGGL((k_wave_shade_b<kLevel, true>), grid, block, 0, s, a);
@@ -672,10 +806,10 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 	}
 }
 
-void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, hipStream_t s)
+void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, unsigned n_cus, hipStream_t s)
 {
-	if (level >= 3) launch_stage_level<3>(stage, first, a, dim3(grid_blocks), s);
-	else launch_stage_level<2>(stage, first, a, dim3(grid_blocks), s);
+	if (level >= 3) launch_stage_level<3>(stage, first, a, dim3(grid_blocks), n_cus, s);
+	else launch_stage_level<2>(stage, first, a, dim3(grid_blocks), n_cus, s);
 }
 
 int wave_workspace_planes() { return WS_COUNT; }
