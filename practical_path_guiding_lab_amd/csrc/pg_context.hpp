@@ -64,6 +64,9 @@ struct Forest {
 	uint32_t n_trees = 0;
 	DevBuf<QuadJump> jump;           // n_trees * kJumpCells entries, rebuilt whenever rec/head change
 	bool jump_valid = false;
+	DevBuf<KdGridEntry> kd_grid;     // kKdGridCells entries, rebuilt whenever the KD tree changes
+	DevBuf<float> kd_planes;         // 3 * kKdGridPlanes cell boundaries (they follow the root box)
+	bool kd_grid_valid = false;
 	// accumulators of the running iteration: [rec_acc | root_acc | leaf_count]
 	DevBuf<long long> acc;
 	uint64_t acc_count() const
@@ -110,7 +113,12 @@ struct pg_context {
 		t.rec = f.rec.p;
 		t.head = f.head.p;
 		t.jump = f.jump_valid ? f.jump.p : nullptr;
-		for (int a = 0; a < 3; ++a) { t.bmin[a] = bmin[a]; t.bmax[a] = bmax[a]; }
+		t.kd_grid = f.kd_grid_valid ? f.kd_grid.p : nullptr;
+		t.kd_planes = f.kd_planes.p;
+		for (int a = 0; a < 3; ++a) {
+			t.bmin[a] = bmin[a]; t.bmax[a] = bmax[a];
+			t.grid_inv[a] = (float)(1 << pg::kKdGridBits) / (bmax[a] - bmin[a]);
+		}
 		t.n_kd = f.n_kd;
 		t.n_rec = f.n_rec;
 		t.n_trees = f.n_trees;

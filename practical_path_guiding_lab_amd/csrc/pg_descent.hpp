@@ -99,6 +99,65 @@ __device__ __forceinline__ uint32_t kd_descend_lds(const KdNode *kd, const uint4
 	return node;
 }
 
+// ---- the KD jump grid (pg_tree.hpp) ----
+// The planes of the grid staged in LDS once per workgroup (3 * kKdGridPlanes floats): every query reads six.
+__device__ __forceinline__ void stage_kd_planes(float *s_planes, const TreeView &t)
+{
+	if (t.kd_grid != nullptr)
+		for (uint32_t i = threadIdx.x; i < 3u * kKdGridPlanes; i += blockDim.x) s_planes[i] = t.kd_planes[i];
+	__syncthreads();
+}
+
+// the cell a point lies strictly inside of, or false; `planes` = the staged copy
+__device__ __forceinline__ bool kd_grid_cell(const TreeView &t, const float *planes, float x, float y, float z, uint32_t &cell)
+{
+	constexpr int G = 1 << kKdGridBits;
+	const float p[3] = {x, y, z};
+	int idx[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+		const float f = (p[a] - t.bmin[a]) * t.grid_inv[a];
+		if (!(f >= 0.0f && f < (float)G)) return false;
+		int i = (int)f;
+		const float *P = planes + a * kKdGridPlanes;
+		// the guess is rounded and the planes are bisection points, not multiples of a width: look next door too
+		if (p[a] <= P[i]) --i;
+		else if (p[a] >= P[i + 1]) ++i;
+		if (i < 0 || i >= G) return false;
+		if (!(p[a] > P[i] && p[a] < P[i + 1])) return false;
+		idx[a] = i;
+	}
+	cell = ((uint32_t)idx[2] << (2 * kKdGridBits)) | ((uint32_t)idx[1] << kKdGridBits) | (uint32_t)idx[0];
+	return true;
+}
+
+// KDTree.getLeafNodeIndex (kdtree.py:435-470) through the jump grid: the same node, leaf record and
+// level count as kd_descend.
+__device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const float *planes, float x, float y, float z, bool search,
+                                                    KdNode &leaf, uint32_t &levels)
+{
+	uint32_t node = 0;
+	levels = 0;
+	uint32_t cell;
+	if (search && t.kd_grid != nullptr && kd_grid_cell(t, planes, x, y, z, cell)) {
+		const uint2 e = *reinterpret_cast<const uint2 *>(t.kd_grid + cell);
+		node = e.x;
+		levels = e.y;
+	}
+	KdNode nd = load_kd(t.kd, node);
+	if (search) {
+		for (int it = (int)levels; it < kMaxLevels && nd.child != 0; ++it) {
+			const uint32_t axis = nd.axis_depth & 3u;
+			const float v = axis == 0 ? x : (axis == 1 ? y : z);
+			node = nd.child + (v >= nd.split ? 1u : 0u);
+			nd = load_kd(t.kd, node);
+			++levels;
+		}
+	}
+	leaf = nd;
+	return node;
+}
+
 struct QuadLoad {
 	float i0, i1, i2, i3;
 	uint32_t c0, c1, c2, c3;

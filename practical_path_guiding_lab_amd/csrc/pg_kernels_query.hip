@@ -312,7 +312,44 @@ __global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__r
 	out[i] = e;
 }
 
+// One thread per cell of the KD jump grid: descend with the cell's interval for as long as every point
+// strictly inside the cell takes the same branch.
+__global__ __launch_bounds__(kBlock) void k_build_kd_grid(TreeView t, KdGridEntry *__restrict__ out)
+{
+	const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+	if (c >= kKdGridCells) return;
+	constexpr uint32_t M = (1u << kKdGridBits) - 1u;
+	const int idx[3] = {(int)(c & M), (int)((c >> kKdGridBits) & M), (int)(c >> (2 * kKdGridBits))};
+	float lo[3], hi[3];
+	for (int a = 0; a < 3; ++a) {
+		lo[a] = t.kd_planes[a * kKdGridPlanes + idx[a]];
+		hi[a] = t.kd_planes[a * kKdGridPlanes + idx[a] + 1];
+	}
+	uint32_t node = 0, levels = 0;
+	KdNode nd = load_kd(t.kd, 0);
+	for (int it = 0; it < kMaxLevels && nd.child != 0; ++it) {
+		const uint32_t axis = nd.axis_depth & 3u;
+		const float l = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]), h = axis == 0 ? hi[0] : (axis == 1 ? hi[1] : hi[2]);
+		uint32_t next;
+		if (l >= nd.split) next = nd.child + 1u;      // every v > l is >= split: right (kdtree.py:462-468)
+		else if (h <= nd.split) next = nd.child;       // every v < h is < split: left
+		else break;                                    // the plane cuts through the cell: queries go on from here
+		node = next;
+		nd = load_kd(t.kd, node);
+		++levels;
+	}
+	KdGridEntry e;
+	e.node = node;
+	e.levels = levels;
+	out[c] = e;
+}
+
 static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_build_kd_grid, grid_for(kKdGridCells), dim3(kBlock), 0, s, t, out);
+}
 
 void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s)
 {

@@ -604,6 +604,34 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 {
 	Forest &f = ctx->f;
 	f.jump_valid = false;
+	// the KD jump grid follows the KD tree (a degenerate root box gets none: every query then descends from the root)
+	f.kd_grid_valid = false;
+	if (f.n_kd > 0 && ctx->bmax[0] > ctx->bmin[0] && ctx->bmax[1] > ctx->bmin[1] && ctx->bmax[2] > ctx->bmin[2]) {
+		// the cell boundaries: [bmin, bmax] bisected like the tree bisects its boxes, mid = (lo + hi) / 2 in fp32
+		// (kdtree.py:270; k_kd_refine above) -- they must ascend strictly for the grid to be usable
+		float planes[3 * kKdGridPlanes];
+		bool ok = true;
+		for (int a = 0; a < 3; ++a) {
+			float *P = planes + a * kKdGridPlanes;
+			P[0] = ctx->bmin[a];
+			P[kKdGridPlanes - 1] = ctx->bmax[a];
+			for (int step = (kKdGridPlanes - 1) / 2; step >= 1; step /= 2)
+				for (int i = step; i < kKdGridPlanes - 1; i += 2 * step) P[i] = (P[i - step] + P[i + step]) / 2.0f;
+			for (int i = 0; i + 1 < kKdGridPlanes; ++i) ok = ok && P[i] < P[i + 1];
+		}
+		TreeView tg = ctx->view();
+		ok = ok && tg.grid_inv[0] < 3.0e38f && tg.grid_inv[1] < 3.0e38f && tg.grid_inv[2] < 3.0e38f;
+		if (ok) {
+			PG_HIP(ctx, f.kd_grid.ensure(kKdGridCells));
+			PG_HIP(ctx, f.kd_planes.ensure(3 * kKdGridPlanes));
+			PG_HIP(ctx, hipMemcpyAsync(f.kd_planes.p, planes, sizeof planes, hipMemcpyHostToDevice, s));
+			PG_HIP(ctx, hipStreamSynchronize(s)); // (planes[] is on this stack frame)
+			tg = ctx->view();
+			launch_build_kd_grid(tg, f.kd_grid.p, s);
+			PG_HIP(ctx, hipGetLastError());
+			f.kd_grid_valid = true;
+		}
+	}
 	// accumulator slots are packed into 26 bits of an entry; forests beyond that walk every level
 	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask) return PG_OK;
 	PG_HIP(ctx, f.jump.ensure((size_t)f.n_trees * kJumpCells, 1.25));

@@ -124,7 +124,11 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, nee_cx, nee_cy);
 	if (active_sd_em) {
 		KdNode leaf;
+#ifdef PG_FUSED_LDS_KD // (A/B switch: the KD top staged in LDS instead of the jump grid)
 		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+#else
+		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+#endif
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
@@ -161,7 +165,11 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	float sdtree_pdf = 1.0f;
 	if ((smp_tree || bsdf_mis) && !tree_known) {
 		KdNode leaf;
+#ifdef PG_FUSED_LDS_KD // (A/B switch: the KD top staged in LDS instead of the jump grid)
 		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+#else
+		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+#endif
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
@@ -258,14 +266,23 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 template <bool kFirst, int kGeneral>
 __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 {
+#ifdef PG_FUSED_LDS_KD
 	__shared__ uint4 s_kd[kLdsKdNodes];
+#else
+	__shared__ float s_planes[3 * kKdGridPlanes];
+	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (bounce_lane's parameter: the staged table of whichever kind)
+#endif
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
 	if (!kFirst && tail_took_over(a, a.bounce)) return;  // a tail launch is finishing these paths
+#ifdef PG_FUSED_LDS_KD
 	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+#else
+	if (a.guided) stage_kd_planes(s_planes, a.tree);
+#endif
 	const bool alive = tid < live;
 	const uint64_t lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
 	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
@@ -304,12 +321,21 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 template <int kGeneral>
 __global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 {
+#ifdef PG_FUSED_LDS_KD
 	__shared__ uint4 s_kd[kLdsKdNodes];
+#else
+	__shared__ float s_planes[3 * kKdGridPlanes];
+	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (bounce_lane's parameter: the staged table of whichever kind)
+#endif
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = (uint64_t)a.live_count[a.bounce - 1];
 	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
+#ifdef PG_FUSED_LDS_KD
 	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+#else
+	if (a.guided) stage_kd_planes(s_planes, a.tree);
+#endif
 	bool alive = tid < live;
 	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
 	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce

@@ -169,7 +169,7 @@ __device__ __forceinline__ bool guide_has_work(const RenderArgs &a, uint32_t fla
 	return do_record || ((flags & F_NEE_LIVE) && a.guided) || (flags & (F_SMP_TREE | F_BSDF_MIS));
 }
 
-__device__ __forceinline__ void stage_guide(const RenderArgs &a, const uint4 *s_kd, Pcg32 &rng, v3 p, v3 ds_d, v3 wo_in,
+__device__ __forceinline__ void stage_guide(const RenderArgs &a, const float *s_planes, Pcg32 &rng, v3 p, v3 ds_d, v3 wo_in,
                                             uint32_t flags, GuideOut &g)
 {
 	const bool active_sd_em = (flags & F_NEE_LIVE) && a.guided; // (a dead emitter sample's pdf would multiply zero: stage_a)
@@ -186,7 +186,7 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const uint4 *s_
 	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, g.nee_cx, g.nee_cy);
 	if (active_sd_em) {
 		KdNode leaf;
-		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
@@ -198,7 +198,7 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const uint4 *s_
 	}
 	if ((smp_tree || bsdf_mis) && !tree_known) {
 		KdNode leaf;
-		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
@@ -574,12 +574,12 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 // ---- :244, 301, 307 ----
 __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 {
-	__shared__ uint4 s_kd[kLdsKdNodes];
+	__shared__ float s_planes[3 * kKdGridPlanes];
 	uint64_t tid, lane;
 	bool alive;
 	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive, lane)) return; }
 	else if (!wave_entry<false>(a, tid, alive, lane)) return;
-	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
 	const uint32_t flags = wsu(a, WS_FLAGS, tid);
 	if (!guide_has_work(a, flags)) return;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
 	rng.inc = a.rng_inc[lane];
 	GuideOut g;
-	stage_guide(a, s_kd, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), ws3(a, WS_WO, tid), flags, g);
+	stage_guide(a, s_planes, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), ws3(a, WS_WO, tid), flags, g);
 	wsput(a, WS_NEE_C, tid, g.nee_cx); wsput(a, WS_NEE_C + 1, tid, g.nee_cy);
 	wsput(a, WS_WO_C, tid, g.wo_cx); wsput(a, WS_WO_C + 1, tid, g.wo_cy);
 	wsput(a, WS_PDF_NEE, tid, g.pdf_nee); wsput(a, WS_PDF_TREE, tid, g.pdf_tree);
@@ -697,13 +697,13 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 template <int kLevel>
 __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 {
-	__shared__ uint4 s_kd[kLdsKdNodes];
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
+	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = (uint64_t)a.live_count[a.bounce - 1];
 	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
-	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	stage_kd_planes(s_planes, a.tree);
 	bool alive = tid < live;
 	const uint64_t N = a.n_lanes;
 	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 			GuideOut g;
 			g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 			g.wo = A.wo;
-			if (guide_has_work(a, A.flags)) stage_guide(a, s_kd, rng, A.p, A.ds_d, A.wo, A.flags, g);
+			if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, A.wo, A.flags, g);
 			bool delta;
 			alive = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, slot, (uint32_t)depth, ray_o, ray_d, prev_pdf, delta);
 			prev_p = A.p;

@@ -60,13 +60,37 @@ struct alignas(16) QuadJump {
 };
 constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
 
+// Jump grid over the top of the KD tree: the root box cut into 2^kKdGridBits cells per axis; entry
+// (iz, iy, ix) holds the node every point strictly inside that cell reaches from the root before a
+// split plane cuts through the cell, and the number of levels taken -- one 8-byte gather instead of a
+// chain of up to 3 * kKdGridBits dependent loads (the splits are midpoints, axis = depth % 3, so a
+// cell of the grid usually lies inside one node 15 levels down).  The table is built by descending
+// with the cell's interval ([lo, hi) decides like every point in it as long as lo >= split or hi <=
+// split); a query verifies with the build's own cell bounds that its point lies strictly inside the
+// cell it computed, and otherwise (a point on a cell face, outside the box, NaN) descends from the
+// root: results are those of KDTree.getLeafNodeIndex (kdtree.py:435-470) either way.
+constexpr int kKdGridBits = 5;
+constexpr uint32_t kKdGridCells = 1u << (3 * kKdGridBits);
+// The cell boundaries are not bmin + i * width: they are made by the KD tree's own arithmetic, bisecting
+// [bmin, bmax] recursively with mid = (lo + hi) / 2 in fp32 (kdtree.py:270), so that they coincide with
+// the split planes of the tree bit for bit and a cell is never cut by a plane that is "its own face but
+// one ulp off".
+constexpr int kKdGridPlanes = (1 << kKdGridBits) + 1;
+struct alignas(8) KdGridEntry {
+	uint32_t node;   // reference node index reached
+	uint32_t levels; // levels descended to get there
+};
+
 // Read-only view handed to the query kernels (sdTree_prev).
 struct TreeView {
 	const KdNode *kd;
 	const QuadRec *rec;
 	const TreeHead *head;
 	const QuadJump *jump; // n_trees * kJumpCells entries, or nullptr
+	const KdGridEntry *kd_grid; // kKdGridCells entries, or nullptr
+	const float *kd_planes;     // 3 * kKdGridPlanes cell boundaries of the grid (x planes, y planes, z planes), ascending
 	float bmin[3], bmax[3]; // root bounding box (kdtree.py:138)
+	float grid_inv[3];      // 2^kKdGridBits / (bmax - bmin): a first guess of the cell index
 	uint32_t n_kd, n_rec, n_trees;
 };
 
