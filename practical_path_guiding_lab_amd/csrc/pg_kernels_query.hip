@@ -42,13 +42,15 @@ __global__ __launch_bounds__(kBlock) void k_leaf_index(TreeView t, uint64_t n, c
                                                        const uint8_t *__restrict__ active,
                                                        uint32_t *__restrict__ node_out)
 {
+	__shared__ float s_planes[3 * kKdGridPlanes];
+	stage_kd_planes(s_planes, t);
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n) return;
 	const float x = p[i], y = p[n + i], z = p[2 * n + i];
 	const bool act = active ? active[i] != 0 : true;
 	KdNode leaf;
 	uint32_t lv;
-	node_out[i] = kd_descend(t.kd, x, y, z, act && inside_root(t, x, y, z), leaf, lv);
+	node_out[i] = kd_descend_grid(t, s_planes, x, y, z, act && inside_root(t, x, y, z), leaf, lv);
 }
 
 __global__ __launch_bounds__(kBlock) void k_sample(TreeView t, uint64_t n, const float *__restrict__ p,
@@ -58,6 +60,8 @@ __global__ __launch_bounds__(kBlock) void k_sample(TreeView t, uint64_t n, const
                                                    float *__restrict__ dir_out, float *__restrict__ pdf_out,
                                                    DepthCounters *dc)
 {
+	__shared__ float s_planes[3 * kKdGridPlanes];
+	stage_kd_planes(s_planes, t);
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	unsigned kd_lv = 0, q_lv = 0, did = 0;
 	if (i < n) {
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(TreeView t, uint64_t n, const
 		if (act) {
 			const float x = p[i], y = p[n + i], z = p[2 * n + i];
 			KdNode leaf;
-			kd_descend(t.kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
+			kd_descend_grid(t, s_planes, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			Pcg32 rng = {rng_state[i], rng_inc[i]};
 			quad_sample(t.rec, t.jump, leaf.tree, load_head(t.head, leaf.tree), rng, dx, dy, dz, pdf, q_lv);
 			rng_state[i] = rng.state;
@@ -85,6 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_pdf(TreeView t, uint64_t n, const fl
                                                 const uint8_t *__restrict__ active,
                                                 float *__restrict__ pdf_out, DepthCounters *dc)
 {
+	__shared__ float s_planes[3 * kKdGridPlanes];
+	stage_kd_planes(s_planes, t);
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	unsigned kd_lv = 0, q_lv = 0, did = 0;
 	if (i < n) {
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_pdf(TreeView t, uint64_t n, const fl
 		if (act) {
 			const float x = p[i], y = p[n + i], z = p[2 * n + i];
 			KdNode leaf;
-			kd_descend(t.kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
+			kd_descend_grid(t, s_planes, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			float cx, cy;
 			dir_to_canonical(dir[i], dir[n + i], dir[2 * n + i], cx, cy);
 			pdf = quad_pdf(t.rec, t.jump, leaf.tree, load_head(t.head, leaf.tree), cx, cy, q_lv);
@@ -123,14 +129,14 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
                                                          const uint32_t *__restrict__ d_lane_count,
                                                          DepthCounters *dc)
 {
-	__shared__ uint4 s_kd[kLdsKdNodes];
+	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	// compacted list: [0, front) from the start of lane_index (sample lanes), the next `back`
 	// entries from its end, walking down (pdf-only lanes): waves are homogeneous in `select`
 	const uint64_t front = lane_index ? (uint64_t)d_lane_count[0] : n;
 	const uint64_t live = lane_index ? front + (uint64_t)d_lane_count[1] : n;
 	if ((uint64_t)blockIdx.x * kBlock >= live) return; // whole workgroup idle (uniform)
-	stage_kd_top(s_kd, t.kd, t.n_kd);
+	stage_kd_planes(s_planes, t);
 	unsigned kd_lv = 0, kd_q = 0, q_lv = 0, q_q = 0;
 	if (tid < live && tid < n) {
 		const uint64_t i = lane_index ? (uint64_t)lane_index[tid < front ? tid : n - 1 - (tid - front)] : tid;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 		if (nee || sel != 0) {
 			const float x = p[i], y = p[n + i], z = p[2 * n + i];
 			KdNode leaf;
-			kd_descend_lds(t.kd, s_kd, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
+			kd_descend_grid(t, s_planes, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			kd_q = 1;
 			const TreeHead head = load_head(t.head, leaf.tree);
 			if (nee) {
