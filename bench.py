@@ -59,7 +59,9 @@ def parse():
                          "max_depth 32 (configs[4])")
     ap.add_argument("--res", type=int, default=None, help="film width (height follows the scene's aspect)")
     ap.add_argument("--depth", type=int, default=None, help="max_depth")
-    ap.add_argument("--spp-per-pass", type=int, default=8, help="samples per pixel traced by one pass")
+    ap.add_argument("--spp-per-pass", type=int, default=16,
+                    help="samples per pixel traced by one pass (16: 33 M paths per step at 1920x1080, and still 4 M per GPU at N = 8; "
+                         "measured on one GPU with every rank's share in turn: 7.4x of 8 at 16 spp per pass, 6.9x at 8)")
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered to train the SD-tree (the configs say 8/10/12)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"], help="N > 1: strong scaling by tiles (default) or weak by passes")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
@@ -214,6 +216,7 @@ def run_render(args):
     if tiles:
         ws.set_shard(rank, world, 4)
     my_pixels = int(ws.local_pixels().shape[0])
+    ws.reserve(integ, args.spp_per_pass)  # the pass buffers, as the reference's setup() allocates its record arrays (:93)
     # the exchange: libpgsd's own ncclAllReduce (pg_allreduce) when every rank has its GPU, else torch.distributed
     exchange = "none"
     reduce_fn = None
@@ -362,6 +365,9 @@ def run_render(args):
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
             "traffic": traffic, "slowest_kernel_of_step": slowest,
+            "limiter": "HBM is the roofline SURVEY 8(d) prescribes for this pointer-chasing path; what the kernel actually waits on "
+                       "is the latency of dependent gathers (SQ_WAIT_ANY 65 % of wave-cycles) and the double-precision series of "
+                       "atan2 / sincos (profiles/r02/pmc_summary.json): its counter traffic stays below its algorithmic bytes",
             "note": ("k_wave_guide holds the SD-tree calls of a bounce and nothing else (KD descent, NEE pdf, sample-or-pdf, the "
                      "canonical coordinates of the record): the hot path of SURVEY 8; its algorithmic bytes are 16 B per KD "
                      "level + 20 B per quadtree level over the levels an instrumented pass counted. The renderer substrate around "
@@ -381,7 +387,8 @@ def run_render(args):
         "metric": f"Msamples/s guided, {args.scene} {film} max_depth {args.depth}", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
         "higher_is_better": True, "scaling": "strong" if (tiles or world == 1) else "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "value_full_schedule": None if full_schedule is None else round(full_schedule, 3),
+        "data": "no dataset: the reference's scene (parameters, meshes and textures packaged from its scene files), sampler "
+                "streams seeded per pass, SD-tree trained inside the run", "value_full_schedule": None if full_schedule is None else round(full_schedule, 3),
         "mse_vs_gt": mse_train, "mse_vs_gt_small": mse_small, "mse_vs_gt_cpu": mse_small_cpu,
         "mse_equal": None if mse_small is None else bool(mse_small == mse_small_cpu),
         "config": {"workload": f"{args.scene} {film} (the whole film per step"

@@ -360,6 +360,11 @@ typedef struct pg_pass_params {
 int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uint8_t *valid_out,
                    float *sumL, float *sumL2, void *stream);
 
+/* Allocates what pg_render_pass needs for passes of up to n_lanes lanes (pixels of the tile x spp) ahead
+ * of time -- the reference allocates its numRays x max_depth record arrays in setup()
+ * (path_guiding_integrator.py:93, 116); without this call the first pass of a size allocates them. */
+int pg_render_reserve(pg_context *ctx, uint64_t n_lanes);
+
 /* Film reconstruction of one full-frame pass with Mitsuba's `tent` reconstruction filter of radius
  * one pixel -- the <rfilter type="tent"/> of the reference's scenes (scenes/cornell-box/scene.xml:27),
  * i.e. the image mi.render returns at main.py:218.  `seed` and `spp` are those of the pass that

@@ -519,6 +519,36 @@ void pg::destroy_render_state(pg_context *ctx)
 	ctx->render = nullptr;
 }
 
+// The buffers a pass over n_lanes lanes needs (the reference allocates its numRays x max_depth record
+// arrays in setup(), path_guiding_integrator.py:93): per-lane path state, the live lists, the record
+// list, and for mesh scenes the ray origins, the per-bounce workspace and the BVH stacks' overflow strips.
+static int ensure_pass_buffers(pg_context *ctx, uint64_t N, bool record)
+{
+	pg_render_state *r = ctx->render;
+	const int D = ctx->max_depth;
+	const uint64_t S = N * (uint64_t)D;
+	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
+	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
+	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
+	if (r->general >= 3) PG_HIP(ctx, r->ior.ensure(N));
+	if (r->general >= 2) {
+		PG_HIP(ctx, r->ray_o.ensure(3 * N));
+		PG_HIP(ctx, r->ws.ensure((size_t)wave_workspace_planes() * N));
+		PG_HIP(ctx, r->shadow_list.ensure(N));
+		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
+		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
+	}
+	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
+	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N));
+	PG_HIP(ctx, r->live_count.ensure((size_t)D + 1 + 3 * (size_t)D));
+	if (record) {
+		PG_HIP(ctx, r->ray_of.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
+		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
+		PG_HIP(ctx, r->r_nee.ensure(3 * S)); PG_HIP(ctx, r->r_dnee.ensure(2 * S)); PG_HIP(ctx, r->r_wp.ensure(S));
+	}
+	return PG_OK;
+}
+
 extern "C" {
 
 int pg_scene_set(pg_context *ctx, uint64_t n_quads, const float *h_quads, const pg_camera *cam)
@@ -743,31 +773,17 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	const uint64_t S = N * (uint64_t)D;
 	if (S > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_render_pass: more than 2^32 record slots in one pass");
 	const bool record = !ctx->is_final;
-	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
-	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
-	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
 	const bool wave = r->general >= 2; // mesh scenes: the split pipeline
-	if (r->general >= 3) PG_HIP(ctx, r->ior.ensure(N));
-	if (wave) {
-		PG_HIP(ctx, r->ray_o.ensure(3 * N));
-		PG_HIP(ctx, r->ws.ensure((size_t)wave_workspace_planes() * N));
-		PG_HIP(ctx, r->shadow_list.ensure(N));
-	}
-	if (wave) // one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
-		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
 	if (sumL && film > ctx->num_rays)
 		return fail(ctx, PG_ERR_INVALID, "pg_render_pass: sumL/sumL2 are sized by pg_setup's num_rays, which is smaller than the film");
-	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
+	{
+		const int rc = ensure_pass_buffers(ctx, N, record);
+		if (rc != PG_OK) return rc;
+	}
 	// counters of a pass, zeroed together: live_count[D + 1] ([D]: entries handed out by the tail launch), then for
 	// mesh scenes cast_count[2 D] and shadow_count[D] of the persistent ray-casting kernels
 	const size_t n_counters = (size_t)D + 1 + 3 * (size_t)D;
-	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N)); PG_HIP(ctx, r->live_count.ensure(n_counters));
 	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, n_counters * sizeof(uint32_t), s));
-	if (record) {
-		PG_HIP(ctx, r->ray_of.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
-		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
-		PG_HIP(ctx, r->r_nee.ensure(3 * S)); PG_HIP(ctx, r->r_dnee.ensure(2 * S)); PG_HIP(ctx, r->r_wp.ensure(S));
-	}
 	RenderArgs a;
 	a.tree = ctx->view();
 	a.shapes.quads = r->quads.p;
@@ -869,6 +885,17 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	}
 	if (r->timing_on) ++r->acc.passes;
 	return PG_OK;
+}
+
+int pg_render_reserve(pg_context *ctx, uint64_t n_lanes)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	if (!ctx->configured) return fail(ctx, PG_ERR_INVALID, "call pg_setup or pg_import first");
+	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: call pg_scene_set first");
+	if (ctx->max_depth <= 0 || n_lanes == 0) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: max_depth and n_lanes must be > 0");
+	if (n_lanes * (uint64_t)ctx->max_depth > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: more than 2^32 record slots in one pass");
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	return ensure_pass_buffers(ctx, n_lanes, true);
 }
 
 int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)

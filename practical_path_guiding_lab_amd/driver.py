@@ -116,6 +116,7 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
     integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
                      quadTreeMaxDepth=quadTreeMaxDepth, isStoreNEERadiance=isStoreNEERadiance,
                      bsdfSamplingFraction=bsdfSamplingFraction)
+    scene.reserve(integrator, max(batch_spp, training_spp_per_pass))  # (:93: the record arrays are allocated in setup())
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
     rec = {k: PerformanceData() for k in ("variance_inIter", "variance_groundTruth_inIter", "mse_groundTruth_inIter",

@@ -130,6 +130,16 @@ class WavefrontScene:
         begin, count = self.pixel_range if self.pixel_range is not None else (0, w * h)
         return np.arange(begin, begin + count, dtype=np.int64)
 
+    def reserve(self, integrator, spp: int) -> None:
+        """Allocates the pass buffers for passes of up to `spp` samples per pixel of this rank's tile now
+        (pg_render_reserve) instead of in the first pass of that size -- as the reference's setup()
+        allocates its record arrays (path_guiding_integrator.py:93)."""
+        tree = integrator.sdTree
+        self._upload(tree)
+        n = int(self.local_pixels().shape[0]) * int(spp)
+        if n:
+            N.check(tree._h, tree._lib.pg_render_reserve(tree._h, n))
+
     @property
     def sharded(self) -> bool:
         return self.stripe is not None or self.pixel_range is not None
