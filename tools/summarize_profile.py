@@ -78,7 +78,7 @@ def agg(sub):
 
 f, w, l2, sq = agg("pmc_fetch"), agg("pmc_write"), agg("pmc_l2"), agg("pmc_sq")
 out = {"config": cfg,
-       "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu 0 --train-iters 4`; means per launch over "
+       "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu 0`; means per launch over "
                "the launches of the timed region (the last 3 passes). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024 applies the gfx950 x2 FETCH correction of MI355X_MICROARCH.md section HBM "
                "(calibrated for wide coalesced reads only: an upper bound here).",
