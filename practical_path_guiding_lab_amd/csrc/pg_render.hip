@@ -461,7 +461,7 @@ struct pg_render_state {
 	DevBuf<uint32_t> textures, texels;
 	bool have_tri_normals = false, have_tri_uvs = false;
 	// mesh scenes: ray origins, the per-bounce workspace and the BVH stacks' overflow strips (pg_render_wave.hip)
-	DevBuf<float> ray_o;
+	DevBuf<uint4> st;
 	DevBuf<uint32_t> ws;
 	DevBuf<uint2> bvh_ovf;
 	DevBuf<uint32_t> shadow_list;
@@ -527,18 +527,19 @@ static int ensure_pass_buffers(pg_context *ctx, uint64_t N, bool record)
 	pg_render_state *r = ctx->render;
 	const int D = ctx->max_depth;
 	const uint64_t S = N * (uint64_t)D;
-	PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
-	PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
-	PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->hit0.ensure(N));
-	if (r->general >= 3) PG_HIP(ctx, r->ior.ensure(N));
-	if (r->general >= 2) {
-		PG_HIP(ctx, r->ray_o.ensure(3 * N));
+	PG_HIP(ctx, r->hit0.ensure(N));
+	if (r->general < 2) {
+		PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
+		PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
+		PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->rng_state.ensure(N));
+	} else {
+		PG_HIP(ctx, r->st.ensure(4 * N));
 		PG_HIP(ctx, r->ws.ensure((size_t)wave_workspace_planes() * N));
 		PG_HIP(ctx, r->shadow_list.ensure(N));
 		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
 		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
 	}
-	PG_HIP(ctx, r->rng_state.ensure(N)); PG_HIP(ctx, r->rng_inc.ensure(N));
+	PG_HIP(ctx, r->rng_inc.ensure(N));
 	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N));
 	PG_HIP(ctx, r->live_count.ensure((size_t)D + 1 + 3 * (size_t)D));
 	if (record) {
@@ -795,7 +796,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.textures = r->textures.p;
 	a.shapes.texels = r->texels.p;
 	a.shapes.srgb_lut = r->srgb_lut.p;
-	a.ray_o = r->ray_o.p;
+	a.st = r->st.p;
 	a.ws = r->ws.p;
 	a.bvh_ovf = r->bvh_ovf.p;
 	a.cast_count = r->live_count.p + (D + 1);

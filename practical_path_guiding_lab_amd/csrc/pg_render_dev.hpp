@@ -1135,11 +1135,17 @@ struct RenderArgs {
 	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth
 	uint32_t *ray_of;
 	float *r_pos, *r_dir, *r_bsdf, *r_tb, *r_tr, *r_nee, *r_dnee, *r_wp;
-	// mesh scenes (the split pipeline of pg_render_wave.hip): the ray origin is state (prev_quad then
-	// holds only the "previous lobe was a delta" bit), `ws` is the per-bounce workspace -- planes of
-	// n_lanes 32-bit words indexed by a lane's position in the live list -- and bvh_ovf the overflow
-	// strips of the BVH stacks (kOvfStack entries per list position)
-	float *ray_o;
+	// mesh scenes (the split pipeline of pg_render_wave.hip): the state of a lane between two bounces is
+	// four 16-byte quads, st[q * n_lanes + lane] (a path that survives is scattered and gathered by lane
+	// number: one 16-byte access moves what four 4-byte ones would, in a quarter of the sectors) --
+	//   q 0 {ray origin, sampler state low word}   q 1 {ray direction, sampler state high word}
+	//   q 2 {throughput, ior with its sign bit = "the previous lobe was a delta"}
+	//   q 3 {previous vertex, previous bsdf pdf}
+	// -- beside rng_inc, L and hit0 above; ray_d, thr, prev_p, prev_pdf, prev_quad, rng_state and ior are
+	// not allocated.  `ws` is the per-bounce workspace -- planes of n_lanes 32-bit words indexed by a
+	// lane's position in the live list -- and bvh_ovf the overflow strips of the BVH stacks (kOvfStack
+	// entries per list position)
+	uint4 *st;
 	uint32_t *ws;
 	uint2 *bvh_ovf;
 	// the ray-casting kernels are persistent: a lane whose ray is done takes the next one of the launch's

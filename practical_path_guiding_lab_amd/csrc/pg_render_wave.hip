@@ -361,6 +361,16 @@ __device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, b
 	return true;
 }
 
+// the state quads of a lane (RenderArgs::st)
+__device__ __forceinline__ uint4 st_load(const RenderArgs &a, int q, uint64_t lane) { return a.st[(uint64_t)q * a.n_lanes + lane]; }
+__device__ __forceinline__ void st_store(const RenderArgs &a, int q, uint64_t lane, v3 v, uint32_t w)
+{
+	a.st[(uint64_t)q * a.n_lanes + lane] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), w);
+}
+__device__ __forceinline__ v3 st_v3(uint4 q) { return V(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z)); }
+// q 2's fourth word: the ior (positive) with the delta bit in its sign
+__device__ __forceinline__ uint32_t st_pack_ior(float ior, bool delta) { return __float_as_uint(ior) | (delta ? 0x80000000u : 0u); }
+
 // ---- :185 scene.ray_intersect: one ray per lane.  (The persistent form below was measured too: the walks of
 // closest-hit rays are all about equally long, handing idle lanes new rays gains nothing after the second
 // bounce and loses a factor of two on the coherent camera rays.) ----
@@ -372,18 +382,16 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
 	if (!alive) return;
-	const uint64_t N = a.n_lanes;
 	v3 ray_o, ray_d;
 	if (kFirst) {
 		Pcg32 rng;
 		camera_ray(a, lane, rng, ray_o, ray_d);
-		a.rng_state[lane] = rng.state;
 		a.rng_inc[lane] = rng.inc;
-		stp(a.ray_o, N, lane, ray_o);
-		stp(a.ray_d, N, lane, ray_d);
+		st_store(a, 0, lane, ray_o, (uint32_t)rng.state);
+		st_store(a, 1, lane, ray_d, (uint32_t)(rng.state >> 32));
 	} else {
-		ray_o = ldp(a.ray_o, N, lane);
-		ray_d = ldp(a.ray_d, N, lane);
+		ray_o = st_v3(st_load(a, 0, lane));
+		ray_d = st_v3(st_load(a, 1, lane));
 	}
 	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
 	HitRec h;
@@ -395,42 +403,39 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	wsput(a, WS_HIT_V, tid, h.v);
 }
 
-// ---- :213 test_visibility (and :185, see above) ----
-// One kernel for both kinds of ray, persistent: the grid is a fixed number of workgroups per compute
-// unit, and a lane whose ray is done does not wait for the slowest ray of its wave -- as soon as
-// kRefillIdle lanes of a wave are idle they take the next rays of the launch's list.  The list is dealt
-// out in chunks of kCastChunk rays, chunk c to wave c mod (number of waves): no atomic counter (one
-// counter word serialises at about 11 ns per atomic -- a counter bumped per refill cost more than the
-// walks, and big chunks per atomic left the waves unevenly loaded at the end), and with some fifty
-// chunks per wave the rays' costs even out.  Incoherent rays take very different numbers of
-// steps: measured on veach-ajar, the one-ray-per-lane form kept 23 % of the lanes of a wave busy in
-// the closest-hit launches after the first bounce and 14 % in the shadow launches.  Every ray still
-// takes exactly the steps intersect() takes for it, in the same order.
-//   kAny = false: the rays are the live list's (or the camera rays, kFirst); the hit goes to WS_HIT_*
-//   kAny = true:  the rays are the entries of the live list flagged F_NEED_SHADOW; WS_OCC receives 0 / 1
+// ---- :213 test_visibility ----
+// Persistent: the grid is as many workgroups as the device holds at once, and a lane whose ray is done
+// does not wait for the slowest ray of its wave -- as soon as kRefillIdle lanes of a wave are idle they
+// take the next rays of the launch's list.  The list is dealt out in chunks of kCastChunk entries, chunk
+// c to wave c mod (number of waves): no atomic counter (one counter word serialises at about 11 ns per
+// atomic -- a counter bumped per refill cost more than the walks, and big chunks per atomic left the
+// waves unevenly loaded at the end), and with some fifty chunks per wave the rays' costs even out.
+// Shadow rays end after very different numbers of steps (an occluder may be the first thing met):
+// measured on veach-ajar, the one-ray-per-lane form kept 14 % of the lanes of a wave busy.  Every ray
+// still takes exactly the steps intersect() takes for it, in the same order.  The rays are the entries
+// of the live list flagged F_NEED_SHADOW; WS_OCC receives 0 / 1.
 constexpr int kRefillIdle = 16;
 constexpr uint32_t kCastChunk = 128;
-template <int kLevel, bool kFirst, bool kAny>
+template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 {
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
 	if (!kFirst && tail_took_over(a, a.bounce)) return; // a tail launch is finishing these paths
 	const uint32_t total = kFirst ? (uint32_t)a.n_lanes : a.live_count[a.bounce - 1];
 	const uint32_t gtid = blockIdx.x * kRBlock + threadIdx.x, n_static = gridDim.x * kRBlock;
-	if (blockIdx.x * kRBlock >= total) return; // (uniform) not even a first ray for this workgroup
+	if (blockIdx.x * kRBlock >= total) return; // (uniform) not even a first entry for this workgroup
 	const unsigned wl = threadIdx.x & 63u;
-	const uint64_t N = a.n_lanes;
 	const Shapes &sh = a.shapes;
 	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + (size_t)gtid * kOvfStack);
 	const int tri_base = sh.n_quads + sh.n_spheres + 6 * sh.n_boxes;
 	BvhWalk w;
 	w.next = kBvhNone; w.sp = 0; w.budget = 0; w.best = -1; w.bt = 0.0f; w.bu = 0.0f; w.bv = 0.0f;
 	bool has = false, first_round = true;
-	bool exhausted = n_static >= total; // no rays beyond the first round
-	uint32_t pool_next = 0, pool_end = 0; // (wave-uniform) the rays of this wave's current chunk not dealt out yet
+	bool exhausted = n_static >= total; // no entries beyond the first round
+	uint32_t pool_next = 0, pool_end = 0; // (wave-uniform) the entries of this wave's current chunk not dealt out yet
 	const uint32_t n_waves = n_static / 64u;
 	uint64_t chunk = gtid / 64u; // this wave's next chunk of the list beyond the first round
-	uint32_t my = 0; // the ray this lane is walking: position in the live list
+	uint32_t my = 0; // the entry this lane is walking the shadow ray of
 	for (;;) {
 		// ---- idle lanes take new rays ----
 		const unsigned long long idle = __ballot(!has);
@@ -454,71 +459,40 @@ __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 				pool_next += take;
 			}
 			first_round = false;
-			if (!has && idx < total) {
-				v3 ray_o, ray_d;
-				float tmax = __builtin_huge_valf();
-				bool wanted = true;
-				if (kAny) { // the shadow rays are the flagged entries of the live list
-					my = idx;
-					wanted = (wsu(a, WS_FLAGS, my) & F_NEED_SHADOW) != 0u;
-					if (wanted) {
-						ray_o = ws3(a, WS_SH_O, my); ray_d = ws3(a, WS_SH_D, my);
-						tmax = wsf(a, WS_SH_T, my);
-					}
-				} else {
-					my = idx;
-					const uint64_t lane = kFirst ? (uint64_t)idx : (uint64_t)a.order_in[idx];
-					if (kFirst) {
-						Pcg32 rng;
-						camera_ray(a, lane, rng, ray_o, ray_d);
-						a.rng_state[lane] = rng.state;
-						a.rng_inc[lane] = rng.inc;
-						stp(a.ray_o, N, lane, ray_o);
-						stp(a.ray_d, N, lane, ray_d);
-					} else {
-						ray_o = ldp(a.ray_o, N, lane);
-						ray_d = ldp(a.ray_d, N, lane);
-					}
-				}
-				if (wanted) {
-					int best = -1;
-					float bt = tmax;
-					intersect_linear<kLevel>(sh, ray_o, ray_d, bt, best);
-					bvh_begin(w, sh, ray_o, ray_d, bt, best);
-					has = true;
-					if (!sh.n_bvh_nodes || (kAny && best >= 0)) { // nothing to walk: the round below finds the stack empty
-						w.budget = 0;
-						w.next = kBvhNone;
-					}
+			if (!has && idx < total && (wsu(a, WS_FLAGS, idx) & F_NEED_SHADOW)) {
+				my = idx;
+				const v3 ray_o = ws3(a, WS_SH_O, my), ray_d = ws3(a, WS_SH_D, my);
+				int best = -1;
+				float bt = wsf(a, WS_SH_T, my);
+				intersect_linear<kLevel>(sh, ray_o, ray_d, bt, best);
+				bvh_begin(w, sh, ray_o, ray_d, bt, best);
+				has = true;
+				if (!sh.n_bvh_nodes || best >= 0) { // nothing to walk: the round below finds the stack empty
+					w.budget = 0;
+					w.next = kBvhNone;
 				}
 			}
 		}
 		if (__ballot(has) == 0ull) {
 			if (exhausted) break;
-			continue; // (every lane idle and rays left: the refill above has just run or runs now)
+			continue; // (every lane idle and entries left: the refill above runs again)
 		}
 		// ---- one round of every lane's walk, the loop body of intersect(): down through nodes to a leaf
-		// (the wave stays in the node loop until all its lanes have left it: the lanes of a wave are in
-		// the same phase most of the time), the leaf's triangles, the next candidate from the stack ----
+		// (the wave stays in the node loop until all its lanes have left it), the leaf's triangles, the
+		// next candidate from the stack ----
 		if (has) {
 			bool done = false;
 			while (!(w.next & 0x80000000u) && w.budget > 0) bvh_node_step(w, sh, stk);
 			if (w.next != kBvhNone && (w.next & 0x80000000u)) {
 				bvh_leaf_step(w, sh, tri_base);
-				if (kAny && w.best >= 0) done = true; // a shadow ray needs one occluder, not the nearest
+				if (w.best >= 0) done = true; // a shadow ray needs one occluder, not the nearest
 			}
 			if (!done) {
 				bvh_pop(w, stk);
 				if (w.next == kBvhNone) done = true;
 			}
 			if (done) {
-				if (kAny) wsputu(a, WS_OCC, my, w.best >= 0 ? 1u : 0u);
-				else {
-					wsputu(a, WS_HIT_PRIM, my, (uint32_t)w.best);
-					wsput(a, WS_HIT_T, my, w.bt);
-					wsput(a, WS_HIT_U, my, w.bu);
-					wsput(a, WS_HIT_V, my, w.bv);
-				}
+				wsputu(a, WS_OCC, my, w.best >= 0 ? 1u : 0u);
 				has = false;
 			}
 		}
@@ -533,19 +507,20 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
 	if (!alive) return;
-	const uint64_t N = a.n_lanes;
 	Pcg32 rng;
-	rng.state = a.rng_state[lane];
+	const uint4 q0 = st_load(a, 0, lane), q1 = st_load(a, 1, lane);
+	rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
 	rng.inc = a.rng_inc[lane];
-	const v3 ray_o = ldp(a.ray_o, N, lane), ray_d = ldp(a.ray_d, N, lane);
+	const v3 ray_o = st_v3(q0), ray_d = st_v3(q1);
 	v3 thr = V(1, 1, 1), prev_p = V(0, 0, 0);
 	float prev_pdf = 1.0f;
 	bool prev_delta = true;
 	if (!kFirst) {
-		thr = ldp(a.thr, N, lane);
-		prev_p = ldp(a.prev_p, N, lane);
-		prev_pdf = a.prev_pdf[lane];
-		prev_delta = (a.prev_quad[lane] >> 31) != 0u;
+		const uint4 q2 = st_load(a, 2, lane), q3 = st_load(a, 3, lane);
+		thr = st_v3(q2);
+		prev_delta = (q2.w >> 31) != 0u;
+		prev_p = st_v3(q3);
+		prev_pdf = __uint_as_float(q3.w);
 	}
 	HitRec h;
 	h.prim = (int)wsu(a, WS_HIT_PRIM, tid);
@@ -647,9 +622,10 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 		v3 thr = V(1, 1, 1), L = V(0, 0, 0);
 		float ior = 1.0f;
 		if (!kFirst) {
-			thr = ldp(a.thr, N, lane);
+			const uint4 q2 = st_load(a, 2, lane);
+			thr = st_v3(q2);
+			ior = __uint_as_float(q2.w & 0x7fffffffu);
 			L = ldp(a.L, N, lane);
-			if (kLevel >= 3) ior = a.ior[lane];
 		}
 		v3 ray_o, ray_d;
 		float prev_pdf;
@@ -660,14 +636,10 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 		stp(a.L, N, lane, L);
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
 		if (cont) {
-			a.rng_state[lane] = rng.state;
-			stp(a.ray_o, N, lane, ray_o);
-			stp(a.ray_d, N, lane, ray_d);
-			stp(a.thr, N, lane, thr);
-			stp(a.prev_p, N, lane, A.p);
-			a.prev_pdf[lane] = prev_pdf;
-			a.prev_quad[lane] = delta ? 0x80000000u : 0u;
-			if (kLevel >= 3) a.ior[lane] = ior;
+			st_store(a, 0, lane, ray_o, (uint32_t)rng.state);
+			st_store(a, 1, lane, ray_d, (uint32_t)(rng.state >> 32));
+			st_store(a, 2, lane, thr, st_pack_ior(ior, delta));
+			st_store(a, 3, lane, A.p, __float_as_uint(prev_pdf));
 		}
 	}
 	if (a.last) return; // nothing survives the last bounce
@@ -719,13 +691,14 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	bool prev_delta = false;
 	rng.state = 0; rng.inc = 1;
 	if (alive) {
-		rng.state = a.rng_state[lane];
+		const uint4 q0 = st_load(a, 0, lane), q1 = st_load(a, 1, lane), q2 = st_load(a, 2, lane), q3 = st_load(a, 3, lane);
+		rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
 		rng.inc = a.rng_inc[lane];
-		ray_o = ldp(a.ray_o, N, lane); ray_d = ldp(a.ray_d, N, lane);
-		thr = ldp(a.thr, N, lane); L = ldp(a.L, N, lane); prev_p = ldp(a.prev_p, N, lane);
-		prev_pdf = a.prev_pdf[lane];
-		prev_delta = (a.prev_quad[lane] >> 31) != 0u;
-		if (kLevel >= 3) ior = a.ior[lane];
+		ray_o = st_v3(q0); ray_d = st_v3(q1); thr = st_v3(q2); prev_p = st_v3(q3);
+		ior = __uint_as_float(q2.w & 0x7fffffffu);
+		prev_delta = (q2.w >> 31) != 0u;
+		prev_pdf = __uint_as_float(q3.w);
+		L = ldp(a.L, N, lane);
 	}
 	for (int depth = a.bounce; depth < a.max_depth; ++depth) {
 		if (alive) {
@@ -783,7 +756,7 @@ template <int kLevel>
 static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 grid, unsigned n_cus, hipStream_t s)
 {
 	const dim3 block(kRBlock);
-	static unsigned occ[4] = {0, 0, 0, 0}; // resident workgroups per CU of the four ray-casting instantiations of this level
+	static unsigned occ[2] = {0, 0}; // resident workgroups per CU of the two shadow-ray instantiations of this level
 	switch (stage) {
 	case 0:
 		if (first) hipLaunchKernelGGL((k_wave_trace<kLevel, true>), grid, block, 0, s, a);
@@ -794,8 +767,8 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		else hipLaunchKernelGGL((k_wave_shade_a<kLevel, false>), grid, block, 0, s, a);
 		break;
 	case 2:
-		if (first) hipLaunchKernelGGL((k_wave_cast<kLevel, true, true>), persistent_grid(k_wave_cast<kLevel, true, true>, occ[2], n_cus, a.n_lanes), block, 0, s, a);
-		else hipLaunchKernelGGL((k_wave_cast<kLevel, false, true>), persistent_grid(k_wave_cast<kLevel, false, true>, occ[3], n_cus, a.n_lanes), block, 0, s, a);
+		if (first) hipLaunchKernelGGL((k_wave_cast<kLevel, true>), persistent_grid(k_wave_cast<kLevel, true>, occ[0], n_cus, a.n_lanes), block, 0, s, a);
+		else hipLaunchKernelGGL((k_wave_cast<kLevel, false>), persistent_grid(k_wave_cast<kLevel, false>, occ[1], n_cus, a.n_lanes), block, 0, s, a);
 		break;
 	case 3: hipLaunchKernelGGL(k_wave_guide, grid, block, 0, s, a); break;
 	case 4:
