@@ -54,10 +54,13 @@ def possible_cumm_spp(budget_spp: int) -> List[int]:
 
 
 def save_image(path_noext: str, image: torch.Tensor):
+    """main.py:277-278, 400-401: the image as `.png` (sRGB) and `.exr` (linear float), plus a `.npy`."""
     from PIL import Image
+    from . import exr
 
     img = image.detach().cpu().numpy().astype(np.float32)
     np.save(path_noext + ".npy", img)
+    exr.write_rgb(path_noext + ".exr", img)
     srgb = np.where(img <= 0.0031308, 12.92 * img, 1.055 * np.power(np.clip(img, 0.0031308, None), 1 / 2.4) - 0.055)
     Image.fromarray((np.clip(srgb, 0, 1) * 255 + 0.5).astype(np.uint8)).save(path_noext + ".png")
 

@@ -309,3 +309,68 @@ def read_rgb(path: str) -> np.ndarray:
     """(H, W, 3) float32 linear RGB, as `mi.TensorXf(mi.Bitmap(path))` yields it (main.py:38-41)."""
     ch, _ = read_exr(path)
     return np.stack([ch["R"], ch["G"], ch["B"]], axis=2)
+
+
+def _zip_predictor(raw: bytes) -> bytes:
+    """The inverse of _undo_zip_predictor: even bytes then odd bytes, then byte differences + 128."""
+    a = np.frombuffer(raw, np.uint8)
+    t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+    d = np.empty_like(t)
+    d[0] = t[0]
+    d[1:] = t[1:] - t[:-1] + 128
+    return (d & 0xFF).astype(np.uint8).tobytes()
+
+
+def _attr(name: str, typ: str, payload: bytes) -> bytes:
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+
+def write_rgb(path: str, image: np.ndarray, half: bool = False, compression: str = "zip") -> None:
+    """Writes an (H, W, 3) linear-RGB image as a scanline OpenEXR file, channels B, G, R (FLOAT, or HALF
+    with `half`), ZIP (16 scanlines per chunk) or uncompressed -- the `.exr` that
+    `mi.util.write_bitmap(imageFileName + '.exr', image)` leaves next to each `.png` (main.py:278, 401).
+    read_rgb() reads it back bit for bit (FLOAT) or to half precision (HALF)."""
+    img = np.ascontiguousarray(np.asarray(image, np.float32))
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("image must be (H, W, 3)")
+    comp = {"none": 0, "zip": 3}.get(compression)
+    if comp is None:
+        raise ValueError("compression must be 'none' or 'zip'")
+    H, W = img.shape[:2]
+    ptype, dt = (1, "<f2") if half else (2, "<f4")
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", ptype, 0, 1, 1) for n in ("B", "G", "R")) + b"\0"
+    box = struct.pack("<iiii", 0, 0, W - 1, H - 1)
+    header = struct.pack("<ii", _MAGIC, 2)
+    header += _attr("channels", "chlist", chlist)
+    header += _attr("compression", "compression", bytes([comp]))
+    header += _attr("dataWindow", "box2i", box)
+    header += _attr("displayWindow", "box2i", box)
+    header += _attr("lineOrder", "lineOrder", b"\0")
+    header += _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    header += _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+    header += _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    header += b"\0"
+    lines = 16 if comp == 3 else 1
+    chunks = []
+    for y in range(0, H, lines):
+        rows = img[y:y + lines]
+        # per scanline: all of B, then all of G, then all of R (channels in alphabetical order)
+        raw = np.concatenate([rows[:, :, c].astype(dt).view(np.uint8).reshape(rows.shape[0], -1) for c in (2, 1, 0)],
+                             axis=1).tobytes()
+        data = raw
+        if comp == 3:
+            z = zlib.compress(_zip_predictor(raw), 6)
+            if len(z) < len(raw):  # (a chunk that does not shrink is stored raw, as the format prescribes)
+                data = z
+        chunks.append(struct.pack("<ii", y, len(data)) + data)
+    table_at = len(header)
+    pos = table_at + 8 * len(chunks)
+    offsets = []
+    for c in chunks:
+        offsets.append(pos)
+        pos += len(c)
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(struct.pack(f"<{len(offsets)}Q", *offsets))
+        for c in chunks:
+            f.write(c)

@@ -44,12 +44,14 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     return acc
 
 
-def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
+def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None, timeout_s: float = 120.0) -> bool:
     """Gives `tree` (an SDTree) its own RCCL communicator over the ranks of `group` (pg_comm_init): rank
     0's ncclUniqueId travels through torch.distributed, then every rank joins.  Afterwards
     tree.allReduce() is the exchange -- one ncclAllReduce issued by libpgsd.so itself, the form a host
-    without PyTorch would use.  Returns False (and leaves the tree untouched) when the ranks do not each
-    have a GPU of their own (RCCL refuses two ranks on one device) or RCCL cannot be loaded."""
+    without PyTorch would use.  Returns False on EVERY rank (and leaves no communicator behind) when the
+    ranks do not each have a GPU of their own (RCCL refuses two ranks on one device), RCCL cannot be
+    loaded, or any rank fails to join within `timeout_s`: the caller then exchanges through
+    torch.distributed (all_reduce_accumulators), which is the same RCCL all-reduce issued by PyTorch."""
     if not dist.is_available() or not dist.is_initialized():
         return False
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -68,8 +70,32 @@ def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
             import warnings
             warnings.warn(f"libpgsd RCCL communicator not available: {err}")
         return False
-    tree.commInit(world, rank, ident[0])
-    return True
+    # join on a helper thread (the call leaves the interpreter lock): a rank that cannot join must not
+    # leave the others waiting in ncclCommInitRank for ever
+    import threading
+    outcome = {}
+
+    def join():
+        try:
+            tree.commInit(world, rank, ident[0])
+            outcome["ok"] = True
+        except Exception as e:
+            outcome["err"] = e
+
+    th = threading.Thread(target=join, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    mine = 1 if outcome.get("ok") else 0
+    flag = torch.tensor([mine], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        return True
+    import warnings
+    warnings.warn(f"libpgsd RCCL communicator: rank {rank} {'joined' if mine else 'did not join'}"
+                  f"{' (' + str(outcome['err']) + ')' if 'err' in outcome else ''}; falling back to torch.distributed")
+    if mine:
+        tree.commDestroy()
+    return False
 
 
 def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -214,6 +214,30 @@ def test_exr_reader_roundtrips_uncompressed_and_zip(tmp_path):
             np.testing.assert_array_equal(got[:, :, k], px[c].astype(np.float32))
 
 
+def test_exr_writer_round_trips_through_the_reader(tmp_path):
+    """write_rgb (main.py:278, 401: the `.exr` beside every `.png`) against read_rgb: FLOAT bit for
+    bit, HALF to half precision, ZIP and uncompressed, odd sizes, non-finite and denormal values."""
+    from practical_path_guiding_lab_amd import exr
+
+    rng = np.random.default_rng(3)
+    for h, w in ((37, 53), (16, 1), (1, 7), (90, 160)):
+        img = (rng.random((h, w, 3), dtype=np.float32) ** 4 * 50).astype(np.float32)
+        img[0, 0] = [0.0, np.inf, 1e-30]
+        for half in (False, True):
+            for comp in ("zip", "none"):
+                f = str(tmp_path / f"w{h}x{w}_{int(half)}_{comp}.exr")
+                exr.write_rgb(f, img, half=half, compression=comp)
+                want = img.astype(np.float16).astype(np.float32) if half else img
+                np.testing.assert_array_equal(exr.read_rgb(f), want)
+    flat = str(tmp_path / "flat.exr")
+    exr.write_rgb(flat, np.full((64, 64, 3), 0.25, np.float32))
+    assert os.path.getsize(flat) < 64 * 64 * 12 // 10  # ZIP really compresses
+    with pytest.raises(ValueError):
+        exr.write_rgb(flat, np.zeros((4, 4), np.float32))
+    with pytest.raises(ValueError):
+        exr.write_rgb(flat, np.zeros((4, 4, 3), np.float32), compression="piz")
+
+
 def test_ground_truth_fixture_is_the_cornell_box():
     gt = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_gt_256_f16.npy")).astype(np.float32)
     assert gt.shape == (256, 256, 3) and np.isfinite(gt).all() and gt.min() >= 0
