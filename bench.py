@@ -42,6 +42,26 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+
+
+def device_copy_rate(dev) -> float:
+    """The achievable-copy figure SURVEY 8(d) asks to be recorded beside the nominal peak: bytes read +
+    bytes written per second of a 1 GiB device-to-device copy on this box (best of 5), GB/s."""
+    import torch
+    n = 1 << 28  # 1 GiB of float32
+    src = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+    dst = torch.empty_like(src)
+    best = float("inf")
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del src, dst
+    return round(2.0 * 4.0 * n / (best * 1e-3) / 1e9, 1)
+
 SCENES = {  # film width, aspect (w, h), max_depth of the BASELINE config
     "veach-ajar": (1920, (16, 9), 13), "cornell-box": (512, (1, 1), 8), "veach-mis": (1280, (16, 9), 3),
     "torus": (1920, (16, 9), 32),
@@ -365,6 +385,7 @@ def run_render(args):
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
             "traffic": traffic, "slowest_kernel_of_step": slowest,
+            "device_copy_GBps": device_copy_rate(torch.device("cuda", local_rank)) if rank == 0 else None,
             "limiter": "HBM is the roofline SURVEY 8(d) prescribes for this pointer-chasing path; what the kernel actually waits on "
                        "is the latency of dependent gathers (SQ_WAIT_ANY 65 % of wave-cycles) and the double-precision series of "
                        "atan2 / sincos (profiles/r02/pmc_summary.json): its counter traffic stays below its algorithmic bytes",

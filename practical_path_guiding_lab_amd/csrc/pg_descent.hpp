@@ -131,6 +131,13 @@ __device__ __forceinline__ bool kd_grid_cell(const TreeView &t, const float *pla
 	return true;
 }
 
+// Each branch below hands the node over as VALUES, loaded inside the branch.  Without the barrier the
+// compiler (ROCm 7.2 clang, gfx950) sinks the load of `child` below the branches, through a pointer that
+// is either &entry.child or &kd[0].child -- and in the fused splat kernels it kept that pointer in
+// registers that kd_grid_cell's early exits use as temporaries: lanes on a cell face then read `child`
+// from a wild address (a memory aperture violation on the device).
+#define PG_KEEP_LOADED(x) asm volatile("" : "+v"(x))
+
 // KDTree.getLeafNodeIndex (kdtree.py:435-470) through the jump grid: the same node, leaf record and
 // level count as kd_descend.
 __device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const float *planes, float x, float y, float z, bool search,
@@ -139,12 +146,20 @@ __device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const flo
 	uint32_t node = 0;
 	levels = 0;
 	uint32_t cell;
+	KdNode nd;
 	if (search && t.kd_grid != nullptr && kd_grid_cell(t, planes, x, y, z, cell)) {
-		const uint2 e = *reinterpret_cast<const uint2 *>(t.kd_grid + cell);
+		const uint4 e = *reinterpret_cast<const uint4 *>(t.kd_grid + cell);
 		node = e.x;
-		levels = e.y;
+		levels = e.y >> 16;
+		nd.child = e.z;
+		nd.axis_depth = e.y & 0xffffu;
+		nd.split = __uint_as_float(e.w); // (meaningful for an inner node)
+		nd.tree = e.w;                   // (meaningful for a leaf; an inner node's is never returned: see below)
+		PG_KEEP_LOADED(nd.child);
+	} else {
+		nd = load_kd(t.kd, node);
+		PG_KEEP_LOADED(nd.child);
 	}
-	KdNode nd = load_kd(t.kd, node);
 	if (search) {
 		for (int it = (int)levels; it < kMaxLevels && nd.child != 0; ++it) {
 			const uint32_t axis = nd.axis_depth & 3u;
@@ -153,6 +168,7 @@ __device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const flo
 			nd = load_kd(t.kd, node);
 			++levels;
 		}
+		if (nd.child != 0) nd = load_kd(t.kd, node); // (kMaxLevels deep without a leaf: not a tree this library holds)
 	}
 	leaf = nd;
 	return node;

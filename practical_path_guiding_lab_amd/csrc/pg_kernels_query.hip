@@ -346,7 +346,9 @@ __global__ __launch_bounds__(kBlock) void k_build_kd_grid(TreeView t, KdGridEntr
 	}
 	KdGridEntry e;
 	e.node = node;
-	e.levels = levels;
+	e.meta = (levels << 16) | (nd.axis_depth & 0xffffu);
+	e.child = nd.child;
+	e.value = nd.child == 0 ? nd.tree : __float_as_uint(nd.split);
 	out[c] = e;
 }
 

@@ -62,23 +62,31 @@ constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
 
 // Jump grid over the top of the KD tree: the root box cut into 2^kKdGridBits cells per axis; entry
 // (iz, iy, ix) holds the node every point strictly inside that cell reaches from the root before a
-// split plane cuts through the cell, and the number of levels taken -- one 8-byte gather instead of a
-// chain of up to 3 * kKdGridBits dependent loads (the splits are midpoints, axis = depth % 3, so a
-// cell of the grid usually lies inside one node 15 levels down).  The table is built by descending
-// with the cell's interval ([lo, hi) decides like every point in it as long as lo >= split or hi <=
-// split); a query verifies with the build's own cell bounds that its point lies strictly inside the
-// cell it computed, and otherwise (a point on a cell face, outside the box, NaN) descends from the
-// root: results are those of KDTree.getLeafNodeIndex (kdtree.py:435-470) either way.
-constexpr int kKdGridBits = 5;
+// split plane cuts through the cell, the number of levels taken, and that node's own record -- one
+// 16-byte gather instead of a chain of up to 3 * kKdGridBits + 1 dependent ones (the splits are
+// midpoints, axis = depth % 3, so a cell of the grid usually lies inside one node 3 * kKdGridBits levels
+// down, or inside a leaf above that: then the gather is the whole descent).  The kernels that walk
+// the tree are bound by the number of divergent gathers their lanes make (profiles/r02/pmc_guide.txt),
+// not by bytes.  The table is built by descending with the cell's interval ([lo, hi) decides like every
+// point in it as long as lo >= split or hi <= split); a query verifies with the build's own cell bounds
+// that its point lies strictly inside the cell it computed, and otherwise (a point on a cell face,
+// outside the box, NaN) descends from the root: results are those of KDTree.getLeafNodeIndex
+// (kdtree.py:435-470) either way.
+#ifndef PG_KD_GRID_BITS
+#define PG_KD_GRID_BITS 6
+#endif
+constexpr int kKdGridBits = PG_KD_GRID_BITS;
 constexpr uint32_t kKdGridCells = 1u << (3 * kKdGridBits);
 // The cell boundaries are not bmin + i * width: they are made by the KD tree's own arithmetic, bisecting
 // [bmin, bmax] recursively with mid = (lo + hi) / 2 in fp32 (kdtree.py:270), so that they coincide with
 // the split planes of the tree bit for bit and a cell is never cut by a plane that is "its own face but
 // one ulp off".
 constexpr int kKdGridPlanes = (1 << kKdGridBits) + 1;
-struct alignas(8) KdGridEntry {
-	uint32_t node;   // reference node index reached
-	uint32_t levels; // levels descended to get there
+struct alignas(16) KdGridEntry {
+	uint32_t node;  // reference node index reached
+	uint32_t meta;  // bits 0-15 the node's axis_depth word, bits 16.. levels descended to get there
+	uint32_t child; // the node's child word (0 = leaf)
+	uint32_t value; // a leaf's quadtree (KdNode::tree), an inner node's split plane (fp32 bits)
 };
 
 // Read-only view handed to the query kernels (sdTree_prev).
