@@ -49,7 +49,10 @@ struct alignas(8) TreeHead {
 // tie rule applies off the cell boundaries), and the pdf product is formed at build time by the
 // same operations in the same order as the level-by-level loop, so results are bit-identical;
 // points on a cell boundary or outside the unit square take the loop from the root.
-constexpr int kJumpBits = 4;
+#ifndef PG_JUMP_BITS
+#define PG_JUMP_BITS 4
+#endif
+constexpr int kJumpBits = PG_JUMP_BITS;
 constexpr uint32_t kJumpCells = 1u << (2 * kJumpBits); // entries per tree
 struct alignas(16) QuadJump {
 	uint32_t next;  // record to continue from; kNoRecord: the walk ended in a leaf within the table
