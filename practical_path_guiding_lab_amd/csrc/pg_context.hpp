@@ -64,9 +64,10 @@ struct Forest {
 	uint32_t n_trees = 0;
 	DevBuf<QuadJump> jump;           // n_trees * kJumpCells entries, rebuilt whenever rec/head change
 	bool jump_valid = false;
-	DevBuf<KdGridEntry> kd_grid;     // kKdGridCells entries, rebuilt whenever the KD tree changes
+	DevBuf<KdGridEntry> kd_grid;     // 8^kd_grid_bits entries, rebuilt whenever the KD tree changes
 	DevBuf<float> kd_planes;         // 3 * kKdGridPlanes cell boundaries (they follow the root box)
 	bool kd_grid_valid = false;
+	int kd_grid_bits = 0;            // cells per axis = 2^kd_grid_bits
 	// accumulators of the running iteration: [rec_acc | root_acc | leaf_count]
 	DevBuf<long long> acc;
 	uint64_t acc_count() const
@@ -117,8 +118,9 @@ struct pg_context {
 		t.kd_planes = f.kd_planes.p;
 		for (int a = 0; a < 3; ++a) {
 			t.bmin[a] = bmin[a]; t.bmax[a] = bmax[a];
-			t.grid_inv[a] = (float)(1 << pg::kKdGridBits) / (bmax[a] - bmin[a]);
+			t.grid_inv[a] = (float)(1 << f.kd_grid_bits) / (bmax[a] - bmin[a]);
 		}
+		t.grid_bits = f.kd_grid_bits;
 		t.n_kd = f.n_kd;
 		t.n_rec = f.n_rec;
 		t.n_trees = f.n_trees;

@@ -111,7 +111,7 @@ __device__ __forceinline__ void stage_kd_planes(float *s_planes, const TreeView 
 // the cell a point lies strictly inside of, or false; `planes` = the staged copy
 __device__ __forceinline__ bool kd_grid_cell(const TreeView &t, const float *planes, float x, float y, float z, uint32_t &cell)
 {
-	constexpr int G = 1 << kKdGridBits;
+	const int G = 1 << t.grid_bits;
 	const float p[3] = {x, y, z};
 	int idx[3];
 #pragma unroll
@@ -127,7 +127,7 @@ __device__ __forceinline__ bool kd_grid_cell(const TreeView &t, const float *pla
 		if (!(p[a] > P[i] && p[a] < P[i + 1])) return false;
 		idx[a] = i;
 	}
-	cell = ((uint32_t)idx[2] << (2 * kKdGridBits)) | ((uint32_t)idx[1] << kKdGridBits) | (uint32_t)idx[0];
+	cell = ((uint32_t)idx[2] << (2 * t.grid_bits)) | ((uint32_t)idx[1] << t.grid_bits) | (uint32_t)idx[0];
 	return true;
 }
 

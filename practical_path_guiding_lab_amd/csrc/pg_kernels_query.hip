@@ -323,9 +323,9 @@ __global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__r
 __global__ __launch_bounds__(kBlock) void k_build_kd_grid(TreeView t, KdGridEntry *__restrict__ out)
 {
 	const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-	if (c >= kKdGridCells) return;
-	constexpr uint32_t M = (1u << kKdGridBits) - 1u;
-	const int idx[3] = {(int)(c & M), (int)((c >> kKdGridBits) & M), (int)(c >> (2 * kKdGridBits))};
+	if (c >= (1u << (3 * t.grid_bits))) return;
+	const uint32_t M = (1u << t.grid_bits) - 1u;
+	const int idx[3] = {(int)(c & M), (int)((c >> t.grid_bits) & M), (int)(c >> (2 * t.grid_bits))};
 	float lo[3], hi[3];
 	for (int a = 0; a < 3; ++a) {
 		lo[a] = t.kd_planes[a * kKdGridPlanes + idx[a]];
@@ -356,7 +356,7 @@ static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1
 
 void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_build_kd_grid, grid_for(kKdGridCells), dim3(kBlock), 0, s, t, out);
+	hipLaunchKernelGGL(k_build_kd_grid, grid_for(1ull << (3 * t.grid_bits)), dim3(kBlock), 0, s, t, out);
 }
 
 void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s)

@@ -609,20 +609,25 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 	if (f.n_kd > 0 && ctx->bmax[0] > ctx->bmin[0] && ctx->bmax[1] > ctx->bmin[1] && ctx->bmax[2] > ctx->bmin[2]) {
 		// the cell boundaries: [bmin, bmax] bisected like the tree bisects its boxes, mid = (lo + hi) / 2 in fp32
 		// (kdtree.py:270; k_kd_refine above) -- they must ascend strictly for the grid to be usable
-		float planes[3 * kKdGridPlanes];
+		// resolution: one level more than a balanced tree of this many leaves has (pg_tree.hpp)
+		int bits = 1;
+		while (bits < kKdGridBits && (1ull << (3 * (bits - 1))) < ((uint64_t)f.n_kd + 1) / 2) ++bits;
+		f.kd_grid_bits = bits;
+		const int G = 1 << bits;
+		float planes[3 * kKdGridPlanes] = {};
 		bool ok = true;
 		for (int a = 0; a < 3; ++a) {
 			float *P = planes + a * kKdGridPlanes;
 			P[0] = ctx->bmin[a];
-			P[kKdGridPlanes - 1] = ctx->bmax[a];
-			for (int step = (kKdGridPlanes - 1) / 2; step >= 1; step /= 2)
-				for (int i = step; i < kKdGridPlanes - 1; i += 2 * step) P[i] = (P[i - step] + P[i + step]) / 2.0f;
-			for (int i = 0; i + 1 < kKdGridPlanes; ++i) ok = ok && P[i] < P[i + 1];
+			P[G] = ctx->bmax[a];
+			for (int step = G / 2; step >= 1; step /= 2)
+				for (int i = step; i < G; i += 2 * step) P[i] = (P[i - step] + P[i + step]) / 2.0f;
+			for (int i = 0; i < G; ++i) ok = ok && P[i] < P[i + 1];
 		}
 		TreeView tg = ctx->view();
 		ok = ok && tg.grid_inv[0] < 3.0e38f && tg.grid_inv[1] < 3.0e38f && tg.grid_inv[2] < 3.0e38f;
 		if (ok) {
-			PG_HIP(ctx, f.kd_grid.ensure(kKdGridCells));
+			PG_HIP(ctx, f.kd_grid.ensure((size_t)1 << (3 * bits)));
 			PG_HIP(ctx, f.kd_planes.ensure(3 * kKdGridPlanes));
 			PG_HIP(ctx, hipMemcpyAsync(f.kd_planes.p, planes, sizeof planes, hipMemcpyHostToDevice, s));
 			PG_HIP(ctx, hipStreamSynchronize(s)); // (planes[] is on this stack frame)

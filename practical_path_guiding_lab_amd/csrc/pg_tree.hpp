@@ -75,10 +75,13 @@ constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
 // that its point lies strictly inside the cell it computed, and otherwise (a point on a cell face,
 // outside the box, NaN) descends from the root: results are those of KDTree.getLeafNodeIndex
 // (kdtree.py:435-470) either way.
+// The resolution follows the tree: 2^bits cells per axis with bits = ceil(log2(leaves) / 3) + 1, at most
+// kKdGridBits (a table much finer than the tree only spreads the queries over more cache lines: uniform
+// random queries into a depth-12 tree ran 15 % slower on a 64^3 table than on a 32^3 one).
 #ifndef PG_KD_GRID_BITS
 #define PG_KD_GRID_BITS 6
 #endif
-constexpr int kKdGridBits = PG_KD_GRID_BITS;
+constexpr int kKdGridBits = PG_KD_GRID_BITS; // the finest grid
 constexpr uint32_t kKdGridCells = 1u << (3 * kKdGridBits);
 // The cell boundaries are not bmin + i * width: they are made by the KD tree's own arithmetic, bisecting
 // [bmin, bmax] recursively with mid = (lo + hi) / 2 in fp32 (kdtree.py:270), so that they coincide with
@@ -101,7 +104,8 @@ struct TreeView {
 	const KdGridEntry *kd_grid; // kKdGridCells entries, or nullptr
 	const float *kd_planes;     // 3 * kKdGridPlanes cell boundaries of the grid (x planes, y planes, z planes), ascending
 	float bmin[3], bmax[3]; // root bounding box (kdtree.py:138)
-	float grid_inv[3];      // 2^kKdGridBits / (bmax - bmin): a first guess of the cell index
+	float grid_inv[3];      // 2^grid_bits / (bmax - bmin): a first guess of the cell index
+	int grid_bits;          // cells per axis = 2^grid_bits (<= kKdGridBits); plane k of an axis at [axis * kKdGridPlanes + k]
 	uint32_t n_kd, n_rec, n_trees;
 };
 
