@@ -387,8 +387,9 @@ def run_render(args):
             "traffic": traffic, "slowest_kernel_of_step": slowest,
             "device_copy_GBps": device_copy_rate(torch.device("cuda", local_rank)) if rank == 0 else None,
             "limiter": "HBM is the roofline SURVEY 8(d) prescribes for this pointer-chasing path; what the kernel actually waits on "
-                       "is the latency of dependent gathers (SQ_WAIT_ANY 65 % of wave-cycles) and the double-precision series of "
-                       "atan2 / sincos (profiles/r02/pmc_summary.json): its counter traffic stays below its algorithmic bytes",
+                       "is the rate at which a CU's texture path takes divergent gathers (address unit busy 82 % of the launch, "
+                       "about 1.6 cycles per lane and gather: profiles/r02/pmc_guide.txt), not bytes and not arithmetic; "
+                       "device_copy_GBps is the read+write rate of a plain device-to-device copy measured in this run",
             "note": ("k_wave_guide holds the SD-tree calls of a bounce and nothing else (KD descent, NEE pdf, sample-or-pdf, the "
                      "canonical coordinates of the record): the hot path of SURVEY 8; its algorithmic bytes are 16 B per KD "
                      "level + 20 B per quadtree level over the levels an instrumented pass counted. The renderer substrate around "
