@@ -94,7 +94,7 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                       stable_variance_spp_threshold: int = 256, train_stop_cumm_spp: int = 1000,
                       record_in_iteration: bool = False, out_dir: Optional[str] = None,
                       all_reduce: Optional[Callable[[torch.Tensor], None]] = None,
-                      log: Callable[[str], None] = print, shard=None) -> Dict:
+                      log: Callable[[str], None] = print, shard=None, gt_mask=None) -> Dict:
     """Runs the whole training + rendering schedule; returns the final image, logs and timings.
 
     Multi-GPU (one process per GPU, torch.distributed initialised): shard = (rank, world[, stripe_rows
@@ -119,6 +119,7 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
     integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
                      quadTreeMaxDepth=quadTreeMaxDepth, isStoreNEERadiance=isStoreNEERadiance,
                      bsdfSamplingFraction=bsdfSamplingFraction)
+    integrator.setGroundTruthMask(gt_mask)  # (the pixels a comparison with the ground truth counts; None: all)
     scene.reserve(integrator, max(batch_spp, training_spp_per_pass))  # (:93: the record arrays are allocated in setup())
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)

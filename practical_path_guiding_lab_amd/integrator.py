@@ -47,6 +47,7 @@ class PathGuidingIntegrator:
         self.device = self.sdTree.device
         self.sumL = None
         self.sumL2 = None
+        self.gt_mask = None
         self._bbox = None
 
     # ---- path_guiding_integrator.py:77-105 ---------------------------------------------------
@@ -63,6 +64,7 @@ class PathGuidingIntegrator:
 
     def resetVarianceCounter(self) -> None:  # :108-110
         self.sumL = torch.zeros((3, max(self.numRays, 1)), dtype=torch.float32, device=self.device)
+        self.gt_mask = None  # (one entry per film pixel: set again after a new setup)
         self.sumL2 = torch.zeros_like(self.sumL)
 
     def setIteration(self, iteration: int, isFinalIter: bool) -> None:  # :121-123
@@ -93,19 +95,36 @@ class PathGuidingIntegrator:
     # ---- metrics (:503-550) ---------------------------------------------------------------------
     # `sums`: whole-film (sumL, sumL2) of a tile-sharded render (parallel.all_reduce_sums) instead of
     # this rank's own arrays
+    def setGroundTruthMask(self, mask) -> None:
+        """Not in the reference: the pixels (bool, film order) a comparison with the ground truth counts.
+        veach-ajar here lacks the six teapot shapes (their mesh files are missing from the reference
+        mount), so the rectangle they cover in TungstenRender.exr says nothing about the estimator
+        (scene.veach_ajar_mask).  None = every pixel, the reference's behaviour."""
+        if mask is None:
+            self.gt_mask = None
+            return
+        m = torch.as_tensor(np.asarray(mask, bool).reshape(-1), device=self.sumL.device)
+        if m.numel() != self.sumL.shape[1]:
+            raise ValueError("ground-truth mask must have one entry per film pixel")
+        self.gt_mask = m
+
+    def _gt_mean(self, per_pixel: torch.Tensor) -> float:
+        m = self.gt_mask
+        return float((per_pixel if m is None else per_pixel[m]).mean().item())
+
     def computeMSE(self, spp: float, groundTruth: torch.Tensor, sums=None) -> float:
         sumL = self.sumL if sums is None else sums[0]
         L = sumL / spp
         mse = (L - groundTruth) ** 2
         mse = torch.clamp(luminance(mse), max=10000.0)
-        return float(mse.mean().item())
+        return self._gt_mean(mse)
 
     def computeVariance(self, spp: float, groundTruth: Optional[torch.Tensor] = None, sums=None) -> float:
         sumL, sumL2 = (self.sumL, self.sumL2) if sums is None else sums
         if groundTruth is not None:
             variance = (sumL2 / spp) - (groundTruth * groundTruth)
             variance = torch.clamp(luminance(variance), max=10000.0)
-            return float(variance.mean().item()) / spp
+            return self._gt_mean(variance) / spp
         L = sumL / spp
         L2 = sumL2 / spp
         variance = torch.clamp(luminance(L2 - L * L), max=10000.0)

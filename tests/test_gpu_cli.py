@@ -53,6 +53,43 @@ def test_main_py_runs_the_schedule_and_writes_its_outputs(tmp_path, scene, w, h)
     assert rows[0] == "time,spp,cumm_spp,iteration,variance,mse" and len(rows) == 4
 
 
+def test_main_py_masks_the_teapots_of_veach_ajar_in_its_mse(tmp_path):
+    """veach-ajar against its ground truth: the rectangle of the (absent) teapots does not count, so the
+    logged MSE is the one bench.py reports, not one dominated by six missing objects."""
+    import torch
+    from practical_path_guiding_lab_amd import scene as S
+    from practical_path_guiding_lab_amd.driver import load_ground_truth
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+
+    out = str(tmp_path / "ajar")
+    gt = os.path.join(ROOT, "tests", "golden", "veach_ajar_gt_320x180_f16.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "veach-ajar", "--width", "320", "--height", "180",
+           "--budget-spp", "28", "--ground-truth", gt, "--out", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "leave out the teapot rectangle" in r.stdout
+    rows = open(os.path.join(out, "mse_groundTruth_endIter.csv")).read().splitlines()
+    masked = float(rows[-1].split(",")[-1])
+    # the mask's arithmetic on the image the run left: the mean of the reference's per-pixel term over the pixels that count
+    g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
+    g.setup(320 * 180, np.zeros(3, np.float32), np.ones(3, np.float32), 20, 20, True, 0.5)
+    gtt = load_ground_truth(gt, 320, 180)
+    img = torch.from_numpy(np.load(os.path.join(out, [f for f in sorted(os.listdir(out)) if f.endswith(".npy")][-1])).reshape(-1, 3).T.copy()).cuda()
+    g.sumL.copy_(img)
+    full = g.computeMSE(1, gtt)
+    g.setGroundTruthMask(S.veach_ajar_mask(320, 180))
+    part = g.computeMSE(1, gtt)
+    m = S.veach_ajar_mask(320, 180).reshape(-1)
+    err = ((img - gtt) ** 2).cpu().numpy().astype(np.float32)
+    lum = np.minimum(np.float32(0.212671) * err[0] + np.float32(0.715160) * err[1] + np.float32(0.072169) * err[2], np.float32(1e4))
+    assert 0 < m.mean() < 1 and abs(part - lum[m].mean()) <= 1e-4 * part and abs(full - lum.mean()) <= 1e-4 * full and part != full
+    assert masked > 0 and np.isfinite(masked)
+    with pytest.raises(ValueError):
+        g.setGroundTruthMask(np.ones(7, bool))
+    g.setGroundTruthMask(None)
+    assert g.computeMSE(1, gtt) == full
+
+
 def test_sdtree_file_round_trip(tmp_path):
     """saveSDTreeToFile -> loadSDTreeFromFile into a fresh integrator: the 23 keys, the same columns,
     and a tree that samples, evaluates and keeps training exactly like the one that was saved."""
