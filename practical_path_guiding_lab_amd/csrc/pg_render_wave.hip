@@ -34,12 +34,17 @@ namespace pg {
 // ---- the workspace: planes of n_lanes 32-bit words ----
 enum : int {
 	WS_HIT_PRIM = 0, WS_HIT_T, WS_HIT_U, WS_HIT_V,
-	WS_P, WS_N = WS_P + 3, WS_NG = WS_N + 3, WS_WI = WS_NG + 3,
-	WS_FLAGS = WS_WI + 3, WS_MAT,
-	WS_REFL, WS_LE = WS_REFL + 3,
+	WS_P, WS_NG = WS_P + 3,
+	WS_FLAGS = WS_NG + 3,
+	// ten planes that hold one of two things, by the lane's class: a lane that takes its next direction from
+	// the tree (F_SMP_TREE) evaluates its BSDF again for that direction in k_wave_shade_b and needs the
+	// shading normal (0-2), wi (3-5), the material (6) and the reflectance (7-9); every other lane keeps its
+	// BSDF sample: wo (0-2), the weight (3-5), the pdf (6).  Neither reads the other's set, so they share the
+	// planes -- 42 bytes less through HBM per lane and bounce than planes of their own.
+	WS_U, WS_LE = WS_U + 10,
 	WS_DS_D = WS_LE + 3, WS_DS_PDF = WS_DS_D + 3, WS_EM_W, WS_BV_EM = WS_EM_W + 3, WS_BP_EM = WS_BV_EM + 3,
 	WS_SH_O, WS_SH_D = WS_SH_O + 3, WS_SH_T = WS_SH_D + 3,
-	WS_WO, WS_BSDF_PDF = WS_WO + 3, WS_BSDF_W, WS_ETA = WS_BSDF_W + 3,
+	WS_WO_T, WS_ETA = WS_WO_T + 3, // the direction k_wave_guide sampled from the tree (F_SMP_TREE lanes); the BSDF sample's eta
 	WS_RNG_LO, WS_RNG_HI,
 	WS_OCC,
 	WS_NEE_C, WS_WO_C = WS_NEE_C + 2, WS_PDF_NEE = WS_WO_C + 2, WS_PDF_TREE,
@@ -527,11 +532,16 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 	h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
 	StageA A;
 	stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
-	// (n, wi, material and reflectance are read back only by sdtree-mis lanes, :304; storing them for those
-	// lanes only was measured no faster: a wave's partial store touches the same sectors)
-	wsput3(a, WS_P, tid, A.p); wsput3(a, WS_N, tid, A.n); wsput3(a, WS_NG, tid, A.ng); wsput3(a, WS_WI, tid, A.wi);
-	wsputu(a, WS_FLAGS, tid, A.flags); wsputu(a, WS_MAT, tid, (uint32_t)A.mat);
-	wsput3(a, WS_REFL, tid, A.refl);
+	// (storing a value for some lanes of a wave only saves nothing by itself -- the partial store touches the same
+	// sectors -- which is why the two classes of lanes share planes instead: WS_U)
+	wsput3(a, WS_P, tid, A.p); wsput3(a, WS_NG, tid, A.ng);
+	wsputu(a, WS_FLAGS, tid, A.flags);
+	if (A.flags & F_SMP_TREE) { // (see WS_U)
+		wsput3(a, WS_U, tid, A.n); wsput3(a, WS_U + 3, tid, A.wi); wsputu(a, WS_U + 6, tid, (uint32_t)A.mat);
+		wsput3(a, WS_U + 7, tid, A.refl);
+	} else {
+		wsput3(a, WS_U, tid, A.wo); wsput3(a, WS_U + 3, tid, A.bsdf_w); wsput(a, WS_U + 6, tid, A.bsdf_pdf);
+	}
 	if (A.flags & F_HAS_LE) wsput3(a, WS_LE, tid, A.Le);
 	wsput3(a, WS_DS_D, tid, A.ds_d);
 	if (A.flags & F_NEE_LIVE) { // (what k_wave_shade_b reads of an emitter sample only when it can contribute)
@@ -541,7 +551,6 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 	if (A.flags & F_NEED_SHADOW) {
 		wsput3(a, WS_SH_O, tid, A.sh_o); wsput3(a, WS_SH_D, tid, A.sh_d); wsput(a, WS_SH_T, tid, A.sh_tmax);
 	}
-	wsput3(a, WS_WO, tid, A.wo); wsput(a, WS_BSDF_PDF, tid, A.bsdf_pdf); wsput3(a, WS_BSDF_W, tid, A.bsdf_w);
 	wsput(a, WS_ETA, tid, A.eta);
 	wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
 }
@@ -562,12 +571,14 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
 	rng.inc = a.rng_inc[lane];
 	GuideOut g;
-	stage_guide(a, s_planes, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), ws3(a, WS_WO, tid), flags, g);
+	// (the BSDF-sampled direction of a lane that keeps it; a lane that samples the tree has none to evaluate)
+	const v3 wo_in = (flags & F_SMP_TREE) ? V(0, 0, 0) : ws3(a, WS_U, tid);
+	stage_guide(a, s_planes, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), wo_in, flags, g);
 	wsput(a, WS_NEE_C, tid, g.nee_cx); wsput(a, WS_NEE_C + 1, tid, g.nee_cy);
 	wsput(a, WS_WO_C, tid, g.wo_cx); wsput(a, WS_WO_C + 1, tid, g.wo_cy);
 	wsput(a, WS_PDF_NEE, tid, g.pdf_nee); wsput(a, WS_PDF_TREE, tid, g.pdf_tree);
 	if (flags & F_SMP_TREE) {
-		wsput3(a, WS_WO, tid, g.wo);
+		wsput3(a, WS_WO_T, tid, g.wo);
 		wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
 	}
 }
@@ -595,8 +606,8 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 		A.p = ws3(a, WS_P, tid); A.ng = ws3(a, WS_NG, tid);
 		A.n = V(0, 0, 1); A.wi = V(0, 0, 1); A.mat = 0; A.refl = V(0, 0, 0);
 		if (A.flags & F_SMP_TREE) { // (only these lanes evaluate their BSDF again)
-			A.n = ws3(a, WS_N, tid); A.wi = ws3(a, WS_WI, tid);
-			A.mat = (int)wsu(a, WS_MAT, tid); A.refl = ws3(a, WS_REFL, tid);
+			A.n = ws3(a, WS_U, tid); A.wi = ws3(a, WS_U + 3, tid);
+			A.mat = (int)wsu(a, WS_U + 6, tid); A.refl = ws3(a, WS_U + 7, tid);
 		}
 		A.Le = (A.flags & F_HAS_LE) ? ws3(a, WS_LE, tid) : V(0, 0, 0);
 		A.ds_d = V(0, 0, 0); // (stage_b does not read it: the record takes the canonical form k_wave_guide made)
@@ -605,11 +616,15 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 			A.ds_pdf = wsf(a, WS_DS_PDF, tid); A.em_w = ws3(a, WS_EM_W, tid);
 			A.bv_em = ws3(a, WS_BV_EM, tid); A.bp_em = wsf(a, WS_BP_EM, tid);
 		}
-		A.wo = ws3(a, WS_WO, tid); A.bsdf_pdf = wsf(a, WS_BSDF_PDF, tid); A.bsdf_w = ws3(a, WS_BSDF_W, tid);
+		// (a tree-sampling lane's own BSDF sample is not used again: its direction comes from k_wave_guide, its
+		// value and pdf from the evaluation in stage_b -- only the sample's eta is, :357)
+		A.wo = V(0, 0, 0); A.bsdf_pdf = 0.0f; A.bsdf_w = V(0, 0, 0);
+		if (A.flags & F_SMP_TREE) A.wo = ws3(a, WS_WO_T, tid);
+		else { A.wo = ws3(a, WS_U, tid); A.bsdf_w = ws3(a, WS_U + 3, tid); A.bsdf_pdf = wsf(a, WS_U + 6, tid); }
 		A.eta = wsf(a, WS_ETA, tid);
 		GuideOut g;
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
-		g.wo = A.wo; // (k_wave_guide has overwritten WS_WO for sdtree-mis lanes)
+		g.wo = A.wo; // (k_wave_guide's direction for the lanes that sample the tree)
 		if (guide_has_work(a, A.flags)) {
 			g.nee_cx = wsf(a, WS_NEE_C, tid); g.nee_cy = wsf(a, WS_NEE_C + 1, tid);
 			g.wo_cx = wsf(a, WS_WO_C, tid); g.wo_cy = wsf(a, WS_WO_C + 1, tid);
