@@ -25,7 +25,8 @@ file's max_depth 13, the 2^(k+2) spp schedule (scenes/veach-ajar/scene.xml, main
 roofline = the SD-tree kernel of the timed region (k_wave_guide for mesh scenes, the fused k_bounce
 otherwise): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
 counted by an instrumented pass) per launch / mean launch time (HIP events recorded by the library on
-the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a step with its share.
+the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a step with its share and, from the
+committed PMC figures of the same configuration (profiles/pmc_traffic.json), its counter traffic per second.
 
 `--synthetic` runs the renderer-free hot-path workload instead (seeded synthetic surface points).
 Launch:  python bench.py [--gpus 1]
@@ -81,7 +82,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=None, help="max_depth")
     ap.add_argument("--spp-per-pass", type=int, default=16,
                     help="samples per pixel traced by one pass (16: 33 M paths per step at 1920x1080, and still 4 M per GPU at N = 8; "
-                         "measured on one GPU with every rank's share in turn: 7.4x of 8 at 16 spp per pass, 6.9x at 8)")
+                         "measured on one GPU with every rank's share in turn: 7.2x of 8 at 16 spp per pass, 6.8x at 8)")
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered to train the SD-tree (the configs say 8/10/12)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"], help="N > 1: strong scaling by tiles (default) or weak by passes")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
@@ -382,6 +383,18 @@ def run_render(args):
                           "resolution from the package data veach_ajar.npz; checkerboard GGX floor, Beckmann door handle; "
                           "the six teapot shapes are absent: their mesh files are missing from the reference mount)"}[args.scene]
     traffic = traffic_for(dom, cfg_key)
+    # every kernel against the HBM roofline by its COUNTER traffic (the committed PMC figure of this configuration,
+    # profiles/pmc_traffic.json, gfx950 FETCH correction applied: an upper bound) over the duration measured in this run
+    for name, parts in (("k_wave_guide", ("k_wave_guide",)), ("k_wave_trace", ("k_wave_trace",)), ("k_wave_shadow", ("k_wave_cast",)),
+                        ("k_wave_shade_a+b", ("k_wave_shade_a", "k_wave_shade_b")), ("k_bounce", ("k_bounce",)),
+                        ("k_process_and_splat", ("k_process_and_splat",)), ("k_finish", ("k_finish",))):
+        if name in kernels and kernels[name]["avg_us"] > 0:
+            tr = [traffic_for(p_, cfg_key) for p_ in parts]
+            if all(t is not None for t in tr):
+                per_launch = sum(tr) / len(tr)
+                kernels[name]["pmc_hbm_bytes_per_launch"] = int(per_launch)
+                kernels[name]["pmc_hbm_GBps"] = round(per_launch / (kernels[name]["avg_us"] * 1e-6) / 1e9, 1)
+                kernels[name]["pmc_frac_of_hbm_peak"] = round(per_launch / (kernels[name]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
             "traffic": traffic, "slowest_kernel_of_step": slowest,
