@@ -146,7 +146,13 @@ def init_dist(args):
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as e:  # RCCL cannot start on this node: the exchange goes through the host (and the line says so)
+            print(f"[bench] rank {rank}: nccl backend failed to initialise ({e}); falling back to gloo", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group(backend="gloo")
     return world, rank, local_rank
 
 
