@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered to train the SD-tree (the configs say 8/10/12)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"], help="N > 1: strong scaling by tiles (default) or weak by passes")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
+    ap.add_argument("--split-pipeline", action="store_true",
+                    help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
+                         "roofline is then read off k_wave_guide, the SD-tree queries alone)")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
@@ -238,7 +241,7 @@ def run_render(args):
     tree = integ.sdTree
     npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
-    ws = WavefrontScene(sc)
+    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline)
     tiles = world > 1 and args.shard == "tiles"
     if tiles:
         ws.set_shard(rank, world, 4)

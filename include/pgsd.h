@@ -365,6 +365,14 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
  * (path_guiding_integrator.py:93, 116); without this call the first pass of a size allocates them. */
 int pg_render_reserve(pg_context *ctx, uint64_t n_lanes);
 
+/* Which kernels run a bounce.  Scenes of quads, boxes, spheres with diffuse / rough-conductor BSDFs run
+ * one fused kernel per bounce; scenes with meshes or the other BSDFs run the split pipeline (ray casting,
+ * shading, the SD-tree queries and the rest of the bounce as kernels of their own).  on != 0: every scene
+ * set from now on runs the split pipeline.  Results are the same bit for bit either way (the two are
+ * independent implementations of path_guiding_integrator.py:126-431: a cross-check, and a way to time the
+ * SD-tree queries of any scene as a kernel of their own).  Takes effect at the next pg_scene_set[_ex]. */
+int pg_render_split_pipeline(pg_context *ctx, int32_t on);
+
 /* Film reconstruction of one full-frame pass with Mitsuba's `tent` reconstruction filter of radius
  * one pixel -- the <rfilter type="tent"/> of the reference's scenes (scenes/cornell-box/scene.xml:27),
  * i.e. the image mi.render returns at main.py:218.  `seed` and `spp` are those of the pass that

@@ -112,6 +112,7 @@ EXPORTS = (
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
     "pg_math_eval", "pg_scene_set_ex", "pg_film",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
+    "pg_render_split_pipeline",
 )
 
 
@@ -184,6 +185,7 @@ def lib() -> C.CDLL:
     L.pg_comm_destroy.argtypes = [V]
     L.pg_allreduce.argtypes = [V, V]
     L.pg_render_reserve.argtypes = [V, U64]
+    L.pg_render_split_pipeline.argtypes = [V, C.c_int32]
     for name in EXPORTS:
         if name not in ("pg_last_error", "pg_abi_version"):
             getattr(L, name).restype = C.c_int

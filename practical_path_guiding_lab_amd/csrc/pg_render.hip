@@ -472,6 +472,7 @@ struct pg_render_state {
 	int general = 0; // feature level of the kernels to launch (0 cornell-box class, 1 veach-mis class, 2 everything)
 	pg_camera cam;
 	bool have_scene = false;
+	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
 	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
 	DevBuf<uint32_t> prev_quad;
 	DevBuf<uint8_t> hit0;
@@ -736,6 +737,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	r->n_quads = (int)nq;
 	r->n_spheres = (int)ns;
 	r->n_emitters = (int)em.size();
+	if (r->split_always && general < 2) general = 2; // pg_render_split_pipeline
 	r->general = general;
 	r->cam = *cam;
 	r->have_scene = true;
@@ -885,6 +887,13 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (r->timing_on) ++r->acc.passes;
+	return PG_OK;
+}
+
+int pg_render_split_pipeline(pg_context *ctx, int32_t on)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	rstate(ctx)->split_always = on != 0;
 	return PG_OK;
 }
 
