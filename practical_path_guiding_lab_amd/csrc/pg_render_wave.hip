@@ -419,8 +419,14 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 // measured on veach-ajar, the one-ray-per-lane form kept 14 % of the lanes of a wave busy.  Every ray
 // still takes exactly the steps intersect() takes for it, in the same order.  The rays are the entries
 // of the live list flagged F_NEED_SHADOW; WS_OCC receives 0 / 1.
-constexpr int kRefillIdle = 16;
-constexpr uint32_t kCastChunk = 128;
+#ifndef PG_REFILL_IDLE
+#define PG_REFILL_IDLE 16
+#endif
+#ifndef PG_CAST_CHUNK
+#define PG_CAST_CHUNK 128
+#endif
+constexpr int kRefillIdle = PG_REFILL_IDLE;
+constexpr uint32_t kCastChunk = PG_CAST_CHUNK;
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 {
