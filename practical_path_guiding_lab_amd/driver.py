@@ -239,3 +239,63 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                 r.saveToFile(os.path.join(out_dir, name + ".csv"))
     return {"image": image, "records": rec, "iterations": per_iter, "cumm_spp": cumm_spp, "time_s": cumm_time,
             "guided_samples": guided_samples, "guided_time_s": guided_time}
+
+
+def repeat_high_spp(scene: WavefrontScene, integrator: PathGuidingIntegrator, tree_dir: str, start_iteration: int,
+                    end_iteration: int, max_tree_iteration: int, iter_spp: int, batch_spp: int = 4, initial_seed: int = 0,
+                    ground_truth: Optional[torch.Tensor] = None, sdTreeMaxDepth: int = 20, quadTreeMaxDepth: int = 20,
+                    isStoreNEERadiance: bool = True, bsdfSamplingFraction: float = 0.5, out_dir: Optional[str] = None,
+                    sim_iter: int = 0, gt_mask=None, log: Callable[[str], None] = print) -> Dict:
+    """repeat_high_spp_renderer.py:26-215 (doFullSimulation): every iteration's SD-tree, frozen, rendered with
+    the same `iter_spp` samples -- what each iteration's tree is worth at equal cost.  Iteration k renders as
+    a final iteration (nothing is recorded) with the tree saved after iteration k - 1
+    (`tree_dir`/sdtree_iter-{k-1}.npz, as run_guided_render leaves them; iterations 0 and 1 are unguided,
+    path_guiding_integrator.py:223), passes of `batch_spp`, seeds initial_seed + cumulative spp.  Returns
+    and (with out_dir) writes the reference's records: variance / variance_groundTruth / mse_groundTruth
+    `_endIter_high_spp_sim-{sim_iter}.csv`, and the image of every iteration."""
+    w, h = scene.film_size
+    bmin, bmax = scene.bbox()
+    eps = np.float32(1e-4)
+    integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
+                     quadTreeMaxDepth=quadTreeMaxDepth, isStoreNEERadiance=isStoreNEERadiance,
+                     bsdfSamplingFraction=bsdfSamplingFraction)
+    integrator.setGroundTruthMask(gt_mask)
+    scene.reserve(integrator, batch_spp)
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    rec = {k: PerformanceData() for k in ("variance_endIter", "variance_groundTruth_endIter", "mse_groundTruth_endIter")}
+    theo_cumm_iter_spp = cumm_spp = 0
+    elapsed = 0.0
+    images = {}
+    for k in range(start_iteration, end_iteration + 1):
+        integrator.resetVarianceCounter()
+        theo_cumm_iter_spp += 2 ** (k + 1) if k > 0 else 0  # :80-84: 0 4 12 28 ...
+        if 0 < k <= max_tree_iteration:  # :87-89
+            integrator.loadSDTreeFromFile(os.path.join(tree_dir, f"sdtree_iter-{k - 1}.npz"))
+        integrator.setIteration(k, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        image, done = None, 0
+        while done < iter_spp:
+            cur = min(batch_spp, iter_spp - done)
+            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp)  # :122
+            wimg = img * float(cur / iter_spp)
+            image = wimg if image is None else image + wimg
+            done += cur
+            cumm_spp += cur
+        torch.cuda.synchronize()
+        elapsed += time.perf_counter() - t0
+        variance = integrator.computeVariance(done)
+        variance_gt = integrator.computeVariance(done, ground_truth) if ground_truth is not None else 0.0
+        mse_gt = integrator.computeMSE(done, ground_truth) if ground_truth is not None else 0.0
+        rec["variance_endIter"].append(elapsed, done, theo_cumm_iter_spp + done, k, variance=variance)
+        rec["variance_groundTruth_endIter"].append(elapsed, done, theo_cumm_iter_spp + done, k, variance=variance_gt)
+        rec["mse_groundTruth_endIter"].append(elapsed, done, theo_cumm_iter_spp + done, k, mse=mse_gt)
+        log(f"Iteration {k} (frozen tree, {done} spp): variance {variance:.6g}  variance_gt {variance_gt:.6g}  mse_gt {mse_gt:.6g}")
+        images[k] = image
+        if out_dir:
+            save_image(os.path.join(out_dir, f"high_spp_iter-{k}_spp-{done}"), image)
+    if out_dir:
+        for name, r in rec.items():
+            r.saveToFile(os.path.join(out_dir, f"{name}_high_spp_sim-{sim_iter}.csv"))
+    return {"records": rec, "images": images, "time_s": elapsed}
