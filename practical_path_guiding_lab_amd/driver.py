@@ -299,3 +299,48 @@ def repeat_high_spp(scene: WavefrontScene, integrator: PathGuidingIntegrator, tr
         for name, r in rec.items():
             r.saveToFile(os.path.join(out_dir, f"{name}_high_spp_sim-{sim_iter}.csv"))
     return {"records": rec, "images": images, "time_s": elapsed}
+
+
+def run_path_tracing(scene: WavefrontScene, integrator: PathGuidingIntegrator, target_spp: Optional[int] = None,
+                     time_budget_s: Optional[float] = None, chunk_spp: int = 4, initial_seed: int = 0,
+                     ground_truth: Optional[torch.Tensor] = None, out_dir: Optional[str] = None, gt_mask=None,
+                     log: Callable[[str], None] = print) -> Dict:
+    """path_tracing_render.py:24-165, the reference's benchmark renderer: the same sample() without the
+    SD-tree -- here the integrator held at iteration 0 as a final iteration (guiding needs iteration > 1,
+    path_guiding_integrator.py:223; nothing is recorded) -- in chunks of `chunk_spp` with seeds
+    initial_seed + pass number, until `target_spp` samples or `time_budget_s` seconds (which overrides).
+    Records (time, spp, variance vs ground truth, MSE) after every chunk: what guiding has to beat."""
+    if (target_spp is None) == (time_budget_s is None):
+        raise ValueError("give target_spp or time_budget_s")
+    w, h = scene.film_size
+    bmin, bmax = scene.bbox()
+    eps = np.float32(1e-4)
+    integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps)
+    integrator.setGroundTruthMask(gt_mask)
+    integrator.setIteration(0, True)
+    integrator.resetVarianceCounter()
+    scene.reserve(integrator, chunk_spp)
+    rec = PerformanceData()
+    image_acc, used, passes = None, 0, 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    elapsed = 0.0
+    while (used < target_spp) if time_budget_s is None else (elapsed < time_budget_s):
+        cur = chunk_spp if time_budget_s is not None else min(chunk_spp, target_spp - used)
+        img = render(scene, integrator, spp=cur, seed=initial_seed + passes)  # :88, 128
+        image_acc = img * cur if image_acc is None else image_acc + img * cur
+        used += cur
+        passes += 1
+        mse = integrator.computeMSE(used, ground_truth) if ground_truth is not None else 0.0
+        var = integrator.computeVariance(used, ground_truth) if ground_truth is not None else integrator.computeVariance(used)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        rec.append(elapsed, used, used, 0, variance=var, mse=mse)
+    image = image_acc / float(used)
+    log(f"path tracing: {used} spp in {elapsed:.2f} s = {w * h * used / max(elapsed, 1e-9) / 1e6:.1f} Msamples/s; "
+        f"variance {rec.rows[-1][4]:.6g}  mse_gt {rec.rows[-1][5]:.6g}")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        save_image(os.path.join(out_dir, f"path_tracing-{used}"), image)
+        rec.saveToFile(os.path.join(out_dir, "variance_groundTruth_path_tracing.csv"))
+    return {"image": image, "record": rec, "spp": used, "time_s": elapsed}

@@ -111,6 +111,22 @@ def test_main_py_repeats_every_iterations_tree_at_equal_spp(tmp_path):
     assert all(f"high_spp_iter-{k}_spp-16.exr" in files for k in range(4))
 
 
+def test_main_py_path_tracing_baseline(tmp_path):
+    """--path-tracing (path_tracing_render.py): the unguided benchmark renderer, by sample count and by time."""
+    out = str(tmp_path / "pt")
+    gt = os.path.join(ROOT, "tests", "golden", "cornell_gt_256_f16.npy")
+    base = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "cornell-box", "--width", "64", "--height", "64",
+            "--ground-truth", gt, "--path-tracing", "--out", out]
+    r = subprocess.run(base + ["--budget-spp", "22", "--batch-spp", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "path tracing: 22 spp" in r.stdout
+    rows = [x.split(",") for x in open(os.path.join(out, "variance_groundTruth_path_tracing.csv")).read().splitlines()[1:]]
+    assert [int(x[1]) for x in rows] == [8, 16, 22] and float(rows[-1][5]) < float(rows[0][5])   # MSE falls with spp
+    assert "path_tracing-22.exr" in os.listdir(out)
+    r = subprocess.run(base + ["--time-budget", "0.2", "--batch-spp", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "path tracing:" in r.stdout
+
+
 def test_sdtree_file_round_trip(tmp_path):
     """saveSDTreeToFile -> loadSDTreeFromFile into a fresh integrator: the 23 keys, the same columns,
     and a tree that samples, evaluates and keeps training exactly like the one that was saved."""
