@@ -64,7 +64,7 @@ struct Forest {
 	uint32_t n_trees = 0;
 	DevBuf<QuadJump> jump;           // n_trees * kJumpCells entries, rebuilt whenever rec/head change
 	bool jump_valid = false;
-	DevBuf<KdGridEntry> kd_grid;     // 8^kd_grid_bits entries, rebuilt whenever the KD tree changes
+	DevBuf<KdGridEntry> kd_grid;     // 8^kd_grid_bits cells + kKdGridRootEntries, rebuilt whenever the KD tree changes
 	DevBuf<float> kd_planes;         // 3 * kKdGridPlanes cell boundaries (they follow the root box)
 	bool kd_grid_valid = false;
 	int kd_grid_bits = 0;            // cells per axis = 2^kd_grid_bits

@@ -9,7 +9,7 @@ namespace pg {
 
 __device__ __forceinline__ KdNode load_kd(const KdNode *kd, uint32_t i)
 {
-	const uint4 v = *reinterpret_cast<const uint4 *>(kd + i);
+	const uint4 v = gather16(kd + i);
 	KdNode n;
 	n.child = v.x;
 	n.split = __uint_as_float(v.y);
@@ -82,13 +82,13 @@ __device__ __forceinline__ uint32_t kd_descend_lds(const KdNode *kd, const uint4
 			v = s_kd[node];
 		}
 		if (node >= kLdsKdNodes) {
-			v = *reinterpret_cast<const uint4 *>(kd + node);
+			v = gather16(kd + node);
 			for (++it; it < kMaxLevels && v.x != 0; ++it) {
 				const uint32_t axis = v.z & 3u;
 				const float c = axis == 0 ? x : (axis == 1 ? y : z);
 				node = v.x + (c >= __uint_as_float(v.y) ? 1u : 0u);
 				++levels;
-				v = *reinterpret_cast<const uint4 *>(kd + node);
+				v = gather16(kd + node);
 			}
 		}
 	}
@@ -131,35 +131,33 @@ __device__ __forceinline__ bool kd_grid_cell(const TreeView &t, const float *pla
 	return true;
 }
 
-// Each branch below hands the node over as VALUES, loaded inside the branch.  Without the barrier the
-// compiler (ROCm 7.2 clang, gfx950) sinks the load of `child` below the branches, through a pointer that
-// is either &entry.child or &kd[0].child -- and in the fused splat kernels it kept that pointer in
-// registers that kd_grid_cell's early exits use as temporaries: lanes on a cell face then read `child`
-// from a wild address (a memory aperture violation on the device).
-#define PG_KEEP_LOADED(x) asm volatile("" : "+v"(x))
-
 // KDTree.getLeafNodeIndex (kdtree.py:435-470) through the jump grid: the same node, leaf record and
 // level count as kd_descend.
+//
+// EVERY lane makes exactly one gather from the table, at one load site: a lane strictly inside a cell
+// reads the cell's entry; a lane on a cell face, outside the box or NaN reads one of the two ROOT
+// entries the build appends behind the cells (k_build_kd_grid) -- [cells] the root as a searching lane
+// starts from it, [cells + 1] the root as a non-searching lane returns it (node 0 with its stale
+// quadtree, kdtree.py:446-447, 224).  There is no "grid entry or kd[0]" branch any more.  Round 2 had
+// one, and ROCm 7.2's clang merged the two loads of the node's child word into a single load through
+// a pointer phi (&entry.child | &kd[0].child) placed after the join (profiles/r03/kd_descend_isa/); a
+// build of that form faulted in the fused splat kernel (a memory-aperture violation for lanes on a
+// cell face) and was held together by an empty asm barrier.  One load site leaves nothing to merge.
 __device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const float *planes, float x, float y, float z, bool search,
                                                     KdNode &leaf, uint32_t &levels)
 {
-	uint32_t node = 0;
-	levels = 0;
-	uint32_t cell;
+	if (t.kd_grid == nullptr) return kd_descend(t.kd, x, y, z, search, leaf, levels); // (uniform: a degenerate root box has no grid)
+	uint32_t cell = 0;
+	const bool in_cell = search && kd_grid_cell(t, planes, x, y, z, cell);
+	const uint32_t root_entry = (1u << (3 * t.grid_bits)) + (search ? 0u : 1u);
+	const uint4 e = gather16(t.kd_grid + (in_cell ? cell : root_entry));
+	uint32_t node = e.x;
+	levels = e.y >> 16;
 	KdNode nd;
-	if (search && t.kd_grid != nullptr && kd_grid_cell(t, planes, x, y, z, cell)) {
-		const uint4 e = *reinterpret_cast<const uint4 *>(t.kd_grid + cell);
-		node = e.x;
-		levels = e.y >> 16;
-		nd.child = e.z;
-		nd.axis_depth = e.y & 0xffffu;
-		nd.split = __uint_as_float(e.w); // (meaningful for an inner node)
-		nd.tree = e.w;                   // (meaningful for a leaf; an inner node's is never returned: see below)
-		PG_KEEP_LOADED(nd.child);
-	} else {
-		nd = load_kd(t.kd, node);
-		PG_KEEP_LOADED(nd.child);
-	}
+	nd.child = e.z;
+	nd.axis_depth = e.y & 0xffffu;
+	nd.split = __uint_as_float(e.w); // (meaningful for an inner node)
+	nd.tree = e.w;                   // (meaningful for a leaf and for the non-searching root entry)
 	if (search) {
 		for (int it = (int)levels; it < kMaxLevels && nd.child != 0; ++it) {
 			const uint32_t axis = nd.axis_depth & 3u;
@@ -181,8 +179,8 @@ struct QuadLoad {
 
 __device__ __forceinline__ QuadLoad load_rec(const QuadRec *rec, uint32_t r)
 {
-	const uint4 a = reinterpret_cast<const uint4 *>(rec + r)[0];
-	const uint4 b = reinterpret_cast<const uint4 *>(rec + r)[1];
+	const uint4 a = gather16(rec + r);
+	const uint4 b = gather16(reinterpret_cast<const uint4 *>(rec + r) + 1);
 	QuadLoad q;
 	q.i0 = __uint_as_float(a.x); q.i1 = __uint_as_float(a.y);
 	q.i2 = __uint_as_float(a.z); q.i3 = __uint_as_float(a.w);
@@ -241,7 +239,7 @@ __device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *ju
 	uint32_t cell;
 	float jx, jy;
 	if (jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) {
-		const uint4 e = *reinterpret_cast<const uint4 *>(jump + (size_t)tree * kJumpCells + cell);
+		const uint4 e = gather16(jump + (size_t)tree * kJumpCells + cell);
 		if (!((e.w >> 30) & 1u)) { // the product is defined along this path
 			levels = (e.w >> 26) & 15u;
 			if (e.x == kNoRecord) return __uint_as_float(e.y); // a leaf within the table: the final value
@@ -371,7 +369,7 @@ __device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t
 	uint32_t cell;
 	float jx, jy;
 	if (c.walking && jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) { // skip the levels the table covers
-		const uint4 e = *reinterpret_cast<const uint4 *>(jump + (size_t)tree * kJumpCells + cell);
+		const uint4 e = gather16(jump + (size_t)tree * kJumpCells + cell);
 		c.levels = (e.w >> 26) & 15u;
 		if (e.x == kNoRecord) {
 			c.slot = e.w & kJumpSlotMask;
@@ -409,8 +407,8 @@ __device__ __forceinline__ void quad_find_leaf_slots2(const QuadRec *rec, LeafCu
 {
 	for (int it = 0; it < kMaxLevels && (a.walking || b.walking); ++it) {
 		// a cursor that has stopped re-reads record 0 (it exists: the other one is inside a record)
-		const uint4 cha = reinterpret_cast<const uint4 *>(rec + (a.walking ? a.r : 0u))[1];
-		const uint4 chb = reinterpret_cast<const uint4 *>(rec + (b.walking ? b.r : 0u))[1];
+		const uint4 cha = gather16(reinterpret_cast<const uint4 *>(rec + (a.walking ? a.r : 0u)) + 1);
+		const uint4 chb = gather16(reinterpret_cast<const uint4 *>(rec + (b.walking ? b.r : 0u)) + 1);
 		if (a.walking) leaf_step(a, cha);
 		if (b.walking) leaf_step(b, chb);
 	}

@@ -33,7 +33,7 @@ void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state,
 
 // (re)builds the quadtree jump table of `t` into out[t.n_trees * kJumpCells] (t.jump is not read)
 void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s);
-// (re)builds the KD jump grid of `t` into out[8^t.grid_bits] (t.kd_grid is not read; t.grid_bits, kd_planes and grid_inv are)
+// (re)builds the KD jump grid of `t` into out[8^t.grid_bits + kKdGridRootEntries] (t.kd_grid is not read; t.grid_bits, kd_planes and grid_inv are)
 void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s);
 
 // ---- recording (pg_kernels_splat.hip) ----

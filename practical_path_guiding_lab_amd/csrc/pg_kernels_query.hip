@@ -31,7 +31,7 @@ __device__ __forceinline__ void count_depths(DepthCounters *dc, unsigned kd_lv, 
 
 __device__ __forceinline__ TreeHead load_head(const TreeHead *h, uint32_t t)
 {
-	const uint2 v = *reinterpret_cast<const uint2 *>(h + t);
+	const uint2 v = gather8(h + t);
 	TreeHead r;
 	r.root_rec = v.x;
 	r.root_irr = __uint_as_float(v.y);
@@ -319,36 +319,41 @@ __global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__r
 }
 
 // One thread per cell of the KD jump grid: descend with the cell's interval for as long as every point
-// strictly inside the cell takes the same branch.
+// strictly inside the cell takes the same branch.  Two more threads write the ROOT entries behind the
+// cells (kd_descend_grid): the root as a searching lane that is in no cell starts from it, and the root
+// as a lane that does not search returns it.
 __global__ __launch_bounds__(kBlock) void k_build_kd_grid(TreeView t, KdGridEntry *__restrict__ out)
 {
 	const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-	if (c >= (1u << (3 * t.grid_bits))) return;
-	const uint32_t M = (1u << t.grid_bits) - 1u;
-	const int idx[3] = {(int)(c & M), (int)((c >> t.grid_bits) & M), (int)(c >> (2 * t.grid_bits))};
-	float lo[3], hi[3];
-	for (int a = 0; a < 3; ++a) {
-		lo[a] = t.kd_planes[a * kKdGridPlanes + idx[a]];
-		hi[a] = t.kd_planes[a * kKdGridPlanes + idx[a] + 1];
-	}
+	const uint32_t n_cells = 1u << (3 * t.grid_bits);
+	if (c >= n_cells + kKdGridRootEntries) return;
 	uint32_t node = 0, levels = 0;
 	KdNode nd = load_kd(t.kd, 0);
-	for (int it = 0; it < kMaxLevels && nd.child != 0; ++it) {
-		const uint32_t axis = nd.axis_depth & 3u;
-		const float l = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]), h = axis == 0 ? hi[0] : (axis == 1 ? hi[1] : hi[2]);
-		uint32_t next;
-		if (l >= nd.split) next = nd.child + 1u;      // every v > l is >= split: right (kdtree.py:462-468)
-		else if (h <= nd.split) next = nd.child;       // every v < h is < split: left
-		else break;                                    // the plane cuts through the cell: queries go on from here
-		node = next;
-		nd = load_kd(t.kd, node);
-		++levels;
+	if (c < n_cells) {
+		const uint32_t M = (1u << t.grid_bits) - 1u;
+		const int idx[3] = {(int)(c & M), (int)((c >> t.grid_bits) & M), (int)(c >> (2 * t.grid_bits))};
+		float lo[3], hi[3];
+		for (int a = 0; a < 3; ++a) {
+			lo[a] = t.kd_planes[a * kKdGridPlanes + idx[a]];
+			hi[a] = t.kd_planes[a * kKdGridPlanes + idx[a] + 1];
+		}
+		for (int it = 0; it < kMaxLevels && nd.child != 0; ++it) {
+			const uint32_t axis = nd.axis_depth & 3u;
+			const float l = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]), h = axis == 0 ? hi[0] : (axis == 1 ? hi[1] : hi[2]);
+			uint32_t next;
+			if (l >= nd.split) next = nd.child + 1u;      // every v > l is >= split: right (kdtree.py:462-468)
+			else if (h <= nd.split) next = nd.child;       // every v < h is < split: left
+			else break;                                    // the plane cuts through the cell: queries go on from here
+			node = next;
+			nd = load_kd(t.kd, node);
+			++levels;
+		}
 	}
 	KdGridEntry e;
 	e.node = node;
 	e.meta = (levels << 16) | (nd.axis_depth & 0xffffu);
 	e.child = nd.child;
-	e.value = nd.child == 0 ? nd.tree : __float_as_uint(nd.split);
+	e.value = (nd.child == 0 || c == n_cells + 1u) ? nd.tree : __float_as_uint(nd.split);
 	out[c] = e;
 }
 
@@ -356,7 +361,7 @@ static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1
 
 void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_build_kd_grid, grid_for(1ull << (3 * t.grid_bits)), dim3(kBlock), 0, s, t, out);
+	hipLaunchKernelGGL(k_build_kd_grid, grid_for((1ull << (3 * t.grid_bits)) + kKdGridRootEntries), dim3(kBlock), 0, s, t, out);
 }
 
 void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s)

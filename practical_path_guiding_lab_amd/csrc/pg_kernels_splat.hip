@@ -20,7 +20,7 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ TreeHead load_head_s(const TreeHead *h, uint32_t t)
 {
-	const uint2 v = *reinterpret_cast<const uint2 *>(h + t);
+	const uint2 v = gather8(h + t);
 	TreeHead r;
 	r.root_rec = v.x;
 	r.root_irr = __uint_as_float(v.y);

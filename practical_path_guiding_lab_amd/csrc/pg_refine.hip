@@ -627,7 +627,7 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 		TreeView tg = ctx->view();
 		ok = ok && tg.grid_inv[0] < 3.0e38f && tg.grid_inv[1] < 3.0e38f && tg.grid_inv[2] < 3.0e38f;
 		if (ok) {
-			PG_HIP(ctx, f.kd_grid.ensure((size_t)1 << (3 * bits)));
+			PG_HIP(ctx, f.kd_grid.ensure(((size_t)1 << (3 * bits)) + kKdGridRootEntries));
 			PG_HIP(ctx, f.kd_planes.ensure(3 * kKdGridPlanes));
 			PG_HIP(ctx, hipMemcpyAsync(f.kd_planes.p, planes, sizeof planes, hipMemcpyHostToDevice, s));
 			PG_HIP(ctx, hipStreamSynchronize(s)); // (planes[] is on this stack frame)

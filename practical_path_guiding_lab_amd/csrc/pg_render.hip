@@ -130,7 +130,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
 #endif
 		c_kd += lv; ++c_kdq;
-		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
+		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
 		tree_known = true;
@@ -171,7 +171,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
 #endif
 		c_kd += lv; ++c_kdq;
-		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
+		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
 		tree_id = leaf.tree;

@@ -193,7 +193,7 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const float *s_
 		KdNode leaf;
 		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
 		c_kd += lv; ++c_kdq;
-		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
+		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
 		tree_known = true;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const float *s_
 		KdNode leaf;
 		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
 		c_kd += lv; ++c_kdq;
-		const uint2 hv = *reinterpret_cast<const uint2 *>(a.tree.head + leaf.tree);
+		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
 		tree_id = leaf.tree;

@@ -23,6 +23,24 @@
 
 namespace pg {
 
+// A tree gather is ONE vector load.  uint4 / uint2 are structs to the compiler: a load through them is four
+// (two) scalar loads that it may or may not put together again, and where the words are used in different
+// blocks it does not -- the 16-byte KD grid entry came out as four dword gathers, a KD node as a dwordx3 in
+// the descent loop plus a dword behind it.  The kernels that walk the trees are bound by the number of
+// divergent gathers their lanes make, so every table access goes through these.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 gather16(const void *p)
+{
+	const u32x4_t v = *reinterpret_cast<const u32x4_t *>(p);
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 gather8(const void *p)
+{
+	const u32x2_t v = *reinterpret_cast<const u32x2_t *>(p);
+	return make_uint2(v.x, v.y);
+}
+
 constexpr uint32_t kNoRecord = 0xffffffffu; // TreeHead.root_rec: the root itself is a leaf
 constexpr int kMaxLevels = 32;              // hard bound on any descent loop
 
@@ -83,6 +101,10 @@ constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
 #endif
 constexpr int kKdGridBits = PG_KD_GRID_BITS; // the finest grid
 constexpr uint32_t kKdGridCells = 1u << (3 * kKdGridBits);
+// Behind the 8^grid_bits cells the table holds two entries for the ROOT: [cells] = node 0 as a searching
+// lane that lies in no cell (on a cell face) starts from it, [cells + 1] = node 0 as a lane that does not
+// search (outside the root box, NaN) returns it -- so that every query is one gather at one load site.
+constexpr uint32_t kKdGridRootEntries = 2;
 // The cell boundaries are not bmin + i * width: they are made by the KD tree's own arithmetic, bisecting
 // [bmin, bmax] recursively with mid = (lo + hi) / 2 in fp32 (kdtree.py:270), so that they coincide with
 // the split planes of the tree bit for bit and a cell is never cut by a plane that is "its own face but
@@ -101,7 +123,7 @@ struct TreeView {
 	const QuadRec *rec;
 	const TreeHead *head;
 	const QuadJump *jump; // n_trees * kJumpCells entries, or nullptr
-	const KdGridEntry *kd_grid; // kKdGridCells entries, or nullptr
+	const KdGridEntry *kd_grid; // 8^grid_bits cell entries + kKdGridRootEntries, or nullptr
 	const float *kd_planes;     // 3 * kKdGridPlanes cell boundaries of the grid (x planes, y planes, z planes), ascending
 	float bmin[3], bmax[3]; // root bounding box (kdtree.py:138)
 	float grid_inv[3];      // 2^grid_bits / (bmax - bmin): a first guess of the cell index

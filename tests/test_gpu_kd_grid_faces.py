@@ -1,0 +1,157 @@
+"""Regression test for the round-2 GPU fault (a memory-aperture violation for lanes lying exactly on a
+face of the KD jump grid, first seen in the fused splat kernel; DESIGN.md 3, profiles/r03/kd_descend_isa/).
+
+kd_descend_grid (csrc/pg_descent.hpp) is inlined into every kernel that asks KDTree.getLeafNodeIndex
+(kdtree.py:435-470) a question: k_leaf_index, k_sample, k_pdf, k_guide_bounce, k_splat,
+k_process_and_splat<dense>, k_process_and_splat<list>, k_wave_guide, k_wave_tail, k_bounce and
+k_bounce_tail.  Each of them is fed positions exactly ON grid planes (the planes are bisection points
+of the root box, multiples of 100/64 for the [0,100]^3 box used here), one ulp beside them, on and
+beyond the faces of the root box, NaN and infinities -- against the CPU oracle, bit for bit, for trees
+whose grid has 8, 16 and 64 cells per axis."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import pg_oracle as po
+from test_gpu_parity import BB0, BB1, check_accumulators, dense_records, dev, gpu_splat, gpu_tree_from
+
+pytestmark = pytest.mark.gpu
+
+
+def face_positions(n, seed):
+    """(3, n) positions in and around [0,100]^3: every coordinate is, with probability 0.45, a plane of
+    the finest (64^3) grid -- so also of every coarser one -- or one ulp beside one; the first columns
+    hold the special values."""
+    u = synth.uniform(n, seed, 9)
+    p = synth.positions_uniform(n, seed + 1, BB0, BB1)
+    plane = np.floor(u[0:3] * np.float32(65)).astype(np.float32) * np.float32(1.5625)  # 0, 1.5625 ... 100: exact
+    coarse = np.floor(u[0:3] * np.float32(9)).astype(np.float32) * np.float32(12.5)     # planes every grid shares
+    plane = np.where(u[6:9] < 0.5, plane, coarse)
+    beside = np.where(u[6:9] < 0.25, np.nextafter(plane, np.float32(-1e9)),
+                      np.where(u[6:9] > 0.75, np.nextafter(plane, np.float32(1e9)), plane)).astype(np.float32)
+    p = np.where(u[3:6] < 0.45, beside, p).astype(np.float32)
+    special = [(-1.0, 50.0, 50.0), (0.0, 0.0, 0.0), (100.0, 100.0, 100.0), (50.0, 50.0, 50.0), (25.0, 75.0, 12.5),
+               (np.nan, 1.0, 1.0), (1.0, np.nan, 1.0), (1.0, 1.0, np.nan), (np.inf, 50.0, 50.0), (50.0, -np.inf, 50.0),
+               (100.00001, 1.0, 1.0), (-0.0, 12.5, 98.4375), (1.5625, 1.5625, 1.5625), (50.0, 3.125, 50.0),
+               (np.nextafter(np.float32(100.0), np.float32(200.0)), 50.0, 50.0), (50.0, 50.0, -1e-30)]
+    for i, s in enumerate(special):
+        p[:, i] = s
+    return p
+
+
+@pytest.fixture(scope="module", params=["8 cells", "16 cells", "64 cells", "skewed"])
+def tree(request):
+    if request.param == "8 cells":
+        return synth.build_balanced(6, 3)      # 64 leaves
+    if request.param == "16 cells":
+        return synth.build_balanced(8, 2)      # 256 leaves
+    if request.param == "64 cells":
+        return synth.build_balanced(13, 1)     # 8192 leaves: the finest grid
+    return synth.build_skewed(1 << 15, 5).prev
+
+
+def test_query_kernels_on_grid_faces(tree):
+    import torch
+    from practical_path_guiding_lab_amd.sdtree import PCG32Sampler
+
+    g = gpu_tree_from(tree)
+    n = 150_001
+    p = face_positions(n, 21)
+    on_plane = (np.mod(p, np.float32(1.5625)) == 0).any(axis=0)
+    assert on_plane.mean() > 0.5  # most lanes have at least one coordinate on a plane
+    act = (synth.uniform(n, 22)[0] < 0.85).astype(np.uint8)
+    dp, dact = dev(torch, p), dev(torch, act)
+    # k_leaf_index
+    np.testing.assert_array_equal(g.getLeafNodeIndex(dp).cpu().numpy().astype(np.uint32), tree.get_leaf_node_index(p))
+    np.testing.assert_array_equal(g.getLeafNodeIndex(dp, dact).cpu().numpy().astype(np.uint32), tree.get_leaf_node_index(p, act))
+    # k_sample
+    smp = PCG32Sampler(g, n, seed=23)
+    st, inc = po.rng_seed(n, 23)
+    d_g, pdf_g = g.sample(dp, smp, dact)
+    d_o, pdf_o = tree.sample(p, st, inc, act)
+    np.testing.assert_array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+    np.testing.assert_array_equal(pdf_g.cpu().numpy().view(np.uint32), pdf_o.view(np.uint32))
+    np.testing.assert_array_equal(smp.state.cpu().numpy().view(np.uint64), st)
+    # k_pdf
+    d = synth.directions_uniform(n, 24)
+    np.testing.assert_array_equal(g.pdf(dp, dev(torch, d), dact).cpu().numpy().view(np.uint32), tree.pdf(p, d, act).view(np.uint32))
+    # k_guide_bounce (path_guiding_integrator.py:244, 301, 307 on one position)
+    d_nee, d_bsdf = synth.directions_uniform(n, 25), synth.directions_uniform(n, 26)
+    u = synth.uniform(n, 27, 2)
+    nee = (u[0] < 0.9).astype(np.uint8)
+    sel = np.where(u[1] < 0.1, 0, np.where(u[1] < 0.55, 1, 2)).astype(np.uint8)
+    smp = PCG32Sampler(g, n, seed=28)
+    st, inc = po.rng_seed(n, 28)
+    dio = dev(torch, d_bsdf)
+    pn_g, po_g = g.guideBounce(dp, dev(torch, d_nee), dev(torch, nee), dev(torch, sel), dio, smp)
+    pn_o = tree.pdf(p, d_nee, nee)
+    ds_o, ps_o = tree.sample(p, st, inc, (sel == 2).astype(np.uint8))
+    pb_o = tree.pdf(p, d_bsdf, (sel == 1).astype(np.uint8))
+    np.testing.assert_array_equal(pn_g.cpu().numpy().view(np.uint32), pn_o.view(np.uint32))
+    exp_pdf = np.where(sel == 2, ps_o, np.where(sel == 1, pb_o, np.float32(1))).astype(np.float32)
+    np.testing.assert_array_equal(po_g.cpu().numpy().view(np.uint32), exp_pdf.view(np.uint32))
+    np.testing.assert_array_equal(dio.cpu().numpy().view(np.uint32), np.where(sel == 2, ds_o, d_bsdf).astype(np.float32).view(np.uint32))
+    torch.cuda.synchronize()
+
+
+def test_splat_kernels_on_grid_faces(tree):
+    import torch
+
+    o = po.OracleTree()
+    o.load(tree.export())
+    o.reset()
+    # k_splat: a compact record stream whose positions sit on the planes
+    g = gpu_tree_from(tree)  # (a loaded tree starts with zero accumulators)
+    m = 120_007
+    rec = synth.records(m, 31, BB0, BB1)
+    rec["position"] = face_positions(m, 32)
+    synth.splat(o, rec)
+    gpu_splat(torch, g, rec)
+    check_accumulators(g, o)
+    # k_process_records + k_splat with the device-side count, and k_process_and_splat<dense>: the reference's
+    # numRays x max_depth buffer (path_guiding_integrator.py:318, 434-500)
+    R, D = 15_013, 8
+    Lfinal, drec_h = dense_records(R, D, 33)
+    pos = face_positions(R * D, 34)
+    pos[..., drec_h["active"] == 0] = 0
+    drec_h["position"] = pos
+    exp = po.process_records(R, D, Lfinal, drec_h)
+    o.reset()
+    synth.splat(o, exp)
+    drec = {k: dev(torch, v) for k, v in drec_h.items()}
+    g1 = gpu_tree_from(tree)
+    out, count = g1.processRecords(R, D, dev(torch, Lfinal), drec)
+    g1.addDataPropagate(out, count)
+    check_accumulators(g1, o)
+    g2 = gpu_tree_from(tree)
+    g2.processAndSplat(R, D, dev(torch, Lfinal), drec)
+    check_accumulators(g2, o)
+    torch.cuda.synchronize()
+
+
+def _scene_and_box(which):
+    """A scene and an SD-tree root box chosen so that whole surfaces lie ON planes of the jump grid (the box's
+    bisection points) and on the box's own faces, and part of the scene lies outside the box: hit points are
+    o + t d in fp32, so a large share of the vertices on such a surface has the plane's coordinate exactly."""
+    from practical_path_guiding_lab_amd import scene as S
+    from test_gpu_render import mixed_scene
+    if which == "cornell-box":  # walls x = -1 and z = -1 on the first bisection plane, x = 1, y = 2, z = 1 on box faces
+        return S.cornell_box(40, 40, 8, 8), (-3.0, -2.0, -3.0), (1.0, 2.0, 1.0)
+    if which == "cornell-box deep":  # k_bounce_tail
+        return S.cornell_box(20, 20, 12, 9), (-3.0, -2.0, -3.0), (1.0, 2.0, 1.0)
+    if which == "veach-mis":    # back wall x = -5 and floor y = 0 on bisection planes; the floor sticks out of z = +-16
+        return S.veach_mis(64, 36, 3, 8), (-25.0, -20.0, -16.0), (15.0, 20.0, 16.0)
+    if which == "mixed":        # floor y = 0 and back wall z = -4 on bisection planes, the floor's edges on box faces
+        return mixed_scene(40), (-4.0, -4.0, -12.0), (4.0, 4.0, 4.0)
+    if which == "mixed deep":   # k_wave_tail
+        return mixed_scene(20, max_depth=13, rr_depth=10), (-4.0, -4.0, -12.0), (4.0, 4.0, 4.0)
+    raise KeyError(which)
+
+
+@pytest.mark.parametrize("which", ["cornell-box", "cornell-box deep", "veach-mis", "mixed", "mixed deep"])
+def test_render_kernels_with_surfaces_on_grid_faces(which):
+    """k_bounce / k_bounce_tail (quad scenes), k_wave_guide / k_wave_tail (mesh scenes) and
+    k_process_and_splat<list> behind them, over a guided lifecycle against the oracle."""
+    from test_gpu_render import _guided_lifecycle_bit_exact
+    sc, bmin, bmax = _scene_and_box(which)
+    _guided_lifecycle_bit_exact(sc, True, bbox=(np.array(bmin, np.float32), np.array(bmax, np.float32)))

@@ -219,12 +219,15 @@ def test_lifecycle_parity_at_larger_sizes(which):
     _guided_lifecycle_bit_exact(sc, True)
 
 
-def _guided_lifecycle_bit_exact(sc, nee):
+def _guided_lifecycle_bit_exact(sc, nee, bbox=None):
+    """bbox: the SD-tree's root box when it is not the scene's own (main.py:55-59)."""
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
     D, RR = sc.max_depth, sc.rr_depth
     bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
+    if bbox is not None:
+        bmin, bmax = bbox
     npix = sc.camera.width * sc.camera.height
     o = po.OracleSDTreePair()
     o.setup(bmin, bmax, 20, 20, nee)
