@@ -29,7 +29,8 @@ the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a st
 committed PMC figures of the same configuration (profiles/pmc_traffic.json), its counter traffic per second.
 
 `--synthetic` runs the renderer-free hot-path workload instead (seeded synthetic surface points).
-Launch:  python bench.py [--gpus 1]
+Launch:  python bench.py [--gpus N]      (N > 1 without WORLD_SIZE in the environment: this process starts N fresh
+                                          rank processes itself -- before anything touches the GPU -- and relays rank 0's line)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 """
 import argparse
@@ -63,6 +64,7 @@ def device_copy_rate(dev) -> float:
     del src, dst
     return round(2.0 * 4.0 * n / (best * 1e-3) / 1e9, 1)
 
+CONFIG_ITERATIONS = {"veach-ajar": 12, "cornell-box": 8, "veach-mis": 10, "torus": 10}  # BASELINE.json configs (torus: as veach-mis)
 SCENES = {  # film width, aspect (w, h), max_depth of the BASELINE config
     "veach-ajar": (1920, (16, 9), 13), "cornell-box": (512, (1, 1), 8), "veach-mis": (1280, (16, 9), 3),
     "torus": (1920, (16, 9), 32),
@@ -85,6 +87,15 @@ def parse():
                          "measured on one GPU with every rank's share in turn: 7.2x of 8 at 16 spp per pass, 6.8x at 8)")
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered to train the SD-tree (the configs say 8/10/12)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"], help="N > 1: strong scaling by tiles (default) or weak by passes")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="N > 1: torch.distributed backend.  auto = nccl (RCCL) when every rank of this node has a GPU of its own, "
+                         "gloo when ranks share devices (a rehearsal: RCCL refuses two ranks on one device).  Decided from the "
+                         "device count before anything is initialised, the same on every rank; a failing nccl initialisation "
+                         "ends the run with a non-zero exit code, it is never replaced by gloo on some ranks only")
+    ap.add_argument("--full-schedule", type=int, default=None,
+                    help="1: after the steady-state steps, run the BASELINE config's WHOLE schedule through driver.run_guided_render "
+                         "(veach-ajar: 12 iterations = 16380 spp, main.py:157-170, with main.py's stop-training rule :334-377) and "
+                         "report value_full_schedule_12it + the final image's MSE; default: 1 at N = 1, 0 otherwise")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
     ap.add_argument("--split-pipeline", action="store_true",
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
@@ -97,6 +108,8 @@ def parse():
         args.res = 512 if args.synthetic else w
     if args.depth is None:
         args.depth = 8 if args.synthetic else d
+    if args.full_schedule is None:
+        args.full_schedule = 1 if (args.gpus == 1 and not args.synthetic) else 0
     return args
 
 
@@ -127,6 +140,69 @@ def traffic_for(kernel, key):
     return None
 
 
+def spawn_ranks(cmd, n, env=None, relay=sys.stdout, grace_s=10.0):
+    """Starts n rank processes of `cmd` (a list for subprocess.Popen) on this node, one per GPU, with the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE,
+    MASTER_ADDR 127.0.0.1, a free MASTER_PORT), relays rank 0's stdout to `relay`, and returns 0 when every rank
+    exited 0.  When a rank fails the others are ended (their exact process ids) and the first failing exit code
+    is returned.  The caller must not have touched the GPU: the children are fresh processes, nothing is exec'ed."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    lines = []
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line)
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            pending.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                print(f"[bench] rank {r} exited with code {c}; ending the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+                t_end = time.time() + grace_s
+                for q in pending:
+                    try:
+                        procs[q].wait(max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        procs[q].kill()
+        time.sleep(0.05)
+    th.join(5.0)
+    for line in lines:
+        relay.write(line)
+    relay.flush()
+    return rc
+
+
+def pick_backend(args, world, ndev):
+    """The torch.distributed backend, decided before anything is initialised and identically on every rank of
+    the node: every rank sees the same device count."""
+    if args.backend != "auto":
+        return args.backend
+    return "nccl" if world <= ndev else "gloo"
+
+
 def init_dist(args):
     import torch
     import torch.distributed as dist
@@ -135,26 +211,20 @@ def init_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
+        raise SystemExit("bench.py --gpus N>1: the rank processes are started by main() or by torch.distributed.run")
+    ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if ndev == 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    ndev = torch.cuda.device_count()
-    if world > 1 and ndev < world:
-        # rehearsal on a box with fewer GPUs than ranks (ranks share devices): RCCL refuses two ranks on
-        # one device, so the exchange goes through gloo; the numbers of such a run are not a result
-        local_rank = local_rank % ndev
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="gloo")
-        return world, rank, local_rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    args.n_devices = min(local_world, ndev) * max(1, world // max(local_world, 1))  # distinct GPUs of the job
+    local_rank = local_rank % ndev  # (ranks share devices only in a rehearsal on a box with fewer GPUs than ranks)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        except Exception as e:  # RCCL cannot start on this node: the exchange goes through the host (and the line says so)
-            print(f"[bench] rank {rank}: nccl backend failed to initialise ({e}); falling back to gloo", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        backend = pick_backend(args, local_world, ndev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # (a failure ends the run)
+        else:
             dist.init_process_group(backend="gloo")
     return world, rank, local_rank
 
@@ -246,13 +316,15 @@ def run_render(args):
     if tiles:
         ws.set_shard(rank, world, 4)
     my_pixels = int(ws.local_pixels().shape[0])
+    from practical_path_guiding_lab_amd.parallel import min_max_over_ranks
+    pix_min, pix_max = min_max_over_ranks(my_pixels)
     ws.reserve(integ, args.spp_per_pass)  # the pass buffers, as the reference's setup() allocates its record arrays (:93)
     # the exchange: libpgsd's own ncclAllReduce (pg_allreduce) when every rank has its GPU, else torch.distributed
     exchange = "none"
     reduce_fn = None
     if world > 1:
         from practical_path_guiding_lab_amd.parallel import init_library_comm
-        if dist.get_backend() == "nccl" and init_library_comm(tree):
+        if init_library_comm(tree):  # (decided collectively: nccl backend and a GPU of its own for every rank)
             exchange = "pg_allreduce (RCCL ncclAllReduce int64 issued by libpgsd.so)"
             reduce_fn = lambda acc: tree.allReduce()  # noqa: E731
         else:
@@ -336,6 +408,20 @@ def run_render(args):
     tree.refineAndPrepare()
     torch.cuda.synchronize()
     t_refine = time.perf_counter() - t1
+    # ---- the reference's own training passes are 1 spp each (main.py:192): the same tree, passes of one sample ----
+    spp1 = None
+    if tiles or world == 1:
+        def step1():
+            integ.sample(ws, IndependentSampler(1, seed[0]))
+            seed[0] += 1
+        n1 = max(16, args.steps)
+        spp1 = npix * n1 / timed_steps(step1, n1, 2, world) / 1e6
+
+    # ---- the config's whole schedule, end to end ----
+    full = None
+    if args.full_schedule:
+        full = full_schedule_leg(args, integ, ws, (rank, world, 4) if tiles else None, reduce_fn, W, H)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -388,8 +474,8 @@ def run_render(args):
                      "data torus_meshes.npz behind a BVH: diffuse donut in a frosted-glass case, aluminium brackets, "
                      "directional light)",
             "veach-ajar": "built-in scene (scenes/veach-ajar/scene.xml parameters; its 15 OBJ meshes present in the reference "
-                          "mount, 4482 triangles with texture coordinates, and its three bitmap textures at reduced "
-                          "resolution from the package data veach_ajar.npz; checkerboard GGX floor, Beckmann door handle; "
+                          "mount, 4482 triangles with texture coordinates, and its three bitmap textures at full "
+                          "resolution (the JPG files' bytes in the package data veach_ajar.npz, decoded with PIL as load_xml does); checkerboard GGX floor, Beckmann door handle; "
                           "the six teapot shapes are absent: their mesh files are missing from the reference mount)"}[args.scene]
     traffic = traffic_for(dom, cfg_key)
     # every kernel against the HBM roofline by its COUNTER traffic (the committed PMC figure of this configuration,
@@ -429,10 +515,13 @@ def run_render(args):
         cpu, mse_small, mse_small_cpu = cpu_leg(args)
     out = {
         "metric": f"Msamples/s guided, {args.scene} {film} max_depth {args.depth}", "value": round(value, 3), "unit": "Msamples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
+        "n_gpus": args.n_devices, "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
         "higher_is_better": True, "scaling": "strong" if (tiles or world == 1) else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "no dataset: the reference's scene (parameters, meshes and textures packaged from its scene files), sampler "
                 "streams seeded per pass, SD-tree trained inside the run", "value_full_schedule": None if full_schedule is None else round(full_schedule, 3),
+        "value_spp1": None if spp1 is None else round(spp1, 3),
+        "value_full_schedule_12it": None if full is None else full["value"], "mse_vs_gt_full_schedule": None if full is None else full["mse_vs_gt"],
+        "full_schedule": full,
         "mse_vs_gt": mse_train, "mse_vs_gt_small": mse_small, "mse_vs_gt_cpu": mse_small_cpu,
         "mse_equal": None if mse_small is None else bool(mse_small == mse_small_cpu),
         "config": {"workload": f"{args.scene} {film} (the whole film per step"
@@ -440,7 +529,8 @@ def run_render(args):
                                + f"), max_depth {args.depth}, guided iteration {k} (SD-tree trained by rendering iterations 0-{k - 1}, "
                                f"{cumm} spp), {args.spp_per_pass} spp per pass; full PathGuidingIntegrator.sample(): camera rays, NEE, "
                                "BSDF/SD-tree MIS, record list, post-process + splat; " + what,
-                   "pixels_this_rank": my_pixels, "spp_per_pass": args.spp_per_pass,
+                   "pixels_this_rank": my_pixels, "pixels_per_rank_min": int(pix_min), "pixels_per_rank_max": int(pix_max),
+                   "spp_per_pass": args.spp_per_pass,
                    "paths_per_step": paths_per_step, "kd_nodes": stats.n_kd_nodes, "kd_leaves": stats.n_kd_leaves,
                    "quad_records": stats.n_quad_records, "mean_kd_leaf_depth": round(stats.mean_kd_leaf_depth, 3),
                    "mean_quad_leaf_depth": round(stats.mean_quad_leaf_depth, 3),
@@ -457,6 +547,46 @@ def run_render(args):
     if world > 1:
         dist.destroy_process_group()
     return out
+
+
+def full_schedule_leg(args, integ, ws, shard, reduce_fn, W, H):
+    """BASELINE.json's configuration as the reference's main.py runs it: budget = 4 + 8 + ... over the config's
+    number of iterations (veach-ajar: 12 -> 16380 spp, main.py:92-99, 170), training passes of --spp-per-pass samples
+    (main.py:192 has 1: a pass is a batch, the tree does not depend on how an iteration is cut into passes), the
+    stop-training rule of main.py:334-377 (training ends once the estimated final variance rises after 256 spp or at
+    1000 spp; the rest of the budget is one final iteration), image blending, variance bookkeeping, exchange and
+    refine -- everything driver.run_guided_render does -- inside one wall clock."""
+    import torch
+    from practical_path_guiding_lab_amd.driver import run_guided_render
+
+    n_it = CONFIG_ITERATIONS[args.scene]
+    budget = 2 ** (n_it + 2) - 4
+    lines = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_guided_render(ws, integ, budget, initial_seed=0, batch_spp=args.spp_per_pass, training_spp_per_pass=args.spp_per_pass,
+                            all_reduce=reduce_fn, shard=shard, log=lines.append)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    rows = res["records"]["variance_endIter"].rows
+    image_spp = int(rows[-1][1])
+    if shard is not None:
+        from practical_path_guiding_lab_amd.parallel import all_reduce_sums
+        sumL = all_reduce_sums(integ.sumL, integ.sumL2)[0]
+    else:
+        sumL = integ.sumL
+    mse, note = image_mse(sumL.cpu().numpy(), image_spp, W, H, args.scene)
+    trained = [it for it in res["iterations"] if it["refine_s"] > 0]
+    return {"value": round(W * H * res["cumm_spp"] / wall / 1e6, 3), "unit": "Msamples/s", "wall_s": round(wall, 2),
+            "budget_spp": budget, "config_iterations": n_it, "iterations_run": len(res["iterations"]),
+            "refines": len(trained), "final_image_spp": image_spp,
+            "guided_value": round(res["guided_samples"] / max(res["guided_time_s"], 1e-9) / 1e6, 3),
+            "mse_vs_gt": mse, "variance_final": rows[-1][4],
+            "per_iteration": [{"iteration": it["iteration"], "spp": it["spp"], "render_s": round(it["render_s"], 3),
+                               "refine_s": round(it["refine_s"], 4)} for it in res["iterations"]],
+            "note": "the whole budget of the BASELINE configuration through driver.run_guided_render (main.py:92-430): all camera paths of "
+                    "all iterations / one wall clock that also holds refine, variance bookkeeping, image development and blending; "
+                    "mse_vs_gt = per-pixel mean of the final image's samples vs the ground truth" + (": " + note if note else "")}
 
 
 def cpu_leg(args, iters=4, width=320):
@@ -581,7 +711,7 @@ def run_synthetic(args):
     kq = sum(x[1] for x in depths["bounce"])
     out = {
         "metric": "Msamples/s guided (SD-tree hot path only, synthetic pass)", "value": round(value, 3),
-        "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "Msamples/s", "n_gpus": args.n_devices, "ranks": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2-synthetic: cornell-box 512x512 pixels x spp_per_pass paths/pass, max_depth 8, SD-tree ops "
@@ -600,6 +730,10 @@ def run_synthetic(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing above has imported
+        # torch or touched HIP, the children are fresh processes (no exec of a process that holds the GPU).
+        sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     out = run_synthetic(args) if args.synthetic else run_render(args)
     if out is not None:
         print(json.dumps(out))

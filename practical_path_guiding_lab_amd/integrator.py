@@ -53,6 +53,8 @@ class PathGuidingIntegrator:
     # ---- path_guiding_integrator.py:77-105 ---------------------------------------------------
     def setup(self, numRays: int, bbox_min, bbox_max, sdTreeMaxDepth: int = 10, quadTreeMaxDepth: int = 30,
               isStoreNEERadiance: bool = True, bsdfSamplingFraction: float = 0.5) -> None:
+        if int(numRays) != self.numRays:
+            self.gt_mask = None  # (one entry per film pixel: a mask does not outlive a change of the film)
         self.numRays = int(numRays)
         self.array_size = self.numRays * self.max_depth
         self.isStoreNEERadiance = bool(isStoreNEERadiance)
@@ -63,8 +65,8 @@ class PathGuidingIntegrator:
         self.resetVarianceCounter()
 
     def resetVarianceCounter(self) -> None:  # :108-110
+        # (the ground-truth mask is NOT part of the counters: every driver resets them at the top of an iteration)
         self.sumL = torch.zeros((3, max(self.numRays, 1)), dtype=torch.float32, device=self.device)
-        self.gt_mask = None  # (one entry per film pixel: set again after a new setup)
         self.sumL2 = torch.zeros_like(self.sumL)
 
     def setIteration(self, iteration: int, isFinalIter: bool) -> None:  # :121-123
@@ -103,8 +105,8 @@ class PathGuidingIntegrator:
         if mask is None:
             self.gt_mask = None
             return
-        m = torch.as_tensor(np.asarray(mask, bool).reshape(-1), device=self.sumL.device)
-        if m.numel() != self.sumL.shape[1]:
+        m = torch.as_tensor(np.asarray(mask, bool).reshape(-1), device=self.device)
+        if m.numel() != max(self.numRays, 1):
             raise ValueError("ground-truth mask must have one entry per film pixel")
         self.gt_mask = m
 

@@ -44,58 +44,47 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     return acc
 
 
-def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None, timeout_s: float = 120.0) -> bool:
+def _flag_device(group):
+    return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+
+def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
     """Gives `tree` (an SDTree) its own RCCL communicator over the ranks of `group` (pg_comm_init): rank
-    0's ncclUniqueId travels through torch.distributed, then every rank joins.  Afterwards
-    tree.allReduce() is the exchange -- one ncclAllReduce issued by libpgsd.so itself, the form a host
-    without PyTorch would use.  Returns False on EVERY rank (and leaves no communicator behind) when the
-    ranks do not each have a GPU of their own (RCCL refuses two ranks on one device), RCCL cannot be
-    loaded, or any rank fails to join within `timeout_s`: the caller then exchanges through
-    torch.distributed (all_reduce_accumulators), which is the same RCCL all-reduce issued by PyTorch."""
+    0's ncclUniqueId travels through torch.distributed, then every rank joins -- on the calling thread.
+    Afterwards tree.allReduce() is the exchange: one ncclAllReduce issued by libpgsd.so itself, the form a
+    host without PyTorch would use.
+
+    Whether the library communicator is used at all is decided COLLECTIVELY before anyone joins (one MIN
+    all-reduce of a flag, no early return ahead of it): it needs the nccl backend and a GPU of its own for
+    every rank of this node (RCCL refuses two ranks on one device; the check uses the LOCAL world size, so
+    multi-node jobs are eligible).  Returns False on every rank when the ranks are not eligible or RCCL
+    cannot be loaded on rank 0 -- the caller then exchanges through torch.distributed
+    (all_reduce_accumulators), the same RCCL all-reduce issued by PyTorch.  Once the ranks have agreed to
+    join, a rank that fails raises: the process ends with a non-zero exit code and the launcher ends the
+    job.  There is no half-joined communicator and no fallback decided by one rank alone."""
     if not dist.is_available() or not dist.is_initialized():
         return False
+    import os
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if world > torch.cuda.device_count():
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    mine = 1 if (dist.get_backend(group) == "nccl" and torch.cuda.is_available()
+                 and local_world <= torch.cuda.device_count()) else 0
+    flag = torch.tensor([mine], dtype=torch.int32, device=_flag_device(group))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
         return False
     ident = [None]
-    err = None
     if rank == 0:
         try:
             ident[0] = tree.commUniqueId()
-        except Exception as e:  # RCCL missing: tell the others instead of leaving them waiting
-            err = e
+        except Exception as e:  # RCCL cannot be loaded: every rank learns it from the broadcast below
+            import warnings
+            warnings.warn(f"libpgsd RCCL communicator not available: {e}")
     dist.broadcast_object_list(ident, src=0, group=group)
     if ident[0] is None:
-        if err is not None and rank == 0:
-            import warnings
-            warnings.warn(f"libpgsd RCCL communicator not available: {err}")
         return False
-    # join on a helper thread (the call leaves the interpreter lock): a rank that cannot join must not
-    # leave the others waiting in ncclCommInitRank for ever
-    import threading
-    outcome = {}
-
-    def join():
-        try:
-            tree.commInit(world, rank, ident[0])
-            outcome["ok"] = True
-        except Exception as e:
-            outcome["err"] = e
-
-    th = threading.Thread(target=join, daemon=True)
-    th.start()
-    th.join(timeout_s)
-    mine = 1 if outcome.get("ok") else 0
-    flag = torch.tensor([mine], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 1:
-        return True
-    import warnings
-    warnings.warn(f"libpgsd RCCL communicator: rank {rank} {'joined' if mine else 'did not join'}"
-                  f"{' (' + str(outcome['err']) + ')' if 'err' in outcome else ''}; falling back to torch.distributed")
-    if mine:
-        tree.commDestroy()
-    return False
+    tree.commInit(world, rank, ident[0])  # ncclCommInitRank; raises on failure
+    return True
 
 
 def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -133,6 +122,15 @@ class LaneGather:
         full = torch.zeros((3, npix * spp), dtype=L.dtype, device=L.device)
         full[:, lanes] = L
         return _all_reduce_sum(full, self.group)  # disjoint tiles: x + 0 is exact
+
+
+def min_max_over_ranks(value: float, group: Optional[dist.ProcessGroup] = None):
+    """(min, max) of a per-rank number over the ranks."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return value, value
+    t = torch.tensor([-float(value), float(value)], dtype=torch.float64, device=_flag_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return -float(t[0].item()), float(t[1].item())
 
 
 def max_over_ranks(seconds: float, device=None, group: Optional[dist.ProcessGroup] = None) -> float:

@@ -510,6 +510,13 @@ def _data_file(name: str) -> str:
 VEACH_AJAR_TEAPOT_RECT = (270, 370, 850, 590)
 
 
+def _decode_jpg(raw: np.ndarray) -> np.ndarray:
+    """The (H, W, 3) 8-bit sRGB image of a JPG file's bytes: what load_xml's `bitmap` reads from the file itself."""
+    import io
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(np.asarray(raw, np.uint8).tobytes())).convert("RGB"))
+
+
 def veach_ajar_mask(width: int, height: int) -> np.ndarray:
     """(height, width) bool: True where a veach-ajar image can be compared with TungstenRender.exr."""
     x0, y0, x1, y1 = VEACH_AJAR_TEAPOT_RECT
@@ -526,13 +533,15 @@ def veach_ajar(width: int = 1280, height: int = 720, max_depth: int = 13, rr_dep
     specular reflectance is a `checkerboard`, GGX hinges, a Beckmann door handle (the one smooth-shaded
     mesh), fov 60, tent filter.  Built from its numeric parameters and the package's data file
     (data/veach_ajar.npz, made by tests/golden/make_ajar_fixture.py: the 15 OBJ meshes present in the
-    reference mount and the three textures at reduced resolution).  The six teapot shapes
+    reference mount and the three JPG textures as their files' bytes, decoded here with PIL exactly as
+    load_xml decodes the files: full resolution, 1920x1280 / 2000x3008 / 1280x1024).  The six teapot shapes
     (scene.xml:252-293) are left out -- their two mesh files are missing from the reference mount --
     and named in `Scene.skipped`; their three materials stay in the table (unused)."""
     from .mesh import triangles
     d = np.load(data or _data_file("veach_ajar.npz"))
     al_eta, al_k = (1.65746, 0.880369, 0.521229), (9.22387, 6.26952, 4.837)
-    textures = [bitmap_texture(d["tex_landscape"]), bitmap_texture(d["tex_table"]), bitmap_texture(d["tex_cherry"]),
+    textures = [bitmap_texture(_decode_jpg(d["jpg_landscape"])), bitmap_texture(_decode_jpg(d["jpg_table"])),
+                bitmap_texture(_decode_jpg(d["jpg_cherry"])),
                 checkerboard_texture((0.8, 0.8, 0.8), (0.2, 0.2, 0.2), (20.0, 80.0, 0.0, 0.0))]
     mats = [diffuse_material((0.5, 0.5, 0.5), texture=0),                                     # 0 LandscapeBSDF
             diffuse_material((0.5, 0.5, 0.5), texture=1),                                     # 1 TableBSDF

@@ -13,14 +13,35 @@ from typing import Optional, Tuple
 import numpy as np
 
 
-def _rows(a, n: int, k: int) -> np.ndarray:
-    """A (n, k) view of a vector column however it was written ((n, k) as Dr.Jit's .numpy() gives, or (k, n))."""
-    a = np.asarray(a, np.float32)
-    if a.shape == (n, k):
-        return a
-    if a.shape == (k, n):
-        return a.T
-    raise ValueError(f"expected a column of {n} vectors of {k}, got {a.shape}")
+def _boxes(bmin, bmax, n: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """The (n, k) bbox_min / bbox_max columns of a saved tree.  The on-disk orientation is the reference's:
+    (n, k), one row per node, as Dr.Jit's `.numpy()` gives a Vector column (kdtree.py:575-602) and as
+    SDTree.saveToFile writes it.  A (k, n) file (a column-major writer) is accepted when its shape says so
+    unambiguously.  With n == k -- a 3-node KD tree, a 2-node quadtree forest -- the shape says nothing: the
+    reading is chosen by what every saved tree satisfies -- no box is inverted and every node's box lies
+    inside node 0's (the KD root holds every node; every quadtree node lies in the unit square that root 0
+    is).  The reference's orientation is taken when it passes (it is the only writer known), the transposed
+    one when only that passes, and a file that passes neither way is refused rather than read wrongly."""
+    bmin, bmax = np.asarray(bmin, np.float32), np.asarray(bmax, np.float32)
+    if bmin.shape != bmax.shape:
+        raise ValueError(f"bbox_min {bmin.shape} and bbox_max {bmax.shape} differ in shape")
+    if n != k:
+        if bmin.shape == (n, k):
+            return bmin, bmax
+        if bmin.shape == (k, n):
+            return bmin.T, bmax.T
+        raise ValueError(f"expected a column of {n} vectors of {k}, got {bmin.shape}")
+    if bmin.shape != (n, k):
+        raise ValueError(f"expected a column of {n} vectors of {k}, got {bmin.shape}")
+
+    def plausible(lo, hi):
+        return bool(np.all(lo <= hi) and np.all(lo >= lo[0]) and np.all(hi <= hi[0]))
+
+    if plausible(bmin, bmax):
+        return bmin, bmax
+    if plausible(bmin.T, bmax.T):
+        return bmin.T, bmax.T
+    raise ValueError(f"{n} nodes of {k} coordinates: neither reading of the square bbox columns is a tree (boxes inside node 0's)")
 
 
 class KDTreeNode:
@@ -29,8 +50,7 @@ class KDTreeNode:
     def loadFromFile(self, dataNumpy) -> None:  # src/kdtree.py:53-63
         self.depth = np.asarray(dataNumpy["kdtree_depth"], np.uint32)
         n = self.depth.shape[0]
-        self.bbox_min = _rows(dataNumpy["kdtree_bbox_min"], n, 3)
-        self.bbox_max = _rows(dataNumpy["kdtree_bbox_max"], n, 3)
+        self.bbox_min, self.bbox_max = _boxes(dataNumpy["kdtree_bbox_min"], dataNumpy["kdtree_bbox_max"], n, 3)
         self.vertCount = np.asarray(dataNumpy["kdtree_vertCount"], np.float32)
         self.isLeaf = np.asarray(dataNumpy["kdtree_isLeaf"], bool)
         self.quadTreeRootIndex = np.asarray(dataNumpy["kdtree_quadTreeRootIndex"], np.uint32)
@@ -73,8 +93,7 @@ class QuadTreeNode:
         self.rootNodeIndex = np.asarray(dataNumpy["quadtree_rootNodeIndex"], np.uint32)
         self.depth = np.asarray(dataNumpy["quadtree_depth"], np.uint32)
         n = self.depth.shape[0]
-        self.bbox_min = _rows(dataNumpy["quadtree_bbox_min"], n, 2)
-        self.bbox_max = _rows(dataNumpy["quadtree_bbox_max"], n, 2)
+        self.bbox_min, self.bbox_max = _boxes(dataNumpy["quadtree_bbox_min"], dataNumpy["quadtree_bbox_max"], n, 2)
         self.irradiance = np.asarray(dataNumpy["quadtree_irradiance"], np.float32)
         self.isLeaf = np.asarray(dataNumpy["quadtree_isLeaf"], bool)
         self.refinementThreshold = np.asarray(dataNumpy["quadtree_refinementThreshold"], np.float32)

@@ -5,9 +5,10 @@
       (Mesh000.obj and Mesh009.obj, the teapots, are missing blobs), read with mesh.read_obj:
       positions (as parsed: float64), integer faces, per-corner texture coordinates as the files hold them, and
       per-corner normals for the one mesh the scene shades smoothly (Mesh015, the door handle);
-      the three JPG textures decoded with PIL to 8-bit sRGB and box-downsampled in linear light
-      (landscape 1920x1280 -> 480x320, table 2000x3008 -> 500x752, cherry wood 1280x1024 -> 640x512)
-      so that the file stays small -- at the film sizes used a texel still covers about a pixel.
+      the three JPG textures as the byte strings of their files (jpg_landscape 1920x1280, jpg_table 2000x3008,
+      jpg_cherry 1280x1024; 2.6 MB): scene.veach_ajar() decodes them with PIL exactly as scene.load_xml does
+      with the files themselves, so the packaged scene has the reference's textures at full resolution
+      (round 2 shipped box-downsampled copies).
   tests/golden/veach_ajar_gt_320x180_f16.npy, veach_ajar_gt_640x360_f16.npy
       scenes/veach-ajar/TungstenRender.exr (1280x720 HALF/PIZ, what main.py:38-41 loads) decoded with
       practical_path_guiding_lab_amd/exr.py and box-downsampled 4x4 / 2x2, float16.
@@ -25,21 +26,10 @@ sys.path.insert(0, ROOT)
 
 from practical_path_guiding_lab_amd import exr  # noqa: E402
 from practical_path_guiding_lab_amd.mesh import read_obj  # noqa: E402
-from practical_path_guiding_lab_amd.scene import srgb_to_linear_lut  # noqa: E402
 
 MESHES = ["Mesh%03d" % i for i in (1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16)]
 SMOOTH = {"Mesh015"}  # every other shape sets face_normals=true (scenes/veach-ajar/scene.xml:133-250)
-TEXTURES = {"landscape": ("landscape-with-a-lake.jpg", 4), "table": ("Good Textures_005844.jpg", 4),
-            "cherry": ("cherry-wood-texture.jpg", 2)}
-
-
-def downsample_srgb(img: np.ndarray, f: int) -> np.ndarray:
-    """Box filter f x f in linear light, back to 8-bit sRGB."""
-    lut = srgb_to_linear_lut().astype(np.float64)
-    h, w = img.shape[0] // f * f, img.shape[1] // f * f
-    lin = lut[img[:h, :w]].reshape(h // f, f, w // f, f, 3).mean(axis=(1, 3))
-    enc = np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(np.maximum(lin, 0.0031308), 1.0 / 2.4) - 0.055)
-    return np.clip(np.rint(enc * 255.0), 0, 255).astype(np.uint8)
+TEXTURES = {"landscape": "landscape-with-a-lake.jpg", "table": "Good Textures_005844.jpg", "cherry": "cherry-wood-texture.jpg"}
 
 
 def main():
@@ -57,11 +47,10 @@ def main():
         if name in SMOOTH:
             out[name + "_n"] = n
         print(name, v.shape[0], "vertices", f.shape[0], "triangles")
-    for key, (fname, f) in TEXTURES.items():
-        img = np.asarray(Image.open(os.path.join(base, "textures", fname)).convert("RGB"))
-        small = downsample_srgb(img, f)
-        out["tex_" + key] = small
-        print(key, img.shape, "->", small.shape)
+    for key, fname in TEXTURES.items():
+        raw = open(os.path.join(base, "textures", fname), "rb").read()
+        out["jpg_" + key] = np.frombuffer(raw, np.uint8)
+        print(key, Image.open(os.path.join(base, "textures", fname)).size, len(raw), "bytes")
     dst = os.path.join(ROOT, "practical_path_guiding_lab_amd", "data", "veach_ajar.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes")

@@ -88,6 +88,25 @@ def test_main_py_masks_the_teapots_of_veach_ajar_in_its_mse(tmp_path):
         g.setGroundTruthMask(np.ones(7, bool))
     g.setGroundTruthMask(None)
     assert g.computeMSE(1, gtt) == full
+    # ... and the logged number IS the masked one: the same schedule in this process with and without the mask (the
+    # drivers reset the variance counters at the top of every iteration -- the mask has to survive that)
+    from practical_path_guiding_lab_amd.driver import run_guided_render
+    from practical_path_guiding_lab_amd.render import WavefrontScene
+
+    def schedule(mask):
+        gi = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
+        res = run_guided_render(WavefrontScene(S.veach_ajar(320, 180)), gi, 28, ground_truth=gtt, batch_spp=4,
+                                training_spp_per_pass=8, gt_mask=mask, log=lambda s_: None)
+        return res["records"]["mse_groundTruth_endIter"].rows[-1], gi
+
+    row_m, gi = schedule(S.veach_ajar_mask(320, 180))
+    row_u, _ = schedule(None)
+    assert gi.gt_mask is not None  # still set after the run
+    assert masked == row_m[5], (masked, row_m[5], row_u[5])   # csv holds repr(float): exact
+    assert masked != row_u[5] and abs(masked - row_u[5]) > 1e-3 * masked
+    err = ((gi.sumL / row_m[1] - gtt) ** 2).cpu().numpy().astype(np.float32)
+    lum = np.minimum(np.float32(0.212671) * err[0] + np.float32(0.715160) * err[1] + np.float32(0.072169) * err[2], np.float32(1e4))
+    assert abs(lum[m].mean() - masked) <= 1e-4 * masked
 
 
 def test_main_py_repeats_every_iterations_tree_at_equal_spp(tmp_path):

@@ -352,4 +352,78 @@ def test_tree_file_readers_the_reference_tools_use(tmp_path):
     irr = qt.sampleIrradiance(tree, c)
     assert (irr >= 0).all() and (qt.sampleIrradiance(tree[:1], np.array([[1.5, 0.5]], np.float32)) == 0).all()
     with pytest.raises(ValueError):
-        TF._rows(np.zeros((4, 5), np.float32), 7, 3)
+        TF._boxes(np.zeros((4, 5), np.float32), np.zeros((4, 5), np.float32), 7, 3)
+    # (k, n) files are read when the shape is unambiguous
+    lo_t, hi_t = TF._boxes(d["kdtree_bbox_min"].T, d["kdtree_bbox_max"].T, kd.getWidth(), 3)
+    assert np.array_equal(lo_t, kd.bbox_min) and np.array_equal(hi_t, kd.bbox_max)
+
+
+def test_tree_file_with_as_many_nodes_as_coordinates(tmp_path):
+    """A 3-node KD tree's bbox columns are 3 x 3 and a two-tree forest of single leaves 2 x 2: the shape cannot tell
+    (n, k) from (k, n).  The reference's (n, k) is read as such; a transposed file is recognised by its boxes not
+    nesting in node 0's; one that nests neither way is refused."""
+    from oracle import pg_oracle as po
+    from practical_path_guiding_lab_amd import treefile as TF
+
+    t = po.OracleTree()
+    t.setup([0.0, -2.0, 1.0], [100.0, 50.0, 9.0], 20, 20, True)
+    t.kd_split(t.kd_all_leaves())          # root + two children, two single-leaf quadtrees
+    t.clean_unused_quadtree()
+    d = t.export()
+    assert d["kdtree_bbox_min"].shape == (3, 3) and d["quadtree_bbox_min"].shape == (2, 2)
+    f = str(tmp_path / "tiny.npz")
+    np.savez_compressed(f, **d)
+    kd, qt = TF.load(f)
+    assert np.array_equal(kd.bbox_min, d["kdtree_bbox_min"]) and np.array_equal(kd.bbox_max, d["kdtree_bbox_max"])
+    assert kd.bbox_min[0].tolist() == [0.0, -2.0, 1.0] and kd.bbox_max[2].tolist() == [100.0, 50.0, 9.0]
+    assert kd.bbox_max[1, 0] == 50.0 and kd.bbox_min[2, 0] == 50.0   # split on x (depth 0)
+    p = np.array([[75.0, 0.0, 5.0], [25.0, 0.0, 5.0], [50.0, 0.0, 5.0]], np.float32)
+    assert kd.getLeafNodeIndex(p).tolist() == [2, 1, 2]               # the plane itself goes right (kdtree.py:462-468)
+    assert qt.bbox_min.tolist() == [[0, 0], [0, 0]] and qt.bbox_max.tolist() == [[1, 1], [1, 1]]
+    # the same tree written column-major
+    dt = dict(d)
+    for key in ("kdtree_bbox_min", "kdtree_bbox_max", "quadtree_bbox_min", "quadtree_bbox_max"):
+        dt[key] = np.ascontiguousarray(d[key].T)
+    np.savez_compressed(f, **dt)
+    kd2, _ = TF.load(f)
+    assert np.array_equal(kd2.bbox_min, kd.bbox_min) and np.array_equal(kd2.bbox_max, kd.bbox_max)
+    assert kd2.getLeafNodeIndex(p).tolist() == [2, 1, 2]
+    bad = np.array([[0, 0, 0], [5, 0, 0], [0, 5, 0]], np.float32)     # nests in node 0 neither way
+    with pytest.raises(ValueError):
+        TF._boxes(bad, bad + 1, 3, 3)
+
+
+def test_ground_truth_mask_survives_the_variance_counter_reset(monkeypatch):
+    """Every driver calls resetVarianceCounter() at the top of an iteration (main.py:161-163), after the mask
+    was set: the mask belongs to the film (numRays), not to the counters, and only a setup() with another
+    film size drops it.  (The integrator's SD-tree is replaced by a stand-in: no GPU here.)"""
+    import torch
+    from practical_path_guiding_lab_amd import integrator as I
+
+    class FakeTree:
+        def __init__(self, device=0):
+            self.device = "cpu"
+
+        def setup(self, *a, **k):
+            pass
+
+    monkeypatch.setattr(I, "SDTree", FakeTree)
+    g = I.PathGuidingIntegrator({"max_depth": 4})
+    g.setup(6, [0, 0, 0], [1, 1, 1])
+    mask = np.array([1, 1, 0, 0, 1, 0], bool)
+    g.setGroundTruthMask(mask)
+    g.resetVarianceCounter()
+    assert g.gt_mask is not None and g.gt_mask.tolist() == mask.tolist()
+    g.sumL += torch.tensor([[1.0, 2, 3, 4, 5, 6]] * 3)
+    gt = torch.zeros((3, 6))
+    lum = 0.212671 + 0.715160 + 0.072169
+    masked = g.computeMSE(1, gt)
+    assert abs(masked - lum * (1 + 4 + 25) / 3) < 1e-5
+    assert abs(g.computeVariance(1, gt) - 0.0) < 1e-9  # sumL2 is zero: (0 - 0) over the masked pixels
+    g.setup(6, [0, 0, 0], [1, 1, 1])        # the same film: the mask stays
+    assert g.gt_mask is not None
+    g.setup(8, [0, 0, 0], [1, 1, 1])        # another film: it cannot apply any more
+    assert g.gt_mask is None
+    with pytest.raises(ValueError):
+        g.setGroundTruthMask(mask)
+    g.setGroundTruthMask(None)

@@ -356,3 +356,87 @@ def test_library_exchange_with_one_rank():
     g.commDestroy()
     with pytest.raises(PgError):
         g.allReduce()
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --gpus N from a bare command line: the launcher
+# ---------------------------------------------------------------------------------------------
+def _bench_module():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    spec = importlib.util.spec_from_file_location("bench_under_test", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_spawn_ranks_gives_every_rank_its_environment_and_relays_rank_zero(tmp_path):
+    """bench.spawn_ranks with stand-in rank processes (no GPU): each gets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR 127.0.0.1 / one common MASTER_PORT, only rank 0's stdout is relayed, exit code 0."""
+    import io
+    import json
+    b = _bench_module()
+    child = ("import os, json, sys; r = os.environ['RANK']; "
+             "open(sys.argv[1] + r, 'w').write(json.dumps({k: os.environ[k] for k in "
+             "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')})); "
+             "print('line of rank ' + r)")
+    relay = io.StringIO()
+    rc = b.spawn_ranks([sys.executable, "-c", child, str(tmp_path / "env")], 3, relay=relay)
+    assert rc == 0
+    assert relay.getvalue() == "line of rank 0\n"
+    envs = [json.load(open(str(tmp_path / "env") + str(r))) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["LOCAL_WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+
+
+def test_spawn_ranks_ends_the_job_when_a_rank_fails():
+    """One rank exits with code 7 while the others would run for a minute: the launcher ends them and
+    returns 7 within seconds; nothing of rank 0's partial output is mistaken for a result line."""
+    import io
+    import time
+    b = _bench_module()
+    child = "import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(60)\nprint('never')"
+    relay = io.StringIO()
+    t0 = time.time()
+    rc = b.spawn_ranks([sys.executable, "-c", child], 3, relay=relay, grace_s=5.0)
+    assert rc == 7 and time.time() - t0 < 30 and relay.getvalue() == ""
+
+
+def test_backend_is_decided_from_the_device_count_alone():
+    """auto: nccl when every rank of the node has a device of its own, gloo for a rehearsal on fewer
+    devices than ranks -- the same answer on every rank, taken before anything is initialised."""
+    import types
+    b = _bench_module()
+    auto = types.SimpleNamespace(backend="auto")
+    assert b.pick_backend(auto, 8, 8) == "nccl" and b.pick_backend(auto, 2, 8) == "nccl"
+    assert b.pick_backend(auto, 2, 1) == "gloo" and b.pick_backend(auto, 8, 4) == "gloo"
+    assert b.pick_backend(types.SimpleNamespace(backend="gloo"), 2, 8) == "gloo"
+    assert b.pick_backend(types.SimpleNamespace(backend="nccl"), 2, 1) == "nccl"
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_from_a_bare_command_line(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it, on the one-GPU box: the parent starts two
+    fresh rank processes before touching the GPU, they rehearse over gloo (two ranks on one device),
+    rank 0's JSON line comes back with the honest device count."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scene", "cornell-box", "--res", "96", "--steps", "2",
+           "--warmup", "1", "--train-iters", "3", "--spp-per-pass", "4", "--cpu", "0", "--full-schedule", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    ndev = torch.cuda.device_count()
+    assert out["ranks"] == 2 and out["n_gpus"] == min(2, ndev)
+    assert out["value"] > 0 and out["scaling"] == "strong"
+    if ndev < 2:
+        assert "gloo" in out["extra"]["exchange"]
+    else:
+        assert "RCCL" in out["extra"]["exchange"] or "nccl" in out["extra"]["exchange"]
+    c = out["config"]
+    assert c["pixels_per_rank_min"] + c["pixels_per_rank_max"] == 96 * 96 and c["pixels_per_rank_min"] > 0
