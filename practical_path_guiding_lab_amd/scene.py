@@ -540,8 +540,9 @@ def veach_ajar(width: int = 1280, height: int = 720, max_depth: int = 13, rr_dep
     from .mesh import triangles
     d = np.load(data or _data_file("veach_ajar.npz"))
     al_eta, al_k = (1.65746, 0.880369, 0.521229), (9.22387, 6.26952, 4.837)
-    textures = [bitmap_texture(_decode_jpg(d["jpg_landscape"])), bitmap_texture(_decode_jpg(d["jpg_table"])),
-                bitmap_texture(_decode_jpg(d["jpg_cherry"])),
+    # (a data file may also hold decoded (H, W, 3) images as tex_*: round 2's reduced copies, kept readable for A/B runs)
+    img = {k: _decode_jpg(d["jpg_" + k]) if ("jpg_" + k) in d.files else d["tex_" + k] for k in ("landscape", "table", "cherry")}
+    textures = [bitmap_texture(img["landscape"]), bitmap_texture(img["table"]), bitmap_texture(img["cherry"]),
                 checkerboard_texture((0.8, 0.8, 0.8), (0.2, 0.2, 0.2), (20.0, 80.0, 0.0, 0.0))]
     mats = [diffuse_material((0.5, 0.5, 0.5), texture=0),                                     # 0 LandscapeBSDF
             diffuse_material((0.5, 0.5, 0.5), texture=1),                                     # 1 TableBSDF

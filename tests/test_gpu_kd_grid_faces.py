@@ -57,7 +57,8 @@ def test_query_kernels_on_grid_faces(tree):
     g = gpu_tree_from(tree)
     n = 150_001
     p = face_positions(n, 21)
-    on_plane = (np.mod(p, np.float32(1.5625)) == 0).any(axis=0)
+    with np.errstate(invalid="ignore"):
+        on_plane = (np.mod(p, np.float32(1.5625)) == 0).any(axis=0)
     assert on_plane.mean() > 0.5  # most lanes have at least one coordinate on a plane
     act = (synth.uniform(n, 22)[0] < 0.85).astype(np.uint8)
     dp, dact = dev(torch, p), dev(torch, act)
