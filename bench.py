@@ -100,6 +100,7 @@ def parse():
     ap.add_argument("--split-pipeline", action="store_true",
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
+    ap.add_argument("--overlap", type=int, default=0, help="pg_render_overlap mode of the timed steps")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
@@ -311,7 +312,7 @@ def run_render(args):
     tree = integ.sdTree
     npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
-    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline)
+    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap)
     tiles = world > 1 and args.shard == "tiles"
     if tiles:
         ws.set_shard(rank, world, 4)
@@ -456,6 +457,8 @@ def run_render(args):
         kernels["k_wave_trace"] = kern(kt.trace_ms, kt.trace_launches)
         kernels["k_wave_shadow"] = kern(kt.shadow_ms, nb)
         kernels["k_wave_shade_a+b"] = kern(kt.shade_ms, 2 * nb)
+        kernels["k_wave_shade_a+b"]["shade_a_ms_per_step"] = round(kt.shade_a_ms / passes, 3)
+        kernels["k_wave_shade_a+b"]["shade_b_ms_per_step"] = round(kt.shade_b_ms / passes, 3)
         kernels["k_wave_tail"] = kern(kt.tail_ms, max(kt.passes, 1))
         dom = "k_wave_guide"
     else:

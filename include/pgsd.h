@@ -360,6 +360,13 @@ typedef struct pg_pass_params {
 int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uint8_t *valid_out,
                    float *sumL, float *sumL2, void *stream);
 
+/* Not in the reference (Dr.Jit orders its kernels by data dependence on one stream): mode 1 lets the two kernels
+ * of a mesh scene's bounce that do not depend on each other -- the SD-tree queries (k_wave_guide,
+ * src/path_guiding_integrator.py:244, 301, 307) and the shadow rays (k_wave_cast, :213 test_visibility) -- run side by
+ * side, the queries on a library-owned stream that forks from and joins the caller's stream inside pg_render_pass.
+ * Results are identical (the two write disjoint buffers).  Default 0: every kernel on the caller's stream. */
+int pg_render_overlap(pg_context *ctx, int32_t mode);
+
 /* Allocates what pg_render_pass needs for passes of up to n_lanes lanes (pixels of the tile x spp) ahead
  * of time -- the reference allocates its numRays x max_depth record arrays in setup()
  * (path_guiding_integrator.py:93, 116); without this call the first pass of a size allocates them. */
@@ -403,6 +410,7 @@ typedef struct pg_kernel_timing {
 	 * bounces.  shade_ms = both shading kernels; tail_ms = the launch that finishes the last paths. */
 	double trace_ms, shade_ms, shadow_ms, guide_ms, tail_ms;
 	uint64_t trace_launches, guide_launches;
+	double shade_a_ms, shade_b_ms; /* the two shading kernels of shade_ms, each on its own */
 } pg_kernel_timing;
 int pg_enable_kernel_timing(pg_context *ctx, int32_t on);
 int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset);

@@ -224,28 +224,52 @@ __device__ __forceinline__ bool jump_cell(float cx, float cy, uint32_t &cell, fl
 	return true;
 }
 
+// ---- accumulator slots ----
+// sdTree_prev and sdTree_current share their topology (path_guiding_integrator.py:582), so the leaf a pdf or
+// sampling walk of sdTree_prev ends in IS the leaf whose accumulator a record with that direction adds to in
+// sdTree_current (quadtree.py:398-441 descends by the same highest-numbered containing child, quadtree.py:
+// 424-438 / 1095-1098).  A walk can therefore hand the accumulator over as a by-product:
+constexpr uint32_t kSlotNone = 0xffffffffu; // the direction reaches no leaf (outside the unit square, quadtree.py:404-405)
+constexpr uint32_t kSlotRoot = 0x80000000u; // the tree's root is the leaf: its root accumulator (the tree is named beside the slot)
+//                                             anything else: rec * 4 + child, the accumulator of a leaf below record `rec`
+__device__ __forceinline__ bool in_unit_square(float cx, float cy) { return cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f; }
+
 // QuadTree.pdfQuadTree (quadtree.py:1001-1101) for canonical position (cx,cy) in [0,1]^2.
 // jump/tree: the quadtree's jump table (nullptr: every level is walked).
-__device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
-                                          float cx, float cy, uint32_t &levels)
+// kSlot: also the accumulator slot of the leaf that holds (cx,cy) -- the walk then goes on to the leaf where the
+// pdf alone would stop (a 0/0 on the way, quadtree.py:1090-1092); the pdf is the same value either way.
+template <bool kSlot>
+__device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                            float cx, float cy, uint32_t &levels, uint32_t &slot)
 {
 	float pdf = 1.0f;
 	levels = 0;
-	if (head.root_rec == kNoRecord) return pdf * kInvFourPiF;
+	slot = kSlotNone;
+	const bool inside = in_unit_square(cx, cy);
+	if (head.root_rec == kNoRecord) {
+		if (kSlot && inside) slot = kSlotRoot;
+		return pdf * kInvFourPiF;
+	}
 	uint32_t r = head.root_rec;
 	float node_irr = head.root_irr;
 	float lox = 0.0f, loy = 0.0f, h = 0.5f;
 	int it0 = 0;
 	uint32_t cell;
 	float jx, jy;
+	bool dead = false; // (kSlot) the product met a 0/0: the value is 0, the walk goes on for the slot
 	if (jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) {
 		const uint4 e = gather16(jump + (size_t)tree * kJumpCells + cell);
-		if (!((e.w >> 30) & 1u)) { // the product is defined along this path
+		const bool undefined = ((e.w >> 30) & 1u) != 0u; // the product is not defined along this path: the loop finds out where
+		if (!undefined || kSlot) {
 			levels = (e.w >> 26) & 15u;
-			if (e.x == kNoRecord) return __uint_as_float(e.y); // a leaf within the table: the final value
+			if (e.x == kNoRecord) { // a leaf within the table: the final value
+				if (kSlot) slot = e.w & kJumpSlotMask;
+				return undefined ? 0.0f : __uint_as_float(e.y);
+			}
 			r = e.x;
 			pdf = __uint_as_float(e.y);
 			node_irr = __uint_as_float(e.z);
+			dead = undefined;
 			lox = jx; loy = jy;
 			h = 0.5f / (float)(1 << kJumpBits);
 			it0 = kJumpBits;
@@ -256,20 +280,35 @@ __device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *ju
 		const float mx = lox + h, my = loy + h;
 		int first, last;
 		quadrant(cx, cy, mx, my, first, last);
-		const float child_irr = first < 0 ? 0.0f : sel4f(first, q.i0, q.i1, q.i2, q.i3);
-		pdf = pdf * ((4.0f * child_irr) / node_irr);
-		if (pdf != pdf) return 0.0f;          // quadtree.py:1090-1092
-		if (last < 0) return pdf;             // outside every child: the reference would spin
+		if (!dead) {
+			const float child_irr = first < 0 ? 0.0f : sel4f(first, q.i0, q.i1, q.i2, q.i3);
+			pdf = pdf * ((4.0f * child_irr) / node_irr);
+			if (pdf != pdf) {                     // quadtree.py:1090-1092
+				if (!kSlot) return 0.0f;
+				dead = true;
+			}
+		}
+		if (last < 0) return dead ? 0.0f : pdf;  // outside every child: the reference would spin
 		++levels;
 		node_irr = sel4f(last, q.i0, q.i1, q.i2, q.i3);
 		const uint32_t c = sel4u(last, q.c0, q.c1, q.c2, q.c3);
 		if (last == 0 || last == 3) lox = mx;
 		if (last == 0 || last == 1) loy = my;
 		h *= 0.5f;
-		if (c == 0) return pdf * kInvFourPiF; // child is a leaf (quadtree.py:1025-1030)
+		if (c == 0) { // child is a leaf (quadtree.py:1025-1030)
+			if (kSlot && inside) slot = r * 4u + (uint32_t)last;
+			return dead ? 0.0f : pdf * kInvFourPiF;
+		}
 		r = c;
 	}
-	return pdf;
+	return dead ? 0.0f : pdf;
+}
+
+__device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                          float cx, float cy, uint32_t &levels)
+{
+	uint32_t slot;
+	return quad_pdf_t<false>(rec, jump, tree, head, cx, cy, levels, slot);
 }
 
 // QuadTree.sampleQuadTree + the pdfQuadTree call of KDTree.sample (kdtree.py:483-484,
@@ -277,15 +316,18 @@ __device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *ju
 // (quadtree.py:956, 980).  The pdf along the sampled path is accumulated on the way down;
 // it equals pdfQuadTree(dir) whenever the round trip dir -> canonical lands strictly inside
 // the sampled leaf cell, otherwise the literal second descent is taken.
-__device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
-                                            Pcg32 &rng, float &dx, float &dy, float &dz, float &pdf_out,
-                                            uint32_t &levels)
+// kSlot: also the accumulator slot of the leaf that holds the canonical form of the sampled direction.
+template <bool kSlot>
+__device__ __forceinline__ void quad_sample_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                              Pcg32 &rng, float &dx, float &dy, float &dz, float &pdf_out,
+                                              uint32_t &levels, uint32_t &slot)
 {
 	float px = 0.0f, py = 0.0f;
 	float lox = 0.0f, loy = 0.0f, size = 1.0f;
 	float pdf = 1.0f, node_irr = head.root_irr;
 	bool dead = false, reached_leaf = false;
 	uint32_t r = head.root_rec;
+	uint32_t leaf_slot = kSlotRoot; // of the node the walk stands on, should it be a leaf
 	levels = 0;
 	for (int it = 0; it < kMaxLevels + 1; ++it) {
 		// draw order per visited node: next_2d (x, y) then next_1d; the leaf uses the first two,
@@ -327,6 +369,7 @@ __device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *
 		if (k == 0 || k == 1) loy = loy + half;
 		size = half;
 		const uint32_t c = sel4u(k, q.c0, q.c1, q.c2, q.c3);
+		leaf_slot = r * 4u + (uint32_t)k;
 		r = c == 0 ? kNoRecord : c;
 	}
 	canonical_to_dir(px, py, dx, dy, dz);
@@ -335,10 +378,19 @@ __device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *
 	const bool strictly_inside = reached_leaf && qx > lox && qx < lox + size && qy > loy && qy < loy + size;
 	if (strictly_inside) {
 		pdf_out = dead ? 0.0f : pdf * kInvFourPiF;
+		slot = leaf_slot;
 	} else {
 		uint32_t lv;
-		pdf_out = quad_pdf(rec, jump, tree, head, qx, qy, lv);
+		pdf_out = quad_pdf_t<kSlot>(rec, jump, tree, head, qx, qy, lv, slot);
 	}
+}
+
+__device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                            Pcg32 &rng, float &dx, float &dy, float &dz, float &pdf_out,
+                                            uint32_t &levels)
+{
+	uint32_t slot;
+	quad_sample_t<false>(rec, jump, tree, head, rng, dx, dy, dz, pdf_out, levels, slot);
 }
 
 // addIrradiancePropagate (quadtree.py:398-441): the accumulator slot of the leaf that (cx,cy) falls
@@ -415,6 +467,12 @@ __device__ __forceinline__ void quad_find_leaf_slots2(const QuadRec *rec, LeafCu
 	// kMaxLevels records deep without reaching a leaf: not a tree this library builds
 	a.walking = false;
 	b.walking = false;
+}
+
+// the slot word of a finished cursor (see kSlotNone / kSlotRoot)
+__device__ __forceinline__ uint32_t cursor_slot(const LeafCursor &c)
+{
+	return !c.found ? kSlotNone : (c.is_root ? kSlotRoot : c.slot);
 }
 
 } // namespace pg

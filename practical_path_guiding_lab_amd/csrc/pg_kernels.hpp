@@ -42,6 +42,21 @@ void launch_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t
 void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l_final,
                             const pg_dense_records &rec, const pg_records_out &out,
                             uint32_t *d_count, hipStream_t s);
+// The record list of the split render pipeline (pg_render_wave.hip): one entry per live path and bounce in visiting
+// order, planes of stride num_rays * max_depth.  An entry holds what processPathData (path_guiding_integrator.py:
+// 434-453) needs of the vertex and -- instead of its position and directions -- the accumulators of sdTree_current
+// they lead to, found by the walks of sdTree_prev the bounce made anyway (same topology, :582).
+struct pg_list_records {
+	const uint32_t *ray_of;    // the path (lane) of the entry, 0xffffffff: the path left the scene there
+	const float *bsdf, *throughput_bsdf, *throughput_radiance; // 3 planes each (:331-341)
+	const float *nee_lum;      // luminance of the NaN-scrubbed radiance_nee (:336, 467, 471)
+	const float *wo_pdf;
+	const uint2 *slot;         // {path direction's, emitter direction's} accumulator: kSlotNone / kSlotRoot / rec * 4 + child
+	const uint32_t *tree;      // quadtree of the vertex's KD leaf; bit 31: inside the root box (counted, kdtree.py:193)
+};
+void launch_splat_list(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays, int32_t max_depth,
+                       const float *l_final, const pg_list_records &rec, const uint32_t *live_count, hipStream_t s);
+
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee,
                               uint64_t num_rays, int32_t max_depth, const float *l_final,
                               const pg_dense_records &rec, DepthCounters *dc, hipStream_t s,

@@ -356,6 +356,88 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 	count_depths_s(dc, kd_lv, did, q_lv, q_q);
 }
 
+// The split render pipeline's list (pg_list_records): processPathData + the filter of scatterDataIntoSDTree
+// (path_guiding_integrator.py:434-478) + the adds of KDTree / QuadTree.addDataPropagate (kdtree.py:180-225,
+// quadtree.py:389-464) at accumulators the entry names -- no tree is walked here: the bounce that made the vertex
+// walked sdTree_prev to these very leaves for its pdfs (stage_guide).  What is left is one gather (the path's
+// final radiance), the division chain of :434-453, and the atomics.
+__global__ __launch_bounds__(kBlock) void k_splat_list(TreeView t, AccumView a, int store_nee, uint64_t num_rays,
+                                                       int32_t max_depth, const float *__restrict__ l_final,
+                                                       pg_list_records r, const uint32_t *__restrict__ live_count)
+{
+	__shared__ long long s_val[kBlock * 4];
+	__shared__ unsigned long long s_ptr[kBlock];
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	uint64_t total = num_rays; // the first bounce visits every path, bounce b+1 the survivors of bounce b
+	for (int b = 0; b + 1 < max_depth; ++b) total += live_count[b];
+	if ((uint64_t)blockIdx.x * kBlock >= total) return;
+	const bool single = t.n_rec == 0 && t.n_trees == 1; // (first iteration: see k_process_and_splat)
+	long long v[4] = {0, 0, 0, 0};
+	for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += (uint64_t)gridDim.x * kBlock) {
+		const uint64_t g = base + threadIdx.x;
+		SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
+		if (g < total) {
+			const uint32_t ray = r.ray_of[g];
+			if (ray != kNoRay) {
+				float in[3];
+#pragma unroll
+				for (int ch = 0; ch < 3; ++ch) {
+					float out = (l_final[ch * num_rays + ray] - r.throughput_radiance[ch * S + g]) / r.throughput_bsdf[ch * S + g];
+					if (out != out) out = 0.0f;                         // :444
+					float q = out / r.bsdf[ch * S + g];
+					if (q != q) q = 0.0f;                               // :449
+					in[ch] = q;
+				}
+				float radiance = luminance(in[0], in[1], in[2]);       // :452
+				if (radiance != radiance) radiance = 0.0f;             // :466
+				const float nee_lum = r.nee_lum[g];
+				const float wp = r.wo_pdf[g];
+				const bool both_zero = (radiance == 0.0f) && (nee_lum == 0.0f); // :470-472
+				if (!both_zero && !(wp == 0.0f) && !(wp != wp)) {      // :475-478
+					const uint2 sl = r.slot[g];
+					const uint32_t tf = r.tree[g], tree = tf & 0x7fffffffu;
+					const bool inside = (tf >> 31) != 0u;
+					const float w = wp > 0.0f ? radiance / wp : 0.0f;  // quadtree.py:451
+					const float wn = wp > 0.0f ? nee_lum / wp : 0.0f;  // quadtree.py:462
+					if (sl.x != kSlotNone) {
+						const Limbs q = quantize_weight(w);
+						path.ptr = sl.x == kSlotRoot ? a.root_acc + (size_t)kAccWords * tree : a.rec_acc + (size_t)kAccWords * sl.x;
+						path.w0 = q.l0; path.w1 = q.l1; path.w2 = q.l2; path.w3 = inside ? 1 : 0;
+					} else if (inside) {
+						atomicAdd(a.leaf_count + tree, 1ull); // counted, but its direction reaches no leaf
+					}
+					if (store_nee && sl.y != kSlotNone) {
+						const Limbs q = quantize_weight(wn);
+						nee.ptr = sl.y == kSlotRoot ? a.root_acc + (size_t)kAccWords * tree : a.rec_acc + (size_t)kAccWords * sl.y;
+						nee.w0 = q.l0; nee.w1 = q.l1; nee.w2 = q.l2; nee.w3 = 0;
+					}
+				}
+			}
+		}
+		if (single) {
+			if (path.ptr) { v[0] += path.w0; v[1] += path.w1; v[2] += path.w2; v[3] += path.w3; }
+			if (nee.ptr) { v[0] += nee.w0; v[1] += nee.w1; v[2] += nee.w2; v[3] += nee.w3; }
+		} else {
+			coop_add(path, s_val, s_ptr);
+			if (store_nee) coop_add(nee, s_val, s_ptr);
+		}
+	}
+	if (single) {
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const unsigned long long sw = wave_sum_s((unsigned long long)v[k]);
+			if ((threadIdx.x & 63) == 0) s_val[(threadIdx.x >> 6) * 4 + k] = (long long)sw;
+		}
+		__syncthreads();
+		if (threadIdx.x < 4) {
+			unsigned long long tot = 0;
+			for (int w = 0; w < kBlock / 64; ++w) tot += (unsigned long long)s_val[w * 4 + threadIdx.x];
+			if (tot) atomicAdd(reinterpret_cast<unsigned long long *>(a.root_acc + threadIdx.x), tot);
+		}
+	}
+}
+
 #ifndef PG_SPLAT_GROUPS_PER_CU
 #define PG_SPLAT_GROUPS_PER_CU 64 // measured (tools/exp_splat_grid.sh): 8 -> 847, 16 -> 798, 32 -> 746, 64 -> 726, 128 -> 755 us on cornell-box
 #endif
@@ -383,14 +465,9 @@ void launch_process_records(uint64_t num_rays, int32_t max_depth, const float *l
 	                   out, d_count);
 }
 
-void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,
-                              int32_t max_depth, const float *l_final, const pg_dense_records &rec,
-                              DepthCounters *dc, hipStream_t s, const uint32_t *ray_of,
-                              const uint32_t *live_count)
+// a fixed grid striding over the tiles (the list's length is known only on the device)
+static dim3 strided_grid(uint64_t S)
 {
-	const uint64_t S = num_rays * (uint64_t)max_depth;
-	if (S == 0) return;
-	// a fixed grid striding over the tiles (the list's length is known only on the device)
 	static int cus[64] = {0};
 	int dev = 0;
 	(void)hipGetDevice(&dev);
@@ -400,7 +477,26 @@ void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_n
 		if (dev >= 0 && dev < 64) cus[dev] = n_cu;
 	}
 	const uint64_t tiles = (S + kBlock - 1) / kBlock, cap = (uint64_t)n_cu * kSplatGroupsPerCu;
-	const dim3 grid((unsigned)(tiles < cap ? tiles : cap));
+	return dim3((unsigned)(tiles < cap ? tiles : cap));
+}
+
+void launch_splat_list(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays, int32_t max_depth,
+                       const float *l_final, const pg_list_records &rec, const uint32_t *live_count, hipStream_t s)
+{
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	if (S == 0) return;
+	hipLaunchKernelGGL(k_splat_list, strided_grid(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays, max_depth, l_final, rec,
+	                   live_count);
+}
+
+void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,
+                              int32_t max_depth, const float *l_final, const pg_dense_records &rec,
+                              DepthCounters *dc, hipStream_t s, const uint32_t *ray_of,
+                              const uint32_t *live_count)
+{
+	const uint64_t S = num_rays * (uint64_t)max_depth;
+	if (S == 0) return;
+	const dim3 grid = strided_grid(S);
 	if (ray_of)
 		hipLaunchKernelGGL(k_process_and_splat<true>, grid, dim3(kBlock), 0, s, t, a, store_nee, num_rays,
 		                   max_depth, l_final, rec, dc, ray_of, live_count);

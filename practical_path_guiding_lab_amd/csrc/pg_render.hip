@@ -473,6 +473,16 @@ struct pg_render_state {
 	pg_camera cam;
 	bool have_scene = false;
 	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
+	// pg_render_overlap: kernels of one pass that do not depend on each other run on library-owned side streams
+	int overlap = 0;
+	hipStream_t side = nullptr;              // k_wave_guide beside k_wave_cast
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	~pg_render_state()
+	{
+		if (ev_fork) (void)hipEventDestroy(ev_fork);
+		if (ev_join) (void)hipEventDestroy(ev_join);
+		if (side) (void)hipStreamDestroy(side);
+	}
 	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
 	DevBuf<uint32_t> prev_quad;
 	DevBuf<uint8_t> hit0;
@@ -480,6 +490,8 @@ struct pg_render_state {
 	DevBuf<uint32_t> order[2], live_count;
 	DevBuf<uint32_t> ray_of;
 	DevBuf<float> r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee, r_wp;
+	DevBuf<uint2> r_slot;   // the split pipeline's list names accumulators instead of positions and directions
+	DevBuf<uint32_t> r_tree;
 	// optional per-kernel timing: (kind, start, stop) event triples still to be read
 	bool timing_on = false;
 	struct Ev { int kind; hipEvent_t a, b; };
@@ -544,9 +556,16 @@ static int ensure_pass_buffers(pg_context *ctx, uint64_t N, bool record)
 	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N));
 	PG_HIP(ctx, r->live_count.ensure((size_t)D + 1 + 3 * (size_t)D));
 	if (record) {
-		PG_HIP(ctx, r->ray_of.ensure(S)); PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
+		PG_HIP(ctx, r->ray_of.ensure(S));
 		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
-		PG_HIP(ctx, r->r_nee.ensure(3 * S)); PG_HIP(ctx, r->r_dnee.ensure(2 * S)); PG_HIP(ctx, r->r_wp.ensure(S));
+		PG_HIP(ctx, r->r_wp.ensure(S));
+		if (r->general < 2) { // the fused bounce kernels: position, directions, three channels of radiance_nee
+			PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
+			PG_HIP(ctx, r->r_nee.ensure(3 * S)); PG_HIP(ctx, r->r_dnee.ensure(2 * S));
+		} else {                                 // the split pipeline: accumulator slots (pg_list_records), 60 B per entry instead of 88
+			PG_HIP(ctx, r->r_nee.ensure(S));
+			PG_HIP(ctx, r->r_slot.ensure(S)); PG_HIP(ctx, r->r_tree.ensure(S));
+		}
 	}
 	return PG_OK;
 }
@@ -835,6 +854,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.rng_state = r->rng_state.p; a.rng_inc = r->rng_inc.p; a.live_count = r->live_count.p;
 	a.ray_of = r->ray_of.p; a.r_pos = r->r_pos.p; a.r_dir = r->r_dir.p; a.r_bsdf = r->r_bsdf.p; a.r_tb = r->r_tb.p;
 	a.r_tr = r->r_tr.p; a.r_nee = r->r_nee.p; a.r_dnee = r->r_dnee.p; a.r_wp = r->r_wp.p;
+	a.r_slot = r->r_slot.p; a.r_tree = r->r_tree.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
 	for (int it = 0; it < D; ++it) {
 		a.bounce = it;
@@ -845,6 +865,30 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
+			}
+			if (r->overlap & 1) {
+				// the SD-tree queries (stage 3) and the shadow rays (stage 2) both read what k_wave_shade_a left and
+				// write planes of their own: one is bound by divergent gathers into the tree, the other by the BVH
+				// walk's dependent loads -- side by side they fill each other's stalls
+				for (int stage = 0; stage < 2; ++stage) {
+					Timed t(r, s, 5 + stage);
+					launch_wave_stage(stage, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
+				}
+				PG_HIP(ctx, hipEventRecord(r->ev_fork, s));
+				PG_HIP(ctx, hipStreamWaitEvent(r->side, r->ev_fork, 0));
+				{
+					Timed t(r, r->side, 8);
+					launch_wave_stage(3, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, r->side);
+				}
+				PG_HIP(ctx, hipEventRecord(r->ev_join, r->side));
+				{
+					Timed t(r, s, 7);
+					launch_wave_stage(2, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
+				}
+				PG_HIP(ctx, hipStreamWaitEvent(s, r->ev_join, 0));
+				Timed t(r, s, 9);
+				launch_wave_stage(4, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
+				continue;
 			}
 			for (int stage = 0; stage < 5; ++stage) {
 				Timed t(r, s, 5 + stage);
@@ -876,8 +920,14 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		d.direction_nee = r->r_dnee.p; d.wo_pdf = r->r_wp.p;
 		Timed t(r, s, 2);
 		// the depth counters of an instrumented pass describe the bounce kernels only
-		launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d, nullptr, s,
-		                         r->ray_of.p, r->live_count.p);
+		if (wave) {
+			pg_list_records lr;
+			lr.ray_of = r->ray_of.p; lr.bsdf = r->r_bsdf.p; lr.throughput_bsdf = r->r_tb.p; lr.throughput_radiance = r->r_tr.p;
+			lr.nee_lum = r->r_nee.p; lr.wo_pdf = r->r_wp.p; lr.slot = r->r_slot.p; lr.tree = r->r_tree.p;
+			launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, lr, r->live_count.p, s);
+		} else
+			launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d, nullptr, s,
+			                         r->ray_of.p, r->live_count.p);
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (valid_out || sumL) {
@@ -894,6 +944,21 @@ int pg_render_split_pipeline(pg_context *ctx, int32_t on)
 {
 	if (!ctx) return PG_ERR_INVALID;
 	rstate(ctx)->split_always = on != 0;
+	return PG_OK;
+}
+
+int pg_render_overlap(pg_context *ctx, int32_t mode)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	if (mode < 0 || mode > 1) return fail(ctx, PG_ERR_INVALID, "pg_render_overlap: mode must be 0 or 1");
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	pg_render_state *r = rstate(ctx);
+	if (mode && !r->side) {
+		PG_HIP(ctx, hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+		PG_HIP(ctx, hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+		PG_HIP(ctx, hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+	}
+	r->overlap = mode;
 	return PG_OK;
 }
 
@@ -975,10 +1040,10 @@ int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
 		case 0: r->acc.generate_ms += ms; break;
 		case 1: r->acc.bounce_ms += ms; ++r->acc.bounce_launches; break;
 		case 5: r->acc.trace_ms += ms; r->acc.bounce_ms += ms; ++r->acc.trace_launches; ++r->acc.bounce_launches; break;
-		case 6: r->acc.shade_ms += ms; r->acc.bounce_ms += ms; break;
+		case 6: r->acc.shade_ms += ms; r->acc.shade_a_ms += ms; r->acc.bounce_ms += ms; break;
 		case 7: r->acc.shadow_ms += ms; r->acc.bounce_ms += ms; break;
 		case 8: r->acc.guide_ms += ms; r->acc.bounce_ms += ms; ++r->acc.guide_launches; break;
-		case 9: r->acc.shade_ms += ms; r->acc.bounce_ms += ms; break;
+		case 9: r->acc.shade_ms += ms; r->acc.shade_b_ms += ms; r->acc.bounce_ms += ms; break;
 		case 10: r->acc.tail_ms += ms; r->acc.bounce_ms += ms; break;
 		case 2: r->acc.splat_ms += ms; ++r->acc.splat_launches; break;
 		case 4: r->acc.compact_ms += ms; break;

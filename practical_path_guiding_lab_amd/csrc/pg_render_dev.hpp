@@ -1135,6 +1135,11 @@ struct RenderArgs {
 	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth
 	uint32_t *ray_of;
 	float *r_pos, *r_dir, *r_bsdf, *r_tb, *r_tr, *r_nee, *r_dnee, *r_wp;
+	// the split pipeline's list (pg_list_records): no position or directions (r_pos, r_dir, r_dnee stay unallocated) but
+	// the accumulators they lead to -- r_slot {path direction's, emitter direction's} and r_tree (the KD leaf's quadtree,
+	// bit 31: counted) -- and r_nee is one plane, the luminance of the emitter sample's share
+	uint2 *r_slot;
+	uint32_t *r_tree;
 	// mesh scenes (the split pipeline of pg_render_wave.hip): the state of a lane between two bounces is
 	// four 16-byte quads, st[q * n_lanes + lane] (a path that survives is scattered and gathered by lane
 	// number: one 16-byte access moves what four 4-byte ones would, in a quarter of the sectors) --

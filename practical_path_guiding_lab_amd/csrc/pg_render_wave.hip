@@ -47,7 +47,7 @@ enum : int {
 	WS_WO_T, WS_ETA = WS_WO_T + 3, // the direction k_wave_guide sampled from the tree (F_SMP_TREE lanes); the BSDF sample's eta
 	WS_RNG_LO, WS_RNG_HI,
 	WS_OCC,
-	WS_NEE_C, WS_WO_C = WS_NEE_C + 2, WS_PDF_NEE = WS_WO_C + 2, WS_PDF_TREE,
+	WS_PDF_NEE, WS_PDF_TREE,
 	WS_COUNT
 };
 
@@ -81,6 +81,10 @@ struct StageA {
 struct GuideOut {
 	float nee_cx, nee_cy, wo_cx, wo_cy, pdf_nee, pdf_tree;
 	v3 wo;
+	// the record's accumulators in sdTree_current (kSlotNone / kSlotRoot / rec * 4 + child, pg_descent.hpp), found by
+	// the walks of sdTree_prev this stage makes anyway; tree_flags = the KD leaf's quadtree, bit 31 = the vertex
+	// lies inside the root box and is counted (kdtree.py:193)
+	uint32_t slot_path, slot_nee, tree_flags;
 };
 
 __device__ __forceinline__ Material material_of(const RenderArgs &a, int mat, v3 refl, int level)
@@ -180,46 +184,53 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const float *s_
 	const bool active_sd_em = (flags & F_NEE_LIVE) && a.guided; // (a dead emitter sample's pdf would multiply zero: stage_a)
 	const bool do_record = a.record && (flags & F_VALID);
 	const bool smp_tree = (flags & F_SMP_TREE) != 0u, bsdf_mis = (flags & F_BSDF_MIS) != 0u;
+	// a recorded vertex names its accumulators (KDTree.addDataPropagate, kdtree.py:180-225): the leaf of its path
+	// direction and, when the emitter sample can carry energy, the leaf of the emitter direction
+	const bool nee_slot_wanted = do_record && a.store_nee && (flags & F_NEE_LIVE);
 	TreeHead head = {kNoRecord, 0.0f};
 	uint32_t tree_id = 0;
-	bool tree_known = false;
 	uint32_t lv;
 	unsigned c_kd = 0, c_kdq = 0, c_q = 0, c_qq = 0; // descent statistics for the byte model
 	g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f;
 	g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 	g.wo = wo_in;
+	g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
 	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, g.nee_cx, g.nee_cy);
-	if (active_sd_em) {
+	if (active_sd_em || smp_tree || bsdf_mis || do_record) { // one KD descent serves every query of the vertex
 		KdNode leaf;
-		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		const bool inside = inside_root(a.tree, p.x, p.y, p.z);
+		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside, leaf, lv);
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
 		head.root_irr = __uint_as_float(hv.y);
-		tree_known = true;
-		tree_id = leaf.tree;
-		g.pdf_nee = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, g.nee_cx, g.nee_cy, lv);
-		c_q += lv; ++c_qq;
+		tree_id = leaf.tree; // (outside the box: node 0's stale tree, kdtree.py:224)
+		g.tree_flags = tree_id | (inside ? 0x80000000u : 0u);
 	}
-	if ((smp_tree || bsdf_mis) && !tree_known) {
-		KdNode leaf;
-		kd_descend_grid(a.tree, s_planes, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
-		c_kd += lv; ++c_kdq;
-		const uint2 hv = gather8(a.tree.head + leaf.tree);
-		head.root_rec = hv.x;
-		head.root_irr = __uint_as_float(hv.y);
-		tree_id = leaf.tree;
+	if (active_sd_em) { // :244
+		g.pdf_nee = quad_pdf_t<true>(a.tree.rec, a.tree.jump, tree_id, head, g.nee_cx, g.nee_cy, lv, g.slot_nee);
+		c_q += lv; ++c_qq;
 	}
 	if (smp_tree) { // :301
 		float dx, dy, dz;
-		quad_sample(a.tree.rec, a.tree.jump, tree_id, head, rng, dx, dy, dz, g.pdf_tree, lv);
+		quad_sample_t<true>(a.tree.rec, a.tree.jump, tree_id, head, rng, dx, dy, dz, g.pdf_tree, lv, g.slot_path);
 		c_q += lv; ++c_qq;
 		g.wo = V(dx, dy, dz);
 	}
 	if (bsdf_mis || do_record) dir_to_canonical(g.wo.x, g.wo.y, g.wo.z, g.wo_cx, g.wo_cy);
 	if (bsdf_mis) { // :307
-		g.pdf_tree = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, g.wo_cx, g.wo_cy, lv);
+		g.pdf_tree = quad_pdf_t<true>(a.tree.rec, a.tree.jump, tree_id, head, g.wo_cx, g.wo_cy, lv, g.slot_path);
 		c_q += lv; ++c_qq;
+	}
+	// the leaves no query has walked to (unguided iterations, delta lobes, the last vertex of a path): the two
+	// walks of QuadTree.addDataPropagate (quadtree.py:443-464), in lock step
+	const bool walk_path = do_record && !smp_tree && !bsdf_mis, walk_nee = nee_slot_wanted && !active_sd_em;
+	if (walk_path || walk_nee) {
+		LeafCursor cp = leaf_cursor(a.tree.jump, tree_id, head, g.wo_cx, g.wo_cy, walk_path);
+		LeafCursor cn = leaf_cursor(a.tree.jump, tree_id, head, g.nee_cx, g.nee_cy, walk_nee);
+		quad_find_leaf_slots2(a.tree.rec, cp, cn);
+		if (walk_path) { g.slot_path = cursor_slot(cp); c_q += cp.levels; ++c_qq; }
+		if (walk_nee) { g.slot_nee = cursor_slot(cn); c_q += cn.levels; ++c_qq; }
 	}
 	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
 		atomicAdd(&a.dc->kd_levels, (unsigned long long)c_kd);
@@ -227,6 +238,13 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const float *s_
 		atomicAdd(&a.dc->quad_levels, (unsigned long long)c_q);
 		atomicAdd(&a.dc->quad_queries, (unsigned long long)c_qq);
 	}
+}
+
+// the accumulators of a recorded vertex go straight into the record list (pg_list_records, pg_kernels.hpp)
+__device__ __forceinline__ void store_slots(const RenderArgs &a, uint64_t rec_slot, const GuideOut &g)
+{
+	a.r_slot[rec_slot] = make_uint2(g.slot_path, g.slot_nee);
+	a.r_tree[rec_slot] = g.tree_flags;
 }
 
 // ---- :247-261, 302-381; returns whether the path continues, with its state for the next bounce in
@@ -277,26 +295,26 @@ __device__ __forceinline__ bool stage_b(const RenderArgs &a, Pcg32 &rng, v3 &thr
 		// the surface; the reference's throughput turns NaN there, here the path simply ends
 		if (!(woPdf > 0.0f)) bsdf_weight = V(0, 0, 0);
 	}
-	// ---- :318-346 record (a list in visiting order, see pg_render.hip) ----
+	// ---- :318-346 record (a list in visiting order, see pg_render.hip).  The list of the split pipeline holds what
+	// processPathData (:434-453) needs of a vertex -- the throughputs, the BSDF weight, woPdf, the luminance of the
+	// emitter sample's share -- and, instead of position and directions, the accumulators they lead to (store_slots) ----
 	const bool do_record = a.record && valid;
 	if (a.record) a.ray_of[rec_slot] = valid ? (uint32_t)lane : 0xffffffffu;
 	if (do_record) {
 		const uint64_t S = N * (uint64_t)D;
 		const uint64_t s = rec_slot;
-		const v3 p = A.p;
-		a.r_pos[s] = p.x; a.r_pos[S + s] = p.y; a.r_pos[2 * S + s] = p.z;
-		a.r_dir[s] = g.wo_cx; a.r_dir[S + s] = g.wo_cy;
 		a.r_bsdf[s] = bsdf_weight.x; a.r_bsdf[S + s] = bsdf_weight.y; a.r_bsdf[2 * S + s] = bsdf_weight.z;
 		a.r_tb[s] = thr.x; a.r_tb[S + s] = thr.y; a.r_tb[2 * S + s] = thr.z;
 		a.r_tr[s] = L.x; a.r_tr[S + s] = L.y; a.r_tr[2 * S + s] = L.z;
-		if (a.store_nee) {
-			const v3 rn = vdiv(Lr_dir, thr);
-			a.r_nee[s] = rn.x; a.r_nee[S + s] = rn.y; a.r_nee[2 * S + s] = rn.z;
-			a.r_dnee[s] = g.nee_cx; a.r_dnee[S + s] = g.nee_cy;
-		} else {
-			a.r_nee[s] = 0.0f; a.r_nee[S + s] = 0.0f; a.r_nee[2 * S + s] = 0.0f;
-			a.r_dnee[s] = 0.0f; a.r_dnee[S + s] = 0.0f;
+		float nee_lum = 0.0f;
+		if (a.store_nee) { // :336, and the NaN scrub + luminance of :467, 471 (the only use of the three channels)
+			v3 rn = vdiv(Lr_dir, thr);
+			if (rn.x != rn.x) rn.x = 0.0f;
+			if (rn.y != rn.y) rn.y = 0.0f;
+			if (rn.z != rn.z) rn.z = 0.0f;
+			nee_lum = luminance(rn.x, rn.y, rn.z);
 		}
+		a.r_nee[s] = nee_lum;
 		a.r_wp[s] = woPdf;
 	}
 	// ---- :352-381 advance ----
@@ -580,8 +598,14 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	// (the BSDF-sampled direction of a lane that keeps it; a lane that samples the tree has none to evaluate)
 	const v3 wo_in = (flags & F_SMP_TREE) ? V(0, 0, 0) : ws3(a, WS_U, tid);
 	stage_guide(a, s_planes, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), wo_in, flags, g);
-	wsput(a, WS_NEE_C, tid, g.nee_cx); wsput(a, WS_NEE_C + 1, tid, g.nee_cy);
-	wsput(a, WS_WO_C, tid, g.wo_cx); wsput(a, WS_WO_C + 1, tid, g.wo_cy);
+	if (a.record && (flags & F_VALID)) { // the entry k_wave_shade_b fills for this vertex
+		uint64_t rec_base = 0;
+		if (a.bounce > 0) {
+			rec_base = a.n_lanes;
+			for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+		}
+		store_slots(a, rec_base + tid, g);
+	}
 	wsput(a, WS_PDF_NEE, tid, g.pdf_nee); wsput(a, WS_PDF_TREE, tid, g.pdf_tree);
 	if (flags & F_SMP_TREE) {
 		wsput3(a, WS_WO_T, tid, g.wo);
@@ -630,12 +654,9 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 		A.eta = wsf(a, WS_ETA, tid);
 		GuideOut g;
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
+		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u; // (k_wave_guide has put them into the record list)
 		g.wo = A.wo; // (k_wave_guide's direction for the lanes that sample the tree)
-		if (guide_has_work(a, A.flags)) {
-			g.nee_cx = wsf(a, WS_NEE_C, tid); g.nee_cy = wsf(a, WS_NEE_C + 1, tid);
-			g.wo_cx = wsf(a, WS_WO_C, tid); g.wo_cy = wsf(a, WS_WO_C + 1, tid);
-			g.pdf_nee = wsf(a, WS_PDF_NEE, tid); g.pdf_tree = wsf(a, WS_PDF_TREE, tid);
-		}
+		if (guide_has_work(a, A.flags)) { g.pdf_nee = wsf(a, WS_PDF_NEE, tid); g.pdf_tree = wsf(a, WS_PDF_TREE, tid); }
 		const bool occluded = (A.flags & F_NEED_SHADOW) && wsu(a, WS_OCC, tid) != 0u;
 		Pcg32 rng;
 		rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
@@ -735,8 +756,10 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 			}
 			GuideOut g;
 			g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
+			g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
 			g.wo = A.wo;
 			if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, A.wo, A.flags, g);
+			if (a.record && (A.flags & F_VALID)) store_slots(a, slot, g);
 			bool delta;
 			alive = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, slot, (uint32_t)depth, ray_o, ray_d, prev_pdf, delta);
 			prev_p = A.p;

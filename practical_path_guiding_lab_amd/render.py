@@ -45,11 +45,12 @@ class WavefrontScene:
     """Device-resident scene (quads + camera) implementing the `trace_pass` protocol of
     PathGuidingIntegrator.sample()."""
 
-    def __init__(self, scene: Scene, split_pipeline: bool = False):
+    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0):
         """split_pipeline: run the bounce as the split pipeline also for a scene the fused kernel could
         run (pg_render_split_pipeline: same results, the SD-tree queries as a kernel of their own)."""
         self.scene = scene
         self.split_pipeline = bool(split_pipeline)
+        self.overlap = int(overlap)  # pg_render_overlap: independent kernels of a pass side by side (same results)
         self._uploaded_to = None
 
     # what main.py reads from mi.Scene (main.py:48-53)
@@ -101,6 +102,7 @@ class WavefrontScene:
             d.n_texels, d.texels = txl.shape[0], (txl.ctypes.data if txl.size else None)
             d.srgb_lut = lut.ctypes.data
         N.check(tree._h, tree._lib.pg_render_split_pipeline(tree._h, 1 if self.split_pipeline else 0))
+        N.check(tree._h, tree._lib.pg_render_overlap(tree._h, self.overlap))
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 
