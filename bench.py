@@ -101,6 +101,8 @@ def parse():
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
     ap.add_argument("--overlap", type=int, default=0, help="pg_render_overlap mode of the timed steps")
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at once")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
@@ -312,7 +314,7 @@ def run_render(args):
     tree = integ.sdTree
     npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
-    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap)
+    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap, in_flight=args.in_flight)
     tiles = world > 1 and args.shard == "tiles"
     if tiles:
         ws.set_shard(rank, world, 4)

@@ -336,7 +336,12 @@ typedef struct pg_pass_params {
 	uint32_t seed;    /* sampler seed of the pass (main.py:218: initial_seed + cumm_spp) */
 	int32_t spp;      /* samples per pixel traced by this pass; lane = pixel*spp + s (:414-417) */
 	int32_t rr_depth; /* Russian roulette from this depth on (:39, 375) */
-	int32_t reserved;
+	/* 0 or 1: the set of pass buffers this pass uses.  The passes of an iteration are independent (main.py:208-218 seeds
+	 * each with initial_seed + cumm_spp), so two may be on the device at once: issue them alternately with slot 0 on one
+	 * stream and slot 1 on another.  The per-pixel sums are still added in the order the passes were issued (the library
+	 * orders the two streams there); sdTree_current receives integer adds, whose order is free.  Passes of one slot must
+	 * be issued on one stream.  0 everywhere = the reference's one-pass-at-a-time behaviour. */
+	int32_t slot;
 	/* image tile traced by this call (multi-GPU sharding): pixels [pixel_begin, pixel_begin +
 	 * pixel_count) in row-major film order; pixel_count 0 = up to the end of the film.  Sampler
 	 * streams are keyed by the global lane id, so the union of tiles equals the full-frame pass.

@@ -83,7 +83,7 @@ class pg_scene_desc(C.Structure):
 
 
 class pg_pass_params(C.Structure):
-    _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32), ("slot", C.c_int32),
                 ("pixel_begin", C.c_uint64), ("pixel_count", C.c_uint64),
                 ("stripe_rows", C.c_uint32), ("stripe_index", C.c_uint32), ("stripe_count", C.c_uint32), ("reserved2", C.c_uint32)]
 

@@ -455,34 +455,17 @@ __global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W,
 
 using namespace pg;
 
-// library-owned renderer state
-struct pg_render_state {
-	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior, tri_normals, tri_uvs, srgb_lut;
-	DevBuf<uint32_t> textures, texels;
-	bool have_tri_normals = false, have_tri_uvs = false;
+// The buffers of one pass in flight.  pg_pass_params.slot picks one of two sets, so that two passes -- issued by the
+// caller on two streams -- can be on the device at once: a pass is a chain of kernels bound by different units (BVH
+// walks and SD-tree queries by the vector-memory path, shading by the vector ALUs and HBM, the splat by L2 atomics),
+// and two chains out of step fill each other's gaps.  Everything a pass writes is in its set, except sdTree_current
+// (integer atomics: any order) and the per-pixel sums (ordered between the sets by events, pg_render_pass).
+struct PassBuf {
 	// mesh scenes: ray origins, the per-bounce workspace and the BVH stacks' overflow strips (pg_render_wave.hip)
 	DevBuf<uint4> st;
 	DevBuf<uint32_t> ws;
 	DevBuf<uint2> bvh_ovf;
 	DevBuf<uint32_t> shadow_list;
-	float bsphere[4] = {0, 0, 0, 0};
-	DevBuf<uint32_t> bvh;
-	DevBuf<int32_t> emitters;
-	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0, n_bvh_nodes = 0;
-	int general = 0; // feature level of the kernels to launch (0 cornell-box class, 1 veach-mis class, 2 everything)
-	pg_camera cam;
-	bool have_scene = false;
-	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
-	// pg_render_overlap: kernels of one pass that do not depend on each other run on library-owned side streams
-	int overlap = 0;
-	hipStream_t side = nullptr;              // k_wave_guide beside k_wave_cast
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	~pg_render_state()
-	{
-		if (ev_fork) (void)hipEventDestroy(ev_fork);
-		if (ev_join) (void)hipEventDestroy(ev_join);
-		if (side) (void)hipStreamDestroy(side);
-	}
 	DevBuf<float> ray_d, thr, prev_p, prev_pdf;
 	DevBuf<uint32_t> prev_quad;
 	DevBuf<uint8_t> hit0;
@@ -492,6 +475,36 @@ struct pg_render_state {
 	DevBuf<float> r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee, r_wp;
 	DevBuf<uint2> r_slot;   // the split pipeline's list names accumulators instead of positions and directions
 	DevBuf<uint32_t> r_tree;
+	// pg_render_overlap: k_wave_guide beside k_wave_cast on a library-owned stream
+	hipStream_t side = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipEvent_t ev_finish = nullptr; // recorded behind this set's k_finish: the other set's next k_finish waits for it
+	bool finish_recorded = false;
+	~PassBuf()
+	{
+		if (ev_fork) (void)hipEventDestroy(ev_fork);
+		if (ev_join) (void)hipEventDestroy(ev_join);
+		if (ev_finish) (void)hipEventDestroy(ev_finish);
+		if (side) (void)hipStreamDestroy(side);
+	}
+};
+
+// library-owned renderer state
+struct pg_render_state {
+	DevBuf<float> quads, spheres, mats, boxes, tris, dir_lights, ior, tri_normals, tri_uvs, srgb_lut;
+	DevBuf<uint32_t> textures, texels;
+	bool have_tri_normals = false, have_tri_uvs = false;
+	float bsphere[4] = {0, 0, 0, 0};
+	DevBuf<uint32_t> bvh;
+	DevBuf<int32_t> emitters;
+	int n_quads = 0, n_spheres = 0, n_emitters = 0, n_boxes = 0, n_bvh_nodes = 0;
+	int general = 0; // feature level of the kernels to launch (0 cornell-box class, 1 veach-mis class, 2 everything)
+	pg_camera cam;
+	bool have_scene = false;
+	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
+	int overlap = 0;           // pg_render_overlap
+	PassBuf pb[2];
+	int last_slot = 0;         // of the most recent pass (pg_render_live_counts)
 	// optional per-kernel timing: (kind, start, stop) event triples still to be read
 	bool timing_on = false;
 	struct Ev { int kind; hipEvent_t a, b; };
@@ -535,36 +548,37 @@ void pg::destroy_render_state(pg_context *ctx)
 // The buffers a pass over n_lanes lanes needs (the reference allocates its numRays x max_depth record
 // arrays in setup(), path_guiding_integrator.py:93): per-lane path state, the live lists, the record
 // list, and for mesh scenes the ray origins, the per-bounce workspace and the BVH stacks' overflow strips.
-static int ensure_pass_buffers(pg_context *ctx, uint64_t N, bool record)
+static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool record)
 {
 	pg_render_state *r = ctx->render;
+	PassBuf &b = r->pb[slot];
 	const int D = ctx->max_depth;
 	const uint64_t S = N * (uint64_t)D;
-	PG_HIP(ctx, r->hit0.ensure(N));
+	PG_HIP(ctx, b.hit0.ensure(N));
 	if (r->general < 2) {
-		PG_HIP(ctx, r->ray_d.ensure(3 * N)); PG_HIP(ctx, r->thr.ensure(3 * N));
-		PG_HIP(ctx, r->prev_p.ensure(3 * N)); PG_HIP(ctx, r->prev_pdf.ensure(N));
-		PG_HIP(ctx, r->prev_quad.ensure(N)); PG_HIP(ctx, r->rng_state.ensure(N));
+		PG_HIP(ctx, b.ray_d.ensure(3 * N)); PG_HIP(ctx, b.thr.ensure(3 * N));
+		PG_HIP(ctx, b.prev_p.ensure(3 * N)); PG_HIP(ctx, b.prev_pdf.ensure(N));
+		PG_HIP(ctx, b.prev_quad.ensure(N)); PG_HIP(ctx, b.rng_state.ensure(N));
 	} else {
-		PG_HIP(ctx, r->st.ensure(4 * N));
-		PG_HIP(ctx, r->ws.ensure((size_t)wave_workspace_planes() * N));
-		PG_HIP(ctx, r->shadow_list.ensure(N));
+		PG_HIP(ctx, b.st.ensure(4 * N));
+		PG_HIP(ctx, b.ws.ensure((size_t)wave_workspace_planes() * N));
+		PG_HIP(ctx, b.shadow_list.ensure(N));
 		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
-		PG_HIP(ctx, r->bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
+		PG_HIP(ctx, b.bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
 	}
-	PG_HIP(ctx, r->rng_inc.ensure(N));
-	PG_HIP(ctx, r->order[0].ensure(N)); PG_HIP(ctx, r->order[1].ensure(N));
-	PG_HIP(ctx, r->live_count.ensure((size_t)D + 1 + 3 * (size_t)D));
+	PG_HIP(ctx, b.rng_inc.ensure(N));
+	PG_HIP(ctx, b.order[0].ensure(N)); PG_HIP(ctx, b.order[1].ensure(N));
+	PG_HIP(ctx, b.live_count.ensure((size_t)D + 1 + 3 * (size_t)D));
 	if (record) {
-		PG_HIP(ctx, r->ray_of.ensure(S));
-		PG_HIP(ctx, r->r_bsdf.ensure(3 * S)); PG_HIP(ctx, r->r_tb.ensure(3 * S)); PG_HIP(ctx, r->r_tr.ensure(3 * S));
-		PG_HIP(ctx, r->r_wp.ensure(S));
+		PG_HIP(ctx, b.ray_of.ensure(S));
+		PG_HIP(ctx, b.r_bsdf.ensure(3 * S)); PG_HIP(ctx, b.r_tb.ensure(3 * S)); PG_HIP(ctx, b.r_tr.ensure(3 * S));
+		PG_HIP(ctx, b.r_wp.ensure(S));
 		if (r->general < 2) { // the fused bounce kernels: position, directions, three channels of radiance_nee
-			PG_HIP(ctx, r->r_pos.ensure(3 * S)); PG_HIP(ctx, r->r_dir.ensure(2 * S));
-			PG_HIP(ctx, r->r_nee.ensure(3 * S)); PG_HIP(ctx, r->r_dnee.ensure(2 * S));
+			PG_HIP(ctx, b.r_pos.ensure(3 * S)); PG_HIP(ctx, b.r_dir.ensure(2 * S));
+			PG_HIP(ctx, b.r_nee.ensure(3 * S)); PG_HIP(ctx, b.r_dnee.ensure(2 * S));
 		} else {                                 // the split pipeline: accumulator slots (pg_list_records), 60 B per entry instead of 88
-			PG_HIP(ctx, r->r_nee.ensure(S));
-			PG_HIP(ctx, r->r_slot.ensure(S)); PG_HIP(ctx, r->r_tree.ensure(S));
+			PG_HIP(ctx, b.r_nee.ensure(S));
+			PG_HIP(ctx, b.r_slot.ensure(S)); PG_HIP(ctx, b.r_tree.ensure(S));
 		}
 	}
 	return PG_OK;
@@ -796,16 +810,20 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	if (S > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_render_pass: more than 2^32 record slots in one pass");
 	const bool record = !ctx->is_final;
 	const bool wave = r->general >= 2; // mesh scenes: the split pipeline
+	if (prm->slot < 0 || prm->slot > 1) return fail(ctx, PG_ERR_INVALID, "pg_render_pass: slot must be 0 or 1");
+	const int slot = prm->slot;
+	PassBuf &b = r->pb[slot];
+	r->last_slot = slot;
 	if (sumL && film > ctx->num_rays)
 		return fail(ctx, PG_ERR_INVALID, "pg_render_pass: sumL/sumL2 are sized by pg_setup's num_rays, which is smaller than the film");
 	{
-		const int rc = ensure_pass_buffers(ctx, N, record);
+		const int rc = ensure_pass_buffers(ctx, slot, N, record);
 		if (rc != PG_OK) return rc;
 	}
 	// counters of a pass, zeroed together: live_count[D + 1] ([D]: entries handed out by the tail launch), then for
 	// mesh scenes cast_count[2 D] and shadow_count[D] of the persistent ray-casting kernels
 	const size_t n_counters = (size_t)D + 1 + 3 * (size_t)D;
-	PG_HIP(ctx, hipMemsetAsync(r->live_count.p, 0, n_counters * sizeof(uint32_t), s));
+	PG_HIP(ctx, hipMemsetAsync(b.live_count.p, 0, n_counters * sizeof(uint32_t), s));
 	RenderArgs a;
 	a.tree = ctx->view();
 	a.shapes.quads = r->quads.p;
@@ -817,12 +835,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.textures = r->textures.p;
 	a.shapes.texels = r->texels.p;
 	a.shapes.srgb_lut = r->srgb_lut.p;
-	a.st = r->st.p;
-	a.ws = r->ws.p;
-	a.bvh_ovf = r->bvh_ovf.p;
-	a.cast_count = r->live_count.p + (D + 1);
-	a.shadow_count = r->live_count.p + (D + 1) + 2 * D;
-	a.shadow_list = r->shadow_list.p;
+	a.st = b.st.p;
+	a.ws = b.ws.p;
+	a.bvh_ovf = b.bvh_ovf.p;
+	a.cast_count = b.live_count.p + (D + 1);
+	a.shadow_count = b.live_count.p + (D + 1) + 2 * D;
+	a.shadow_list = b.shadow_list.p;
 	a.shapes.bvh = r->bvh.p;
 	a.shapes.n_bvh_nodes = r->n_bvh_nodes;
 	a.shapes.n_quads = r->n_quads;
@@ -849,24 +867,29 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.frac = ctx->bsdf_fraction;
 	a.seed = prm->seed;
 	a.dc = ctx->dc_on ? ctx->dc : nullptr;
-	a.ray_d = r->ray_d.p; a.thr = r->thr.p; a.L = L_out; a.prev_p = r->prev_p.p;
-	a.prev_pdf = r->prev_pdf.p; a.prev_quad = r->prev_quad.p; a.hit0 = r->hit0.p;
-	a.rng_state = r->rng_state.p; a.rng_inc = r->rng_inc.p; a.live_count = r->live_count.p;
-	a.ray_of = r->ray_of.p; a.r_pos = r->r_pos.p; a.r_dir = r->r_dir.p; a.r_bsdf = r->r_bsdf.p; a.r_tb = r->r_tb.p;
-	a.r_tr = r->r_tr.p; a.r_nee = r->r_nee.p; a.r_dnee = r->r_dnee.p; a.r_wp = r->r_wp.p;
-	a.r_slot = r->r_slot.p; a.r_tree = r->r_tree.p;
+	a.ray_d = b.ray_d.p; a.thr = b.thr.p; a.L = L_out; a.prev_p = b.prev_p.p;
+	a.prev_pdf = b.prev_pdf.p; a.prev_quad = b.prev_quad.p; a.hit0 = b.hit0.p;
+	a.rng_state = b.rng_state.p; a.rng_inc = b.rng_inc.p; a.live_count = b.live_count.p;
+	a.ray_of = b.ray_of.p; a.r_pos = b.r_pos.p; a.r_dir = b.r_dir.p; a.r_bsdf = b.r_bsdf.p; a.r_tb = b.r_tb.p;
+	a.r_tr = b.r_tr.p; a.r_nee = b.r_nee.p; a.r_dnee = b.r_dnee.p; a.r_wp = b.r_wp.p;
+	a.r_slot = b.r_slot.p; a.r_tree = b.r_tree.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
 	for (int it = 0; it < D; ++it) {
 		a.bounce = it;
 		a.last = it + 1 == D ? 1 : 0;
-		a.order_in = r->order[it & 1].p;
-		a.order_out = r->order[(it + 1) & 1].p;
+		a.order_in = b.order[it & 1].p;
+		a.order_out = b.order[(it + 1) & 1].p;
 		if (wave) { // pg_render_wave.hip: five kernels per bounce, each timed on its own (kinds 5-9; 10 = tail)
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
 			}
 			if (r->overlap & 1) {
+				if (!b.side) {
+					PG_HIP(ctx, hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking));
+					PG_HIP(ctx, hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
+					PG_HIP(ctx, hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
+				}
 				// the SD-tree queries (stage 3) and the shadow rays (stage 2) both read what k_wave_shade_a left and
 				// write planes of their own: one is bound by divergent gathers into the tree, the other by the BVH
 				// walk's dependent loads -- side by side they fill each other's stalls
@@ -874,18 +897,18 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 					Timed t(r, s, 5 + stage);
 					launch_wave_stage(stage, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
 				}
-				PG_HIP(ctx, hipEventRecord(r->ev_fork, s));
-				PG_HIP(ctx, hipStreamWaitEvent(r->side, r->ev_fork, 0));
+				PG_HIP(ctx, hipEventRecord(b.ev_fork, s));
+				PG_HIP(ctx, hipStreamWaitEvent(b.side, b.ev_fork, 0));
 				{
-					Timed t(r, r->side, 8);
-					launch_wave_stage(3, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, r->side);
+					Timed t(r, b.side, 8);
+					launch_wave_stage(3, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, b.side);
 				}
-				PG_HIP(ctx, hipEventRecord(r->ev_join, r->side));
+				PG_HIP(ctx, hipEventRecord(b.ev_join, b.side));
 				{
 					Timed t(r, s, 7);
 					launch_wave_stage(2, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
 				}
-				PG_HIP(ctx, hipStreamWaitEvent(s, r->ev_join, 0));
+				PG_HIP(ctx, hipStreamWaitEvent(s, b.ev_join, 0));
 				Timed t(r, s, 9);
 				launch_wave_stage(4, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
 				continue;
@@ -915,26 +938,35 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	PG_HIP(ctx, hipGetLastError());
 	if (record) {
 		pg_dense_records d;
-		d.active = nullptr; d.position = r->r_pos.p; d.direction = r->r_dir.p; d.bsdf = r->r_bsdf.p;
-		d.throughput_bsdf = r->r_tb.p; d.throughput_radiance = r->r_tr.p; d.radiance_nee = r->r_nee.p;
-		d.direction_nee = r->r_dnee.p; d.wo_pdf = r->r_wp.p;
+		d.active = nullptr; d.position = b.r_pos.p; d.direction = b.r_dir.p; d.bsdf = b.r_bsdf.p;
+		d.throughput_bsdf = b.r_tb.p; d.throughput_radiance = b.r_tr.p; d.radiance_nee = b.r_nee.p;
+		d.direction_nee = b.r_dnee.p; d.wo_pdf = b.r_wp.p;
 		Timed t(r, s, 2);
 		// the depth counters of an instrumented pass describe the bounce kernels only
 		if (wave) {
 			pg_list_records lr;
-			lr.ray_of = r->ray_of.p; lr.bsdf = r->r_bsdf.p; lr.throughput_bsdf = r->r_tb.p; lr.throughput_radiance = r->r_tr.p;
-			lr.nee_lum = r->r_nee.p; lr.wo_pdf = r->r_wp.p; lr.slot = r->r_slot.p; lr.tree = r->r_tree.p;
-			launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, lr, r->live_count.p, s);
+			lr.ray_of = b.ray_of.p; lr.bsdf = b.r_bsdf.p; lr.throughput_bsdf = b.r_tb.p; lr.throughput_radiance = b.r_tr.p;
+			lr.nee_lum = b.r_nee.p; lr.wo_pdf = b.r_wp.p; lr.slot = b.r_slot.p; lr.tree = b.r_tree.p;
+			launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, lr, b.live_count.p, s);
 		} else
 			launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d, nullptr, s,
-			                         r->ray_of.p, r->live_count.p);
+			                         b.ray_of.p, b.live_count.p);
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (valid_out || sumL) {
+		// the per-pixel sums are read, added to and written back (fp32: the order of the passes is part of the result,
+		// :400-429): a pass of the other buffer set that was issued before this one finishes its sums first
+		PassBuf &other = r->pb[1 - slot];
+		if (sumL && other.finish_recorded) PG_HIP(ctx, hipStreamWaitEvent(s, other.ev_finish, 0));
 		Timed t(r, s, 3);
 		hipLaunchKernelGGL(k_finish, dim3((unsigned)((P + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, s, a, valid_out,
 		                   sumL, sumL2);
 		PG_HIP(ctx, hipGetLastError());
+		if (sumL) {
+			if (!b.ev_finish) PG_HIP(ctx, hipEventCreateWithFlags(&b.ev_finish, hipEventDisableTiming));
+			PG_HIP(ctx, hipEventRecord(b.ev_finish, s));
+			b.finish_recorded = true;
+		}
 	}
 	if (r->timing_on) ++r->acc.passes;
 	return PG_OK;
@@ -951,14 +983,7 @@ int pg_render_overlap(pg_context *ctx, int32_t mode)
 {
 	if (!ctx) return PG_ERR_INVALID;
 	if (mode < 0 || mode > 1) return fail(ctx, PG_ERR_INVALID, "pg_render_overlap: mode must be 0 or 1");
-	PG_HIP(ctx, hipSetDevice(ctx->device));
-	pg_render_state *r = rstate(ctx);
-	if (mode && !r->side) {
-		PG_HIP(ctx, hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
-		PG_HIP(ctx, hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
-		PG_HIP(ctx, hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
-	}
-	r->overlap = mode;
+	rstate(ctx)->overlap = mode; // (the side stream of a buffer set is made by the first pass that needs it)
 	return PG_OK;
 }
 
@@ -970,7 +995,7 @@ int pg_render_reserve(pg_context *ctx, uint64_t n_lanes)
 	if (ctx->max_depth <= 0 || n_lanes == 0) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: max_depth and n_lanes must be > 0");
 	if (n_lanes * (uint64_t)ctx->max_depth > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: more than 2^32 record slots in one pass");
 	PG_HIP(ctx, hipSetDevice(ctx->device));
-	return ensure_pass_buffers(ctx, n_lanes, true);
+	return ensure_pass_buffers(ctx, 0, n_lanes, true); // (a second set, pg_pass_params.slot 1, is allocated by its first pass)
 }
 
 int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)
@@ -1011,12 +1036,13 @@ int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, flo
 int pg_render_live_counts(pg_context *ctx, uint32_t *out, int32_t n)
 {
 	if (!ctx || !out || n < 0) return PG_ERR_INVALID;
-	if (!ctx->render || !ctx->render->live_count.p) return fail(ctx, PG_ERR_INVALID, "pg_render_live_counts: no pass rendered yet");
+	if (!ctx->render || !ctx->render->pb[ctx->render->last_slot].live_count.p) return fail(ctx, PG_ERR_INVALID, "pg_render_live_counts: no pass rendered yet");
+	PassBuf &b = ctx->render->pb[ctx->render->last_slot];
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	PG_HIP(ctx, hipDeviceSynchronize());
 	int m = n < ctx->max_depth ? n : ctx->max_depth;
-	if ((size_t)m > ctx->render->live_count.cap) m = (int)ctx->render->live_count.cap;
-	PG_HIP(ctx, hipMemcpy(out, ctx->render->live_count.p, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	if ((size_t)m > b.live_count.cap) m = (int)b.live_count.cap;
+	PG_HIP(ctx, hipMemcpy(out, b.live_count.p, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return PG_OK;
 }
 

@@ -528,9 +528,16 @@ __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 	}
 }
 
+// (A/B switch: waves per SIMD the two shading kernels are compiled for; default = what their registers allow)
+#ifdef PG_SHADE_WAVES
+#define PG_SHADE_OCC __attribute__((amdgpu_waves_per_eu(PG_SHADE_WAVES)))
+#else
+#define PG_SHADE_OCC
+#endif
+
 // ---- :189-220, 272-297 ----
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArgs a)
 {
 	uint64_t tid, lane;
 	bool alive;
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 
 // ---- :247-261, 302-381 ----
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArgs a)
 {
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;

@@ -49,10 +49,21 @@ class PathGuidingIntegrator:
         self.sumL2 = None
         self.gt_mask = None
         self._bbox = None
+        # passes in flight on streams of their own (WavefrontScene(in_flight=2)): `_epoch` counts the changes a later pass
+        # has to see (the scene makes its streams wait for the current one when it moves), `_join()` makes the current
+        # stream wait for the passes before anything here reads what they write
+        self._epoch = 0
+        self._inflight_scene = None
 
     # ---- path_guiding_integrator.py:77-105 ---------------------------------------------------
+    def _join(self) -> None:
+        if self._inflight_scene is not None:
+            self._inflight_scene.join()
+        self._epoch += 1
+
     def setup(self, numRays: int, bbox_min, bbox_max, sdTreeMaxDepth: int = 10, quadTreeMaxDepth: int = 30,
               isStoreNEERadiance: bool = True, bsdfSamplingFraction: float = 0.5) -> None:
+        self._join()
         if int(numRays) != self.numRays:
             self.gt_mask = None  # (one entry per film pixel: a mask does not outlive a change of the film)
         self.numRays = int(numRays)
@@ -65,11 +76,13 @@ class PathGuidingIntegrator:
         self.resetVarianceCounter()
 
     def resetVarianceCounter(self) -> None:  # :108-110
+        self._join()
         # (the ground-truth mask is NOT part of the counters: every driver resets them at the top of an iteration)
         self.sumL = torch.zeros((3, max(self.numRays, 1)), dtype=torch.float32, device=self.device)
         self.sumL2 = torch.zeros_like(self.sumL)
 
     def setIteration(self, iteration: int, isFinalIter: bool) -> None:  # :121-123
+        self._join()
         self.iteration = int(iteration)
         self.isFinalIter = bool(isFinalIter)
         self.sdTree.setIteration(self.iteration, self.isFinalIter)
@@ -115,6 +128,7 @@ class PathGuidingIntegrator:
         return float((per_pixel if m is None else per_pixel[m]).mean().item())
 
     def computeMSE(self, spp: float, groundTruth: torch.Tensor, sums=None) -> float:
+        self._join()
         sumL = self.sumL if sums is None else sums[0]
         L = sumL / spp
         mse = (L - groundTruth) ** 2
@@ -122,6 +136,7 @@ class PathGuidingIntegrator:
         return self._gt_mean(mse)
 
     def computeVariance(self, spp: float, groundTruth: Optional[torch.Tensor] = None, sums=None) -> float:
+        self._join()
         sumL, sumL2 = (self.sumL, self.sumL2) if sums is None else sums
         if groundTruth is not None:
             variance = (sumL2 / spp) - (groundTruth * groundTruth)
@@ -139,15 +154,18 @@ class PathGuidingIntegrator:
     def refineAndPrepareSDTreeForNextIteration(self, all_reduce=None) -> None:
         """all_reduce: optional callable(int64 tensor) -> None summing the accumulators over ranks
         (torch.distributed.all_reduce on the RCCL group) before the deterministic refine."""
+        self._join()
         if all_reduce is not None:
             all_reduce(self.sdTree.accumulators())
         self.sdTree.refineAndPrepare()
 
     # ---- files (:589-615) -----------------------------------------------------------------------
     def saveSDTreeToFile(self, fileName: str) -> None:
+        self._join()
         self.sdTree.saveToFile(fileName)
 
     def loadSDTreeFromFile(self, fileName: str) -> None:
+        self._join()
         self.sdTree.loadFromFile(fileName)
         self.isStoreNEERadiance = self.sdTree.store_nee
 

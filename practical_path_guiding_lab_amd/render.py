@@ -45,12 +45,21 @@ class WavefrontScene:
     """Device-resident scene (quads + camera) implementing the `trace_pass` protocol of
     PathGuidingIntegrator.sample()."""
 
-    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0):
+    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0, in_flight: int = 1):
         """split_pipeline: run the bounce as the split pipeline also for a scene the fused kernel could
         run (pg_render_split_pipeline: same results, the SD-tree queries as a kernel of their own)."""
         self.scene = scene
         self.split_pipeline = bool(split_pipeline)
         self.overlap = int(overlap)  # pg_render_overlap: independent kernels of a pass side by side (same results)
+        # in_flight = 2: consecutive passes alternate between two buffer sets (pg_pass_params.slot) and two streams of
+        # their own, so that two are on the device at once (the passes of an iteration are independent, main.py:208-218;
+        # same results).  What a pass returns is then valid once join() has made the current stream wait for them.
+        if in_flight not in (1, 2):
+            raise ValueError("in_flight must be 1 or 2")
+        self.in_flight = int(in_flight)
+        self._streams = None
+        self._n_pass = 0
+        self._seen_epoch = None
         self._uploaded_to = None
 
     # what main.py reads from mi.Scene (main.py:48-53)
@@ -146,6 +155,13 @@ class WavefrontScene:
         if n:
             N.check(tree._h, tree._lib.pg_render_reserve(tree._h, n))
 
+    def join(self) -> None:
+        """in_flight = 2: the current stream waits for every pass issued so far (no host synchronisation)."""
+        if self._streams is not None:
+            cur = torch.cuda.current_stream()
+            for st in self._streams:
+                cur.wait_stream(st)
+
     @property
     def sharded(self) -> bool:
         return self.stripe is not None or self.pixel_range is not None
@@ -163,20 +179,41 @@ class WavefrontScene:
             begin, count = self.pixel_range if self.pixel_range is not None else (0, cam.width * cam.height)
             stripe = (0, 0, 0)
         n = count * spp
-        L = torch.empty((3, n), dtype=torch.float32, device=tree.device)
-        valid = torch.empty(n, dtype=torch.uint8, device=tree.device)
-        if n == 0:
-            return L, valid, spp
-        p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth), 0, begin, count,
-                             stripe[0], stripe[1], stripe[2], 0)
         if accumulate and tuple(integrator.sumL.shape) != (3, cam.width * cam.height):
             # k_finish indexes the sums by film pixel: setup(numRays) must have been given the film size
             raise ValueError(f"integrator.setup(numRays={integrator.sumL.shape[1]}) does not match the film "
                              f"{cam.width}x{cam.height}: call setup again for this scene")
-        sl = integrator.sumL.data_ptr() if accumulate else None
-        sl2 = integrator.sumL2.data_ptr() if accumulate else None
-        N.check(tree._h, tree._lib.pg_render_pass(tree._h, C.byref(p), L.data_ptr(), valid.data_ptr(), sl, sl2,
-                                                  torch.cuda.current_stream().cuda_stream))
+        slot, stream = 0, torch.cuda.current_stream()
+        if self.in_flight == 2 and n:
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=tree.device), torch.cuda.Stream(device=tree.device)]
+            slot = self._n_pass & 1
+            self._n_pass += 1
+            stream = self._streams[slot]
+            # whatever the integrator did on the current stream since the last pass (zeroed sums, a refined tree, a new
+            # iteration) comes first -- once per such change, not per pass: the passes themselves must not wait for
+            # each other through the current stream
+            epoch = getattr(integrator, "_epoch", 0)
+            if self._seen_epoch != (id(integrator), epoch):
+                for st in self._streams:
+                    st.wait_stream(torch.cuda.current_stream())
+                self._seen_epoch = (id(integrator), epoch)
+            integrator._inflight_scene = self
+        with torch.cuda.stream(stream):
+            L = torch.empty((3, n), dtype=torch.float32, device=tree.device)
+            valid = torch.empty(n, dtype=torch.uint8, device=tree.device)
+            if n == 0:
+                return L, valid, spp
+            p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth), slot, begin, count,
+                                 stripe[0], stripe[1], stripe[2], 0)
+            sl = integrator.sumL.data_ptr() if accumulate else None
+            sl2 = integrator.sumL2.data_ptr() if accumulate else None
+            N.check(tree._h, tree._lib.pg_render_pass(tree._h, C.byref(p), L.data_ptr(), valid.data_ptr(), sl, sl2,
+                                                      stream.cuda_stream))
+        if stream is not torch.cuda.current_stream():
+            # (the tensors were allocated on the pass's stream and will be read on the current one after join())
+            L.record_stream(torch.cuda.current_stream())
+            valid.record_stream(torch.cuda.current_stream())
         return L, valid, spp
 
 
@@ -192,6 +229,7 @@ def render(scene: WavefrontScene, integrator, spp: int, seed: int, gather=None) 
     tile as (pixels, 1, 3) per-pixel means."""
     sampler = IndependentSampler(spp, seed)
     L, _, _ = integrator.sample(scene, sampler)
+    scene.join()  # (in_flight = 2: the film below reads L on the current stream)
     w, h = scene.film_size
     if scene.sharded:
         if gather is None:

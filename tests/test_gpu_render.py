@@ -490,3 +490,61 @@ def test_fused_kernel_and_split_pipeline_are_two_implementations_of_one_bounce(w
     assert torch.equal(sa.view(torch.int32), sb.view(torch.int32)) and torch.equal(s2a.view(torch.int32), s2b.view(torch.int32))
     _same_tree(ta, tb)
     assert ta["kdtree_depth"].shape[0] > 100   # a trained tree, not the initial leaf
+
+
+@pytest.mark.parametrize("which", ["veach-ajar", "cornell-box", "mixed"])
+def test_two_passes_in_flight_equal_one_at_a_time(which):
+    """WavefrontScene(in_flight=2): consecutive passes alternate between the two buffer sets of pg_pass_params.slot on
+    two streams of their own, two on the device at once, with pg_render_overlap on top.  Radiance of every pass, the
+    per-pixel sums (added in issue order: fp32), the accumulators and the refined trees equal the
+    one-pass-at-a-time run bit for bit over a guided lifecycle of many small passes."""
+    import torch
+    from practical_path_guiding_lab_amd import scene as S
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+
+    sc = {"veach-ajar": lambda: S.veach_ajar(96, 54), "cornell-box": lambda: S.cornell_box(64, 64, 8, 8),
+          "mixed": lambda: mixed_scene(48)}[which]()
+    npix = sc.camera.width * sc.camera.height
+    bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
+
+    def run(in_flight, overlap):
+        g = PathGuidingIntegrator({"max_depth": sc.max_depth, "rr_depth": sc.rr_depth})
+        g.setup(npix, bmin, bmax, 20, 20, True, 0.5)
+        ws = WavefrontScene(sc, in_flight=in_flight, overlap=overlap)
+        out = []
+        cumm = 0
+        for k in range(4):
+            g.setIteration(k, k == 3)
+            g.resetVarianceCounter()
+            Ls = []
+            for _ in range(7):  # an odd number of passes: the sets alternate across iterations too
+                L, valid, _ = g.sample(ws, IndependentSampler(2, 900 + cumm))
+                Ls.append((L, valid))
+                cumm += 2
+            ws.join()
+            torch.cuda.synchronize()
+            out.append([(L.cpu().numpy(), v.cpu().numpy()) for L, v in Ls])
+            out.append((g.sumL.cpu().numpy(), g.sumL2.cpu().numpy()))
+            out.append(g.sdTree.exportAccumulators())
+            if k < 3:
+                g.refineAndPrepareSDTreeForNextIteration()
+                out.append(g.sdTree.export())
+        return out
+
+    def same(a, b):
+        if isinstance(a, dict):
+            _same_tree(a, b)
+        elif isinstance(a, (list, tuple)):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                same(x, y)
+        else:
+            a, b = np.asarray(a), np.asarray(b)
+            np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+
+    ref = run(1, 0)
+    assert np.isfinite(ref[1][0]).all() and ref[1][0].max() > 0
+    same(ref, run(2, 0))
+    same(ref, run(2, 1))
+    same(ref, run(1, 1))
