@@ -462,7 +462,8 @@ using namespace pg;
 // (integer atomics: any order) and the per-pixel sums (ordered between the sets by events, pg_render_pass).
 struct PassBuf {
 	// mesh scenes: ray origins, the per-bounce workspace and the BVH stacks' overflow strips (pg_render_wave.hip)
-	DevBuf<uint4> st;
+	DevBuf<uint4> st[2];       // two sets of five entries per path, swapped per bounce (pg_render_wave.hip, st_load)
+	DevBuf<uint64_t> inc[2];   // and of the sampler increments
 	DevBuf<uint32_t> ws;
 	DevBuf<uint2> bvh_ovf;
 	DevBuf<uint32_t> shadow_list;
@@ -560,7 +561,7 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 		PG_HIP(ctx, b.prev_p.ensure(3 * N)); PG_HIP(ctx, b.prev_pdf.ensure(N));
 		PG_HIP(ctx, b.prev_quad.ensure(N)); PG_HIP(ctx, b.rng_state.ensure(N));
 	} else {
-		PG_HIP(ctx, b.st.ensure(4 * N));
+		for (int k = 0; k < 2; ++k) { PG_HIP(ctx, b.st[k].ensure(5 * N)); PG_HIP(ctx, b.inc[k].ensure(N)); }
 		PG_HIP(ctx, b.ws.ensure((size_t)wave_workspace_planes() * N));
 		PG_HIP(ctx, b.shadow_list.ensure(N));
 		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
@@ -835,7 +836,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.textures = r->textures.p;
 	a.shapes.texels = r->texels.p;
 	a.shapes.srgb_lut = r->srgb_lut.p;
-	a.st = b.st.p;
+	a.st_in = nullptr; a.st_out = nullptr; a.inc_in = nullptr; a.inc_out = nullptr; // (set per bounce below)
 	a.ws = b.ws.p;
 	a.bvh_ovf = b.bvh_ovf.p;
 	a.cast_count = b.live_count.p + (D + 1);
@@ -880,6 +881,10 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		a.order_in = b.order[it & 1].p;
 		a.order_out = b.order[(it + 1) & 1].p;
 		if (wave) { // pg_render_wave.hip: five kernels per bounce, each timed on its own (kinds 5-9; 10 = tail)
+			// the state set this bounce reads and the one its survivors are written to; the camera rays of the first
+			// launch go to the set the first bounce reads
+			a.st_in = b.st[it & 1].p; a.inc_in = b.inc[it & 1].p;
+			a.st_out = b.st[(it + 1) & 1].p; a.inc_out = b.inc[(it + 1) & 1].p;
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);

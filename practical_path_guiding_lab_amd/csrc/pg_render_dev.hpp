@@ -1140,17 +1140,17 @@ struct RenderArgs {
 	// bit 31: counted) -- and r_nee is one plane, the luminance of the emitter sample's share
 	uint2 *r_slot;
 	uint32_t *r_tree;
-	// mesh scenes (the split pipeline of pg_render_wave.hip): the state of a lane between two bounces is
-	// four 16-byte quads, st[q * n_lanes + lane] (a path that survives is scattered and gathered by lane
-	// number: one 16-byte access moves what four 4-byte ones would, in a quarter of the sectors) --
-	//   q 0 {ray origin, sampler state low word}   q 1 {ray direction, sampler state high word}
-	//   q 2 {throughput, ior with its sign bit = "the previous lobe was a delta"}
-	//   q 3 {previous vertex, previous bsdf pdf}
-	// -- beside rng_inc, L and hit0 above; ray_d, thr, prev_p, prev_pdf, prev_quad, rng_state and ior are
-	// not allocated.  `ws` is the per-bounce workspace -- planes of n_lanes 32-bit words indexed by a
-	// lane's position in the live list -- and bvh_ovf the overflow strips of the BVH stacks (kOvfStack
-	// entries per list position)
-	uint4 *st;
+	// mesh scenes (the split pipeline of pg_render_wave.hip): the state of a path between two bounces travels with
+	// its place in the live list (pg_render_wave.hip, st_load): five 16-byte entries st[q * n_lanes + place] and the
+	// sampler increment, read from st_in / inc_in and written -- survivors only, to their places in the next list --
+	// to st_out / inc_out; the two sets swap per bounce.  L is the OUTPUT column (written once per path, where it
+	// ends); ray_d, thr, prev_p, prev_pdf, prev_quad, rng_state, rng_inc, ior and the order lists are not used.
+	// `ws` is the per-bounce workspace -- planes of n_lanes 32-bit words indexed by the place in the live list --
+	// and bvh_ovf the overflow strips of the BVH stacks (kOvfStack entries per list position)
+	const uint4 *st_in;
+	uint4 *st_out;
+	const uint64_t *inc_in;
+	uint64_t *inc_out;
 	uint32_t *ws;
 	uint2 *bvh_ovf;
 	// the ray-casting kernels are persistent: a lane whose ray is done takes the next one of the launch's

@@ -373,22 +373,30 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, P
 // which live-list entry does this thread serve, if any: false for a whole workgroup past the list or
 // when a tail launch is finishing the paths (both uniform over the workgroup)
 template <bool kFirst>
-__device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, bool &alive, uint64_t &lane)
+__device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, bool &alive)
 {
 	tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return false;
 	if (!kFirst && tail_took_over(a, a.bounce)) return false;
 	alive = tid < live;
-	lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
 	return true;
 }
 
-// the state quads of a lane (RenderArgs::st)
-__device__ __forceinline__ uint4 st_load(const RenderArgs &a, int q, uint64_t lane) { return a.st[(uint64_t)q * a.n_lanes + lane]; }
-__device__ __forceinline__ void st_store(const RenderArgs &a, int q, uint64_t lane, v3 v, uint32_t w)
+// The state of a path TRAVELS WITH ITS PLACE IN THE LIVE LIST: the survivor that k_wave_shade_b appends at
+// place `off` of the next bounce's list gets its state written to place `off` of the other state set (two sets,
+// swapped per bounce), so that every kernel of the next bounce reads state[place] -- whole cache lines, no
+// gather through a list of lane numbers, no dependent load before the first useful one.  Six entries per path:
+//   q 0 {ray origin, sampler state low word}   q 1 {ray direction, sampler state high word}
+//   q 2 {throughput, ior with its sign bit = "the previous lobe was a delta"}
+//   q 3 {previous vertex, previous bsdf pdf}   q 4 {radiance so far, the path's lane (pixel * spp + s)}
+//   and the sampler's increment (8 bytes)
+// The radiance is written to L_out[lane] once, where the path ends.  (Round 2 kept the state in place, indexed by
+// lane: scattered 16-byte accesses whose share of each cache line shrank with every bounce's survivors.)
+__device__ __forceinline__ uint4 st_load(const uint4 *st, const RenderArgs &a, int q, uint64_t i) { return st[(uint64_t)q * a.n_lanes + i]; }
+__device__ __forceinline__ void st_store(uint4 *st, const RenderArgs &a, int q, uint64_t i, v3 v, uint32_t w)
 {
-	a.st[(uint64_t)q * a.n_lanes + lane] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), w);
+	st[(uint64_t)q * a.n_lanes + i] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), w);
 }
 __device__ __forceinline__ v3 st_v3(uint4 q) { return V(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z)); }
 // q 2's fourth word: the ior (positive) with the delta bit in its sign
@@ -401,20 +409,21 @@ template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 {
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
-	uint64_t tid, lane;
+	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	if (!alive) return;
 	v3 ray_o, ray_d;
-	if (kFirst) {
+	if (kFirst) { // (place = lane in the first list)
 		Pcg32 rng;
-		camera_ray(a, lane, rng, ray_o, ray_d);
-		a.rng_inc[lane] = rng.inc;
-		st_store(a, 0, lane, ray_o, (uint32_t)rng.state);
-		st_store(a, 1, lane, ray_d, (uint32_t)(rng.state >> 32));
+		camera_ray(a, tid, rng, ray_o, ray_d);
+		// (this launch FILLS the set the first bounce reads: the only writer of an "in" set)
+		const_cast<uint64_t *>(a.inc_in)[tid] = rng.inc;
+		st_store(const_cast<uint4 *>(a.st_in), a, 0, tid, ray_o, (uint32_t)rng.state);
+		st_store(const_cast<uint4 *>(a.st_in), a, 1, tid, ray_d, (uint32_t)(rng.state >> 32));
 	} else {
-		ray_o = st_v3(st_load(a, 0, lane));
-		ray_d = st_v3(st_load(a, 1, lane));
+		ray_o = st_v3(st_load(a.st_in, a, 0, tid));
+		ray_d = st_v3(st_load(a.st_in, a, 1, tid));
 	}
 	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
 	HitRec h;
@@ -539,20 +548,20 @@ __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArgs a)
 {
-	uint64_t tid, lane;
+	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	if (!alive) return;
 	Pcg32 rng;
-	const uint4 q0 = st_load(a, 0, lane), q1 = st_load(a, 1, lane);
+	const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid);
 	rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
-	rng.inc = a.rng_inc[lane];
+	rng.inc = a.inc_in[tid];
 	const v3 ray_o = st_v3(q0), ray_d = st_v3(q1);
 	v3 thr = V(1, 1, 1), prev_p = V(0, 0, 0);
 	float prev_pdf = 1.0f;
 	bool prev_delta = true;
 	if (!kFirst) {
-		const uint4 q2 = st_load(a, 2, lane), q3 = st_load(a, 3, lane);
+		const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid);
 		thr = st_v3(q2);
 		prev_delta = (q2.w >> 31) != 0u;
 		prev_p = st_v3(q3);
@@ -590,17 +599,17 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 {
 	__shared__ float s_planes[3 * kKdGridPlanes];
-	uint64_t tid, lane;
+	uint64_t tid;
 	bool alive;
-	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive, lane)) return; }
-	else if (!wave_entry<false>(a, tid, alive, lane)) return;
+	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive)) return; }
+	else if (!wave_entry<false>(a, tid, alive)) return;
 	stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
 	const uint32_t flags = wsu(a, WS_FLAGS, tid);
 	if (!guide_has_work(a, flags)) return;
 	Pcg32 rng;
 	rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
-	rng.inc = a.rng_inc[lane];
+	rng.inc = a.inc_in[tid];
 	GuideOut g;
 	// (the BSDF-sampled direction of a lane that keeps it; a lane that samples the tree has none to evaluate)
 	const v3 wo_in = (flags & F_SMP_TREE) ? V(0, 0, 0) : ws3(a, WS_U, tid);
@@ -626,9 +635,9 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 {
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
-	uint64_t tid, lane;
+	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive, lane)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	const uint64_t N = a.n_lanes;
 	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
 	uint64_t rec_base = 0;
@@ -637,6 +646,13 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
 	}
 	bool cont = false;
+	// what a survivor takes along to its place in the next list
+	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(1, 1, 1), L = V(0, 0, 0), p_here = V(0, 0, 0);
+	float ior = 1.0f, prev_pdf = 1.0f;
+	bool delta = false;
+	uint64_t lane = tid; // (the first list is in lane order)
+	Pcg32 rng;
+	rng.state = 0; rng.inc = 1;
 	if (alive) {
 		StageA A;
 		A.flags = wsu(a, WS_FLAGS, tid);
@@ -665,31 +681,20 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		g.wo = A.wo; // (k_wave_guide's direction for the lanes that sample the tree)
 		if (guide_has_work(a, A.flags)) { g.pdf_nee = wsf(a, WS_PDF_NEE, tid); g.pdf_tree = wsf(a, WS_PDF_TREE, tid); }
 		const bool occluded = (A.flags & F_NEED_SHADOW) && wsu(a, WS_OCC, tid) != 0u;
-		Pcg32 rng;
 		rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
-		rng.inc = a.rng_inc[lane];
-		v3 thr = V(1, 1, 1), L = V(0, 0, 0);
-		float ior = 1.0f;
+		rng.inc = a.inc_in[tid];
 		if (!kFirst) {
-			const uint4 q2 = st_load(a, 2, lane);
+			const uint4 q2 = st_load(a.st_in, a, 2, tid), q4 = st_load(a.st_in, a, 4, tid);
 			thr = st_v3(q2);
 			ior = __uint_as_float(q2.w & 0x7fffffffu);
-			L = ldp(a.L, N, lane);
+			L = st_v3(q4);
+			lane = q4.w;
 		}
-		v3 ray_o, ray_d;
-		float prev_pdf;
-		bool delta;
 		cont = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, rec_base + tid, (uint32_t)a.bounce, ray_o, ray_d,
 		                       prev_pdf, delta);
-		// ---- state for the next bounce; a path that ends here leaves only its radiance ----
-		stp(a.L, N, lane, L);
+		p_here = A.p;
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
-		if (cont) {
-			st_store(a, 0, lane, ray_o, (uint32_t)rng.state);
-			st_store(a, 1, lane, ray_d, (uint32_t)(rng.state >> 32));
-			st_store(a, 2, lane, thr, st_pack_ior(ior, delta));
-			st_store(a, 3, lane, A.p, __float_as_uint(prev_pdf));
-		}
+		if (!cont) stp(a.L, N, lane, L); // the path ends here: its radiance (:431), written once
 	}
 	if (a.last) return; // nothing survives the last bounce
 	const unsigned long long ballot = __ballot(cont);
@@ -702,10 +707,15 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		s_base = tot ? atomicAdd(&a.live_count[a.bounce], tot) : 0u;
 	}
 	__syncthreads();
-	if (cont) {
+	if (cont) { // the survivor's state goes to its place in the next list (whole lines: a wave's survivors are neighbours)
 		uint32_t off = s_base + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
 		for (unsigned w = 0; w < wv; ++w) off += s_wave[w];
-		a.order_out[off] = (uint32_t)lane;
+		st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
+		st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
+		st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
+		st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
+		st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
+		a.inc_out[off] = rng.inc;
 	}
 }
 
@@ -727,7 +737,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	stage_kd_planes(s_planes, a.tree);
 	bool alive = tid < live;
 	const uint64_t N = a.n_lanes;
-	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
+	uint64_t lane = 0;
 	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce
 	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
 	const uint64_t tail_base = rec_base + live; // behind the entries of bounce a.bounce
@@ -740,14 +750,16 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	bool prev_delta = false;
 	rng.state = 0; rng.inc = 1;
 	if (alive) {
-		const uint4 q0 = st_load(a, 0, lane), q1 = st_load(a, 1, lane), q2 = st_load(a, 2, lane), q3 = st_load(a, 3, lane);
+		const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid), q2 = st_load(a.st_in, a, 2, tid),
+		            q3 = st_load(a.st_in, a, 3, tid), q4 = st_load(a.st_in, a, 4, tid);
 		rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
-		rng.inc = a.rng_inc[lane];
+		rng.inc = a.inc_in[tid];
 		ray_o = st_v3(q0); ray_d = st_v3(q1); thr = st_v3(q2); prev_p = st_v3(q3);
 		ior = __uint_as_float(q2.w & 0x7fffffffu);
 		prev_delta = (q2.w >> 31) != 0u;
 		prev_pdf = __uint_as_float(q3.w);
-		L = ldp(a.L, N, lane);
+		L = st_v3(q4);
+		lane = q4.w;
 	}
 	for (int depth = a.bounce; depth < a.max_depth; ++depth) {
 		if (alive) {
@@ -771,7 +783,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 			alive = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, slot, (uint32_t)depth, ray_o, ray_d, prev_pdf, delta);
 			prev_p = A.p;
 			prev_delta = delta;
-			stp(a.L, N, lane, L);
+			if (!alive) stp(a.L, N, lane, L); // the path ends here: its radiance, written once
 		}
 		const unsigned long long ballot = __ballot(alive);
 		if (ballot == 0ull) break; // (nothing survives the last bounce)
