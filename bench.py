@@ -96,6 +96,7 @@ def parse():
                     help="1: after the steady-state steps, run the BASELINE config's WHOLE schedule through driver.run_guided_render "
                          "(veach-ajar: 12 iterations = 16380 spp, main.py:157-170, with main.py's stop-training rule :334-377) and "
                          "report value_full_schedule_12it + the final image's MSE; default: 1 at N = 1, 0 otherwise")
+    ap.add_argument("--spp1", type=int, default=1, help="0: skip the leg that times 1-spp passes (value_spp1)")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
     ap.add_argument("--split-pipeline", action="store_true",
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
@@ -413,7 +414,7 @@ def run_render(args):
     t_refine = time.perf_counter() - t1
     # ---- the reference's own training passes are 1 spp each (main.py:192): the same tree, passes of one sample ----
     spp1 = None
-    if tiles or world == 1:
+    if args.spp1 and (tiles or world == 1):
         def step1():
             integ.sample(ws, IndependentSampler(1, seed[0]))
             seed[0] += 1

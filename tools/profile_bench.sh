@@ -11,10 +11,10 @@ R=$PWD
 D=$R/gpurun_out/$OUT
 mkdir -p $D
 cd /tmp
-FILTER="k_bounce|k_wave_|k_process_and_splat|k_finish"
-rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 --cpu 0 $EXTRA > $D/bench_under_trace.json 2> $D/trace.err &&
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 $EXTRA > /dev/null 2> $D/pmc_fetch.err &&
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 $EXTRA > /dev/null 2> $D/pmc_write.err &&
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_l2 -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 $EXTRA > /dev/null 2> $D/pmc_l2.err &&
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 $EXTRA > /dev/null 2> $D/pmc_sq.err
+FILTER="k_bounce|k_wave_|k_process_and_splat|k_splat_list|k_finish"
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 --cpu 0 --full-schedule 0 --spp1 0 $EXTRA > $D/bench_under_trace.json 2> $D/trace.err &&
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 --full-schedule 0 --spp1 0 $EXTRA > /dev/null 2> $D/pmc_fetch.err &&
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 --full-schedule 0 --spp1 0 $EXTRA > /dev/null 2> $D/pmc_write.err &&
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_l2 -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 --full-schedule 0 --spp1 0 $EXTRA > /dev/null 2> $D/pmc_l2.err &&
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --cpu 0 --full-schedule 0 --spp1 0 $EXTRA > /dev/null 2> $D/pmc_sq.err
 echo rc=$?

@@ -13,7 +13,7 @@ import sys
 src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 BOUNCES = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # k_bounce launches per pass = max_depth
 os.makedirs(dst, exist_ok=True)
-KERNELS = ("k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_tail", "k_bounce",
+KERNELS = ("k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_tail", "k_bounce", "k_splat_list",
            "k_process_and_splat", "k_finish")  # k_wave_cast = the persistent any-hit kernel of the shadow rays
 PER_BOUNCE = ("k_bounce", "k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b")
 
