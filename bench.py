@@ -131,14 +131,26 @@ def make_scene(name, width, depth):
     return S.cornell_box(width, height, depth, 8)
 
 
+ATOMIC_CEILING_GPS = 23.6  # G sector-updates/s chip-wide: tools/atomic_probe.hip on MI355X (round 1), scattered 64-bit adds
+
+
 def traffic_for(kernel, key):
-    """HBM bytes per launch from the committed PMC summary of the same configuration, else None."""
+    """Counter figures per launch of `kernel` from the committed PMC summary of the same configuration
+    (profiles/pmc_traffic.json, tools/summarize_profile.py) -- {"hi": HBM bytes with the gfx950 x2 FETCH correction of
+    MI355X_MICROARCH.md (an upper bound for scattered reads), "lo": as counted, "atomics": L2 atomic sector updates} --
+    or None when none is committed or when it was taken of OTHER CODE: the summary records the hash of the library's
+    sources, and a figure whose hash differs from the sources this run was built from is refused."""
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
+        from practical_path_guiding_lab_amd._native import source_hash
         j = json.load(open(pmc))
         k = j.get("configs", {}).get(key, {})
+        if k.get("_source_hash") != source_hash():
+            return None
         if kernel in k:
-            return k[kernel]["hbm_bytes_per_launch"]
+            e = k[kernel]
+            return {"hi": e["hbm_bytes_per_launch"], "lo": e.get("hbm_bytes_per_launch_uncorrected"),
+                    "atomics": e.get("atomic_sector_updates_per_launch")}
     except Exception:
         pass
     return None
@@ -308,6 +320,8 @@ def run_render(args):
     from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators, all_reduce_sums
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
+    from practical_path_guiding_lab_amd._native import LIB_PATH as N_LIB_PATH, source_hash
+    SRC_HASH = source_hash()
     world, rank, local_rank = init_dist(args)
     sc = make_scene(args.scene, args.res, args.depth)
     W, H = sc.camera.width, sc.camera.height
@@ -320,6 +334,7 @@ def run_render(args):
     if tiles:
         ws.set_shard(rank, world, 4)
     my_pixels = int(ws.local_pixels().shape[0])
+    npix_local = my_pixels
     from practical_path_guiding_lab_amd.parallel import min_max_over_ranks
     pix_min, pix_max = min_max_over_ranks(my_pixels)
     ws.reserve(integ, args.spp_per_pass)  # the pass buffers, as the reference's setup() allocates its record arrays (:93)
@@ -421,6 +436,15 @@ def run_render(args):
         n1 = max(16, args.steps)
         spp1 = npix * n1 / timed_steps(step1, n1, 2, world) / 1e6
 
+    # ---- two passes in flight (pg_pass_params.slot): the same passes, alternating between two buffer sets and streams ----
+    two_in_flight = None
+    if args.spp1 and args.in_flight == 1 and (tiles or world == 1):
+        ws.in_flight = 2
+        two_in_flight = npix * args.spp_per_pass * args.steps / timed_steps(step, args.steps, 2, world) / 1e6
+        ws.join()
+        torch.cuda.synchronize()
+        ws.in_flight = 1
+
     # ---- the config's whole schedule, end to end ----
     full = None
     if args.full_schedule:
@@ -467,8 +491,19 @@ def run_render(args):
     else:
         kernels["k_bounce"] = kern(kt.bounce_ms, kt.bounce_launches, tree_bytes)
         dom = "k_bounce"
-    kernels["k_process_and_splat"] = kern(kt.splat_ms, kt.splat_launches, splat_bytes)
-    kernels["k_process_and_splat"]["records_per_launch"] = int(records_per_pass)
+    splat_name = "k_splat_list" if wave else "k_process_and_splat"
+    kernels[splat_name] = kern(kt.splat_ms, kt.splat_launches, splat_bytes)
+    kernels[splat_name]["records_per_launch"] = int(records_per_pass)
+    if wave:
+        entries = npix_local * args.spp_per_pass + sum(live[:-1])  # one list entry per live path and bounce
+        kernels[splat_name]["list_entries_per_launch"] = int(entries)
+        kernels[splat_name]["streamed_bytes_per_launch"] = int(entries * 72)
+        kernels[splat_name]["alg_model_note"] = (
+            "alg_bytes_per_launch prices SURVEY 8d's B_rec = 16 D_kd + 4 + 48 + 12 per quadtree level and descent: the descents of "
+            "KDTree / QuadTree.addDataPropagate.  k_splat_list makes none of them -- the bounce that made a vertex walked sdTree_prev to "
+            "the very leaves the record adds to (same topology) and the list names those accumulators -- so alg_GBps prices bytes this "
+            "kernel does not move; what it moves is at most streamed_bytes_per_launch (72 B per list entry) plus one 32-byte atomic "
+            "sector update per direction of a kept record, and it is bound by the latter (atomics_G_per_s vs atomic_ceiling_G_per_s)")
     kernels["k_finish"] = kern(kt.finish_ms, passes)
     slowest = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     cfg_key = f"{args.scene} res={args.res} depth={args.depth} spp={args.spp_per_pass}"
@@ -483,22 +518,50 @@ def run_render(args):
                           "mount, 4482 triangles with texture coordinates, and its three bitmap textures at full "
                           "resolution (the JPG files' bytes in the package data veach_ajar.npz, decoded with PIL as load_xml does); checkerboard GGX floor, Beckmann door handle; "
                           "the six teapot shapes are absent: their mesh files are missing from the reference mount)"}[args.scene]
-    traffic = traffic_for(dom, cfg_key)
-    # every kernel against the HBM roofline by its COUNTER traffic (the committed PMC figure of this configuration,
-    # profiles/pmc_traffic.json, gfx950 FETCH correction applied: an upper bound) over the duration measured in this run
+    tr_dom = traffic_for(dom, cfg_key)
+    traffic = None if tr_dom is None else tr_dom["hi"]
+    # every kernel against the HBM roofline by its COUNTER traffic (the committed PMC figures of this configuration and of
+    # THIS code, profiles/pmc_traffic.json: as counted, and with the gfx950 FETCH correction, an upper bound) over the
+    # duration measured in this run
     for name, parts in (("k_wave_guide", ("k_wave_guide",)), ("k_wave_trace", ("k_wave_trace",)), ("k_wave_shadow", ("k_wave_cast",)),
                         ("k_wave_shade_a+b", ("k_wave_shade_a", "k_wave_shade_b")), ("k_bounce", ("k_bounce",)),
-                        ("k_process_and_splat", ("k_process_and_splat",)), ("k_finish", ("k_finish",))):
+                        ("k_process_and_splat", ("k_process_and_splat",)), ("k_splat_list", ("k_splat_list",)),
+                        ("k_finish", ("k_finish",))):
         if name in kernels and kernels[name]["avg_us"] > 0:
             tr = [traffic_for(p_, cfg_key) for p_ in parts]
             if all(t is not None for t in tr):
-                per_launch = sum(tr) / len(tr)
-                kernels[name]["pmc_hbm_bytes_per_launch"] = int(per_launch)
-                kernels[name]["pmc_hbm_GBps"] = round(per_launch / (kernels[name]["avg_us"] * 1e-6) / 1e9, 1)
-                kernels[name]["pmc_frac_of_hbm_peak"] = round(per_launch / (kernels[name]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+                sec = kernels[name]["avg_us"] * 1e-6
+                hi = sum(t["hi"] for t in tr) / len(tr)
+                kernels[name]["pmc_hbm_bytes_per_launch"] = int(hi)
+                kernels[name]["pmc_hbm_GBps"] = round(hi / sec / 1e9, 1)
+                kernels[name]["pmc_frac_of_hbm_peak"] = round(hi / sec / 1e9 / HBM_PEAK_GBS, 3)
+                if all(t["lo"] is not None for t in tr):
+                    lo = sum(t["lo"] for t in tr) / len(tr)
+                    kernels[name]["pmc_hbm_bytes_per_launch_uncorrected"] = int(lo)
+                    kernels[name]["pmc_frac_of_hbm_peak_uncorrected"] = round(lo / sec / 1e9 / HBM_PEAK_GBS, 3)
+                if tr[0]["atomics"]:
+                    kernels[name]["atomic_sector_updates_per_launch"] = int(tr[0]["atomics"])
+                    kernels[name]["atomics_G_per_s"] = round(tr[0]["atomics"] / sec / 1e9, 2)
+                    kernels[name]["atomic_ceiling_G_per_s"] = ATOMIC_CEILING_GPS
+    dom_sec = kernels[dom]["avg_us"] * 1e-6
+    kd_share = 16.0 * dc.kd_levels / max(tree_bytes, 1.0)
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "slowest_kernel_of_step": slowest,
+            "traffic": traffic,
+            # the counter-honest fractions: HBM bytes of the PMC counters per launch / this run's launch time / peak --
+            # lo as counted, hi with the guide's x2 FETCH correction (an upper bound for scattered reads)
+            "frac_counter_lo": None if (tr_dom is None or tr_dom["lo"] is None or dom_sec <= 0) else round(tr_dom["lo"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_counter_hi": None if (tr_dom is None or dom_sec <= 0) else round(tr_dom["hi"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
+            "model_note": (f"`frac` is SURVEY 8d's ALGORITHMIC model (16 B per KD level + 20 B per quadtree level walked by the reference's "
+                           f"descents), not a bandwidth measurement: {100 * kd_share:.0f} % of those bytes are KD levels ({dc.kd_levels / max(dc.kd_queries, 1):.1f} per "
+                           "query) that the KD jump grid replaces by ONE 16-byte gather for most queries, and the top four quadtree levels of "
+                           "a pdf walk are one 16-byte jump-table gather: the kernel moves far fewer bytes than the model prices -- read "
+                           "frac_counter_lo / frac_counter_hi for what it moves, and `limiter` for what it waits on"),
+            "traffic_note": ("traffic / frac_counter_*: PMC figures of this configuration taken of exactly this code (source hash checked)"
+                             if tr_dom is not None else
+                             "traffic null: no PMC figures of this configuration taken of THIS code are committed (profiles/pmc_traffic.json "
+                             "records the hash of the sources it was taken of; a mismatch is refused rather than paired with new timings)"),
+            "slowest_kernel_of_step": slowest,
             "device_copy_GBps": device_copy_rate(torch.device("cuda", local_rank)) if rank == 0 else None,
             "limiter": "HBM is the roofline SURVEY 8(d) prescribes for this pointer-chasing path; what the kernel actually waits on "
                        "is the rate at which a CU's texture path takes divergent gathers (address unit busy 82 % of the launch, "
@@ -512,9 +575,8 @@ def run_render(args):
                      "k_bounce is one whole bounce of the wavefront (ray casting, NEE incl. shadow ray, shading, SD-tree "
                      "queries, record store, state load/store); its algorithmic bytes count only the SD-tree descents "
                      "(16 B/KD level, 20 B/quadtree level, SURVEY 8d). ")
-                    + "k_process_and_splat is bound by scattered atomics, not HBM (DESIGN.md 5). `traffic` is not measured in "
-                      "this run: it is the PMC figure of the same configuration committed in profiles/pmc_traffic.json "
-                      "(null: none committed)."}
+                    + "The splat is bound by scattered L2 atomics, not HBM (DESIGN.md 5). `traffic` is not measured in this run: it "
+                      "is the PMC figure of the same configuration and code committed in profiles/pmc_traffic.json."}
     cpu = None
     mse_small = mse_small_cpu = None
     if args.cpu and world == 1:
@@ -526,6 +588,7 @@ def run_render(args):
         "data": "no dataset: the reference's scene (parameters, meshes and textures packaged from its scene files), sampler "
                 "streams seeded per pass, SD-tree trained inside the run", "value_full_schedule": None if full_schedule is None else round(full_schedule, 3),
         "value_spp1": None if spp1 is None else round(spp1, 3),
+        "value_two_in_flight": None if two_in_flight is None else round(two_in_flight, 3),
         "value_full_schedule_12it": None if full is None else full["value"], "mse_vs_gt_full_schedule": None if full is None else full["mse_vs_gt"],
         "full_schedule": full,
         "mse_vs_gt": mse_train, "mse_vs_gt_small": mse_small, "mse_vs_gt_cpu": mse_small_cpu,
@@ -547,7 +610,8 @@ def run_render(args):
                              "accumulator exchange and refine (main.py:159,394); mse_vs_gt = the last trained iteration's "
                              f"image ({last_spp} spp) vs the ground truth" + (": " + mse_note if mse_note else ""),
                      "iterations": per_iter, "trained_spp": cumm},
-        "extra": {"allreduce_ms": round(1e3 * t_allreduce, 3), "refine_ms": round(1e3 * t_refine, 3), "exchange": exchange,
+        "extra": {"library": os.path.relpath(N_LIB_PATH, ROOT), "source_hash": SRC_HASH,
+                  "allreduce_ms": round(1e3 * t_allreduce, 3), "refine_ms": round(1e3 * t_refine, 3), "exchange": exchange,
                   "accumulator_bytes": int(tree.accumulators().numel()) * 8},
     }
     if world > 1:

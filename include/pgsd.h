@@ -399,6 +399,14 @@ int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, fl
 #define PG_FILTER_GAUSSIAN 1
 int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream);
 
+/* The same for a film sharded by interleaved bands of rows (pg_pass_params.stripe_*; not in the reference, which has
+ * one device): develops only the pixels of the rows r with (r / stripe_rows) % stripe_count == stripe_index and leaves
+ * the rest of image_out untouched.  L is still indexed by the full frame's lanes, but only this rank's rows and the
+ * filter's reach beyond them -- one row for the tent filter, two for the gaussian -- are read: what a rank has to
+ * fetch from its neighbours is that halo, not the film.  stripe_count 0 or 1: the whole film (pg_film). */
+int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out,
+                    uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream);
+
 /* Element-wise evaluation of the library's own fp32 transcendental functions (fixed
  * sequences of double operations, no vendor math library), so that a caller -- the parity tests --
  * can compare them with another implementation of the same contract.

@@ -111,10 +111,24 @@ EXPORTS = (
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
-    "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_render_overlap",
+    "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_render_overlap",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
     "pg_render_split_pipeline",
 )
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the library's sources (csrc/*.hip, csrc/*.hpp, include/pgsd.h): names the code a
+    profile was taken of (profiles/pmc_traffic.json) so that bench.py never pairs old counters with new kernels."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+    files.append(os.path.join(os.path.dirname(_PKG), "include", "pgsd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False) -> str:
@@ -178,6 +192,7 @@ def lib() -> C.CDLL:
     L.pg_render_live_counts.argtypes = [V, C.POINTER(C.c_uint32), I32]
     L.pg_film_tent.argtypes = [V, U32, I32, V, V, V]
     L.pg_film.argtypes = [V, I32, U32, I32, V, V, V]
+    L.pg_film_stripes.argtypes = [V, I32, U32, I32, V, V, U32, U32, U32, V]
     L.pg_render_overlap.argtypes = [V, I32]
     L.pg_math_eval.argtypes = [V, I32, U64, V, V, V]
     L.pg_scene_set_ex.argtypes = [V, C.POINTER(pg_scene_desc), C.POINTER(pg_camera)]

@@ -420,13 +420,16 @@ __device__ __forceinline__ float gauss1(float d)
 
 template <int kFilter> // 0 tent (3x3 neighbourhood), 1 gaussian (5x5)
 __global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W, int H,
-                                                  const float *__restrict__ L, float *__restrict__ out)
+                                                  const float *__restrict__ L, float *__restrict__ out,
+                                                  uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count)
 {
 	constexpr int R = kFilter == 1 ? 2 : 1;
 	const uint64_t npix = (uint64_t)W * (uint64_t)H, N = npix * (uint64_t)spp;
 	const uint64_t o = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	if (o >= npix) return;
 	const int x = (int)(o % (uint64_t)W), y = (int)(o / (uint64_t)W);
+	// (pg_film_stripes: the pixels of this rank's bands only; the others keep what `out` held)
+	if (stripe_count > 1u && ((uint32_t)y / stripe_rows) % stripe_count != stripe_index) return;
 	const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
 	float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;
 	for (int ny = y - R; ny <= y + R; ++ny)
@@ -1010,18 +1013,27 @@ int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, fl
 
 int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)
 {
+	return pg_film_stripes(ctx, filter, seed, spp, L, image_out, 0, 0, 0, stream);
+}
+
+int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out,
+                    uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
+{
 	if (!ctx) return PG_ERR_INVALID;
 	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_film: call pg_scene_set first");
 	if (!L || !image_out || spp <= 0) return fail(ctx, PG_ERR_INVALID, "pg_film: NULL pointer or spp <= 0");
+	if (stripe_count > 1 && (stripe_rows == 0 || stripe_index >= stripe_count)) return fail(ctx, PG_ERR_INVALID, "pg_film_stripes: bad stripe parameters");
 	if (filter != PG_FILTER_TENT && filter != PG_FILTER_GAUSSIAN) return fail(ctx, PG_ERR_INVALID, "pg_film: unknown filter");
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	const pg_camera &cam = ctx->render->cam;
 	const uint64_t npix = (uint64_t)cam.width * (uint64_t)cam.height;
 	const dim3 grid((unsigned)((npix + kRBlock - 1) / kRBlock));
 	if (filter == PG_FILTER_GAUSSIAN)
-		hipLaunchKernelGGL(k_film<1>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out);
+		hipLaunchKernelGGL(k_film<1>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out,
+		                   stripe_rows, stripe_index, stripe_count);
 	else
-		hipLaunchKernelGGL(k_film<0>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out);
+		hipLaunchKernelGGL(k_film<0>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out,
+		                   stripe_rows, stripe_index, stripe_count);
 	PG_HIP(ctx, hipGetLastError());
 	return PG_OK;
 }

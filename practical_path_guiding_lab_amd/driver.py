@@ -106,14 +106,17 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
     w, h = scene.film_size
     gather = sums_of = None
     if shard is not None and shard[1] > 1:
-        from .parallel import LaneGather, all_reduce_accumulators, all_reduce_sums
+        from .parallel import HaloExchange, LaneGather, all_reduce_accumulators, all_reduce_sums
         rank, world = shard[0], shard[1]
         group = shard[3] if len(shard) > 3 else None
         scene.set_shard(rank, world, shard[2] if len(shard) > 2 else 4)
-        gather = LaneGather(group)
+        # bands of rows: every rank develops its own rows and fetches the filter's halo from its neighbours; the
+        # images are summed once per iteration.  (One contiguous pixel range per rank: the lanes are gathered whole.)
+        gather = HaloExchange(group) if scene.stripe is not None and scene.stripe[0] >= 2 else LaneGather(group)
         sums_of = lambda: all_reduce_sums(integrator.sumL, integrator.sumL2, group)  # noqa: E731
         if all_reduce is None:
             all_reduce = lambda acc: all_reduce_accumulators(acc, group)  # noqa: E731
+    whole = gather.reduce_image if hasattr(gather, "reduce_image") else (lambda img: img)
     bmin, bmax = scene.bbox()
     eps = np.float32(1e-4)  # main.py:55-59
     integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
@@ -176,8 +179,10 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                                                          mse=integrator.computeMSE(image_spp, ground_truth, sums))
             if is_final and cumm_spp in possible and prev_iter_image is not None and out_dir:
                 cur_cnt = cumm_spp - cumm_spp_prev
-                blend = (curr_iter_acc / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
+                acc_now = whole(curr_iter_acc)
+                blend = (acc_now / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
                 save_image(os.path.join(out_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), blend)
+        curr_iter_image = whole(curr_iter_image)  # (sharded with a halo exchange: the ranks' rows become the film, once)
         torch.cuda.synchronize()
         t_render = time.perf_counter() - t_iter
         if k >= 2 or is_final and not is_train:

@@ -109,7 +109,8 @@ def all_reduce_sums(sumL: torch.Tensor, sumL2: torch.Tensor, group=None):
 
 class LaneGather:
     """Collects the lanes every rank traced for its tile into full-frame lane order (lane = pixel *
-    spp + s), for the film reconstruction that needs a pixel's neighbours (render.render)."""
+    spp + s) on EVERY rank: the whole film's samples travel (3 * pixels * spp floats per pass).  Kept for
+    shardings that are not bands of rows; the band sharding of the driver uses HaloExchange."""
 
     def __init__(self, group=None):
         self.group = group
@@ -122,6 +123,104 @@ class LaneGather:
         full = torch.zeros((3, npix * spp), dtype=L.dtype, device=L.device)
         full[:, lanes] = L
         return _all_reduce_sum(full, self.group)  # disjoint tiles: x + 0 is exact
+
+
+def halo_plan(height: int, stripe_rows: int, rank: int, world: int, reach: int):
+    """Which rows of the film travel when every rank develops its own bands (interleaved bands of
+    `stripe_rows` rows, band b on rank b % world) with a reconstruction filter that reaches `reach` rows
+    beyond a pixel (tent 1, gaussian 2; reach <= stripe_rows, so a band's halo lies in its two neighbour
+    bands, which belong to the ring neighbours rank - 1 and rank + 1).  Returns four ascending lists of
+    global row numbers: (send_next, send_prev, recv_prev, recv_next) -- the rows this rank owns that
+    rank + 1 / rank - 1 need, and the rows it needs from rank - 1 / rank + 1.  send_next of rank r is
+    recv_prev of rank r + 1 by construction, so both ends derive the same message."""
+    if not (0 < reach <= stripe_rows):
+        raise ValueError("the filter must not reach beyond the neighbouring band")
+    n_bands = (height + stripe_rows - 1) // stripe_rows
+
+    def needs(q):
+        above, below = [], []
+        for b in range(q, n_bands, world):
+            top = b * stripe_rows
+            above += [r for r in range(top - reach, top) if r >= 0]                       # in band b - 1
+            below += [r for r in range(top + stripe_rows, top + stripe_rows + reach) if r < height]  # in band b + 1
+        return above, below
+
+    recv_prev, recv_next = needs(rank)
+    send_next = needs((rank + 1) % world)[0]   # what rank + 1 needs from the bands above its own: mine
+    send_prev = needs((rank - 1) % world)[1]
+    return send_next, send_prev, recv_prev, recv_next
+
+
+class HaloExchange:
+    """Film development of a band-sharded render without moving the film: every rank develops the pixels
+    of its own bands (pg_film_stripes) and fetches only the filter's reach beyond them from its two ring
+    neighbours -- per pass and neighbour `reach` rows x width x spp x 12 bytes per band, instead of the
+    all-reduce of the whole film's samples LaneGather does.  The developed images of the ranks (zero outside
+    their own rows) are summed once per iteration (reduce_image; x + 0 is exact)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._full = None
+        self._plans = {}
+
+    def _plan(self, scene, reach):
+        key = (scene.film_size, scene.stripe, reach)
+        if key not in self._plans:
+            rows, index, count = scene.stripe
+            self._plans[key] = halo_plan(scene.film_size[1], rows, index, count, reach)
+        return self._plans[key]
+
+    def _local_row(self, scene, y: int) -> int:
+        rows, _, count = scene.stripe
+        return (y // rows // count) * rows + y % rows
+
+    def __call__(self, L: torch.Tensor, scene, spp: int, reach: int) -> torch.Tensor:
+        """(3, pixels * spp) in full-frame lane order, valid on this rank's rows and `reach` rows around its bands."""
+        if scene.stripe is None:
+            raise ValueError("HaloExchange needs the band sharding of WavefrontScene.set_shard(rank, world, stripe_rows > 0)")
+        w, h = scene.film_size
+        rows, index, count = scene.stripe
+        n = 3 * w * h * spp
+        if self._full is None or self._full.numel() != n or self._full.device != L.device:
+            self._full = torch.zeros((3, h, w * spp), dtype=L.dtype, device=L.device)
+        full = self._full
+        own = [y for y in range(h) if (y // rows) % count == index]
+        Lr = L.reshape(3, len(own), w * spp)
+        full[:, torch.as_tensor(own, device=L.device)] = Lr
+        send_next, send_prev, recv_prev, recv_next = self._plan(scene, reach)
+        nxt, prv = (index + 1) % count, (index - 1) % count
+        host = dist.get_backend(self.group) == "gloo" and L.is_cuda  # (gloo moves host memory)
+
+        def pick(ys):
+            t = Lr[:, torch.as_tensor([self._local_row(scene, y) for y in ys], dtype=torch.long, device=L.device)].contiguous()
+            return t.cpu() if host else t
+
+        def room(ys):
+            return torch.empty((3, len(ys), w * spp), dtype=L.dtype, device="cpu" if host else L.device)
+
+        ops, got = [], []
+        # tags keep the two messages apart when both neighbours are the same rank (two ranks)
+        if send_next:
+            ops.append(dist.P2POp(dist.isend, pick(send_next), nxt, self.group, 0))
+        if send_prev:
+            ops.append(dist.P2POp(dist.isend, pick(send_prev), prv, self.group, 1))
+        if recv_prev:
+            got.append((recv_prev, room(recv_prev)))
+            ops.append(dist.P2POp(dist.irecv, got[-1][1], prv, self.group, 0))
+        if recv_next:
+            got.append((recv_next, room(recv_next)))
+            ops.append(dist.P2POp(dist.irecv, got[-1][1], nxt, self.group, 1))
+        self.bytes_last_pass = sum(op.tensor.numel() * 4 for op in ops if op.op is dist.isend)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for ys, buf in got:
+            full[:, torch.as_tensor(ys, device=L.device)] = buf.to(L.device)
+        return full.reshape(3, h * w * spp)
+
+    def reduce_image(self, image: torch.Tensor) -> torch.Tensor:
+        """The film of all ranks from the images they developed for their own rows (zero elsewhere)."""
+        return _all_reduce_sum(image.clone(), self.group)
 
 
 def min_max_over_ranks(value: float, group: Optional[dist.ProcessGroup] = None):

@@ -223,23 +223,37 @@ def render(scene: WavefrontScene, integrator, spp: int, seed: int, gather=None) 
     per-pixel mean (`box`).  The integrator's own sums (computeMSE/computeVariance) are raw per-pixel
     sums either way, as in the reference (:400-429).
 
-    A sharded scene (set_shard) traces this rank's tile only; `gather` (parallel.LaneGather) then
-    collects every rank's lanes into the full-frame lane order before the film is developed, so every
-    rank returns the same image a single rank would.  Without `gather` a sharded scene returns its
-    tile as (pixels, 1, 3) per-pixel means."""
+    A sharded scene (set_shard) traces this rank's tile only.  gather = parallel.HaloExchange (bands of rows): the
+    rank develops its own rows, fetching only the filter's reach beyond them from its ring neighbours, and returns
+    a film that is zero outside its rows -- the driver sums those once per iteration (reduce_image).  gather =
+    parallel.LaneGather: every rank's lanes are collected into the full-frame lane order first and every rank
+    returns the whole image.  Without `gather` a sharded scene returns its tile as (pixels, 1, 3) per-pixel means."""
     sampler = IndependentSampler(spp, seed)
     L, _, _ = integrator.sample(scene, sampler)
     scene.join()  # (in_flight = 2: the film below reads L on the current stream)
     w, h = scene.film_size
+    tree = integrator.sdTree
+    filt = scene.scene.rfilter
+    stripes = (0, 0, 0)
+    partial = False
     if scene.sharded:
         if gather is None:
             return L.reshape(3, -1, spp).mean(dim=2).T.reshape(-1, 1, 3).contiguous()
-        L = gather(L, scene, spp)
-    if scene.scene.rfilter in ("tent", "gaussian"):
-        tree = integrator.sdTree
-        img = torch.empty((3, h * w), dtype=torch.float32, device=tree.device)
-        N.check(tree._h, tree._lib.pg_film(tree._h, ("tent", "gaussian").index(scene.scene.rfilter),
-                                           sampler.seed_value & 0xFFFFFFFF, spp, L.data_ptr(), img.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream))
+        if hasattr(gather, "reduce_image"):  # parallel.HaloExchange: this rank develops its own rows
+            partial = True
+            stripes = scene.stripe
+            if filt in ("tent", "gaussian"):
+                L = gather(L, scene, spp, 1 if filt == "tent" else 2)
+        else:
+            L = gather(L, scene, spp)
+    if filt in ("tent", "gaussian"):
+        img = (torch.zeros if partial else torch.empty)((3, h * w), dtype=torch.float32, device=tree.device)
+        N.check(tree._h, tree._lib.pg_film_stripes(tree._h, ("tent", "gaussian").index(filt), sampler.seed_value & 0xFFFFFFFF,
+                                                   spp, L.data_ptr(), img.data_ptr(), stripes[0], stripes[1], stripes[2],
+                                                   torch.cuda.current_stream().cuda_stream))
+        return img.reshape(3, h, w).permute(1, 2, 0).contiguous()
+    if partial:  # box filter: the per-pixel means of this rank's rows in a film that is zero elsewhere
+        img = torch.zeros((3, h * w), dtype=torch.float32, device=tree.device)
+        img[:, torch.from_numpy(scene.local_pixels()).to(tree.device)] = L.reshape(3, -1, spp).mean(dim=2)
         return img.reshape(3, h, w).permute(1, 2, 0).contiguous()
     return L.reshape(3, h, w, spp).mean(dim=3).permute(1, 2, 0).contiguous()

@@ -285,6 +285,69 @@ def test_lane_gather_and_reduced_sums_two_ranks(tmp_path):
     assert all(bool(np.load(out % r)[0]) for r in range(2))
 
 
+def test_halo_plan_is_the_same_message_at_both_ends():
+    """parallel.halo_plan: what rank r sends down is what rank r + 1 expects from above (and the other way round),
+    every row a band's filter reaches is covered, nothing but `reach` rows per band and neighbour travels."""
+    from practical_path_guiding_lab_amd.parallel import halo_plan
+    for h, rows, world, reach in ((22, 4, 2, 1), (22, 4, 3, 2), (1080, 4, 8, 1), (9, 2, 5, 2), (16, 4, 4, 2), (7, 4, 2, 1)):
+        plans = [halo_plan(h, rows, r, world, reach) for r in range(world)]
+        for r in range(world):
+            sn, sp, rp, rn = plans[r]
+            assert sn == plans[(r + 1) % world][2] and sp == plans[(r - 1) % world][3]
+            own = {y for y in range(h) if (y // rows) % world == r}
+            assert set(sn) <= own and set(sp) <= own and not (set(rp) | set(rn)) & own
+            need = {y + d for y in own for d in range(-reach, reach + 1) if 0 <= y + d < h} - own
+            assert need == set(rp) | set(rn)
+            n_bands = len(range(r, (h + rows - 1) // rows, world))
+            assert len(sn) <= reach * n_bands + reach and len(sp) <= reach * n_bands + reach
+    with pytest.raises(ValueError):
+        halo_plan(16, 1, 0, 2, 2)  # the gaussian filter reaches beyond a one-row band's neighbour
+
+
+def _worker_halo(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from practical_path_guiding_lab_amd.parallel import HaloExchange
+    from practical_path_guiding_lab_amd.render import WavefrontScene
+    from practical_path_guiding_lab_amd.scene import cornell_box
+
+    ok = True
+    for (w, h, spp, rows, reach) in ((10, 22, 3, 4, 1), (6, 17, 2, 4, 2), (5, 9, 1, 2, 2)):
+        ws = WavefrontScene(cornell_box(w, h, 4, 8))
+        ws.set_shard(rank, world, rows)
+        px = ws.local_pixels()
+        lanes = (px[:, None] * spp + np.arange(spp)[None, :]).reshape(-1)
+        full = np.arange(3 * w * h * spp, dtype=np.float32).reshape(3, -1) * 0.5 + 1.0  # what a single rank would have traced
+        hx = HaloExchange()
+        got = hx(torch.from_numpy(full[:, lanes].copy()), ws, spp, reach).numpy().reshape(3, h, w * spp)
+        own = sorted({int(p) // w for p in px})
+        valid = sorted({y + d for y in own for d in range(-reach, reach + 1) if 0 <= y + d < h})
+        ok = ok and bool((got[:, valid] == full.reshape(3, h, w * spp)[:, valid]).all())
+        # per pass and neighbour at most `reach` rows per band: 3 channels x rows x width x spp x 4 bytes
+        n_bands = len({y // rows for y in own})
+        ok = ok and hx.bytes_last_pass <= 2 * (n_bands + 1) * reach * w * spp * 12
+        ok = ok and hx.bytes_last_pass < 3 * w * h * spp * 4  # (less than the film LaneGather would move)
+        img = torch.zeros(3, h * w)
+        img[:, torch.from_numpy(px)] = float(rank + 1)
+        tot = hx.reduce_image(img)
+        ok = ok and bool((tot.min() >= 1).item() and float(img.sum()) == 3.0 * (rank + 1) * px.shape[0])
+    np.save(out % rank, np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29617), (3, 29618)])
+def test_halo_exchange_moves_the_filters_reach_not_the_film(tmp_path, world, port):
+    """parallel.HaloExchange over gloo (CPU tensors): after the exchange a rank holds its own rows and the rows its
+    reconstruction filter reaches (one for the tent filter, two for the gaussian) exactly as a single rank traced
+    them, having sent no more than that many rows per band to each ring neighbour -- with two ranks both neighbours
+    are the same process and the two messages are kept apart by their tags."""
+    out = str(tmp_path / "h%d.npy")
+    mp.spawn(_worker_halo, args=(world, port, out), nprocs=world, join=True)
+    assert all(bool(np.load(out % r)[0]) for r in range(world))
+
+
 def _drive(shard_arg, out_dir=None):
     from practical_path_guiding_lab_amd.driver import run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator

@@ -107,6 +107,13 @@ try:
         traffic = {"configs": {}}
 except Exception:
     traffic = {"configs": {}}
-traffic["configs"][cfg] = {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in out["kernels"].items()}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from practical_path_guiding_lab_amd._native import source_hash  # noqa: E402
+# (run this right after the profile, before the sources change: the hash names the code the counters belong to)
+traffic["configs"][cfg] = {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                               "hbm_bytes_per_launch_uncorrected": v["hbm_bytes_per_launch_uncorrected"],
+                               "atomic_sector_updates_per_launch": v.get("TCC_EA0_ATOMIC_sum")}
+                           for k, v in out["kernels"].items()}
+traffic["configs"][cfg]["_source_hash"] = source_hash()
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps(out, indent=1))

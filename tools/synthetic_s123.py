@@ -66,6 +66,10 @@ def line(name, n, ms, alg_bytes, cpu_rate=None, extra=None):
     d = {"kernel": name, "units": int(n), "ms": round(ms, 4), "Munits_per_s": round(n / ms / 1e3, 1),
          "alg_bytes_per_launch": int(alg_bytes), "alg_GBps": round(alg_bytes / ms / 1e6, 1),
          "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / PEAK, 4)}
+    # SURVEY 8d's algorithmic bytes price every level of the reference's descents; the jump tables (KD grid, quadtree
+    # jump table) turn the top levels into one gather served from L2.  A fraction above 1 is therefore not a bandwidth:
+    if d["frac_of_hbm_peak"] > 1.0:
+        d["model"] = "served from L2 -- model not applicable (the tables elide the levels the model prices)"
     if cpu_rate is not None:
         d["cpu_oracle_Munits_per_s_1_thread"] = round(cpu_rate, 3)
     if extra:
