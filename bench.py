@@ -491,10 +491,10 @@ def run_render(args):
     else:
         kernels["k_bounce"] = kern(kt.bounce_ms, kt.bounce_launches, tree_bytes)
         dom = "k_bounce"
-    splat_name = "k_splat_list" if wave else "k_process_and_splat"
+    splat_name = "k_splat_list"
     kernels[splat_name] = kern(kt.splat_ms, kt.splat_launches, splat_bytes)
     kernels[splat_name]["records_per_launch"] = int(records_per_pass)
-    if wave:
+    if True:
         entries = npix_local * args.spp_per_pass + sum(live[:-1])  # one list entry per live path and bounce
         kernels[splat_name]["list_entries_per_launch"] = int(entries)
         kernels[splat_name]["streamed_bytes_per_launch"] = int(entries * 72)

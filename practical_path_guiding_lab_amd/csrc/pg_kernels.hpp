@@ -59,7 +59,6 @@ void launch_splat_list(const TreeView &t, const AccumView &a, int store_nee, uin
 
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee,
                               uint64_t num_rays, int32_t max_depth, const float *l_final,
-                              const pg_dense_records &rec, DepthCounters *dc, hipStream_t s,
-                              const uint32_t *ray_of = nullptr, const uint32_t *live_count = nullptr);
+                              const pg_dense_records &rec, DepthCounters *dc, hipStream_t s);
 
 } // namespace pg

@@ -260,26 +260,17 @@ __global__ __launch_bounds__(kBlock) void k_process_records(uint64_t num_rays, i
 	}
 }
 
-// kList = false: the reference's dense buffer, slot = ray*max_depth + depth (:318), every slot visited.
-// kList = true: the library's own renderer appends one record per live path and bounce (the order
-// the bounce kernels visit them in: coalesced stores, no empty tail), `ray_of[g]` names the path a
-// record belongs to (kNoRay = the path left the scene there) and the number of records is the sum
-// of the per-bounce live counts, known only on the device.
-constexpr uint32_t kNoRay = 0xffffffffu;
+// The reference's dense record buffer behind pg_process_and_splat: slot = ray*max_depth + depth (:318), every slot
+// visited.  (The library's own renderer does not come here: its list names the accumulators, k_splat_list below.)
+constexpr uint32_t kNoRay = 0xffffffffu; // k_splat_list: the path left the scene at this entry
 
-// The number of entries is known only on the device, so the grid is fixed (kSplatGroupsPerCu
-// workgroups per CU, enough of them to even out tiles of unequal cost) and every workgroup strides
-// over the 256-entry tiles: a grid sized for the worst case N * max_depth would be 93 % empty
-// workgroups at max_depth 30 (0.8 ms of launch work on the torus scene), the top of the KD-tree is
-// staged once per workgroup instead of once per tile, and the first iteration's single accumulator
-// gets four atomics per workgroup.
-template <bool kList>
+// A fixed grid (kSplatGroupsPerCu workgroups per CU, enough of them to even out tiles of unequal cost) striding
+// over the 256-entry tiles: the jump grid's planes are staged once per workgroup instead of once per tile, and the
+// first iteration's single accumulator gets four atomics per workgroup.
 __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumView a, int store_nee,
                                                               uint64_t num_rays, int32_t max_depth,
                                                               const float *__restrict__ l_final,
-                                                              pg_dense_records r, DepthCounters *dc,
-                                                              const uint32_t *__restrict__ ray_of,
-                                                              const uint32_t *__restrict__ live_count)
+                                                              pg_dense_records r, DepthCounters *dc)
 {
 #ifdef PG_SPLAT_LDS_KD
 	__shared__ uint4 s_kd[kLdsKdNodes];
@@ -290,12 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 	__shared__ long long s_val[kBlock * 4];
 	__shared__ unsigned long long s_ptr[kBlock];
 	const uint64_t S = num_rays * (uint64_t)max_depth;
-	uint64_t total = S;
-	if (kList) {
-		total = num_rays; // the first bounce visits every path, bounce b+1 the survivors of bounce b
-		for (int b = 0; b + 1 < max_depth; ++b) total += live_count[b];
-		if ((uint64_t)blockIdx.x * kBlock >= total) return;
-	}
+	const uint64_t total = S;
 #ifdef PG_SPLAT_LDS_KD
 	stage_kd_top(s_kd, t.kd, t.n_kd);
 #else
@@ -312,19 +298,7 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 		float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
 		SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
 		bool keep = false;
-		if (g < total) {
-			uint64_t ray;
-			bool active;
-			if (kList) {
-				const uint32_t rr = ray_of[g];
-				active = rr != kNoRay;
-				ray = active ? rr : 0;
-			} else {
-				ray = g / (uint64_t)max_depth;
-				active = r.active[g] != 0;
-			}
-			keep = process_slot(g, S, num_rays, ray, active, l_final, r, radiance, nee_lum, wp);
-		}
+		if (g < total) keep = process_slot(g, S, num_rays, g / (uint64_t)max_depth, r.active[g] != 0, l_final, r, radiance, nee_lum, wp);
 		if (keep) {
 			plan_record(t, a, s_kd, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
 			            r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum, path, nee,
@@ -491,18 +465,12 @@ void launch_splat_list(const TreeView &t, const AccumView &a, int store_nee, uin
 
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,
                               int32_t max_depth, const float *l_final, const pg_dense_records &rec,
-                              DepthCounters *dc, hipStream_t s, const uint32_t *ray_of,
-                              const uint32_t *live_count)
+                              DepthCounters *dc, hipStream_t s)
 {
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	if (S == 0) return;
-	const dim3 grid = strided_grid(S);
-	if (ray_of)
-		hipLaunchKernelGGL(k_process_and_splat<true>, grid, dim3(kBlock), 0, s, t, a, store_nee, num_rays,
-		                   max_depth, l_final, rec, dc, ray_of, live_count);
-	else
-		hipLaunchKernelGGL(k_process_and_splat<false>, grid, dim3(kBlock), 0, s, t, a, store_nee, num_rays,
-		                   max_depth, l_final, rec, dc, ray_of, live_count);
+	hipLaunchKernelGGL(k_process_and_splat, strided_grid(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays, max_depth, l_final,
+	                   rec, dc);
 }
 
 } // namespace pg

@@ -121,13 +121,18 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	// dirToCanonical of the emitter direction feeds the NEE pdf query (:244) and the record (:338):
 	// one evaluation serves both
 	float nee_cx = 0.0f, nee_cy = 0.0f;
+	// a recorded vertex names its accumulators in sdTree_current (pg_list_records): the leaves the walks of sdTree_prev
+	// below end in (same topology, :582), or -- unguided iterations, the last vertex of a path -- walks made for them
+	uint32_t slot_path = kSlotNone, slot_nee = kSlotNone, tree_flags = 0u;
+	const bool nee_slot_wanted = do_record && a.store_nee && active_em;
 	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, nee_cx, nee_cy);
-	if (active_sd_em) {
+	if (active_sd_em || do_record) {
 		KdNode leaf;
+		const bool inside = inside_root(a.tree, p.x, p.y, p.z);
 #ifdef PG_FUSED_LDS_KD // (A/B switch: the KD top staged in LDS instead of the jump grid)
-		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside, leaf, lv);
 #else
-		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
+		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside, leaf, lv);
 #endif
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = gather8(a.tree.head + leaf.tree);
@@ -135,7 +140,10 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		head.root_irr = __uint_as_float(hv.y);
 		tree_known = true;
 		tree_id = leaf.tree;
-		sdtree_pdf_em = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, nee_cx, nee_cy, lv);
+		tree_flags = tree_id | (inside ? 0x80000000u : 0u);
+	}
+	if (active_sd_em) {
+		sdtree_pdf_em = quad_pdf_t<true>(a.tree.rec, a.tree.jump, tree_id, head, nee_cx, nee_cy, lv, slot_nee);
 		c_q += lv; ++c_qq;
 	}
 	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
@@ -178,7 +186,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	}
 	if (smp_tree) { // :301-304
 		float dx, dy, dz;
-		quad_sample(a.tree.rec, a.tree.jump, tree_id, head, rng, dx, dy, dz, sdtree_pdf, lv);
+		quad_sample_t<true>(a.tree.rec, a.tree.jump, tree_id, head, rng, dx, dy, dz, sdtree_pdf, lv, slot_path);
 		c_q += lv; ++c_qq;
 		wo_world = V(dx, dy, dz);
 		wo_local = to_local(fr, wo_world);
@@ -188,8 +196,18 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	float wo_cx = 0.0f, wo_cy = 0.0f;
 	if (bsdf_mis || do_record) dir_to_canonical(wo_world.x, wo_world.y, wo_world.z, wo_cx, wo_cy);
 	if (bsdf_mis) { // :307
-		sdtree_pdf = quad_pdf(a.tree.rec, a.tree.jump, tree_id, head, wo_cx, wo_cy, lv);
+		sdtree_pdf = quad_pdf_t<true>(a.tree.rec, a.tree.jump, tree_id, head, wo_cx, wo_cy, lv, slot_path);
 		c_q += lv; ++c_qq;
+	}
+	{ // the leaves no query has walked to: the two walks of QuadTree.addDataPropagate (quadtree.py:443-464), in lock step
+		const bool walk_path = do_record && !smp_tree && !bsdf_mis, walk_nee = nee_slot_wanted && !active_sd_em;
+		if (walk_path || walk_nee) {
+			LeafCursor cp = leaf_cursor(a.tree.jump, tree_id, head, wo_cx, wo_cy, walk_path);
+			LeafCursor cn = leaf_cursor(a.tree.jump, tree_id, head, nee_cx, nee_cy, walk_nee);
+			quad_find_leaf_slots2(a.tree.rec, cp, cn);
+			if (walk_path) { slot_path = cursor_slot(cp); c_q += cp.levels; ++c_qq; }
+			if (walk_nee) { slot_nee = cursor_slot(cn); c_q += cn.levels; ++c_qq; }
+		}
 	}
 	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
 		atomicAdd(&a.dc->kd_levels, (unsigned long long)c_kd);
@@ -208,26 +226,28 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	// The reference's slot is ray*max_depth + depth (:318), a stride-max_depth scatter into a buffer
 	// that is mostly empty at the deeper bounces.  The library's own buffer is a list instead: this
 	// launch's thread t owns entry rec_slot = (records of the earlier bounces) + t, so a wavefront's
-	// stores coalesce and the splat visits no empty tail; ray_of names the path (pg_process_and_splat
-	// looks its final radiance up, :440), kNoRay marks a path that left the scene here.
+	// stores coalesce and the splat visits no empty tail; ray_of names the path (k_splat_list looks its
+	// final radiance up, :440), kNoRay marks a path that left the scene here.  An entry holds what
+	// processPathData (:434-453) needs and the accumulators found above (pg_list_records).
 	if (a.record) a.ray_of[rec_slot] = valid ? (uint32_t)lane : 0xffffffffu;
 	if (do_record) {
 		const uint64_t S = N * (uint64_t)D;
 		const uint64_t g = rec_slot;
-		a.r_pos[g] = p.x; a.r_pos[S + g] = p.y; a.r_pos[2 * S + g] = p.z;
-		a.r_dir[g] = wo_cx; a.r_dir[S + g] = wo_cy;
 		a.r_bsdf[g] = bsdf_weight.x; a.r_bsdf[S + g] = bsdf_weight.y; a.r_bsdf[2 * S + g] = bsdf_weight.z;
 		a.r_tb[g] = thr.x; a.r_tb[S + g] = thr.y; a.r_tb[2 * S + g] = thr.z;
 		a.r_tr[g] = L.x; a.r_tr[S + g] = L.y; a.r_tr[2 * S + g] = L.z;
-		if (a.store_nee) {
-			const v3 rn = vdiv(Lr_dir, thr);
-			a.r_nee[g] = rn.x; a.r_nee[S + g] = rn.y; a.r_nee[2 * S + g] = rn.z;
-			a.r_dnee[g] = nee_cx; a.r_dnee[S + g] = nee_cy;
-		} else {
-			a.r_nee[g] = 0.0f; a.r_nee[S + g] = 0.0f; a.r_nee[2 * S + g] = 0.0f;
-			a.r_dnee[g] = 0.0f; a.r_dnee[S + g] = 0.0f;
+		float nee_lum = 0.0f;
+		if (a.store_nee) { // :336, and the NaN scrub + luminance of :467, 471 (the only use of the three channels)
+			v3 rn = vdiv(Lr_dir, thr);
+			if (rn.x != rn.x) rn.x = 0.0f;
+			if (rn.y != rn.y) rn.y = 0.0f;
+			if (rn.z != rn.z) rn.z = 0.0f;
+			nee_lum = luminance(rn.x, rn.y, rn.z);
 		}
+		a.r_nee[g] = nee_lum;
 		a.r_wp[g] = woPdf;
+		a.r_slot[g] = make_uint2(slot_path, slot_nee);
+		a.r_tree[g] = tree_flags;
 	}
 	// ---- :352-381 advance ----
 	// ior (:357): without a dielectric every sampled direction has eta = 1, the running product stays
@@ -279,9 +299,9 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
 	if (!kFirst && tail_took_over(a, a.bounce)) return;  // a tail launch is finishing these paths
 #ifdef PG_FUSED_LDS_KD
-	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	if (a.guided || a.record) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
 #else
-	if (a.guided) stage_kd_planes(s_planes, a.tree);
+	if (a.guided || a.record) stage_kd_planes(s_planes, a.tree); // (a recorded vertex descends the KD tree too: its accumulators)
 #endif
 	const bool alive = tid < live;
 	const uint64_t lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
@@ -332,9 +352,9 @@ __global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
 #ifdef PG_FUSED_LDS_KD
-	if (a.guided) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
+	if (a.guided || a.record) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
 #else
-	if (a.guided) stage_kd_planes(s_planes, a.tree);
+	if (a.guided || a.record) stage_kd_planes(s_planes, a.tree); // (a recorded vertex descends the KD tree too: its accumulators)
 #endif
 	bool alive = tid < live;
 	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
@@ -476,8 +496,8 @@ struct PassBuf {
 	DevBuf<uint64_t> rng_state, rng_inc;
 	DevBuf<uint32_t> order[2], live_count;
 	DevBuf<uint32_t> ray_of;
-	DevBuf<float> r_pos, r_dir, r_bsdf, r_tb, r_tr, r_nee, r_dnee, r_wp;
-	DevBuf<uint2> r_slot;   // the split pipeline's list names accumulators instead of positions and directions
+	DevBuf<float> r_bsdf, r_tb, r_tr, r_nee, r_wp;
+	DevBuf<uint2> r_slot;   // the list names accumulators instead of positions and directions (pg_list_records)
 	DevBuf<uint32_t> r_tree;
 	// pg_render_overlap: k_wave_guide beside k_wave_cast on a library-owned stream
 	hipStream_t side = nullptr;
@@ -577,13 +597,9 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 		PG_HIP(ctx, b.ray_of.ensure(S));
 		PG_HIP(ctx, b.r_bsdf.ensure(3 * S)); PG_HIP(ctx, b.r_tb.ensure(3 * S)); PG_HIP(ctx, b.r_tr.ensure(3 * S));
 		PG_HIP(ctx, b.r_wp.ensure(S));
-		if (r->general < 2) { // the fused bounce kernels: position, directions, three channels of radiance_nee
-			PG_HIP(ctx, b.r_pos.ensure(3 * S)); PG_HIP(ctx, b.r_dir.ensure(2 * S));
-			PG_HIP(ctx, b.r_nee.ensure(3 * S)); PG_HIP(ctx, b.r_dnee.ensure(2 * S));
-		} else {                                 // the split pipeline: accumulator slots (pg_list_records), 60 B per entry instead of 88
-			PG_HIP(ctx, b.r_nee.ensure(S));
-			PG_HIP(ctx, b.r_slot.ensure(S)); PG_HIP(ctx, b.r_tree.ensure(S));
-		}
+		// (pg_list_records: 60 B per entry -- no position, no directions, one plane of radiance_nee)
+		PG_HIP(ctx, b.r_nee.ensure(S));
+		PG_HIP(ctx, b.r_slot.ensure(S)); PG_HIP(ctx, b.r_tree.ensure(S));
 	}
 	return PG_OK;
 }
@@ -874,8 +890,8 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.ray_d = b.ray_d.p; a.thr = b.thr.p; a.L = L_out; a.prev_p = b.prev_p.p;
 	a.prev_pdf = b.prev_pdf.p; a.prev_quad = b.prev_quad.p; a.hit0 = b.hit0.p;
 	a.rng_state = b.rng_state.p; a.rng_inc = b.rng_inc.p; a.live_count = b.live_count.p;
-	a.ray_of = b.ray_of.p; a.r_pos = b.r_pos.p; a.r_dir = b.r_dir.p; a.r_bsdf = b.r_bsdf.p; a.r_tb = b.r_tb.p;
-	a.r_tr = b.r_tr.p; a.r_nee = b.r_nee.p; a.r_dnee = b.r_dnee.p; a.r_wp = b.r_wp.p;
+	a.ray_of = b.ray_of.p; a.r_bsdf = b.r_bsdf.p; a.r_tb = b.r_tb.p;
+	a.r_tr = b.r_tr.p; a.r_nee = b.r_nee.p; a.r_wp = b.r_wp.p;
 	a.r_slot = b.r_slot.p; a.r_tree = b.r_tree.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
 	for (int it = 0; it < D; ++it) {
@@ -945,20 +961,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	}
 	PG_HIP(ctx, hipGetLastError());
 	if (record) {
-		pg_dense_records d;
-		d.active = nullptr; d.position = b.r_pos.p; d.direction = b.r_dir.p; d.bsdf = b.r_bsdf.p;
-		d.throughput_bsdf = b.r_tb.p; d.throughput_radiance = b.r_tr.p; d.radiance_nee = b.r_nee.p;
-		d.direction_nee = b.r_dnee.p; d.wo_pdf = b.r_wp.p;
 		Timed t(r, s, 2);
 		// the depth counters of an instrumented pass describe the bounce kernels only
-		if (wave) {
-			pg_list_records lr;
-			lr.ray_of = b.ray_of.p; lr.bsdf = b.r_bsdf.p; lr.throughput_bsdf = b.r_tb.p; lr.throughput_radiance = b.r_tr.p;
-			lr.nee_lum = b.r_nee.p; lr.wo_pdf = b.r_wp.p; lr.slot = b.r_slot.p; lr.tree = b.r_tree.p;
-			launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, lr, b.live_count.p, s);
-		} else
-			launch_process_and_splat(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, d, nullptr, s,
-			                         b.ray_of.p, b.live_count.p);
+		pg_list_records lr;
+		lr.ray_of = b.ray_of.p; lr.bsdf = b.r_bsdf.p; lr.throughput_bsdf = b.r_tb.p; lr.throughput_radiance = b.r_tr.p;
+		lr.nee_lum = b.r_nee.p; lr.wo_pdf = b.r_wp.p; lr.slot = b.r_slot.p; lr.tree = b.r_tree.p;
+		launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, lr, b.live_count.p, s);
 		PG_HIP(ctx, hipGetLastError());
 	}
 	if (valid_out || sumL) {

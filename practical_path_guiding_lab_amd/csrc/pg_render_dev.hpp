@@ -1132,12 +1132,12 @@ struct RenderArgs {
 	uint32_t *prev_quad; // shape number of the previous vertex
 	uint8_t *hit0; // the first bounce hit something (the `valid` flag, :400)
 	uint64_t *rng_state, *rng_inc;
-	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth
+	// path-vertex records: a list in visiting order, planes of stride n_lanes*max_depth (pg_list_records): what
+	// processPathData needs of a vertex -- bsdf weight, the two throughputs (3 planes each), the luminance of the emitter
+	// sample's share, woPdf -- and, instead of its position and directions, the accumulators they lead to: r_slot
+	// {path direction's, emitter direction's} and r_tree (the KD leaf's quadtree, bit 31: counted)
 	uint32_t *ray_of;
-	float *r_pos, *r_dir, *r_bsdf, *r_tb, *r_tr, *r_nee, *r_dnee, *r_wp;
-	// the split pipeline's list (pg_list_records): no position or directions (r_pos, r_dir, r_dnee stay unallocated) but
-	// the accumulators they lead to -- r_slot {path direction's, emitter direction's} and r_tree (the KD leaf's quadtree,
-	// bit 31: counted) -- and r_nee is one plane, the luminance of the emitter sample's share
+	float *r_bsdf, *r_tb, *r_tr, *r_nee, *r_wp;
 	uint2 *r_slot;
 	uint32_t *r_tree;
 	// mesh scenes (the split pipeline of pg_render_wave.hip): the state of a path between two bounces travels with

@@ -3,8 +3,8 @@ face of the KD jump grid, first seen in the fused splat kernel; DESIGN.md 3, pro
 
 kd_descend_grid (csrc/pg_descent.hpp) is inlined into every kernel that asks KDTree.getLeafNodeIndex
 (kdtree.py:435-470) a question: k_leaf_index, k_sample, k_pdf, k_guide_bounce, k_splat,
-k_process_and_splat<dense>, k_process_and_splat<list>, k_wave_guide, k_wave_tail, k_bounce and
-k_bounce_tail.  Each of them is fed positions exactly ON grid planes (the planes are bisection points
+k_process_and_splat, k_wave_guide, k_wave_tail, k_bounce and k_bounce_tail (the renderer's own splat,
+k_splat_list, walks no tree: the bounce kernels name the accumulators).  Each of them is fed positions exactly ON grid planes (the planes are bisection points
 of the root box, multiples of 100/64 for the [0,100]^3 box used here), one ulp beside them, on and
 beyond the faces of the root box, NaN and infinities -- against the CPU oracle, bit for bit, for trees
 whose grid has 8, 16 and 64 cells per axis."""
@@ -151,8 +151,8 @@ def _scene_and_box(which):
 
 @pytest.mark.parametrize("which", ["cornell-box", "cornell-box deep", "veach-mis", "mixed", "mixed deep"])
 def test_render_kernels_with_surfaces_on_grid_faces(which):
-    """k_bounce / k_bounce_tail (quad scenes), k_wave_guide / k_wave_tail (mesh scenes) and
-    k_process_and_splat<list> behind them, over a guided lifecycle against the oracle."""
+    """k_bounce / k_bounce_tail (quad scenes), k_wave_guide / k_wave_tail (mesh scenes) and k_splat_list behind them
+    (the accumulators those kernels name for vertices on the faces), over a guided lifecycle against the oracle."""
     from test_gpu_render import _guided_lifecycle_bit_exact
     sc, bmin, bmax = _scene_and_box(which)
     _guided_lifecycle_bit_exact(sc, True, bbox=(np.array(bmin, np.float32), np.array(bmax, np.float32)))
