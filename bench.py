@@ -102,6 +102,7 @@ def parse():
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
     ap.add_argument("--overlap", type=int, default=0, help="pg_render_overlap mode of the timed steps")
+    ap.add_argument("--sort", type=int, default=0, help="pg_render_sort: the live list of a bounce in a global spatial order")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at once")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
@@ -329,7 +330,7 @@ def run_render(args):
     tree = integ.sdTree
     npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
-    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap, in_flight=args.in_flight)
+    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap, in_flight=args.in_flight, sort=bool(args.sort))
     tiles = world > 1 and args.shard == "tiles"
     if tiles:
         ws.set_shard(rank, world, 4)
@@ -487,6 +488,8 @@ def run_render(args):
         kernels["k_wave_shade_a+b"]["shade_a_ms_per_step"] = round(kt.shade_a_ms / passes, 3)
         kernels["k_wave_shade_a+b"]["shade_b_ms_per_step"] = round(kt.shade_b_ms / passes, 3)
         kernels["k_wave_tail"] = kern(kt.tail_ms, max(kt.passes, 1))
+        if kt.sort_ms > 0:
+            kernels["radix_sort"] = kern(kt.sort_ms, max(kt.passes, 1))
         dom = "k_wave_guide"
     else:
         kernels["k_bounce"] = kern(kt.bounce_ms, kt.bounce_launches, tree_bytes)

@@ -372,6 +372,14 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
  * Results are identical (the two write disjoint buffers).  Default 0: every kernel on the caller's stream. */
 int pg_render_overlap(pg_context *ctx, int32_t mode);
 
+/* Not in the reference (Dr.Jit's wavefront keeps pixel order): with `on`, the bounces of a mesh scene from the second one
+ * up to rr_depth process the live list in a global spatial order -- the places sorted by the Morton cell of the vertex
+ * the ray has just found (a device radix sort of 16-bit keys per bounce) -- so that the lanes of a wave stand next to
+ * each other in the scene for the shading, the shadow rays, the SD-tree queries and, after the survivors are appended
+ * in that order, the next bounce's closest hits.  A lane's result depends on its own state only: radiance, sums,
+ * accumulators and trees are those of the unsorted run, bit for bit.  Default 0. */
+int pg_render_sort(pg_context *ctx, int32_t on);
+
 /* Allocates what pg_render_pass needs for passes of up to n_lanes lanes (pixels of the tile x spp) ahead
  * of time -- the reference allocates its numRays x max_depth record arrays in setup()
  * (path_guiding_integrator.py:93, 116); without this call the first pass of a size allocates them. */
@@ -424,6 +432,7 @@ typedef struct pg_kernel_timing {
 	double trace_ms, shade_ms, shadow_ms, guide_ms, tail_ms;
 	uint64_t trace_launches, guide_launches;
 	double shade_a_ms, shade_b_ms; /* the two shading kernels of shade_ms, each on its own */
+	double sort_ms;                /* pg_render_sort: the radix sorts of the sorted bounces */
 } pg_kernel_timing;
 int pg_enable_kernel_timing(pg_context *ctx, int32_t on);
 int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset);

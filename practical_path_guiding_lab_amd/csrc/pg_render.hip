@@ -403,6 +403,12 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	}
 }
 
+__global__ __launch_bounds__(kRBlock) void k_iota(uint32_t *__restrict__ out, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	if (i < n) out[i] = (uint32_t)i;
+}
+
 // element-wise evaluation of the library's deterministic fp32 functions (pg_math_eval)
 __global__ __launch_bounds__(kRBlock) void k_math_eval(int which, uint64_t n, const float *__restrict__ x,
                                                        float *__restrict__ out)
@@ -497,6 +503,12 @@ struct PassBuf {
 	DevBuf<uint32_t> order[2], live_count;
 	DevBuf<uint32_t> ray_of;
 	DevBuf<float> r_bsdf, r_tb, r_tr, r_nee, r_wp;
+	// pg_render_sort: keys of the places (written by k_wave_trace), the sorted keys, the identity, the places in sorted
+	// order, rocPRIM's temporary storage
+	DevBuf<uint32_t> sort_key, sort_key_out, sort_iota, sort_perm;
+	DevBuf<char> sort_tmp;
+	size_t sort_tmp_bytes = 0;
+	uint64_t sort_iota_n = 0;
 	DevBuf<uint2> r_slot;   // the list names accumulators instead of positions and directions (pg_list_records)
 	DevBuf<uint32_t> r_tree;
 	// pg_render_overlap: k_wave_guide beside k_wave_cast on a library-owned stream
@@ -527,6 +539,7 @@ struct pg_render_state {
 	bool have_scene = false;
 	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
 	int overlap = 0;           // pg_render_overlap
+	int sort = 0;              // pg_render_sort
 	PassBuf pb[2];
 	int last_slot = 0;         // of the most recent pass (pg_render_live_counts)
 	// optional per-kernel timing: (kind, start, stop) event triples still to be read
@@ -856,6 +869,21 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.texels = r->texels.p;
 	a.shapes.srgb_lut = r->srgb_lut.p;
 	a.st_in = nullptr; a.st_out = nullptr; a.inc_in = nullptr; a.inc_out = nullptr; // (set per bounce below)
+	a.sort_key = nullptr; a.perm = nullptr;
+	// sorted bounces (pg_render_sort): from the second bounce (camera rays find neighbouring vertices by themselves) to
+	// the depth at which Russian roulette thins the list out (:375: a sort costs what 33 M pairs cost however few are alive)
+	const int sort_until = wave && r->sort ? (prm->rr_depth < D ? prm->rr_depth : D) : 0;
+	if (sort_until > 1) {
+		if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
+		PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
+		PG_HIP(ctx, b.sort_iota.ensure(N));
+		if (b.sort_iota_n < N) {
+			hipLaunchKernelGGL(k_iota, dim3((unsigned)((N + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, s, b.sort_iota.p, N);
+			b.sort_iota_n = N;
+		}
+		const size_t need = sort_pairs_temp_bytes((uint32_t)N);
+		if (need > b.sort_tmp_bytes) { PG_HIP(ctx, b.sort_tmp.ensure(need)); b.sort_tmp_bytes = need; }
+	}
 	a.ws = b.ws.p;
 	a.bvh_ovf = b.bvh_ovf.p;
 	a.cast_count = b.live_count.p + (D + 1);
@@ -906,7 +934,29 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			a.st_out = b.st[(it + 1) & 1].p; a.inc_out = b.inc[(it + 1) & 1].p;
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
+				a.sort_key = nullptr; a.perm = nullptr;
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
+			}
+			const bool sorted = it >= 1 && it < sort_until;
+			a.sort_key = sorted ? b.sort_key.p : nullptr;
+			a.perm = nullptr;
+			if (sorted) { // closest hits in list order (they write every live place's key), the sort, then everything else at k
+				PG_HIP(ctx, hipMemsetAsync(b.sort_key.p, 0xff, N * sizeof(uint32_t), s)); // (0xffff: a place without a path)
+				{
+					Timed t(r, s, 5);
+					launch_wave_stage(0, r->general, false, a, grid.x, (unsigned)ctx->n_cus, s);
+				}
+				{
+					Timed t(r, s, 11);
+					PG_HIP(ctx, sort_pairs16(b.sort_tmp.p, b.sort_tmp_bytes, b.sort_key.p, b.sort_key_out.p, b.sort_iota.p, b.sort_perm.p,
+					                         (uint32_t)N, s));
+				}
+				a.perm = b.sort_perm.p;
+				for (int stage = 1; stage < 5; ++stage) {
+					Timed t(r, s, 5 + stage);
+					launch_wave_stage(stage, r->general, false, a, grid.x, (unsigned)ctx->n_cus, s);
+				}
+				continue;
 			}
 			if (r->overlap & 1) {
 				if (!b.side) {
@@ -1003,6 +1053,13 @@ int pg_render_overlap(pg_context *ctx, int32_t mode)
 	return PG_OK;
 }
 
+int pg_render_sort(pg_context *ctx, int32_t on)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	rstate(ctx)->sort = on != 0;
+	return PG_OK;
+}
+
 int pg_render_reserve(pg_context *ctx, uint64_t n_lanes)
 {
 	if (!ctx) return PG_ERR_INVALID;
@@ -1096,6 +1153,7 @@ int pg_read_kernel_timing(pg_context *ctx, pg_kernel_timing *out, int32_t reset)
 		case 8: r->acc.guide_ms += ms; r->acc.bounce_ms += ms; ++r->acc.guide_launches; break;
 		case 9: r->acc.shade_ms += ms; r->acc.shade_b_ms += ms; r->acc.bounce_ms += ms; break;
 		case 10: r->acc.tail_ms += ms; r->acc.bounce_ms += ms; break;
+		case 11: r->acc.sort_ms += ms; r->acc.bounce_ms += ms; break;
 		case 2: r->acc.splat_ms += ms; ++r->acc.splat_launches; break;
 		case 4: r->acc.compact_ms += ms; break;
 		default: r->acc.finish_ms += ms; break;

@@ -1151,6 +1151,10 @@ struct RenderArgs {
 	uint4 *st_out;
 	const uint64_t *inc_in;
 	uint64_t *inc_out;
+	// pg_render_sort: sort_key (k_wave_trace writes the key of every place it serves; nullptr = this bounce is not sorted)
+	// and perm (the places in sorted order, read by k_wave_shade_a; nullptr = list order)
+	uint32_t *sort_key;
+	const uint32_t *perm;
 	uint32_t *ws;
 	uint2 *bvh_ovf;
 	// the ray-casting kernels are persistent: a lane whose ray is done takes the next one of the launch's

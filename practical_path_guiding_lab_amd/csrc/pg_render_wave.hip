@@ -48,7 +48,11 @@ enum : int {
 	WS_RNG_LO, WS_RNG_HI,
 	WS_OCC,
 	WS_PDF_NEE, WS_PDF_TREE,
-	WS_COUNT
+	// sorted bounces (pg_render_sort): k_wave_shade_a is the one kernel that reads the state through the permutation; what
+	// k_wave_guide and k_wave_shade_b need of it travels on in ten planes -- throughput (3), ior word, radiance (3), lane,
+	// sampler increment (2)
+	WS_FWD,
+	WS_COUNT = WS_FWD + 10
 };
 
 // lane classes and switches a bounce decides in stage_a
@@ -402,6 +406,27 @@ __device__ __forceinline__ v3 st_v3(uint4 q) { return V(__uint_as_float(q.x), __
 // q 2's fourth word: the ior (positive) with the delta bit in its sign
 __device__ __forceinline__ uint32_t st_pack_ior(float ior, bool delta) { return __float_as_uint(ior) | (delta ? 0x80000000u : 0u); }
 
+// The sort key of a vertex (pg_sort.hip): the Morton code of its cell in a 32^3 grid over the SD-tree's root box
+// (15 bits); 0xfffe for a ray that left the scene (it still has to be shaded: :189-200 does not apply, the path ends);
+// places of the list that hold no path keep the 0xffff the buffer was filled with and sort behind everything.
+__device__ __forceinline__ uint32_t spread5(uint32_t v) // bits 0-4 -> bits 0, 3, 6, 9, 12
+{
+	return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+__device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p)
+{
+	uint32_t c[3];
+	const float q[3] = {p.x, p.y, p.z};
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		float f = (q[k] - a.tree.bmin[k]) / (a.tree.bmax[k] - a.tree.bmin[k]) * 32.0f;
+		if (!(f > 0.0f)) f = 0.0f; // (NaN too)
+		if (f > 31.0f) f = 31.0f;
+		c[k] = (uint32_t)f;
+	}
+	return spread5(c[0]) | (spread5(c[1]) << 1) | (spread5(c[2]) << 2);
+}
+
 // ---- :185 scene.ray_intersect: one ray per lane.  (The persistent form below was measured too: the walks of
 // closest-hit rays are all about equally long, handing idle lanes new rays gains nothing after the second
 // bounce and loses a factor of two on the coherent camera rays.) ----
@@ -433,6 +458,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	wsput(a, WS_HIT_T, tid, h.t);
 	wsput(a, WS_HIT_U, tid, h.u);
 	wsput(a, WS_HIT_V, tid, h.v);
+	if (a.sort_key) a.sort_key[tid] = h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu;
 }
 
 // ---- :213 test_visibility ----
@@ -553,23 +579,32 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	if (!alive) return;
 	Pcg32 rng;
-	const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid);
+	// a sorted bounce: this thread serves the place the sort put k-th -- the one gather through the permutation; every
+	// kernel after this one reads what it needs at k
+	const uint64_t place = a.perm ? (uint64_t)a.perm[tid] : tid;
+	const uint4 q0 = st_load(a.st_in, a, 0, place), q1 = st_load(a.st_in, a, 1, place);
 	rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
-	rng.inc = a.inc_in[tid];
+	rng.inc = a.inc_in[place];
 	const v3 ray_o = st_v3(q0), ray_d = st_v3(q1);
 	v3 thr = V(1, 1, 1), prev_p = V(0, 0, 0);
 	float prev_pdf = 1.0f;
 	bool prev_delta = true;
 	if (!kFirst) {
-		const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid);
+		const uint4 q2 = st_load(a.st_in, a, 2, place), q3 = st_load(a.st_in, a, 3, place);
 		thr = st_v3(q2);
 		prev_delta = (q2.w >> 31) != 0u;
 		prev_p = st_v3(q3);
 		prev_pdf = __uint_as_float(q3.w);
+		if (a.perm) { // what k_wave_guide and k_wave_shade_b need of the state, at k
+			const uint4 q4 = st_load(a.st_in, a, 4, place);
+			wsputu(a, WS_FWD + 0, tid, q2.x); wsputu(a, WS_FWD + 1, tid, q2.y); wsputu(a, WS_FWD + 2, tid, q2.z); wsputu(a, WS_FWD + 3, tid, q2.w);
+			wsputu(a, WS_FWD + 4, tid, q4.x); wsputu(a, WS_FWD + 5, tid, q4.y); wsputu(a, WS_FWD + 6, tid, q4.z); wsputu(a, WS_FWD + 7, tid, q4.w);
+			wsputu(a, WS_FWD + 8, tid, (uint32_t)rng.inc); wsputu(a, WS_FWD + 9, tid, (uint32_t)(rng.inc >> 32));
+		}
 	}
 	HitRec h;
-	h.prim = (int)wsu(a, WS_HIT_PRIM, tid);
-	h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
+	h.prim = (int)wsu(a, WS_HIT_PRIM, place);
+	h.t = wsf(a, WS_HIT_T, place); h.u = wsf(a, WS_HIT_U, place); h.v = wsf(a, WS_HIT_V, place);
 	StageA A;
 	stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
 	// (storing a value for some lanes of a wave only saves nothing by itself -- the partial store touches the same
@@ -609,7 +644,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	if (!guide_has_work(a, flags)) return;
 	Pcg32 rng;
 	rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
-	rng.inc = a.inc_in[tid];
+	rng.inc = a.perm ? ((uint64_t)wsu(a, WS_FWD + 8, tid) | ((uint64_t)wsu(a, WS_FWD + 9, tid) << 32)) : a.inc_in[tid];
 	GuideOut g;
 	// (the BSDF-sampled direction of a lane that keeps it; a lane that samples the tree has none to evaluate)
 	const v3 wo_in = (flags & F_SMP_TREE) ? V(0, 0, 0) : ws3(a, WS_U, tid);
@@ -682,9 +717,16 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		if (guide_has_work(a, A.flags)) { g.pdf_nee = wsf(a, WS_PDF_NEE, tid); g.pdf_tree = wsf(a, WS_PDF_TREE, tid); }
 		const bool occluded = (A.flags & F_NEED_SHADOW) && wsu(a, WS_OCC, tid) != 0u;
 		rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
-		rng.inc = a.inc_in[tid];
+		rng.inc = a.perm ? ((uint64_t)wsu(a, WS_FWD + 8, tid) | ((uint64_t)wsu(a, WS_FWD + 9, tid) << 32)) : a.inc_in[tid];
 		if (!kFirst) {
-			const uint4 q2 = st_load(a.st_in, a, 2, tid), q4 = st_load(a.st_in, a, 4, tid);
+			uint4 q2, q4;
+			if (a.perm) { // (a sorted bounce: k_wave_shade_a has brought them along)
+				q2 = make_uint4(wsu(a, WS_FWD + 0, tid), wsu(a, WS_FWD + 1, tid), wsu(a, WS_FWD + 2, tid), wsu(a, WS_FWD + 3, tid));
+				q4 = make_uint4(wsu(a, WS_FWD + 4, tid), wsu(a, WS_FWD + 5, tid), wsu(a, WS_FWD + 6, tid), wsu(a, WS_FWD + 7, tid));
+			} else {
+				q2 = st_load(a.st_in, a, 2, tid);
+				q4 = st_load(a.st_in, a, 4, tid);
+			}
 			thr = st_v3(q2);
 			ior = __uint_as_float(q2.w & 0x7fffffffu);
 			L = st_v3(q4);

@@ -494,7 +494,7 @@ def test_fused_kernel_and_split_pipeline_are_two_implementations_of_one_bounce(w
 
 @pytest.mark.parametrize("which", ["veach-ajar", "cornell-box", "mixed"])
 def test_two_passes_in_flight_equal_one_at_a_time(which):
-    """WavefrontScene(in_flight=2): consecutive passes alternate between the two buffer sets of pg_pass_params.slot on
+    """Scheduling switches change no result.  WavefrontScene(in_flight=2): consecutive passes alternate between the two buffer sets of pg_pass_params.slot on
     two streams of their own, two on the device at once, with pg_render_overlap on top.  Radiance of every pass, the
     per-pixel sums (added in issue order: fp32), the accumulators and the refined trees equal the
     one-pass-at-a-time run bit for bit over a guided lifecycle of many small passes."""
@@ -508,10 +508,10 @@ def test_two_passes_in_flight_equal_one_at_a_time(which):
     npix = sc.camera.width * sc.camera.height
     bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
 
-    def run(in_flight, overlap):
+    def run(in_flight, overlap, sort=False):
         g = PathGuidingIntegrator({"max_depth": sc.max_depth, "rr_depth": sc.rr_depth})
         g.setup(npix, bmin, bmax, 20, 20, True, 0.5)
-        ws = WavefrontScene(sc, in_flight=in_flight, overlap=overlap)
+        ws = WavefrontScene(sc, in_flight=in_flight, overlap=overlap, sort=sort)
         out = []
         cumm = 0
         for k in range(4):
@@ -548,3 +548,6 @@ def test_two_passes_in_flight_equal_one_at_a_time(which):
     same(ref, run(2, 0))
     same(ref, run(2, 1))
     same(ref, run(1, 1))
+    # pg_render_sort: the bounces below rr_depth in a global spatial order (mesh scenes; a no-op for the fused kernels)
+    same(ref, run(1, 0, sort=True))
+    same(ref, run(2, 0, sort=True))
