@@ -102,7 +102,7 @@ def parse():
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
     ap.add_argument("--overlap", type=int, default=0, help="pg_render_overlap mode of the timed steps")
-    ap.add_argument("--sort", type=int, default=0, help="pg_render_sort: the live list of a bounce in a global spatial order")
+    ap.add_argument("--sort", type=int, default=1, help="pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (0: list order)")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at once")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")

@@ -54,8 +54,10 @@ struct pg_list_records {
 	const uint2 *slot;         // {path direction's, emitter direction's} accumulator: kSlotNone / kSlotRoot / rec * 4 + child
 	const uint32_t *tree;      // quadtree of the vertex's KD leaf; bit 31: inside the root box (counted, kdtree.py:193)
 };
+// l_final (3, num_rays) planar, or -- when l_final_q is given -- one 16-byte entry per path
 void launch_splat_list(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays, int32_t max_depth,
-                       const float *l_final, const pg_list_records &rec, const uint32_t *live_count, hipStream_t s);
+                       const float *l_final, const uint4 *l_final_q, const pg_list_records &rec, const uint32_t *live_count,
+                       hipStream_t s);
 
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee,
                               uint64_t num_rays, int32_t max_depth, const float *l_final,

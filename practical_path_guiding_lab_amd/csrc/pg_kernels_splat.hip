@@ -337,7 +337,8 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 // final radiance), the division chain of :434-453, and the atomics.
 __global__ __launch_bounds__(kBlock) void k_splat_list(TreeView t, AccumView a, int store_nee, uint64_t num_rays,
                                                        int32_t max_depth, const float *__restrict__ l_final,
-                                                       pg_list_records r, const uint32_t *__restrict__ live_count)
+                                                       const uint4 *__restrict__ l_final_q, pg_list_records r,
+                                                       const uint32_t *__restrict__ live_count)
 {
 	__shared__ long long s_val[kBlock * 4];
 	__shared__ unsigned long long s_ptr[kBlock];
@@ -353,10 +354,16 @@ __global__ __launch_bounds__(kBlock) void k_splat_list(TreeView t, AccumView a, 
 		if (g < total) {
 			const uint32_t ray = r.ray_of[g];
 			if (ray != kNoRay) {
-				float in[3];
+				float in[3], lf[3];
+				if (l_final_q) { // (the split pipeline keeps a path's final radiance as one 16-byte entry: one gather)
+					const uint4 q = l_final_q[ray];
+					lf[0] = __uint_as_float(q.x); lf[1] = __uint_as_float(q.y); lf[2] = __uint_as_float(q.z);
+				} else {
+					lf[0] = l_final[ray]; lf[1] = l_final[num_rays + ray]; lf[2] = l_final[2 * num_rays + ray];
+				}
 #pragma unroll
 				for (int ch = 0; ch < 3; ++ch) {
-					float out = (l_final[ch * num_rays + ray] - r.throughput_radiance[ch * S + g]) / r.throughput_bsdf[ch * S + g];
+					float out = (lf[ch] - r.throughput_radiance[ch * S + g]) / r.throughput_bsdf[ch * S + g];
 					if (out != out) out = 0.0f;                         // :444
 					float q = out / r.bsdf[ch * S + g];
 					if (q != q) q = 0.0f;                               // :449
@@ -455,12 +462,13 @@ static dim3 strided_grid(uint64_t S)
 }
 
 void launch_splat_list(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays, int32_t max_depth,
-                       const float *l_final, const pg_list_records &rec, const uint32_t *live_count, hipStream_t s)
+                       const float *l_final, const uint4 *l_final_q, const pg_list_records &rec, const uint32_t *live_count,
+                       hipStream_t s)
 {
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	if (S == 0) return;
-	hipLaunchKernelGGL(k_splat_list, strided_grid(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays, max_depth, l_final, rec,
-	                   live_count);
+	hipLaunchKernelGGL(k_splat_list, strided_grid(S), dim3(kBlock), 0, s, t, a, store_nee, num_rays, max_depth, l_final, l_final_q,
+	                   rec, live_count);
 }
 
 void launch_process_and_splat(const TreeView &t, const AccumView &a, int store_nee, uint64_t num_rays,

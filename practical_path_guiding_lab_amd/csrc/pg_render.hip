@@ -378,6 +378,16 @@ __global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 	}
 }
 
+// the split pipeline left the radiance of lane l in Lq[l] (one 16-byte entry, written where the path ended): the output
+// column L (3, N), one thread per lane
+__global__ __launch_bounds__(kRBlock) void k_layout_L(const uint4 *__restrict__ Lq, float *__restrict__ L, uint64_t N)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
+	if (i >= N) return;
+	const uint4 q = Lq[i];
+	L[i] = __uint_as_float(q.x); L[N + i] = __uint_as_float(q.y); L[2 * N + i] = __uint_as_float(q.z);
+}
+
 // :400-431: valid flag and per-pixel sums, samples of a pixel added in lane order
 __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__restrict__ valid_out,
                                                     float *__restrict__ sumL, float *__restrict__ sumL2)
@@ -506,6 +516,8 @@ struct PassBuf {
 	// pg_render_sort: keys of the places (written by k_wave_trace), the sorted keys, the identity, the places in sorted
 	// order, rocPRIM's temporary storage
 	DevBuf<uint32_t> sort_key, sort_key_out, sort_iota, sort_perm;
+	DevBuf<uint4> carry; // the paths' 128-byte records of a sorted bounce (RenderArgs::carry_in)
+	DevBuf<uint4> Lq;    // the split pipeline's radiance by lane (RenderArgs::Lq)
 	DevBuf<char> sort_tmp;
 	size_t sort_tmp_bytes = 0;
 	uint64_t sort_iota_n = 0;
@@ -598,6 +610,7 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 		PG_HIP(ctx, b.prev_quad.ensure(N)); PG_HIP(ctx, b.rng_state.ensure(N));
 	} else {
 		for (int k = 0; k < 2; ++k) { PG_HIP(ctx, b.st[k].ensure(5 * N)); PG_HIP(ctx, b.inc[k].ensure(N)); }
+		PG_HIP(ctx, b.Lq.ensure(N));
 		PG_HIP(ctx, b.ws.ensure((size_t)wave_workspace_planes() * N));
 		PG_HIP(ctx, b.shadow_list.ensure(N));
 		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
@@ -869,14 +882,15 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.texels = r->texels.p;
 	a.shapes.srgb_lut = r->srgb_lut.p;
 	a.st_in = nullptr; a.st_out = nullptr; a.inc_in = nullptr; a.inc_out = nullptr; // (set per bounce below)
-	a.sort_key = nullptr; a.perm = nullptr;
+	a.sort_key = nullptr; a.perm = nullptr; a.carry_in = nullptr; a.carry_out = nullptr;
+	a.Lq = wave ? b.Lq.p : nullptr;
 	// sorted bounces (pg_render_sort): from the second bounce (camera rays find neighbouring vertices by themselves) to
 	// the depth at which Russian roulette thins the list out (:375: a sort costs what 33 M pairs cost however few are alive)
 	const int sort_until = wave && r->sort ? (prm->rr_depth < D ? prm->rr_depth : D) : 0;
 	if (sort_until > 1) {
 		if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
 		PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
-		PG_HIP(ctx, b.sort_iota.ensure(N));
+		PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry.ensure(8 * N));
 		if (b.sort_iota_n < N) {
 			hipLaunchKernelGGL(k_iota, dim3((unsigned)((N + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, s, b.sort_iota.p, N);
 			b.sort_iota_n = N;
@@ -934,11 +948,15 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			a.st_out = b.st[(it + 1) & 1].p; a.inc_out = b.inc[(it + 1) & 1].p;
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
-				a.sort_key = nullptr; a.perm = nullptr;
+				// (the state of a bounce that would be sorted is in the paths' records: the tail launch reads it there)
+				a.sort_key = nullptr; a.perm = nullptr; a.carry_out = nullptr;
+				a.carry_in = (it >= 1 && it < sort_until) ? b.carry.p : nullptr;
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
 			}
-			const bool sorted = it >= 1 && it < sort_until;
+			const bool sorted = it >= 1 && it < sort_until, next_sorted = it + 1 >= 1 && it + 1 < sort_until;
 			a.sort_key = sorted ? b.sort_key.p : nullptr;
+			a.carry_in = sorted ? b.carry.p : nullptr;
+			a.carry_out = next_sorted ? b.carry.p : nullptr;
 			a.perm = nullptr;
 			if (sorted) { // closest hits in list order (they write every live place's key), the sort, then everything else at k
 				PG_HIP(ctx, hipMemsetAsync(b.sort_key.p, 0xff, N * sizeof(uint32_t), s)); // (0xffff: a place without a path)
@@ -1016,8 +1034,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		pg_list_records lr;
 		lr.ray_of = b.ray_of.p; lr.bsdf = b.r_bsdf.p; lr.throughput_bsdf = b.r_tb.p; lr.throughput_radiance = b.r_tr.p;
 		lr.nee_lum = b.r_nee.p; lr.wo_pdf = b.r_wp.p; lr.slot = b.r_slot.p; lr.tree = b.r_tree.p;
-		launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, lr, b.live_count.p, s);
+		launch_splat_list(ctx->view(), ctx->f.accum_view(), ctx->store_nee, N, D, L_out, a.Lq, lr, b.live_count.p, s);
 		PG_HIP(ctx, hipGetLastError());
+	}
+	if (wave) {
+		Timed t(r, s, 3);
+		hipLaunchKernelGGL(k_layout_L, grid, dim3(kRBlock), 0, s, b.Lq.p, L_out, N);
 	}
 	if (valid_out || sumL) {
 		// the per-pixel sums are read, added to and written back (fp32: the order of the passes is part of the result,

@@ -1155,6 +1155,13 @@ struct RenderArgs {
 	// and perm (the places in sorted order, read by k_wave_shade_a; nullptr = list order)
 	uint32_t *sort_key;
 	const uint32_t *perm;
+	// ... and the 128-byte records of the paths (8 entries of 16 bytes per place: the five state entries, the sampler
+	// increment, the hit): carry_in = this bounce is sorted (k_wave_trace adds the hit, k_wave_shade_a reads the record
+	// through perm), carry_out = the next one is (k_wave_shade_b writes the survivors' records)
+	uint4 *carry_in, *carry_out;
+	// the split pipeline writes a path's radiance where the path ends, by lane -- scattered -- as ONE 16-byte entry of
+	// Lq; k_finish lays the output column L out from it (nullptr: the fused kernels keep L itself up to date)
+	uint4 *Lq;
 	uint32_t *ws;
 	uint2 *bvh_ovf;
 	// the ray-casting kernels are persistent: a lane whose ray is done takes the next one of the launch's

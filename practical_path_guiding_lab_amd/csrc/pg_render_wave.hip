@@ -446,6 +446,9 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 		const_cast<uint64_t *>(a.inc_in)[tid] = rng.inc;
 		st_store(const_cast<uint4 *>(a.st_in), a, 0, tid, ray_o, (uint32_t)rng.state);
 		st_store(const_cast<uint4 *>(a.st_in), a, 1, tid, ray_d, (uint32_t)(rng.state >> 32));
+	} else if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
+		ray_o = st_v3(a.carry_in[tid * 8 + 0]);
+		ray_d = st_v3(a.carry_in[tid * 8 + 1]);
 	} else {
 		ray_o = st_v3(st_load(a.st_in, a, 0, tid));
 		ray_d = st_v3(st_load(a.st_in, a, 1, tid));
@@ -454,11 +457,15 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	HitRec h;
 	h.u = 0.0f; h.v = 0.0f;
 	h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
+	if (a.carry_in) { // a sorted bounce: the hit joins the path's 128-byte record, which k_wave_shade_a reads through the permutation
+		a.carry_in[tid * 8 + 6] = make_uint4((uint32_t)h.prim, __float_as_uint(h.t), __float_as_uint(h.u), __float_as_uint(h.v));
+		a.sort_key[tid] = h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu;
+		return;
+	}
 	wsputu(a, WS_HIT_PRIM, tid, (uint32_t)h.prim);
 	wsput(a, WS_HIT_T, tid, h.t);
 	wsput(a, WS_HIT_U, tid, h.u);
 	wsput(a, WS_HIT_V, tid, h.v);
-	if (a.sort_key) a.sort_key[tid] = h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu;
 }
 
 // ---- :213 test_visibility ----
@@ -579,36 +586,47 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	if (!alive) return;
 	Pcg32 rng;
-	// a sorted bounce: this thread serves the place the sort put k-th -- the one gather through the permutation; every
-	// kernel after this one reads what it needs at k
-	const uint64_t place = a.perm ? (uint64_t)a.perm[tid] : tid;
-	const uint4 q0 = st_load(a.st_in, a, 0, place), q1 = st_load(a.st_in, a, 1, place);
-	rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
-	rng.inc = a.inc_in[place];
-	const v3 ray_o = st_v3(q0), ray_d = st_v3(q1);
-	v3 thr = V(1, 1, 1), prev_p = V(0, 0, 0);
+	v3 ray_o, ray_d, thr = V(1, 1, 1), prev_p = V(0, 0, 0);
 	float prev_pdf = 1.0f;
 	bool prev_delta = true;
-	if (!kFirst) {
-		const uint4 q2 = st_load(a.st_in, a, 2, place), q3 = st_load(a.st_in, a, 3, place);
+	HitRec h;
+	if (!kFirst && a.perm) {
+		// a sorted bounce: this thread serves the place the sort put k-th.  The one random pass over the state: the
+		// path's 128-byte record (k_wave_shade_b and k_wave_trace filled it) is one cache line; what k_wave_guide and
+		// k_wave_shade_b need of it travels on at k (WS_FWD), so that nothing after this kernel looks through the permutation
+		const uint4 *rec = a.carry_in + (uint64_t)a.perm[tid] * 8;
+		const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+		rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
+		rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
+		ray_o = st_v3(q0); ray_d = st_v3(q1);
 		thr = st_v3(q2);
 		prev_delta = (q2.w >> 31) != 0u;
 		prev_p = st_v3(q3);
 		prev_pdf = __uint_as_float(q3.w);
-		if (a.perm) { // what k_wave_guide and k_wave_shade_b need of the state, at k
-			const uint4 q4 = st_load(a.st_in, a, 4, place);
-			wsputu(a, WS_FWD + 0, tid, q2.x); wsputu(a, WS_FWD + 1, tid, q2.y); wsputu(a, WS_FWD + 2, tid, q2.z); wsputu(a, WS_FWD + 3, tid, q2.w);
-			wsputu(a, WS_FWD + 4, tid, q4.x); wsputu(a, WS_FWD + 5, tid, q4.y); wsputu(a, WS_FWD + 6, tid, q4.z); wsputu(a, WS_FWD + 7, tid, q4.w);
-			wsputu(a, WS_FWD + 8, tid, (uint32_t)rng.inc); wsputu(a, WS_FWD + 9, tid, (uint32_t)(rng.inc >> 32));
+		h.prim = (int)q6.x; h.t = __uint_as_float(q6.y); h.u = __uint_as_float(q6.z); h.v = __uint_as_float(q6.w);
+		wsputu(a, WS_FWD + 0, tid, q2.x); wsputu(a, WS_FWD + 1, tid, q2.y); wsputu(a, WS_FWD + 2, tid, q2.z); wsputu(a, WS_FWD + 3, tid, q2.w);
+		wsputu(a, WS_FWD + 4, tid, q4.x); wsputu(a, WS_FWD + 5, tid, q4.y); wsputu(a, WS_FWD + 6, tid, q4.z); wsputu(a, WS_FWD + 7, tid, q4.w);
+		wsputu(a, WS_FWD + 8, tid, q5.x); wsputu(a, WS_FWD + 9, tid, q5.y);
+	} else {
+		const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid);
+		rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
+		rng.inc = a.inc_in[tid];
+		ray_o = st_v3(q0); ray_d = st_v3(q1);
+		if (!kFirst) {
+			const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid);
+			thr = st_v3(q2);
+			prev_delta = (q2.w >> 31) != 0u;
+			prev_p = st_v3(q3);
+			prev_pdf = __uint_as_float(q3.w);
 		}
+		h.prim = (int)wsu(a, WS_HIT_PRIM, tid);
+		h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
 	}
-	HitRec h;
-	h.prim = (int)wsu(a, WS_HIT_PRIM, place);
-	h.t = wsf(a, WS_HIT_T, place); h.u = wsf(a, WS_HIT_U, place); h.v = wsf(a, WS_HIT_V, place);
 	StageA A;
 	stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
 	// (storing a value for some lanes of a wave only saves nothing by itself -- the partial store touches the same
-	// sectors -- which is why the two classes of lanes share planes instead: WS_U)
+	// sectors -- which is why the two classes of lanes share planes instead: WS_U; making every lane store so that no
+	// line is written in part was measured too: no different, 84.0 vs 84.8 ms per step)
 	wsput3(a, WS_P, tid, A.p); wsput3(a, WS_NG, tid, A.ng);
 	wsputu(a, WS_FLAGS, tid, A.flags);
 	if (A.flags & F_SMP_TREE) { // (see WS_U)
@@ -670,6 +688,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 {
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
+	extern __shared__ uint4 s_rec[]; // kRBlock * 8 entries when the next bounce is sorted (a.carry_out), else none
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		                       prev_pdf, delta);
 		p_here = A.p;
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
-		if (!cont) stp(a.L, N, lane, L); // the path ends here: its radiance (:431), written once
+		if (!cont) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here: its radiance (:431), written once -- one 16-byte store (k_finish lays the output column out)
 	}
 	if (a.last) return; // nothing survives the last bounce
 	const unsigned long long ballot = __ballot(cont);
@@ -752,12 +771,35 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	if (cont) { // the survivor's state goes to its place in the next list (whole lines: a wave's survivors are neighbours)
 		uint32_t off = s_base + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
 		for (unsigned w = 0; w < wv; ++w) off += s_wave[w];
-		st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
-		st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
-		st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
-		st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
-		st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
-		a.inc_out[off] = rng.inc;
+		if (a.carry_out) {
+			// the next bounce is sorted: the state goes into ONE 128-byte record per path and nowhere else -- k_wave_shade_a,
+			// the only kernel that looks through the permutation, reads it as one cache line; k_wave_trace takes the ray from
+			// it and adds the hit.  The records are written as WHOLE lines, all 128 bytes of each, by consecutive threads
+			// (through LDS, below): 96 of the 128 bytes -- by the lanes themselves or through LDS alike -- cost
+			// k_wave_shade_b 13.6 -> 18.4 ms per step.  A line written in part is read, merged and written back.
+			uint4 *rec = s_rec + (off - s_base) * 8u;
+			rec[0] = make_uint4(__float_as_uint(ray_o.x), __float_as_uint(ray_o.y), __float_as_uint(ray_o.z), (uint32_t)rng.state);
+			rec[1] = make_uint4(__float_as_uint(ray_d.x), __float_as_uint(ray_d.y), __float_as_uint(ray_d.z), (uint32_t)(rng.state >> 32));
+			rec[2] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), st_pack_ior(ior, delta));
+			rec[3] = make_uint4(__float_as_uint(p_here.x), __float_as_uint(p_here.y), __float_as_uint(p_here.z), __float_as_uint(prev_pdf));
+			rec[4] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), (uint32_t)lane);
+			rec[5] = make_uint4((uint32_t)rng.inc, (uint32_t)(rng.inc >> 32), 0u, 0u);
+			rec[6] = make_uint4(0u, 0u, 0u, 0u); rec[7] = make_uint4(0u, 0u, 0u, 0u); // (the hit: k_wave_trace; spare)
+		} else {
+			st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
+			st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
+			st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
+			st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
+			st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
+			a.inc_out[off] = rng.inc;
+		}
+	}
+	if (a.carry_out) { // the workgroup's records leave through LDS as WHOLE 128-byte lines (see above)
+		__syncthreads();
+		uint32_t tot = 0;
+		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
+		uint4 *dst = a.carry_out + (uint64_t)s_base * 8;
+		for (uint32_t j = threadIdx.x; j < tot * 8u; j += kRBlock) dst[j] = s_rec[j];
 	}
 }
 
@@ -792,10 +834,18 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	bool prev_delta = false;
 	rng.state = 0; rng.inc = 1;
 	if (alive) {
-		const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid), q2 = st_load(a.st_in, a, 2, tid),
-		            q3 = st_load(a.st_in, a, 3, tid), q4 = st_load(a.st_in, a, 4, tid);
+		uint4 q0, q1, q2, q3, q4;
+		if (a.carry_in) { // the bounce taken over would have been a sorted one: its state is in the paths' records
+			const uint4 *rec = a.carry_in + tid * 8;
+			q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4];
+			const uint4 q5 = rec[5];
+			rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
+		} else {
+			q0 = st_load(a.st_in, a, 0, tid); q1 = st_load(a.st_in, a, 1, tid); q2 = st_load(a.st_in, a, 2, tid);
+			q3 = st_load(a.st_in, a, 3, tid); q4 = st_load(a.st_in, a, 4, tid);
+			rng.inc = a.inc_in[tid];
+		}
 		rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
-		rng.inc = a.inc_in[tid];
 		ray_o = st_v3(q0); ray_d = st_v3(q1); thr = st_v3(q2); prev_p = st_v3(q3);
 		ior = __uint_as_float(q2.w & 0x7fffffffu);
 		prev_delta = (q2.w >> 31) != 0u;
@@ -825,7 +875,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 			alive = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, slot, (uint32_t)depth, ray_o, ray_d, prev_pdf, delta);
 			prev_p = A.p;
 			prev_delta = delta;
-			if (!alive) stp(a.L, N, lane, L); // the path ends here: its radiance, written once
+			if (!alive) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here
 		}
 		const unsigned long long ballot = __ballot(alive);
 		if (ballot == 0ull) break; // (nothing survives the last bounce)
@@ -876,10 +926,12 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		else hipLaunchKernelGGL((k_wave_cast<kLevel, false>), persistent_grid(k_wave_cast<kLevel, false>, occ[1], n_cus, a.n_lanes), block, 0, s, a);
 		break;
 	case 3: hipLaunchKernelGGL(k_wave_guide, grid, block, 0, s, a); break;
-	case 4:
-		if (first) hipLaunchKernelGGL((k_wave_shade_b<kLevel, true>), grid, block, 0, s, a);
-		else hipLaunchKernelGGL((k_wave_shade_b<kLevel, false>), grid, block, 0, s, a);
+	case 4: {
+		const size_t lds = a.carry_out ? (size_t)kRBlock * 8 * sizeof(uint4) : 0; // (the survivors' records of a sorted next bounce)
+		if (first) hipLaunchKernelGGL((k_wave_shade_b<kLevel, true>), grid, block, lds, s, a);
+		else hipLaunchKernelGGL((k_wave_shade_b<kLevel, false>), grid, block, lds, s, a);
 		break;
+	}
 	default: hipLaunchKernelGGL((k_wave_tail<kLevel>), grid, block, 0, s, a); break;
 	}
 }

@@ -45,13 +45,15 @@ class WavefrontScene:
     """Device-resident scene (quads + camera) implementing the `trace_pass` protocol of
     PathGuidingIntegrator.sample()."""
 
-    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0, in_flight: int = 1, sort: bool = False):
+    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0, in_flight: int = 1, sort: bool = True):
         """split_pipeline: run the bounce as the split pipeline also for a scene the fused kernel could
         run (pg_render_split_pipeline: same results, the SD-tree queries as a kernel of their own)."""
         self.scene = scene
         self.split_pipeline = bool(split_pipeline)
         self.overlap = int(overlap)  # pg_render_overlap: independent kernels of a pass side by side (same results)
-        self.sort = bool(sort)       # pg_render_sort: the live list in a global spatial order per bounce (same results)
+        # pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (same results, +10 % on
+        # veach-ajar; the fused kernels of quad scenes ignore it)
+        self.sort = bool(sort)
         # in_flight = 2: consecutive passes alternate between two buffer sets (pg_pass_params.slot) and two streams of
         # their own, so that two are on the device at once (the passes of an iteration are independent, main.py:208-218;
         # same results).  What a pass returns is then valid once join() has made the current stream wait for them.

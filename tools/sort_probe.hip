@@ -23,7 +23,7 @@ int main()
 	(void)hipMalloc(&k0, nmax * 4); (void)hipMalloc(&k1, nmax * 4); (void)hipMalloc(&v0, nmax * 4); (void)hipMalloc(&v1, nmax * 4);
 	hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
 	for (uint32_t n : {17u << 20, 33u << 20})
-		for (int bits : {12, 16, 20}) {
+		for (int bits : {6, 8, 10, 12, 16}) {
 			size_t tmp_bytes = 0;
 			(void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, n, 0, bits, 0);
 			void *tmp; (void)hipMalloc(&tmp, tmp_bytes);
