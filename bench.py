@@ -551,6 +551,10 @@ def run_render(args):
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
             "traffic": traffic,
+            # above 1 the algorithmic model is not a bandwidth at all: in a spatially sorted list (pg_render_sort) the lanes of a
+            # wave walk the same KD leaves and quadtrees, their gathers meet in L1/L2 and the bytes the model prices per lane are
+            # fetched once per wave -- frac_counter_* say what reaches HBM
+            "model_applicable": bool(kernels[dom].get("alg_GBps", 0.0) <= HBM_PEAK_GBS),
             # the counter-honest fractions: HBM bytes of the PMC counters per launch / this run's launch time / peak --
             # lo as counted, hi with the guide's x2 FETCH correction (an upper bound for scattered reads)
             "frac_counter_lo": None if (tr_dom is None or tr_dom["lo"] is None or dom_sec <= 0) else round(tr_dom["lo"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
