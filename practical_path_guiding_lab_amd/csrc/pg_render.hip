@@ -517,6 +517,15 @@ struct PassBuf {
 	// order, rocPRIM's temporary storage
 	DevBuf<uint32_t> sort_key, sort_key_out, sort_iota, sort_perm;
 	DevBuf<uint4> carry; // the paths' 128-byte records of a sorted bounce (RenderArgs::carry_in)
+	// which bounces are worth a sort is read off the PREVIOUS pass of this set: its live counts come back to the host
+	// behind the pass (pinned memory, an event), and a bounce is sorted when at least kSortMinLive of the lanes were alive
+	// going into it -- a sort costs what N pairs cost however few are left (scenes/torus: 24 % after the second bounce)
+	uint32_t *h_live = nullptr;       // pinned, max_depth entries
+	int h_live_n = 0;
+	hipEvent_t ev_live = nullptr;
+	bool live_pending = false, live_known = false;
+	std::vector<uint32_t> live_prev;
+	uint64_t live_prev_lanes = 0;
 	DevBuf<uint4> Lq;    // the split pipeline's radiance by lane (RenderArgs::Lq)
 	DevBuf<char> sort_tmp;
 	size_t sort_tmp_bytes = 0;
@@ -533,9 +542,14 @@ struct PassBuf {
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
 		if (ev_join) (void)hipEventDestroy(ev_join);
 		if (ev_finish) (void)hipEventDestroy(ev_finish);
+		if (ev_live) (void)hipEventDestroy(ev_live);
+		if (h_live) (void)hipHostFree(h_live);
 		if (side) (void)hipStreamDestroy(side);
 	}
 };
+
+// pg_render_sort: a bounce is sorted when at least 3/10 of the pass's lanes were alive going into it (last pass's counts)
+constexpr uint64_t kSortMinLiveNum = 3, kSortMinLiveDen = 10;
 
 // library-owned renderer state
 struct pg_render_state {
@@ -888,6 +902,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	// the depth at which Russian roulette thins the list out (:375: a sort costs what 33 M pairs cost however few are alive)
 	const int sort_until = wave && r->sort ? (prm->rr_depth < D ? prm->rr_depth : D) : 0;
 	if (sort_until > 1) {
+		if (b.live_pending && hipEventQuery(b.ev_live) == hipSuccess) { // the previous pass's live counts have arrived
+			b.live_prev.assign(b.h_live, b.h_live + b.h_live_n);
+			b.live_pending = false;
+			b.live_known = true;
+		}
+		if (b.live_known && (b.live_prev_lanes != N || (int)b.live_prev.size() != D)) b.live_known = false; // (another pass size)
 		if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
 		PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
 		PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry.ensure(8 * N));
@@ -946,14 +966,19 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			// launch go to the set the first bounce reads
 			a.st_in = b.st[it & 1].p; a.inc_in = b.inc[it & 1].p;
 			a.st_out = b.st[(it + 1) & 1].p; a.inc_out = b.inc[(it + 1) & 1].p;
+			// (the choice changes no result: without counts of a previous pass every bounce below rr_depth is sorted)
+			auto worth_sorting = [&](int bounce) {
+				if (bounce < 1 || bounce >= sort_until) return false;
+				return !b.live_known || (uint64_t)b.live_prev[bounce - 1] * kSortMinLiveDen >= N * kSortMinLiveNum;
+			};
 			if (tail_checkpoint(it, D)) {
 				Timed t(r, s, 10);
-				// (the state of a bounce that would be sorted is in the paths' records: the tail launch reads it there)
+				// (the state of a sorted bounce is in the paths' records: the tail launch reads it there)
 				a.sort_key = nullptr; a.perm = nullptr; a.carry_out = nullptr;
-				a.carry_in = (it >= 1 && it < sort_until) ? b.carry.p : nullptr;
+				a.carry_in = worth_sorting(it) ? b.carry.p : nullptr;
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
 			}
-			const bool sorted = it >= 1 && it < sort_until, next_sorted = it + 1 >= 1 && it + 1 < sort_until;
+			const bool sorted = worth_sorting(it), next_sorted = worth_sorting(it + 1);
 			a.sort_key = sorted ? b.sort_key.p : nullptr;
 			a.carry_in = sorted ? b.carry.p : nullptr;
 			a.carry_out = next_sorted ? b.carry.p : nullptr;
@@ -1054,6 +1079,21 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			if (!b.ev_finish) PG_HIP(ctx, hipEventCreateWithFlags(&b.ev_finish, hipEventDisableTiming));
 			PG_HIP(ctx, hipEventRecord(b.ev_finish, s));
 			b.finish_recorded = true;
+		}
+	}
+	if (sort_until > 1) { // this pass's live counts, for the next pass of this set to decide by
+		if (!b.h_live || b.h_live_n != D) {
+			if (b.h_live) (void)hipHostFree(b.h_live);
+			b.h_live = nullptr;
+			PG_HIP(ctx, hipHostMalloc((void **)&b.h_live, (size_t)D * sizeof(uint32_t)));
+			b.h_live_n = D;
+		}
+		if (!b.ev_live) PG_HIP(ctx, hipEventCreateWithFlags(&b.ev_live, hipEventDisableTiming));
+		if (!b.live_pending) {
+			PG_HIP(ctx, hipMemcpyAsync(b.h_live, b.live_count.p, (size_t)D * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+			PG_HIP(ctx, hipEventRecord(b.ev_live, s));
+			b.live_pending = true;
+			b.live_prev_lanes = N;
 		}
 	}
 	if (r->timing_on) ++r->acc.passes;
