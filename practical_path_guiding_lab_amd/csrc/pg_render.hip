@@ -896,7 +896,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.shapes.texels = r->texels.p;
 	a.shapes.srgb_lut = r->srgb_lut.p;
 	a.st_in = nullptr; a.st_out = nullptr; a.inc_in = nullptr; a.inc_out = nullptr; // (set per bounce below)
-	a.sort_key = nullptr; a.perm = nullptr; a.carry_in = nullptr; a.carry_out = nullptr;
+	a.sort_key = nullptr; a.perm = nullptr; a.carry_in = nullptr; a.carry_out = nullptr; a.n_sort = 0;
 	a.Lq = wave ? b.Lq.p : nullptr;
 	// sorted bounces (pg_render_sort): from the second bounce (camera rays find neighbouring vertices by themselves) to
 	// the depth at which Russian roulette thins the list out (:375: a sort costs what 33 M pairs cost however few are alive)
@@ -984,7 +984,16 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			a.carry_out = next_sorted ? b.carry.p : nullptr;
 			a.perm = nullptr;
 			if (sorted) { // closest hits in list order (they write every live place's key), the sort, then everything else at k
-				PG_HIP(ctx, hipMemsetAsync(b.sort_key.p, 0xff, N * sizeof(uint32_t), s)); // (0xffff: a place without a path)
+				// the sort covers the first n_sort places: all N without counts of a previous pass, else a little more than
+				// were alive then (a radix sort costs what its n costs).  Places beyond n_sort -- none, unless this pass keeps
+				// more paths alive than the last -- are served in list order (k_wave_shade_a): correct either way.
+				uint64_t n_sort = N;
+				if (b.live_known) {
+					n_sort = (uint64_t)b.live_prev[it - 1] + (uint64_t)b.live_prev[it - 1] / 32 + 65536;
+					if (n_sort > N) n_sort = N;
+				}
+				a.n_sort = (uint32_t)n_sort;
+				PG_HIP(ctx, hipMemsetAsync(b.sort_key.p, 0xff, n_sort * sizeof(uint32_t), s)); // (0xffff: a place without a path)
 				{
 					Timed t(r, s, 5);
 					launch_wave_stage(0, r->general, false, a, grid.x, (unsigned)ctx->n_cus, s);
@@ -992,7 +1001,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 				{
 					Timed t(r, s, 11);
 					PG_HIP(ctx, sort_pairs16(b.sort_tmp.p, b.sort_tmp_bytes, b.sort_key.p, b.sort_key_out.p, b.sort_iota.p, b.sort_perm.p,
-					                         (uint32_t)N, s));
+					                         (uint32_t)n_sort, s));
 				}
 				a.perm = b.sort_perm.p;
 				for (int stage = 1; stage < 5; ++stage) {

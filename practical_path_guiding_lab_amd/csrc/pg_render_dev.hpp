@@ -1155,6 +1155,7 @@ struct RenderArgs {
 	// and perm (the places in sorted order, read by k_wave_shade_a; nullptr = list order)
 	uint32_t *sort_key;
 	const uint32_t *perm;
+	uint32_t n_sort; // perm covers the places [0, n_sort); a live place beyond it is served in list order
 	// ... and the 128-byte records of the paths (8 entries of 16 bytes per place: the five state entries, the sampler
 	// increment, the hit): carry_in = this bounce is sorted (k_wave_trace adds the hit, k_wave_shade_a reads the record
 	// through perm), carry_out = the next one is (k_wave_shade_b writes the survivors' records)

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
 	if (a.carry_in) { // a sorted bounce: the hit joins the path's 128-byte record, which k_wave_shade_a reads through the permutation
 		a.carry_in[tid * 8 + 6] = make_uint4((uint32_t)h.prim, __float_as_uint(h.t), __float_as_uint(h.u), __float_as_uint(h.v));
-		a.sort_key[tid] = h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu;
+		if (tid < (uint64_t)a.n_sort) a.sort_key[tid] = h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu;
 		return;
 	}
 	wsputu(a, WS_HIT_PRIM, tid, (uint32_t)h.prim);
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 		// a sorted bounce: this thread serves the place the sort put k-th.  The one random pass over the state: the
 		// path's 128-byte record (k_wave_shade_b and k_wave_trace filled it) is one cache line; what k_wave_guide and
 		// k_wave_shade_b need of it travels on at k (WS_FWD), so that nothing after this kernel looks through the permutation
-		const uint4 *rec = a.carry_in + (uint64_t)a.perm[tid] * 8;
+		const uint4 *rec = a.carry_in + (tid < (uint64_t)a.n_sort ? (uint64_t)a.perm[tid] : tid) * 8;
 		const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
 		rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
 		rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
