@@ -625,6 +625,13 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 	} else {
 		for (int k = 0; k < 2; ++k) { PG_HIP(ctx, b.st[k].ensure(5 * N)); PG_HIP(ctx, b.inc[k].ensure(N)); }
 		PG_HIP(ctx, b.Lq.ensure(N));
+		if (r->sort) { // pg_render_sort: keys, the sorted places, the paths' 128-byte records, rocPRIM's temporary storage
+			if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
+			PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
+			PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry.ensure(8 * N));
+			const size_t need = sort_pairs_temp_bytes((uint32_t)N);
+			if (need > b.sort_tmp_bytes) { PG_HIP(ctx, b.sort_tmp.ensure(need)); b.sort_tmp_bytes = need; }
+		}
 		PG_HIP(ctx, b.ws.ensure((size_t)wave_workspace_planes() * N));
 		PG_HIP(ctx, b.shadow_list.ensure(N));
 		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
@@ -908,15 +915,10 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			b.live_known = true;
 		}
 		if (b.live_known && (b.live_prev_lanes != N || (int)b.live_prev.size() != D)) b.live_known = false; // (another pass size)
-		if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
-		PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
-		PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry.ensure(8 * N));
-		if (b.sort_iota_n < N) {
+		if (b.sort_iota_n < N) { // (the buffers themselves: ensure_pass_buffers)
 			hipLaunchKernelGGL(k_iota, dim3((unsigned)((N + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, s, b.sort_iota.p, N);
 			b.sort_iota_n = N;
 		}
-		const size_t need = sort_pairs_temp_bytes((uint32_t)N);
-		if (need > b.sort_tmp_bytes) { PG_HIP(ctx, b.sort_tmp.ensure(need)); b.sort_tmp_bytes = need; }
 	}
 	a.ws = b.ws.p;
 	a.bvh_ovf = b.bvh_ovf.p;
