@@ -761,6 +761,18 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	const unsigned long long ballot = __ballot(cont);
 	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	if (wl == 0) s_wave[wv] = (uint32_t)__popcll(ballot);
+	// The survivors of a workgroup are appended grouped by the octant of their next direction (the order inside a
+	// workgroup is free): on a sorted bounce the workgroup holds neighbours in space, and a wave of the next closest-hit
+	// launch then walks the BVH from one corner in one direction -- k_wave_trace 17.5 -> 16.4 ms per step (two of the three
+	// signs, so that a bin fills a wave: 16.7).  In list order the grouping changes nothing (round 2 measured that).
+	__shared__ uint32_t s_oct[kRBlock / 64][8];
+	const unsigned oct = (__float_as_uint(ray_d.x) >> 31) | ((__float_as_uint(ray_d.y) >> 31) << 1) | ((__float_as_uint(ray_d.z) >> 31) << 2);
+	uint32_t rank_in_bin = 0;
+	for (unsigned k = 0; k < 8; ++k) {
+		const unsigned long long m = __ballot(cont && oct == k);
+		if (wl == 0) s_oct[wv][k] = (uint32_t)__popcll(m);
+		if (oct == k) rank_in_bin = (uint32_t)__popcll(m & ((1ull << wl) - 1ull));
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint32_t tot = 0;
@@ -769,8 +781,10 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	}
 	__syncthreads();
 	if (cont) { // the survivor's state goes to its place in the next list (whole lines: a wave's survivors are neighbours)
-		uint32_t off = s_base + (uint32_t)__popcll(ballot & ((1ull << wl) - 1ull));
-		for (unsigned w = 0; w < wv; ++w) off += s_wave[w];
+		uint32_t off = s_base + rank_in_bin;
+		for (unsigned k = 0; k < oct; ++k)
+			for (unsigned w = 0; w < kRBlock / 64; ++w) off += s_oct[w][k]; // (every earlier bin of the workgroup)
+		for (unsigned w = 0; w < wv; ++w) off += s_oct[w][oct];           // (this bin, the earlier waves)
 		if (a.carry_out) {
 			// the next bounce is sorted: the state goes into ONE 128-byte record per path and nowhere else -- k_wave_shade_a,
 			// the only kernel that looks through the permutation, reads it as one cache line; k_wave_trace takes the ray from
