@@ -451,6 +451,13 @@ def run_render(args):
     if args.full_schedule:
         full = full_schedule_leg(args, integ, ws, (rank, world, 4) if tiles else None, reduce_fn, W, H)
 
+    if world > 1:
+        # every rank lets go of the library's communicator at the same point (nothing collective follows; a rank must
+        # not sit in ncclCommDestroy at interpreter exit while the others are already gone)
+        torch.cuda.synchronize()
+        if exchange.startswith("pg_allreduce"):
+            tree.commDestroy()
+        dist.barrier()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
