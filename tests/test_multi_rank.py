@@ -503,3 +503,48 @@ def test_bench_gpus_2_from_a_bare_command_line(tmp_path):
         assert "RCCL" in out["extra"]["exchange"] or "nccl" in out["extra"]["exchange"]
     c = out["config"]
     assert c["pixels_per_rank_min"] + c["pixels_per_rank_max"] == 96 * 96 and c["pixels_per_rank_min"] > 0
+
+
+def _worker_nccl_one_rank(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["LOCAL_WORLD_SIZE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from practical_path_guiding_lab_amd.parallel import (all_reduce_accumulators, all_reduce_sums, init_library_comm,
+                                                         max_over_ranks, min_max_over_ranks)
+    from practical_path_guiding_lab_amd.sdtree import SDTree
+
+    g = SDTree(0)
+    g.load(_base_tree())
+    g.setIteration(3, False)
+    rec = synth.records(5000, 11, BB0, BB1)
+    g.addDataPropagate({k: torch.from_numpy(v).cuda() for k, v in rec.items()})
+    before = g.accumulators().clone()
+    ok = init_library_comm(g)            # the vote, rank 0's id through broadcast_object_list, ncclCommInitRank
+    if ok:
+        g.allReduce()                    # pg_allreduce: ncclAllReduce issued by libpgsd.so
+    all_reduce_accumulators(g.accumulators())   # and the torch.distributed route (a no-op sum with one rank)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(g.accumulators(), before))
+    s1, s2 = all_reduce_sums(torch.ones(3, 8, device="cuda"), torch.full((3, 8), 2.0, device="cuda"))
+    lo, hi = min_max_over_ranks(7.0)
+    t = max_over_ranks(0.25, device="cuda")
+    if ok:
+        g.commDestroy()
+    dist.barrier()
+    dist.destroy_process_group()
+    np.save(out, np.array([ok, same, float(s1.sum()) == 24.0 and float(s2.sum()) == 48.0, lo == 7.0 and hi == 7.0, t == 0.25]))
+
+
+@pytest.mark.gpu
+def test_nccl_backend_code_paths_with_one_rank(tmp_path):
+    """What a one-GPU box can run of the N > 1 RCCL route: a process group on the `nccl` backend with one rank, the
+    collective vote and the id broadcast of parallel.init_library_comm, ncclCommInitRank + pg_allreduce issued by
+    libpgsd.so, and every helper bench.py calls with CUDA tensors on that backend (flag devices, reductions of
+    timings and pixel counts).  The transport between GPUs stays untested: no such hardware is reachable from here."""
+    out = str(tmp_path / "nccl1.npy")
+    mp.spawn(_worker_nccl_one_rank, args=(1, 29619, out), nprocs=1, join=True)
+    res = np.load(out)
+    assert res.all(), res
