@@ -12,7 +12,7 @@ run() {
 	python - <<EOF
 import json
 d = json.load(open("$OUT/$1.json"))
-print("%-14s value %7.1f  ms %.3f  bounce %.1f us  splat %.1f us" % ("$1", d["value"], d["ms_per_step"], d["kernels"]["k_bounce"]["avg_us"], d["kernels"]["k_process_and_splat"]["avg_us"]))
+print("%-14s value %7.1f  ms %.3f  bounce %.1f us  splat %.1f us" % ("$1", d["value"], d["ms_per_step"], d["kernels"]["k_bounce"]["avg_us"], d["kernels"]["k_splat_list"]["avg_us"]))
 EOF
 }
 run baseline

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev experiment (GPU box, repo root): workgroups per CU of the grid-stride k_process_and_splat.
+# Dev experiment (GPU box, repo root): workgroups per CU of the grid-stride splat kernels (k_splat_list, k_process_and_splat).
 # Rebuilds the library per value and prints the bench's kernel times for the three scenes.
 # whatever happens, leave the DEFAULT build behind: variant objects are newer than the sources, so a later
 # `make` (or __graft_entry__.build()) would otherwise keep shipping the experiment
@@ -15,7 +15,7 @@ for g in ${@:-8 16 32 64 128}; do
 		python - <<EOF
 import json
 d = json.load(open("$OUT/$s.$g.json"))
-print("groups/CU %4d  %-12s value %7.1f  ms %.3f  bounce %.1f us  splat %.1f us" % ($g, "$s", d["value"], d["ms_per_step"], d["kernels"]["k_bounce"]["avg_us"], d["kernels"]["k_process_and_splat"]["avg_us"]))
+print("groups/CU %4d  %-12s value %7.1f  ms %.3f  bounce %.1f us  splat %.1f us" % ($g, "$s", d["value"], d["ms_per_step"], d["kernels"]["k_bounce"]["avg_us"], d["kernels"]["k_splat_list"]["avg_us"]))
 EOF
 	done
 done

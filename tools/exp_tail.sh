@@ -18,7 +18,7 @@ for t in ${@:-524288 131072 32768 2097152}; do
 	python - <<EOF
 import json
 d = json.load(open("$OUT/torus.$t.json"))
-print("tail paths %8d  value %7.1f  ms %.3f  bounce step %.1f us  splat %.1f us" % ($t, d["value"], d["ms_per_step"], d["kernels"]["k_bounce"]["avg_us"], d["kernels"]["k_process_and_splat"]["avg_us"]))
+print("tail paths %8d  value %7.1f  ms %.3f  bounce step %.1f us  splat %.1f us" % ($t, d["value"], d["ms_per_step"], d["kernels"]["k_bounce"]["avg_us"], d["kernels"]["k_splat_list"]["avg_us"]))
 EOF
 	if [ $first = 1 ]; then
 		first=0
