@@ -1,0 +1,50 @@
+"""Dev tool (GPU box): the scheduling switches change no result, at a size where races would show -- veach-ajar 960x540,
+six iterations of 16-spp passes: list order one pass at a time vs sorted bounces with two passes in flight and the
+guide kernel beside the shadow rays.  Per-pixel sums and the refined trees must be identical.
+    python tools/stress_schedules.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from practical_path_guiding_lab_amd import scene as S  # noqa: E402
+from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator  # noqa: E402
+from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene  # noqa: E402
+
+
+def run(**kw):
+    sc = S.veach_ajar(960, 540)
+    npix = 960 * 540
+    g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
+    g.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
+    ws = WavefrontScene(sc, **kw)
+    cumm = 0
+    sums = []
+    for k in range(6):
+        g.setIteration(k, False)
+        g.resetVarianceCounter()
+        for _ in range(max(1, 2 ** (k + 2) // 16)):
+            spp = min(16, 2 ** (k + 2))
+            g.sample(ws, IndependentSampler(spp, cumm))
+            cumm += spp
+        ws.join()
+        torch.cuda.synchronize()
+        sums.append((g.sumL.cpu().numpy().copy(), g.sumL2.cpu().numpy().copy(), [a.copy() for a in g.sdTree.exportAccumulators()]))
+        g.refineAndPrepareSDTreeForNextIteration()
+    return sums, g.sdTree.export()
+
+
+a_s, a_t = run(sort=0, in_flight=1, overlap=0)
+for kw in (dict(sort=1, in_flight=2, overlap=1), dict(sort=1, in_flight=1, overlap=0), dict(sort=0, in_flight=2, overlap=0)):
+    b_s, b_t = run(**kw)
+    for k, (x, y) in enumerate(zip(a_s, b_s)):
+        assert (x[0].view(np.uint32) == y[0].view(np.uint32)).all() and (x[1].view(np.uint32) == y[1].view(np.uint32)).all(), (kw, k)
+        for u, v in zip(x[2], y[2]):
+            assert (u == v).all(), (kw, k)
+    for key in a_t:
+        assert (np.asarray(a_t[key]).astype(np.float64) == np.asarray(b_t[key]).astype(np.float64)).all(), (kw, key)
+    print("identical:", kw, flush=True)
+print("stress ok")
