@@ -756,7 +756,8 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	// children follow their parent (no cycles, one parent each), leaves stay inside the triangle
 	// array, and no walk can have more than kLdsStack + kOvfStack siblings waiting on its stack
 	const uint64_t nt = sc->n_tris, nn = sc->n_bvh_nodes;
-	if ((nt == 0) != (nn == 0) || (nt && (!sc->tris || !sc->bvh)) || nt > 0x0fffffffull || nn > 0x7fffffffull)
+	// (the walk addresses a node by a 32-bit byte offset: 2^25 nodes of 128 bytes)
+	if ((nt == 0) != (nn == 0) || (nt && (!sc->tris || !sc->bvh)) || nt > 0x0fffffffull || nn > 0x02000000ull)
 		return fail(ctx, PG_ERR_INVALID, "pg_scene_set: triangles and BVH nodes go together");
 	if (nt && !sc->materials) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: meshes need a material table");
 	if (nn) {
@@ -812,7 +813,16 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 	r->n_boxes = (int)nb;
 	PG_HIP(ctx, r->tris.ensure(nt * kTriStride)); PG_HIP(ctx, r->bvh.ensure(nn * kBvhStride));
 	if (nt) PG_HIP(ctx, hipMemcpy(r->tris.p, sc->tris, nt * kTriStride * sizeof(float), hipMemcpyHostToDevice));
-	if (nn) PG_HIP(ctx, hipMemcpy(r->bvh.p, sc->bvh, nn * kBvhStride * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (nn) {
+		// an absent child gets a box no ray reaches, (+inf, -inf) on every axis, whatever the caller left there: the walk
+		// then needs no test of the reference (bvh_node_step)
+		std::vector<uint32_t> nodes(sc->bvh, sc->bvh + nn * kBvhStride);
+		for (uint64_t i = 0; i < nn; ++i)
+			for (int c = 0; c < 4; ++c)
+				if (nodes[i * kBvhStride + 24 + c] == 0xffffffffu)
+					for (int row = 0; row < 6; ++row) nodes[i * kBvhStride + row * 4 + c] = row < 3 ? 0x7f800000u : 0xff800000u;
+		PG_HIP(ctx, hipMemcpy(r->bvh.p, nodes.data(), nn * kBvhStride * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	r->n_bvh_nodes = (int)nn;
 	r->have_tri_normals = nt && sc->tri_normals;
 	if (r->have_tri_normals) {

@@ -427,6 +427,21 @@ __device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p)
 	return spread5(c[0]) | (spread5(c[1]) << 1) | (spread5(c[2]) << 2);
 }
 
+// The first nodes of the BVH in LDS (bvh_node_step): every thread of the workgroup calls this.  How many: what the LDS
+// leaves beside the walks' stacks at seven workgroups per compute unit (16 KB of stack + 6 KB of nodes each).  Measured on
+// veach-ajar, ms per step: closest hits 12.7 / 11.8 / 11.6 with 16 / 32 / 48 nodes (15.1 with none); shadow rays 6.9 /
+// 6.6 / 6.6 with 32 / 64 / 80 at six waves per SIMD (7.9 with none), 6.5 / 6.4 with 32 / 48 at seven.
+constexpr int kBvhTopNodes = 48;
+template <int kNodes>
+__device__ __forceinline__ void stage_bvh_top(u32x4_t *s_top, const RenderArgs &a, BvhStack &stk)
+{
+	const uint32_t n = a.shapes.n_bvh_nodes < kNodes ? (uint32_t)a.shapes.n_bvh_nodes : (uint32_t)kNodes;
+	for (uint32_t i = threadIdx.x; i < n * 8u; i += kRBlock) s_top[i] = reinterpret_cast<const u32x4_t *>(a.shapes.bvh)[i];
+	__syncthreads();
+	stk.top = (const LdsQuad *)s_top;
+	stk.n_top = n;
+}
+
 // ---- :185 scene.ray_intersect: one ray per lane.  (The persistent form below was measured too: the walks of
 // closest-hit rays are all about equally long, handing idle lanes new rays gains nothing after the second
 // bounce and loses a factor of two on the coherent camera rays.) ----
@@ -437,6 +452,9 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
+	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
+	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
 	if (!alive) return;
 	v3 ray_o, ray_d;
 	if (kFirst) { // (place = lane in the first list)
@@ -453,7 +471,6 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 		ray_o = st_v3(st_load(a.st_in, a, 0, tid));
 		ray_d = st_v3(st_load(a.st_in, a, 1, tid));
 	}
-	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
 	HitRec h;
 	h.u = 0.0f; h.v = 0.0f;
 	h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
@@ -487,8 +504,9 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 #endif
 constexpr int kRefillIdle = PG_REFILL_IDLE;
 constexpr uint32_t kCastChunk = PG_CAST_CHUNK;
+// (compiled for seven waves per SIMD -- 72 vector registers, none spilled; left alone the compiler takes 77 and six fit)
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(7))) void k_wave_cast(RenderArgs a)
 {
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
 	if (!kFirst && tail_took_over(a, a.bounce)) return; // a tail launch is finishing these paths
@@ -497,7 +515,9 @@ __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 	if (blockIdx.x * kRBlock >= total) return; // (uniform) not even a first entry for this workgroup
 	const unsigned wl = threadIdx.x & 63u;
 	const Shapes &sh = a.shapes;
-	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + (size_t)gtid * kOvfStack);
+	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
+	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + (size_t)gtid * kOvfStack);
+	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
 	const int tri_base = sh.n_quads + sh.n_spheres + 6 * sh.n_boxes;
 	BvhWalk w;
 	w.next = kBvhNone; w.sp = 0; w.budget = 0; w.best = -1; w.bt = 0.0f; w.bu = 0.0f; w.bv = 0.0f;
@@ -553,7 +573,10 @@ __global__ __launch_bounds__(kRBlock) void k_wave_cast(RenderArgs a)
 		// next candidate from the stack ----
 		if (has) {
 			bool done = false;
-			while (!(w.next & 0x80000000u) && w.budget > 0) bvh_node_step(w, sh, stk);
+			while (!(w.next & 0x80000000u) && w.budget > 0) { // (see intersect)
+				bvh_node_step(w, sh, stk);
+				if (w.next == kBvhNone) bvh_pop(w, stk);
+			}
 			if (w.next != kBvhNone && (w.next & 0x80000000u)) {
 				bvh_leaf_step(w, sh, tri_base);
 				if (w.best >= 0) done = true; // a shadow ray needs one occluder, not the nearest
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 	if (A.flags & F_NEED_SHADOW) {
 		wsput3(a, WS_SH_O, tid, A.sh_o); wsput3(a, WS_SH_D, tid, A.sh_d); wsput(a, WS_SH_T, tid, A.sh_tmax);
 	}
-	wsput(a, WS_ETA, tid, A.eta);
+	if (kLevel >= 3) wsput(a, WS_ETA, tid, A.eta); // (:357: only the dielectrics of level 3 have an eta other than 1)
 	wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
 }
 
@@ -728,7 +751,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		A.wo = V(0, 0, 0); A.bsdf_pdf = 0.0f; A.bsdf_w = V(0, 0, 0);
 		if (A.flags & F_SMP_TREE) A.wo = ws3(a, WS_WO_T, tid);
 		else { A.wo = ws3(a, WS_U, tid); A.bsdf_w = ws3(a, WS_U + 3, tid); A.bsdf_pdf = wsf(a, WS_U + 6, tid); }
-		A.eta = wsf(a, WS_ETA, tid);
+		A.eta = kLevel >= 3 ? wsf(a, WS_ETA, tid) : 1.0f;
 		GuideOut g;
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u; // (k_wave_guide has put them into the record list)

@@ -24,6 +24,7 @@ import numpy as np
 
 TRI_STRIDE = 16
 BVH_STRIDE = 32
+BVH_HOT_NODES = 96  # numbered first, by box area (see build_bvh)
 BVH_WIDTH = 4
 LEAF_FLAG = 0x80000000
 EMPTY_CHILD = 0xFFFFFFFF
@@ -236,22 +237,26 @@ def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
         todo.append((left, first, mid, depth + 1))
     # Collapse to four children per node: a node adopts the children of its (by surface area) biggest
     # inner child until it has four -- half the dependent steps of a walk.  Leaves are referenced
-    # straight from their parent.  Nodes are numbered in the order they are first reached, so children
-    # come after their parent.
+    # straight from their parent.  Numbering: the first BVH_HOT_NODES numbers go to the nodes with the
+    # biggest boxes -- the ones most rays open; the ray-casting kernels keep the first few dozen nodes
+    # of the table in LDS -- and the rest are numbered depth first, a subtree's nodes together.  Either
+    # way a node is numbered after its parent.
     def is_leaf(b):
         return bool(nodes[b][1] & LEAF_FLAG)
 
     def area(b):
         return float(half_area(bounds[b][0].astype(np.float64), bounds[b][1].astype(np.float64)))
 
-    wide: List[List[int]] = []  # per wide node: the binary nodes that are its children
-    ids = {0: 0}
-    queue = [0]
+    sequence: List[int] = []                  # binary nodes that become wide nodes, in numbering order
+    kids_of = {}
+    frontier = [] if is_leaf(0) else [0]
     if is_leaf(0):
-        wide.append([0])  # a mesh of <= MAX_LEAF triangles: one node with one leaf child
-        queue = []
-    while queue:
-        b = queue.pop()
+        sequence, kids_of = [0], {0: [0]}     # a mesh of <= MAX_LEAF triangles: one node with one leaf child
+    while frontier:
+        if len(sequence) < BVH_HOT_NODES:
+            b = frontier.pop(max(range(len(frontier)), key=lambda q: (area(frontier[q]), q)))
+        else:
+            b = frontier.pop()
         kids = [nodes[b][0], nodes[b][1] & 0x1FFFFFFF]
         while len(kids) < BVH_WIDTH:
             inner = [k for k in kids if not is_leaf(k)]
@@ -260,15 +265,13 @@ def build_bvh(tris: np.ndarray, per_triangle: np.ndarray = None):
             big = max(inner, key=area)
             at = kids.index(big)
             kids[at:at + 1] = [nodes[big][0], nodes[big][1] & 0x1FFFFFFF]
-        me = ids[b]
-        while len(wide) <= me:
-            wide.append([])
-        wide[me] = kids
+        sequence.append(b)
+        kids_of[b] = kids
         for k in reversed(kids):  # (a stack: the first child's subtree is numbered first)
             if not is_leaf(k):
-                ids[k] = len(ids)
-                queue.append(k)
-    # ids were handed out when a node was pushed, so every child id exceeds its parent's
+                frontier.append(k)
+    ids = {b: i for i, b in enumerate(sequence)}
+    wide = [kids_of[b] for b in sequence]
     out = np.zeros((len(wide), BVH_STRIDE), np.uint32)
     inf = np.float32(np.inf)
     for i, kids in enumerate(wide):
