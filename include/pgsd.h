@@ -299,8 +299,12 @@ typedef struct pg_scene_desc {
 	 *     index, or 0x80000000 | (count-1) << 28 | first triangle for a leaf of 1..8 triangles, or
 	 *     0xffffffff for none; 28-31 unused by the library.  Node 0 is the root (also when it holds
 	 *     a single leaf), children have larger indices than their parent and one parent each, leaves
-	 *     stay inside the triangle array, no root-to-node path leaves more than 64 siblings waiting
-	 *     (all checked).  Shape numbers of triangles follow the box faces. */
+	 *     stay inside the triangle array, no root-to-node path leaves more than 32 siblings waiting,
+	 *     at most 2^25 nodes (all checked).  The boxes of absent children are ignored.  The ray-casting
+	 *     kernels read the first 48 nodes of the table from LDS: a builder that gives the lowest numbers
+	 *     to the nodes most rays open (the biggest boxes; mesh.build_bvh does) makes them faster, any
+	 *     numbering that keeps children behind their parent is walked correctly.  Shape numbers of
+	 *     triangles follow the box faces. */
 	uint64_t n_tris;
 	const float *tris;
 	uint64_t n_bvh_nodes;
