@@ -102,6 +102,9 @@ def parse():
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
     ap.add_argument("--overlap", type=int, default=0, help="pg_render_overlap mode of the timed steps")
+    ap.add_argument("--guide-kernel", type=int, default=0,
+                    help="1: the SD-tree calls of a mesh scene's bounce as a kernel of their own in the timed region too (pg_render_guide_kernel; "
+                         "default 0: inside k_wave_shade_a, and bench.py times k_wave_guide in a second region for the roofline)")
     ap.add_argument("--sort", type=int, default=1, help="pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (0: list order)")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at once")
@@ -330,7 +333,8 @@ def run_render(args):
     tree = integ.sdTree
     npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
-    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap, in_flight=args.in_flight, sort=bool(args.sort))
+    ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap, in_flight=args.in_flight, sort=bool(args.sort),
+                        guide_kernel=bool(args.guide_kernel))
     tiles = world > 1 and args.shard == "tiles"
     if tiles:
         ws.set_shard(rank, world, 4)
@@ -415,6 +419,18 @@ def run_render(args):
     tree.readKernelTiming(reset=True)
     elapsed = timed_steps(step, args.steps, 0, world)
     kt = tree.readKernelTiming(reset=True)
+    # ---- the roofline region: the SAME passes again with the SD-tree calls of a bounce in a kernel of their own
+    # (pg_render_guide_kernel: k_wave_guide; in the region above they are the tail of k_wave_shade_a, where they cannot
+    # be timed apart).  Its K steps follow the K steps of `value` immediately and are not part of `value`. ----
+    kt_roof, elapsed_roof = None, None
+    if kt.trace_launches > 0 and kt.guide_launches == 0:
+        ws.set_guide_kernel(integ, True)
+        for _ in range(min(args.warmup, 2)):
+            step()
+        tree.readKernelTiming(reset=True)
+        elapsed_roof = timed_steps(step, args.steps, 0, world)
+        kt_roof = tree.readKernelTiming(reset=True)
+        ws.set_guide_kernel(integ, False)
     tree.enableKernelTiming(False)
 
     # per-iteration exchange + refine (not part of `value`)
@@ -473,7 +489,7 @@ def run_render(args):
     d_q = dc.quad_levels / max(dc.quad_queries, 1)
     splat_bytes = records_per_pass * (16.0 * d_kd + 4.0 + 48.0 + 12.0 * 2.0 * d_q)
     passes = max(kt.passes, 1)
-    wave = kt.guide_launches > 0
+    wave = kt.trace_launches > 0  # the split pipeline of pg_render_wave.hip ran (mesh scenes, or --split-pipeline)
     step_ms = 1e3 * elapsed / args.steps
 
     def kern(ms, launches, alg_bytes_per_pass=None):
@@ -488,7 +504,20 @@ def run_render(args):
     kernels = {}
     if wave:
         nb = kt.bounce_launches  # bounces
-        kernels["k_wave_guide"] = kern(kt.guide_ms, kt.guide_launches, tree_bytes)
+        if kt_roof is None:  # (--guide-kernel 1 / --overlap 1: the SD-tree calls ran as k_wave_guide in the timed region itself)
+            kernels["k_wave_guide"] = kern(kt.guide_ms, kt.guide_launches, tree_bytes)
+        else:
+            p2 = max(kt_roof.passes, 1)
+            ms2 = kt_roof.guide_ms
+            kernels["k_wave_guide"] = {
+                "launches": int(kt_roof.guide_launches), "avg_us": round(1e3 * ms2 / max(kt_roof.guide_launches, 1), 2),
+                "ms_per_step": round(ms2 / p2, 3), "region": "roofline",
+                "alg_bytes_per_launch": round(tree_bytes / max(kt_roof.guide_launches / p2, 1)),
+                "alg_GBps": round(tree_bytes * p2 / (ms2 * 1e-3) / 1e9, 2) if ms2 > 0 else 0.0,
+                "note": "timed in the roofline region (roofline.region), where the SD-tree calls are a kernel of their own; in the region "
+                        "`value` is quoted on they are the tail of k_wave_shade_a and their time is inside k_wave_shade_a+b",
+                "step_ms_of_that_region": round(1e3 * elapsed_roof / args.steps, 4),
+                "shade_a_ms_per_step_of_that_region": round(kt_roof.shade_a_ms / p2, 3)}
         kernels["k_wave_trace"] = kern(kt.trace_ms, kt.trace_launches)
         kernels["k_wave_shadow"] = kern(kt.shadow_ms, nb)
         kernels["k_wave_shade_a+b"] = kern(kt.shade_ms, 2 * nb)
@@ -515,7 +544,7 @@ def run_render(args):
             "kernel does not move; what it moves is at most streamed_bytes_per_launch (72 B per list entry) plus one 32-byte atomic "
             "sector update per direction of a kept record, and it is bound by the latter (atomics_G_per_s vs atomic_ceiling_G_per_s)")
     kernels["k_finish"] = kern(kt.finish_ms, passes)
-    slowest = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+    slowest = max((n for n in kernels if kernels[n].get("region") != "roofline"), key=lambda n: kernels[n]["ms_per_step"])
     cfg_key = f"{args.scene} res={args.res} depth={args.depth} spp={args.spp_per_pass}"
     film = f"{W}x{H}"
     what = {"cornell-box": "built-in scene (Mitsuba cornell-box parameters), no textures",
@@ -575,6 +604,10 @@ def run_render(args):
                              if tr_dom is not None else
                              "traffic null: no PMC figures of this configuration taken of THIS code are committed (profiles/pmc_traffic.json "
                              "records the hash of the sources it was taken of; a mismatch is refused rather than paired with new timings)"),
+            "region": ("the timed region of `value`" if kt_roof is None else
+                       f"steps {args.steps + 1}-{2 * args.steps} of the run: the passes of `value`'s region again with pg_render_guide_kernel(1) -- the "
+                       "SD-tree calls of a bounce as k_wave_guide instead of the tail of k_wave_shade_a, the default, where they "
+                       f"cannot be timed apart; that region ran at {1e3 * elapsed_roof / args.steps:.2f} ms per step against {step_ms:.2f} of the default"),
             "slowest_kernel_of_step": slowest,
             "device_copy_GBps": device_copy_rate(torch.device("cuda", local_rank)) if rank == 0 else None,
             "limiter": "HBM is the roofline SURVEY 8(d) prescribes for this pointer-chasing path; what the kernel actually waits on "

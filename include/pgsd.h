@@ -376,6 +376,13 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
  * Results are identical (the two write disjoint buffers).  Default 0: every kernel on the caller's stream. */
 int pg_render_overlap(pg_context *ctx, int32_t mode);
 
+/* The split pipeline of mesh scenes makes the SD-tree calls of a bounce (src/path_guiding_integrator.py:244, 301, 307 and
+ * the leaves a record adds to) at the end of k_wave_shade_a, with the vertex still in registers.  With `on` they run as a
+ * kernel of their own instead, k_wave_guide, which reads the vertex back from the workspace: the hot path of SURVEY 8 by
+ * itself, for timing and counters (pg_kernel_timing.guide_ms; bench.py measures its roofline this way).  Results are
+ * identical.  pg_render_overlap(1) implies it.  Default 0. */
+int pg_render_guide_kernel(pg_context *ctx, int32_t on);
+
 /* Not in the reference (Dr.Jit's wavefront keeps pixel order): with `on`, the bounces of a mesh scene from the second one
  * up to rr_depth process the live list in a global spatial order -- the places sorted by the Morton cell of the vertex
  * the ray has just found (a device radix sort of 16-bit keys per bounce) -- so that the lanes of a wave stand next to

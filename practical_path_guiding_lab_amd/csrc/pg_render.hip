@@ -565,6 +565,7 @@ struct pg_render_state {
 	bool have_scene = false;
 	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
 	int overlap = 0;           // pg_render_overlap
+	int guide_kernel = 0;      // pg_render_guide_kernel
 	int sort = 0;              // pg_render_sort
 	PassBuf pb[2];
 	int last_slot = 0;         // of the most recent pass (pg_render_live_counts)
@@ -968,6 +969,9 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.r_tr = b.r_tr.p; a.r_nee = b.r_nee.p; a.r_wp = b.r_wp.p;
 	a.r_slot = b.r_slot.p; a.r_tree = b.r_tree.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
+	// the SD-tree calls of a bounce inside k_wave_shade_a unless a kernel of their own was asked for (pg_render_guide_kernel)
+	// or is needed to run beside the shadow rays (pg_render_overlap)
+	a.fuse_guide = wave && !r->guide_kernel && !(r->overlap & 1) ? 1 : 0;
 	for (int it = 0; it < D; ++it) {
 		a.bounce = it;
 		a.last = it + 1 == D ? 1 : 0;
@@ -1017,6 +1021,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 				}
 				a.perm = b.sort_perm.p;
 				for (int stage = 1; stage < 5; ++stage) {
+					if (stage == 3 && a.fuse_guide) continue;
 					Timed t(r, s, 5 + stage);
 					launch_wave_stage(stage, r->general, false, a, grid.x, (unsigned)ctx->n_cus, s);
 				}
@@ -1052,6 +1057,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 				continue;
 			}
 			for (int stage = 0; stage < 5; ++stage) {
+				if (stage == 3 && a.fuse_guide) continue;
 				Timed t(r, s, 5 + stage);
 				launch_wave_stage(stage, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
 			}
@@ -1133,6 +1139,13 @@ int pg_render_overlap(pg_context *ctx, int32_t mode)
 	if (!ctx) return PG_ERR_INVALID;
 	if (mode < 0 || mode > 1) return fail(ctx, PG_ERR_INVALID, "pg_render_overlap: mode must be 0 or 1");
 	rstate(ctx)->overlap = mode; // (the side stream of a buffer set is made by the first pass that needs it)
+	return PG_OK;
+}
+
+int pg_render_guide_kernel(pg_context *ctx, int32_t on)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	rstate(ctx)->guide_kernel = on != 0;
 	return PG_OK;
 }
 

@@ -1154,6 +1154,7 @@ struct RenderArgs {
 	uint32_t seed;
 	DepthCounters *dc;
 	int bounce, last;          // index of this launch = path depth of every live lane; last launch of the pass
+	int fuse_guide;            // split pipeline: k_wave_shade_a also makes the SD-tree calls, no k_wave_guide launch
 	const uint32_t *order_in;  // live-ray list written by the previous bounce (unused by the first)
 	uint32_t *order_out;       // live-ray list for the next bounce
 	uint32_t *live_count;      // [max_depth + 1]: live_count[b] = lanes alive after bounce b; [max_depth]: see k_bounce_tail (zeroed per pass)

@@ -601,12 +601,15 @@ __global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(7))) vo
 #endif
 
 // ---- :189-220, 272-297 ----
-template <int kLevel, bool kFirst>
+// kGuide: the SD-tree calls of the bounce (stage_guide, otherwise k_wave_guide's) follow in the same kernel
+template <int kLevel, bool kFirst, bool kGuide>
 __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArgs a)
 {
+	__shared__ float s_planes[kGuide ? 3 * kKdGridPlanes : 1];
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	if (kGuide) stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
 	Pcg32 rng;
 	v3 ray_o, ray_d, thr = V(1, 1, 1), prev_p = V(0, 0, 0);
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 		wsput3(a, WS_U, tid, A.wo); wsput3(a, WS_U + 3, tid, A.bsdf_w); wsput(a, WS_U + 6, tid, A.bsdf_pdf);
 	}
 	if (A.flags & F_HAS_LE) wsput3(a, WS_LE, tid, A.Le);
-	wsput3(a, WS_DS_D, tid, A.ds_d);
+	if (!kGuide) wsput3(a, WS_DS_D, tid, A.ds_d); // (only k_wave_guide reads it)
 	if (A.flags & F_NEE_LIVE) { // (what k_wave_shade_b reads of an emitter sample only when it can contribute)
 		wsput(a, WS_DS_PDF, tid, A.ds_pdf); wsput3(a, WS_EM_W, tid, A.em_w);
 		wsput3(a, WS_BV_EM, tid, A.bv_em); wsput(a, WS_BP_EM, tid, A.bp_em);
@@ -668,6 +671,20 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 		wsput3(a, WS_SH_O, tid, A.sh_o); wsput3(a, WS_SH_D, tid, A.sh_d); wsput(a, WS_SH_T, tid, A.sh_tmax);
 	}
 	if (kLevel >= 3) wsput(a, WS_ETA, tid, A.eta); // (:357: only the dielectrics of level 3 have an eta other than 1)
+	if (kGuide && guide_has_work(a, A.flags)) { // what k_wave_guide does, with its inputs still in registers
+		GuideOut g;
+		stage_guide(a, s_planes, rng, A.p, A.ds_d, (A.flags & F_SMP_TREE) ? V(0, 0, 0) : A.wo, A.flags, g);
+		if (a.record && (A.flags & F_VALID)) {
+			uint64_t rec_base = 0;
+			if (!kFirst) {
+				rec_base = a.n_lanes;
+				for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+			}
+			store_slots(a, rec_base + tid, g);
+		}
+		wsput(a, WS_PDF_NEE, tid, g.pdf_nee); wsput(a, WS_PDF_TREE, tid, g.pdf_tree);
+		if (A.flags & F_SMP_TREE) wsput3(a, WS_WO_T, tid, g.wo);
+	}
 	wsputu(a, WS_RNG_LO, tid, (uint32_t)rng.state); wsputu(a, WS_RNG_HI, tid, (uint32_t)(rng.state >> 32));
 }
 
@@ -955,8 +972,11 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		else hipLaunchKernelGGL((k_wave_trace<kLevel, false>), grid, block, 0, s, a);
 		break;
 	case 1:
-		if (first) hipLaunchKernelGGL((k_wave_shade_a<kLevel, true>), grid, block, 0, s, a);
-		else hipLaunchKernelGGL((k_wave_shade_a<kLevel, false>), grid, block, 0, s, a);
+		if (a.fuse_guide) {
+			if (first) hipLaunchKernelGGL((k_wave_shade_a<kLevel, true, true>), grid, block, 0, s, a);
+			else hipLaunchKernelGGL((k_wave_shade_a<kLevel, false, true>), grid, block, 0, s, a);
+		} else if (first) hipLaunchKernelGGL((k_wave_shade_a<kLevel, true, false>), grid, block, 0, s, a);
+		else hipLaunchKernelGGL((k_wave_shade_a<kLevel, false, false>), grid, block, 0, s, a);
 		break;
 	case 2:
 		if (first) hipLaunchKernelGGL((k_wave_cast<kLevel, true>), persistent_grid(k_wave_cast<kLevel, true>, occ[0], n_cus, a.n_lanes), block, 0, s, a);

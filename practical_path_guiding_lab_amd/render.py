@@ -45,7 +45,8 @@ class WavefrontScene:
     """Device-resident scene (quads + camera) implementing the `trace_pass` protocol of
     PathGuidingIntegrator.sample()."""
 
-    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0, in_flight: int = 1, sort: bool = True):
+    def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0, in_flight: int = 1, sort: bool = True,
+                 guide_kernel: bool = False):
         """split_pipeline: run the bounce as the split pipeline also for a scene the fused kernel could
         run (pg_render_split_pipeline: same results, the SD-tree queries as a kernel of their own)."""
         self.scene = scene
@@ -54,6 +55,9 @@ class WavefrontScene:
         # pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (same results, +10 % on
         # veach-ajar; the fused kernels of quad scenes ignore it)
         self.sort = bool(sort)
+        # pg_render_guide_kernel: the SD-tree calls of a mesh scene's bounce as a kernel of their own (k_wave_guide) instead
+        # of the tail of k_wave_shade_a -- same results; how the hot path is timed by itself
+        self.guide_kernel = bool(guide_kernel)
         # in_flight = 2: consecutive passes alternate between two buffer sets (pg_pass_params.slot) and two streams of
         # their own, so that two are on the device at once (the passes of an iteration are independent, main.py:208-218;
         # same results).  What a pass returns is then valid once join() has made the current stream wait for them.
@@ -116,6 +120,7 @@ class WavefrontScene:
         N.check(tree._h, tree._lib.pg_render_split_pipeline(tree._h, 1 if self.split_pipeline else 0))
         N.check(tree._h, tree._lib.pg_render_overlap(tree._h, self.overlap))
         N.check(tree._h, tree._lib.pg_render_sort(tree._h, 1 if self.sort else 0))
+        N.check(tree._h, tree._lib.pg_render_guide_kernel(tree._h, 1 if self.guide_kernel else 0))
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 
@@ -158,6 +163,13 @@ class WavefrontScene:
         n = int(self.local_pixels().shape[0]) * int(spp)
         if n:
             N.check(tree._h, tree._lib.pg_render_reserve(tree._h, n))
+
+    def set_guide_kernel(self, integrator, on: bool) -> None:
+        """pg_render_guide_kernel, from the next pass on (a scheduling switch: results do not change)."""
+        self.guide_kernel = bool(on)
+        tree = integrator.sdTree
+        self._upload(tree)
+        N.check(tree._h, tree._lib.pg_render_guide_kernel(tree._h, 1 if self.guide_kernel else 0))
 
     def join(self) -> None:
         """in_flight = 2: the current stream waits for every pass issued so far (no host synchronisation)."""
