@@ -22,8 +22,10 @@ file's max_depth 13, the 2^(k+2) spp schedule (scenes/veach-ajar/scene.xml, main
           CPU oracle: equal spp, equal seeds, the two MSEs must be equal (`mse_equal`).
   cpu_baseline   the CPU oracle ("port") timed on the guided passes of that 320x180 run, all host cores.
 
-roofline = the SD-tree kernel of the timed region (k_wave_guide for mesh scenes, the fused k_bounce
-otherwise): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
+roofline = the SD-tree kernel (the fused k_bounce of quad scenes in the timed region; for mesh scenes k_wave_guide,
+timed in a SECOND region of K steps that follows the K steps of `value` at once: the same passes with
+pg_render_guide_kernel(1) -- by default the SD-tree calls are the tail of k_wave_shade_a, where they cannot be timed
+apart; `roofline.region` says which region the figures are of): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
 counted by an instrumented pass) per launch / mean launch time (HIP events recorded by the library on
 the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a step with its share and, from the
 committed PMC figures of the same configuration (profiles/pmc_traffic.json), its counter traffic per second.

@@ -42,6 +42,14 @@ for r in csv.DictReader(open(trace)):
     k = short(r["Kernel_Name"])
     if k:
         dur[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+# bench.py times two regions: the default build of the pipeline (the SD-tree calls at the end of k_wave_shade_a), then the
+# same passes with pg_render_guide_kernel(1), k_wave_guide's only launches.  Every kernel but k_wave_guide is summarised over
+# the FIRST region: the launches before the first k_wave_guide.
+t_split = min((t for t, _ in dur.get("k_wave_guide", [])), default=None)
+if t_split is not None:
+    for k in list(dur):
+        if k != "k_wave_guide":
+            dur[k] = [(t, d) for t, d in dur[k] if t < t_split]
 trace_summary = {}
 for k, v in dur.items():
     v.sort()
@@ -63,6 +71,9 @@ def agg(sub):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     if fs:
         rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
+        first_guide = min((int(r["Dispatch_Id"]) for r in rows if short(r["Kernel_Name"]) == "k_wave_guide"), default=None)
+        if first_guide is not None:  # (see above: the other kernels over the first region only)
+            rows = [r for r in rows if short(r["Kernel_Name"]) == "k_wave_guide" or int(r["Dispatch_Id"]) < first_guide]
         for r in rows:
             k = short(r["Kernel_Name"])
             if k:
@@ -79,7 +90,7 @@ def agg(sub):
 f, w, l2, sq = agg("pmc_fetch"), agg("pmc_write"), agg("pmc_l2"), agg("pmc_sq")
 out = {"config": cfg,
        "note": "rocprofv3 --pmc, one counter set per pass, `bench.py --steps 3 --warmup 1 --cpu 0`; means per launch over "
-               "the launches of the timed region (the last 3 passes). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
+               "the launches of the timed region (its last 3 passes; k_wave_guide: of bench.py's roofline region, the other kernels: of the region `value` is quoted on). FETCH_SIZE/WRITE_SIZE are KiB as reported. hbm_bytes_per_launch = "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024 applies the gfx950 x2 FETCH correction of MI355X_MICROARCH.md section HBM "
                "(calibrated for wide coalesced reads only: an upper bound here).",
        "kernels": {}, "trace": trace_summary}
