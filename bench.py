@@ -211,8 +211,8 @@ def spawn_ranks(cmd, n, env=None, relay=sys.stdout, grace_s=10.0):
                         procs[q].kill()
         time.sleep(0.05)
     th.join(5.0)
-    for line in lines:
-        relay.write(line)
+    for line in lines:  # rank 0's JSON line goes on; anything else a library wrote to its stdout is diagnostics
+        (relay if line.lstrip().startswith("{") else sys.stderr).write(line)
     relay.flush()
     return rc
 
@@ -247,7 +247,18 @@ def init_dist(args):
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # (a failure ends the run)
         else:
-            dist.init_process_group(backend="gloo")
+            # (the Gloo library prints a connection banner on STDOUT when its context comes up: stdout is for the one JSON
+            # line, so file descriptor 1 points at stderr while the group is made and first used)
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
     return world, rank, local_rank
 
 

@@ -435,18 +435,19 @@ def _bench_module():
 
 def test_spawn_ranks_gives_every_rank_its_environment_and_relays_rank_zero(tmp_path):
     """bench.spawn_ranks with stand-in rank processes (no GPU): each gets RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR 127.0.0.1 / one common MASTER_PORT, only rank 0's stdout is relayed, exit code 0."""
+    MASTER_ADDR 127.0.0.1 / one common MASTER_PORT; of rank 0's stdout the JSON line is relayed (a banner a library
+    printed there -- Gloo does -- goes to stderr), nothing of the other ranks'; exit code 0."""
     import io
     import json
     b = _bench_module()
     child = ("import os, json, sys; r = os.environ['RANK']; "
              "open(sys.argv[1] + r, 'w').write(json.dumps({k: os.environ[k] for k in "
              "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')})); "
-             "print('line of rank ' + r)")
+             "print('[Gloo] a banner of rank ' + r); print(json.dumps({'rank': r}))")
     relay = io.StringIO()
     rc = b.spawn_ranks([sys.executable, "-c", child, str(tmp_path / "env")], 3, relay=relay)
     assert rc == 0
-    assert relay.getvalue() == "line of rank 0\n"
+    assert relay.getvalue() == '{"rank": "0"}\n'
     envs = [json.load(open(str(tmp_path / "env") + str(r))) for r in range(3)]
     assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
     assert all(e["WORLD_SIZE"] == "3" and e["LOCAL_WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
