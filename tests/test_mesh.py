@@ -198,3 +198,26 @@ def test_oracle_mesh_matches_the_sphere_it_tessellates():
     inner = np.s_[:, 18:30, 26:38]  # well inside the silhouette
     e_smooth, e_flat = np.abs(smooth[inner] - ref[inner]).mean(), np.abs(flat[inner] - ref[inner]).mean()
     assert ref[inner].mean() > 0.05 and e_smooth < 0.25 * e_flat and e_smooth < 0.02 * ref[inner].mean(), (e_smooth, e_flat)
+
+
+def test_bvh_numbers_the_biggest_boxes_first():
+    """The ray-casting kernels read the first nodes of the table from LDS: build_bvh gives the lowest numbers to the nodes
+    with the biggest boxes -- the ones most rays open.  Among the first BVH_HOT_NODES the half-areas do not increase
+    with the number, and no later node has a bigger box than the last of them."""
+    v, f = M.icosphere(4)                                   # 5120 triangles: some 1400 nodes
+    nodes, _ = M.build_bvh(M.triangles(v, f, np.diag([1.0, 2.0, 0.5, 1.0]), 0))
+    n = nodes.shape[0]
+    assert n > 4 * M.BVH_HOT_NODES
+    area = np.full(n, np.nan)
+    area[0] = np.inf
+    for i in range(n):
+        box = nodes[i, 0:24].view(np.float32).reshape(6, 4).astype(np.float64)
+        for k in range(int(nodes[i, 28])):
+            ref = int(nodes[i, 24 + k])
+            if not ref & M.LEAF_FLAG:
+                e = box[3:6, k] - box[0:3, k]
+                area[ref] = e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
+    assert not np.isnan(area).any()
+    hot = area[:M.BVH_HOT_NODES]
+    assert (np.diff(hot) <= 0).all()
+    assert area[M.BVH_HOT_NODES:].max() <= hot[-1]
