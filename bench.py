@@ -24,8 +24,8 @@ file's max_depth 13, the 2^(k+2) spp schedule (scenes/veach-ajar/scene.xml, main
 
 roofline = the SD-tree kernel (the fused k_bounce of quad scenes in the timed region; for mesh scenes k_wave_guide,
 timed in a SECOND region of K steps that follows the K steps of `value` at once: the same passes with
-pg_render_guide_kernel(1) -- by default the SD-tree calls are the tail of k_wave_shade_a, where they cannot be timed
-apart; `roofline.region` says which region the figures are of): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
+pg_render_stages(2) -- by default a bounce's shading, SD-tree calls and shadow ray are ONE kernel, k_wave_shade, in which
+they cannot be timed apart; `roofline.region` says which region the figures are of): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
 counted by an instrumented pass) per launch / mean launch time (HIP events recorded by the library on
 the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a step with its share and, from the
 committed PMC figures of the same configuration (profiles/pmc_traffic.json), its counter traffic per second.
@@ -104,9 +104,10 @@ def parse():
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
     ap.add_argument("--overlap", type=int, default=0, help="pg_render_overlap mode of the timed steps")
-    ap.add_argument("--guide-kernel", type=int, default=0,
-                    help="1: the SD-tree calls of a mesh scene's bounce as a kernel of their own in the timed region too (pg_render_guide_kernel; "
-                         "default 0: inside k_wave_shade_a, and bench.py times k_wave_guide in a second region for the roofline)")
+    ap.add_argument("--stages", type=int, default=0, choices=[0, 1, 2],
+                    help="pg_render_stages of the timed region: 0 one shading kernel per bounce (default; bench.py then times k_wave_guide "
+                         "in a second region for the roofline), 1 k_wave_shade_a with the SD-tree calls | k_wave_cast | k_wave_shade_b, "
+                         "2 those with k_wave_guide on its own")
     ap.add_argument("--sort", type=int, default=1, help="pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (0: list order)")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at once")
@@ -347,7 +348,7 @@ def run_render(args):
     npix = W * H
     integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)  # main.py:56-64
     ws = WavefrontScene(sc, split_pipeline=args.split_pipeline, overlap=args.overlap, in_flight=args.in_flight, sort=bool(args.sort),
-                        guide_kernel=bool(args.guide_kernel))
+                        stages=args.stages)
     tiles = world > 1 and args.shard == "tiles"
     if tiles:
         ws.set_shard(rank, world, 4)
@@ -433,17 +434,17 @@ def run_render(args):
     elapsed = timed_steps(step, args.steps, 0, world)
     kt = tree.readKernelTiming(reset=True)
     # ---- the roofline region: the SAME passes again with the SD-tree calls of a bounce in a kernel of their own
-    # (pg_render_guide_kernel: k_wave_guide; in the region above they are the tail of k_wave_shade_a, where they cannot
-    # be timed apart).  Its K steps follow the K steps of `value` immediately and are not part of `value`. ----
+    # (pg_render_stages(2): k_wave_guide; in the region above they are part of k_wave_shade, where they cannot be timed
+    # apart).  Its K steps follow the K steps of `value` immediately and are not part of `value`. ----
     kt_roof, elapsed_roof = None, None
     if kt.trace_launches > 0 and kt.guide_launches == 0:
-        ws.set_guide_kernel(integ, True)
+        ws.set_stages(integ, 2)
         for _ in range(min(args.warmup, 2)):
             step()
         tree.readKernelTiming(reset=True)
         elapsed_roof = timed_steps(step, args.steps, 0, world)
         kt_roof = tree.readKernelTiming(reset=True)
-        ws.set_guide_kernel(integ, False)
+        ws.set_stages(integ, args.stages)
     tree.enableKernelTiming(False)
 
     # per-iteration exchange + refine (not part of `value`)
@@ -517,7 +518,7 @@ def run_render(args):
     kernels = {}
     if wave:
         nb = kt.bounce_launches  # bounces
-        if kt_roof is None:  # (--guide-kernel 1 / --overlap 1: the SD-tree calls ran as k_wave_guide in the timed region itself)
+        if kt_roof is None:  # (--stages 2 / --overlap 1: the SD-tree calls ran as k_wave_guide in the timed region itself)
             kernels["k_wave_guide"] = kern(kt.guide_ms, kt.guide_launches, tree_bytes)
         else:
             p2 = max(kt_roof.passes, 1)
@@ -528,14 +529,19 @@ def run_render(args):
                 "alg_bytes_per_launch": round(tree_bytes / max(kt_roof.guide_launches / p2, 1)),
                 "alg_GBps": round(tree_bytes * p2 / (ms2 * 1e-3) / 1e9, 2) if ms2 > 0 else 0.0,
                 "note": "timed in the roofline region (roofline.region), where the SD-tree calls are a kernel of their own; in the region "
-                        "`value` is quoted on they are the tail of k_wave_shade_a and their time is inside k_wave_shade_a+b",
+                        "`value` is quoted on they are part of k_wave_shade (--stages 1: of k_wave_shade_a) and their time is inside it",
                 "step_ms_of_that_region": round(1e3 * elapsed_roof / args.steps, 4),
                 "shade_a_ms_per_step_of_that_region": round(kt_roof.shade_a_ms / p2, 3)}
         kernels["k_wave_trace"] = kern(kt.trace_ms, kt.trace_launches)
-        kernels["k_wave_shadow"] = kern(kt.shadow_ms, nb)
-        kernels["k_wave_shade_a+b"] = kern(kt.shade_ms, 2 * nb)
-        kernels["k_wave_shade_a+b"]["shade_a_ms_per_step"] = round(kt.shade_a_ms / passes, 3)
-        kernels["k_wave_shade_a+b"]["shade_b_ms_per_step"] = round(kt.shade_b_ms / passes, 3)
+        if kt.shade_b_ms == 0 and kt.shadow_ms == 0:  # pg_render_stages 0: one shading kernel per bounce
+            kernels["k_wave_shade"] = kern(kt.shade_ms, nb)
+            kernels["k_wave_shade"]["holds"] = ("surface + textures, emitter sample, BSDF sample, the SD-tree calls, the shadow ray (inline any-hit "
+                                                "walk), mixture pdfs, record, throughput, roulette, the next ray, the survivors' append")
+        else:
+            kernels["k_wave_shadow"] = kern(kt.shadow_ms, nb)
+            kernels["k_wave_shade_a+b"] = kern(kt.shade_ms, 2 * nb)
+            kernels["k_wave_shade_a+b"]["shade_a_ms_per_step"] = round(kt.shade_a_ms / passes, 3)
+            kernels["k_wave_shade_a+b"]["shade_b_ms_per_step"] = round(kt.shade_b_ms / passes, 3)
         kernels["k_wave_tail"] = kern(kt.tail_ms, max(kt.passes, 1))
         if kt.sort_ms > 0:
             kernels["radix_sort"] = kern(kt.sort_ms, max(kt.passes, 1))
@@ -576,7 +582,7 @@ def run_render(args):
     # THIS code, profiles/pmc_traffic.json: as counted, and with the gfx950 FETCH correction, an upper bound) over the
     # duration measured in this run
     for name, parts in (("k_wave_guide", ("k_wave_guide",)), ("k_wave_trace", ("k_wave_trace",)), ("k_wave_shadow", ("k_wave_cast",)),
-                        ("k_wave_shade_a+b", ("k_wave_shade_a", "k_wave_shade_b")), ("k_bounce", ("k_bounce",)),
+                        ("k_wave_shade_a+b", ("k_wave_shade_a", "k_wave_shade_b")), ("k_wave_shade", ("k_wave_shade",)), ("k_bounce", ("k_bounce",)),
                         ("k_process_and_splat", ("k_process_and_splat",)), ("k_splat_list", ("k_splat_list",)),
                         ("k_finish", ("k_finish",))):
         if name in kernels and kernels[name]["avg_us"] > 0:
@@ -619,7 +625,7 @@ def run_render(args):
                              "records the hash of the sources it was taken of; a mismatch is refused rather than paired with new timings)"),
             "region": ("the timed region of `value`" if kt_roof is None else
                        f"steps {args.steps + 1}-{2 * args.steps} of the run: the passes of `value`'s region again with pg_render_guide_kernel(1) -- the "
-                       "SD-tree calls of a bounce as k_wave_guide instead of the tail of k_wave_shade_a, the default, where they "
+                       "SD-tree calls of a bounce as k_wave_guide (four kernels behind the closest hits) instead of inside the one shading kernel of the default, where they "
                        f"cannot be timed apart; that region ran at {1e3 * elapsed_roof / args.steps:.2f} ms per step against {step_ms:.2f} of the default"),
             "slowest_kernel_of_step": slowest,
             "device_copy_GBps": device_copy_rate(torch.device("cuda", local_rank)) if rank == 0 else None,

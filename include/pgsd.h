@@ -376,12 +376,17 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
  * Results are identical (the two write disjoint buffers).  Default 0: every kernel on the caller's stream. */
 int pg_render_overlap(pg_context *ctx, int32_t mode);
 
-/* The split pipeline of mesh scenes makes the SD-tree calls of a bounce (src/path_guiding_integrator.py:244, 301, 307 and
- * the leaves a record adds to) at the end of k_wave_shade_a, with the vertex still in registers.  With `on` they run as a
- * kernel of their own instead, k_wave_guide, which reads the vertex back from the workspace: the hot path of SURVEY 8 by
- * itself, for timing and counters (pg_kernel_timing.guide_ms; bench.py measures its roofline this way).  Results are
- * identical.  pg_render_overlap(1) implies it.  Default 0. */
-int pg_render_guide_kernel(pg_context *ctx, int32_t on);
+/* How the pipeline of mesh scenes cuts a bounce into kernels behind the closest hits (k_wave_trace) -- the same device
+ * functions on the same numbers either way, results identical:
+ *   0 (default)  one kernel, k_wave_shade: surface, emitter sample, BSDF sample, the SD-tree calls
+ *                (src/path_guiding_integrator.py:244, 301, 307 and the leaves a record adds to), the shadow ray (:213), mixture
+ *                pdfs, record, throughput, roulette, the next ray -- on one lane's registers, nothing of it through memory;
+ *   1            three: k_wave_shade_a (:189-220, 272-297 and the SD-tree calls), k_wave_cast (:213, a persistent any-hit
+ *                kernel), k_wave_shade_b (:247-261, 302-381), handing their results on through workspace planes;
+ *   2            four: the SD-tree calls as a kernel of their own, k_wave_guide, which reads the vertex back from the
+ *                workspace -- the hot path of SURVEY 8 by itself, for timing and counters (pg_kernel_timing.guide_ms;
+ *                bench.py measures its roofline this way).  pg_render_overlap(1) implies it. */
+int pg_render_stages(pg_context *ctx, int32_t mode);
 
 /* Not in the reference (Dr.Jit's wavefront keeps pixel order): with `on`, the bounces of a mesh scene from the second one
  * up to rr_depth process the live list in a global spatial order -- the places sorted by the Morton cell of the vertex

@@ -516,7 +516,8 @@ struct PassBuf {
 	// pg_render_sort: keys of the places (written by k_wave_trace), the sorted keys, the identity, the places in sorted
 	// order, rocPRIM's temporary storage
 	DevBuf<uint32_t> sort_key, sort_key_out, sort_iota, sort_perm;
-	DevBuf<uint4> carry; // the paths' 128-byte records of a sorted bounce (RenderArgs::carry_in)
+	DevBuf<uint4> carry[2]; // the paths' 128-byte records of a sorted bounce (RenderArgs::carry_in), two sets swapped per bounce:
+	                        // k_wave_shade reads the records of its bounce and writes the next bounce's in one launch
 	// which bounces are worth a sort is read off the PREVIOUS pass of this set: its live counts come back to the host
 	// behind the pass (pinned memory, an event), and a bounce is sorted when at least kSortMinLive of the lanes were alive
 	// going into it -- a sort costs what N pairs cost however few are left (scenes/torus: 24 % after the second bounce)
@@ -565,7 +566,7 @@ struct pg_render_state {
 	bool have_scene = false;
 	bool split_always = false; // pg_render_split_pipeline: quad scenes run the split pipeline too
 	int overlap = 0;           // pg_render_overlap
-	int guide_kernel = 0;      // pg_render_guide_kernel
+	int stages = 0;            // pg_render_stages
 	int sort = 0;              // pg_render_sort
 	PassBuf pb[2];
 	int last_slot = 0;         // of the most recent pass (pg_render_live_counts)
@@ -629,7 +630,7 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 		if (r->sort) { // pg_render_sort: keys, the sorted places, the paths' 128-byte records, rocPRIM's temporary storage
 			if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
 			PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
-			PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry.ensure(8 * N));
+			PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry[0].ensure(8 * N)); PG_HIP(ctx, b.carry[1].ensure(8 * N));
 			const size_t need = sort_pairs_temp_bytes((uint32_t)N);
 			if (need > b.sort_tmp_bytes) { PG_HIP(ctx, b.sort_tmp.ensure(need)); b.sort_tmp_bytes = need; }
 		}
@@ -969,9 +970,12 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.r_tr = b.r_tr.p; a.r_nee = b.r_nee.p; a.r_wp = b.r_wp.p;
 	a.r_slot = b.r_slot.p; a.r_tree = b.r_tree.p;
 	const dim3 grid((unsigned)((N + kRBlock - 1) / kRBlock));
-	// the SD-tree calls of a bounce inside k_wave_shade_a unless a kernel of their own was asked for (pg_render_guide_kernel)
-	// or is needed to run beside the shadow rays (pg_render_overlap)
-	a.fuse_guide = wave && !r->guide_kernel && !(r->overlap & 1) ? 1 : 0;
+	// pg_render_stages: one shading kernel per bounce (k_wave_shade), or k_wave_shade_a with the SD-tree calls in it |
+	// k_wave_cast | k_wave_shade_b, or those with k_wave_guide on its own -- which pg_render_overlap needs, to run it beside
+	// the shadow rays
+	const int stages = (r->overlap & 1) ? 2 : r->stages;
+	a.fuse_guide = wave && stages < 2 ? 1 : 0;
+	const bool joint = wave && stages == 0;
 	for (int it = 0; it < D; ++it) {
 		a.bounce = it;
 		a.last = it + 1 == D ? 1 : 0;
@@ -991,13 +995,13 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 				Timed t(r, s, 10);
 				// (the state of a sorted bounce is in the paths' records: the tail launch reads it there)
 				a.sort_key = nullptr; a.perm = nullptr; a.carry_out = nullptr;
-				a.carry_in = worth_sorting(it) ? b.carry.p : nullptr;
+				a.carry_in = worth_sorting(it) ? b.carry[it & 1].p : nullptr;
 				launch_wave_stage(5, r->general, false, a, (unsigned)((kTailPaths + kRBlock - 1) / kRBlock), (unsigned)ctx->n_cus, s);
 			}
 			const bool sorted = worth_sorting(it), next_sorted = worth_sorting(it + 1);
 			a.sort_key = sorted ? b.sort_key.p : nullptr;
-			a.carry_in = sorted ? b.carry.p : nullptr;
-			a.carry_out = next_sorted ? b.carry.p : nullptr;
+			a.carry_in = sorted ? b.carry[it & 1].p : nullptr;
+			a.carry_out = next_sorted ? b.carry[(it + 1) & 1].p : nullptr;
 			a.perm = nullptr;
 			if (sorted) { // closest hits in list order (they write every live place's key), the sort, then everything else at k
 				// the sort covers the first n_sort places: all N without counts of a previous pass, else a little more than
@@ -1020,6 +1024,11 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 					                         (uint32_t)n_sort, s));
 				}
 				a.perm = b.sort_perm.p;
+				if (joint) {
+					Timed t(r, s, 6);
+					launch_wave_stage(6, r->general, false, a, grid.x, (unsigned)ctx->n_cus, s);
+					continue;
+				}
 				for (int stage = 1; stage < 5; ++stage) {
 					if (stage == 3 && a.fuse_guide) continue;
 					Timed t(r, s, 5 + stage);
@@ -1054,6 +1063,15 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 				PG_HIP(ctx, hipStreamWaitEvent(s, b.ev_join, 0));
 				Timed t(r, s, 9);
 				launch_wave_stage(4, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
+				continue;
+			}
+			if (joint) {
+				{
+					Timed t(r, s, 5);
+					launch_wave_stage(0, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
+				}
+				Timed t(r, s, 6);
+				launch_wave_stage(6, r->general, it == 0, a, grid.x, (unsigned)ctx->n_cus, s);
 				continue;
 			}
 			for (int stage = 0; stage < 5; ++stage) {
@@ -1142,10 +1160,11 @@ int pg_render_overlap(pg_context *ctx, int32_t mode)
 	return PG_OK;
 }
 
-int pg_render_guide_kernel(pg_context *ctx, int32_t on)
+int pg_render_stages(pg_context *ctx, int32_t mode)
 {
 	if (!ctx) return PG_ERR_INVALID;
-	rstate(ctx)->guide_kernel = on != 0;
+	if (mode < 0 || mode > 2) return fail(ctx, PG_ERR_INVALID, "pg_render_stages: mode must be 0, 1 or 2");
+	rstate(ctx)->stages = mode;
 	return PG_OK;
 }
 

@@ -722,12 +722,78 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	}
 }
 
+// The survivors of a workgroup go to the next live list with their state (k_wave_shade_b, k_wave_shade): every thread of
+// the workgroup calls this.  s_rec: kRBlock * 8 entries of LDS when the next bounce is sorted (a.carry_out), else unused.
+__device__ __forceinline__ void append_survivors(const RenderArgs &a, bool cont, v3 ray_o, v3 ray_d, v3 thr, float ior, bool delta, v3 p_here,
+                                                 float prev_pdf, v3 L, uint64_t lane, const Pcg32 &rng, uint32_t *s_wave, uint32_t &s_base,
+                                                 uint32_t (*s_oct)[8], uint4 *s_rec)
+{
+	if (a.last) return; // nothing survives the last bounce
+	const unsigned long long ballot = __ballot(cont);
+	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	if (wl == 0) s_wave[wv] = (uint32_t)__popcll(ballot);
+	// The survivors of a workgroup are appended grouped by the octant of their next direction (the order inside a
+	// workgroup is free): on a sorted bounce the workgroup holds neighbours in space, and a wave of the next closest-hit
+	// launch then walks the BVH from one corner in one direction -- k_wave_trace 17.5 -> 16.4 ms per step (two of the three
+	// signs, so that a bin fills a wave: 16.7).  In list order the grouping changes nothing (round 2 measured that).
+	const unsigned oct = (__float_as_uint(ray_d.x) >> 31) | ((__float_as_uint(ray_d.y) >> 31) << 1) | ((__float_as_uint(ray_d.z) >> 31) << 2);
+	uint32_t rank_in_bin = 0;
+	for (unsigned k = 0; k < 8; ++k) {
+		const unsigned long long m = __ballot(cont && oct == k);
+		if (wl == 0) s_oct[wv][k] = (uint32_t)__popcll(m);
+		if (oct == k) rank_in_bin = (uint32_t)__popcll(m & ((1ull << wl) - 1ull));
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
+		s_base = tot ? atomicAdd(&a.live_count[a.bounce], tot) : 0u;
+	}
+	__syncthreads();
+	if (cont) { // the survivor's state goes to its place in the next list (whole lines: a wave's survivors are neighbours)
+		uint32_t off = s_base + rank_in_bin;
+		for (unsigned k = 0; k < oct; ++k)
+			for (unsigned w = 0; w < kRBlock / 64; ++w) off += s_oct[w][k]; // (every earlier bin of the workgroup)
+		for (unsigned w = 0; w < wv; ++w) off += s_oct[w][oct];           // (this bin, the earlier waves)
+		if (a.carry_out) {
+			// the next bounce is sorted: the state goes into ONE 128-byte record per path and nowhere else -- k_wave_shade_a,
+			// the only kernel that looks through the permutation, reads it as one cache line; k_wave_trace takes the ray from
+			// it and adds the hit.  The records are written as WHOLE lines, all 128 bytes of each, by consecutive threads
+			// (through LDS, below): 96 of the 128 bytes -- by the lanes themselves or through LDS alike -- cost
+			// k_wave_shade_b 13.6 -> 18.4 ms per step.  A line written in part is read, merged and written back.
+			uint4 *rec = s_rec + (off - s_base) * 8u;
+			rec[0] = make_uint4(__float_as_uint(ray_o.x), __float_as_uint(ray_o.y), __float_as_uint(ray_o.z), (uint32_t)rng.state);
+			rec[1] = make_uint4(__float_as_uint(ray_d.x), __float_as_uint(ray_d.y), __float_as_uint(ray_d.z), (uint32_t)(rng.state >> 32));
+			rec[2] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), st_pack_ior(ior, delta));
+			rec[3] = make_uint4(__float_as_uint(p_here.x), __float_as_uint(p_here.y), __float_as_uint(p_here.z), __float_as_uint(prev_pdf));
+			rec[4] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), (uint32_t)lane);
+			rec[5] = make_uint4((uint32_t)rng.inc, (uint32_t)(rng.inc >> 32), 0u, 0u);
+			rec[6] = make_uint4(0u, 0u, 0u, 0u); rec[7] = make_uint4(0u, 0u, 0u, 0u); // (the hit: k_wave_trace; spare)
+		} else {
+			st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
+			st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
+			st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
+			st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
+			st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
+			a.inc_out[off] = rng.inc;
+		}
+	}
+	if (a.carry_out) { // the workgroup's records leave through LDS as WHOLE 128-byte lines (see above)
+		__syncthreads();
+		uint32_t tot = 0;
+		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
+		uint4 *dst = a.carry_out + (uint64_t)s_base * 8;
+		for (uint32_t j = threadIdx.x; j < tot * 8u; j += kRBlock) dst[j] = s_rec[j];
+	}
+}
+
 // ---- :247-261, 302-381 ----
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArgs a)
 {
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
+	__shared__ uint32_t s_oct[kRBlock / 64][8];
 	extern __shared__ uint4 s_rec[]; // kRBlock * 8 entries when the next bounce is sorted (a.carry_out), else none
 	uint64_t tid;
 	bool alive;
@@ -797,64 +863,100 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
 		if (!cont) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here: its radiance (:431), written once -- one 16-byte store (k_finish lays the output column out)
 	}
-	if (a.last) return; // nothing survives the last bounce
-	const unsigned long long ballot = __ballot(cont);
-	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	if (wl == 0) s_wave[wv] = (uint32_t)__popcll(ballot);
-	// The survivors of a workgroup are appended grouped by the octant of their next direction (the order inside a
-	// workgroup is free): on a sorted bounce the workgroup holds neighbours in space, and a wave of the next closest-hit
-	// launch then walks the BVH from one corner in one direction -- k_wave_trace 17.5 -> 16.4 ms per step (two of the three
-	// signs, so that a bin fills a wave: 16.7).  In list order the grouping changes nothing (round 2 measured that).
+	append_survivors(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_rec);
+}
+
+// ---- :189-381 in one kernel: everything of a bounce but the closest hit ----
+// stage_a, the SD-tree calls, the shadow ray (an any-hit walk inline) and stage_b on one lane's registers: none of the
+// workspace planes the split kernels hand each other is written or read -- about 360 of the 900 bytes a lane and bounce move
+// through HBM.  The price: the shadow ray is walked by the lane that made it (no handing of finished lanes' slots to other
+// rays as in k_wave_cast), and the tree walks run at the occupancy the shading's registers leave.  LDS: the walk's stacks
+// and the hottest BVH nodes, and -- over the same bytes, once every walk of the workgroup is done -- the survivors'
+// records of a sorted next bounce.
+constexpr int kShadeLdsQuads = kRBlock * 8; // 32 KB: the records; the stacks (16 KB) and the BVH top (6 KB) fit below that
+template <int kLevel, bool kFirst>
+__global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
+{
+	__shared__ float s_planes[3 * kKdGridPlanes];
+	__shared__ uint32_t s_wave[kRBlock / 64];
+	__shared__ uint32_t s_base;
 	__shared__ uint32_t s_oct[kRBlock / 64][8];
-	const unsigned oct = (__float_as_uint(ray_d.x) >> 31) | ((__float_as_uint(ray_d.y) >> 31) << 1) | ((__float_as_uint(ray_d.z) >> 31) << 2);
-	uint32_t rank_in_bin = 0;
-	for (unsigned k = 0; k < 8; ++k) {
-		const unsigned long long m = __ballot(cont && oct == k);
-		if (wl == 0) s_oct[wv][k] = (uint32_t)__popcll(m);
-		if (oct == k) rank_in_bin = (uint32_t)__popcll(m & ((1ull << wl) - 1ull));
+	extern __shared__ uint4 s_dyn[]; // kShadeLdsQuads entries: [stacks kLdsStack * kRBlock * 8 B][BVH top][...], later the records
+	static_assert(kLdsStack * kRBlock * 8 + kBvhTopNodes * 128 <= kShadeLdsQuads * 16, "the stacks and the BVH top lie inside the record area");
+	uint64_t tid;
+	bool alive;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	stage_kd_planes(s_planes, a.tree);
+	uint2 *s_stack = reinterpret_cast<uint2 *>(s_dyn);
+	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kLdsStack * kRBlock / 2;
+	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf + tid * kOvfStack);
+	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
+	bool cont = false;
+	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(1, 1, 1), L = V(0, 0, 0), p_here = V(0, 0, 0), prev_p = V(0, 0, 0);
+	float ior = 1.0f, prev_pdf = 1.0f;
+	bool delta = false, prev_delta = true;
+	uint64_t lane = tid; // (the first list is in lane order)
+	Pcg32 rng;
+	rng.state = 0; rng.inc = 1;
+	uint64_t rec_base = 0;
+	if (!kFirst) {
+		rec_base = a.n_lanes;
+		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
 	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t tot = 0;
-		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
-		s_base = tot ? atomicAdd(&a.live_count[a.bounce], tot) : 0u;
-	}
-	__syncthreads();
-	if (cont) { // the survivor's state goes to its place in the next list (whole lines: a wave's survivors are neighbours)
-		uint32_t off = s_base + rank_in_bin;
-		for (unsigned k = 0; k < oct; ++k)
-			for (unsigned w = 0; w < kRBlock / 64; ++w) off += s_oct[w][k]; // (every earlier bin of the workgroup)
-		for (unsigned w = 0; w < wv; ++w) off += s_oct[w][oct];           // (this bin, the earlier waves)
-		if (a.carry_out) {
-			// the next bounce is sorted: the state goes into ONE 128-byte record per path and nowhere else -- k_wave_shade_a,
-			// the only kernel that looks through the permutation, reads it as one cache line; k_wave_trace takes the ray from
-			// it and adds the hit.  The records are written as WHOLE lines, all 128 bytes of each, by consecutive threads
-			// (through LDS, below): 96 of the 128 bytes -- by the lanes themselves or through LDS alike -- cost
-			// k_wave_shade_b 13.6 -> 18.4 ms per step.  A line written in part is read, merged and written back.
-			uint4 *rec = s_rec + (off - s_base) * 8u;
-			rec[0] = make_uint4(__float_as_uint(ray_o.x), __float_as_uint(ray_o.y), __float_as_uint(ray_o.z), (uint32_t)rng.state);
-			rec[1] = make_uint4(__float_as_uint(ray_d.x), __float_as_uint(ray_d.y), __float_as_uint(ray_d.z), (uint32_t)(rng.state >> 32));
-			rec[2] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), st_pack_ior(ior, delta));
-			rec[3] = make_uint4(__float_as_uint(p_here.x), __float_as_uint(p_here.y), __float_as_uint(p_here.z), __float_as_uint(prev_pdf));
-			rec[4] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), (uint32_t)lane);
-			rec[5] = make_uint4((uint32_t)rng.inc, (uint32_t)(rng.inc >> 32), 0u, 0u);
-			rec[6] = make_uint4(0u, 0u, 0u, 0u); rec[7] = make_uint4(0u, 0u, 0u, 0u); // (the hit: k_wave_trace; spare)
+	if (alive) {
+		HitRec h;
+		if (!kFirst && a.perm) { // a sorted bounce: the path's 128-byte record, through the permutation
+			const uint4 *rec = a.carry_in + (tid < (uint64_t)a.n_sort ? (uint64_t)a.perm[tid] : tid) * 8;
+			const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+			rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
+			rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
+			ray_o = st_v3(q0); ray_d = st_v3(q1);
+			thr = st_v3(q2);
+			ior = __uint_as_float(q2.w & 0x7fffffffu);
+			prev_delta = (q2.w >> 31) != 0u;
+			prev_p = st_v3(q3);
+			prev_pdf = __uint_as_float(q3.w);
+			L = st_v3(q4);
+			lane = q4.w;
+			h.prim = (int)q6.x; h.t = __uint_as_float(q6.y); h.u = __uint_as_float(q6.z); h.v = __uint_as_float(q6.w);
 		} else {
-			st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
-			st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
-			st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
-			st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
-			st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
-			a.inc_out[off] = rng.inc;
+			const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid);
+			rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
+			rng.inc = a.inc_in[tid];
+			ray_o = st_v3(q0); ray_d = st_v3(q1);
+			if (!kFirst) {
+				const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid), q4 = st_load(a.st_in, a, 4, tid);
+				thr = st_v3(q2);
+				ior = __uint_as_float(q2.w & 0x7fffffffu);
+				prev_delta = (q2.w >> 31) != 0u;
+				prev_p = st_v3(q3);
+				prev_pdf = __uint_as_float(q3.w);
+				L = st_v3(q4);
+				lane = q4.w;
+			}
+			h.prim = (int)wsu(a, WS_HIT_PRIM, tid);
+			h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
 		}
+		StageA A;
+		stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
+		GuideOut g;
+		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
+		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
+		g.wo = A.wo;
+		if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, (A.flags & F_SMP_TREE) ? V(0, 0, 0) : A.wo, A.flags, g);
+		if (a.record && (A.flags & F_VALID)) store_slots(a, rec_base + tid, g);
+		bool occluded = false;
+		if (A.flags & F_NEED_SHADOW) { // :213 test_visibility
+			float th, bu, bv;
+			occluded = intersect<kLevel, true>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
+		}
+		cont = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, rec_base + tid, (uint32_t)a.bounce, ray_o, ray_d, prev_pdf, delta);
+		p_here = A.p;
+		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
+		if (!cont) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here
 	}
-	if (a.carry_out) { // the workgroup's records leave through LDS as WHOLE 128-byte lines (see above)
-		__syncthreads();
-		uint32_t tot = 0;
-		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
-		uint4 *dst = a.carry_out + (uint64_t)s_base * 8;
-		for (uint32_t j = threadIdx.x; j < tot * 8u; j += kRBlock) dst[j] = s_rec[j];
-	}
+	// (append_survivors' first barrier comes after every walk of the workgroup: from there on the stacks' bytes hold records)
+	append_survivors(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_dyn);
 }
 
 // See tail_checkpoint (pg_render_dev.hpp): launched before the launches of bounce a.bounce with a grid
@@ -987,6 +1089,12 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		const size_t lds = a.carry_out ? (size_t)kRBlock * 8 * sizeof(uint4) : 0; // (the survivors' records of a sorted next bounce)
 		if (first) hipLaunchKernelGGL((k_wave_shade_b<kLevel, true>), grid, block, lds, s, a);
 		else hipLaunchKernelGGL((k_wave_shade_b<kLevel, false>), grid, block, lds, s, a);
+		break;
+	}
+	case 6: {
+		const size_t lds = (size_t)kShadeLdsQuads * sizeof(uint4);
+		if (first) hipLaunchKernelGGL((k_wave_shade<kLevel, true>), grid, block, lds, s, a);
+		else hipLaunchKernelGGL((k_wave_shade<kLevel, false>), grid, block, lds, s, a);
 		break;
 	}
 	default: hipLaunchKernelGGL((k_wave_tail<kLevel>), grid, block, 0, s, a); break;

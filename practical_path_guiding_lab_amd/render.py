@@ -46,7 +46,7 @@ class WavefrontScene:
     PathGuidingIntegrator.sample()."""
 
     def __init__(self, scene: Scene, split_pipeline: bool = False, overlap: int = 0, in_flight: int = 1, sort: bool = True,
-                 guide_kernel: bool = False):
+                 stages: int = 0):
         """split_pipeline: run the bounce as the split pipeline also for a scene the fused kernel could
         run (pg_render_split_pipeline: same results, the SD-tree queries as a kernel of their own)."""
         self.scene = scene
@@ -55,9 +55,12 @@ class WavefrontScene:
         # pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (same results, +10 % on
         # veach-ajar; the fused kernels of quad scenes ignore it)
         self.sort = bool(sort)
-        # pg_render_guide_kernel: the SD-tree calls of a mesh scene's bounce as a kernel of their own (k_wave_guide) instead
-        # of the tail of k_wave_shade_a -- same results; how the hot path is timed by itself
-        self.guide_kernel = bool(guide_kernel)
+        # pg_render_stages: how a mesh scene's bounce is cut into kernels behind the closest hits -- 0: one (k_wave_shade),
+        # 1: k_wave_shade_a with the SD-tree calls | k_wave_cast | k_wave_shade_b, 2: those with k_wave_guide on its own
+        # (how the hot path is timed by itself).  Same results.
+        if stages not in (0, 1, 2):
+            raise ValueError("stages must be 0, 1 or 2")
+        self.stages = int(stages)
         # in_flight = 2: consecutive passes alternate between two buffer sets (pg_pass_params.slot) and two streams of
         # their own, so that two are on the device at once (the passes of an iteration are independent, main.py:208-218;
         # same results).  What a pass returns is then valid once join() has made the current stream wait for them.
@@ -120,7 +123,7 @@ class WavefrontScene:
         N.check(tree._h, tree._lib.pg_render_split_pipeline(tree._h, 1 if self.split_pipeline else 0))
         N.check(tree._h, tree._lib.pg_render_overlap(tree._h, self.overlap))
         N.check(tree._h, tree._lib.pg_render_sort(tree._h, 1 if self.sort else 0))
-        N.check(tree._h, tree._lib.pg_render_guide_kernel(tree._h, 1 if self.guide_kernel else 0))
+        N.check(tree._h, tree._lib.pg_render_stages(tree._h, self.stages))
         N.check(tree._h, tree._lib.pg_scene_set_ex(tree._h, C.byref(d), C.byref(c)))
         self._uploaded_to = tree
 
@@ -164,12 +167,12 @@ class WavefrontScene:
         if n:
             N.check(tree._h, tree._lib.pg_render_reserve(tree._h, n))
 
-    def set_guide_kernel(self, integrator, on: bool) -> None:
-        """pg_render_guide_kernel, from the next pass on (a scheduling switch: results do not change)."""
-        self.guide_kernel = bool(on)
+    def set_stages(self, integrator, stages: int) -> None:
+        """pg_render_stages, from the next pass on (a scheduling switch: results do not change)."""
+        self.stages = int(stages)
         tree = integrator.sdTree
         self._upload(tree)
-        N.check(tree._h, tree._lib.pg_render_guide_kernel(tree._h, 1 if self.guide_kernel else 0))
+        N.check(tree._h, tree._lib.pg_render_stages(tree._h, self.stages))
 
     def join(self) -> None:
         """in_flight = 2: the current stream waits for every pass issued so far (no host synchronisation)."""

@@ -151,10 +151,10 @@ def _scene_and_box(which):
 
 @pytest.mark.parametrize("which", ["cornell-box", "cornell-box deep", "veach-mis", "mixed", "mixed deep"])
 def test_render_kernels_with_surfaces_on_grid_faces(which):
-    """k_bounce / k_bounce_tail (quad scenes), k_wave_shade_a's SD-tree tail, k_wave_guide and k_wave_tail (mesh scenes)
+    """k_bounce / k_bounce_tail (quad scenes), k_wave_shade, k_wave_shade_a's SD-tree tail, k_wave_guide and k_wave_tail (mesh scenes)
     and k_splat_list behind them (the accumulators those kernels name for vertices on the faces), over a guided lifecycle
     against the oracle."""
     from test_gpu_render import _guided_lifecycle_bit_exact
     sc, bmin, bmax = _scene_and_box(which)
-    for guide_kernel in ((False, True) if which.startswith("mixed") else (False,)):
-        _guided_lifecycle_bit_exact(sc, True, bbox=(np.array(bmin, np.float32), np.array(bmax, np.float32)), guide_kernel=guide_kernel)
+    for stages in ((0, 1, 2) if which.startswith("mixed") else (0,)):
+        _guided_lifecycle_bit_exact(sc, True, bbox=(np.array(bmin, np.float32), np.array(bmax, np.float32)), stages=stages)

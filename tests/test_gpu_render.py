@@ -148,7 +148,8 @@ def test_torus_scene_bit_exact():
     against the oracle over a guided lifecycle."""
     from practical_path_guiding_lab_amd.scene import torus
     _guided_lifecycle_bit_exact(torus(48, 36), True)
-    _guided_lifecycle_bit_exact(torus(48, 36), True, guide_kernel=True)  # the SD-tree calls as k_wave_guide
+    _guided_lifecycle_bit_exact(torus(48, 36), True, stages=1)  # k_wave_shade_a with the SD-tree calls | k_wave_cast | k_wave_shade_b
+    _guided_lifecycle_bit_exact(torus(48, 36), True, stages=2)  # ... and the SD-tree calls as k_wave_guide
 
 
 def test_veach_ajar_scene_bit_exact():
@@ -158,13 +159,16 @@ def test_veach_ajar_scene_bit_exact():
     the oracle over a guided lifecycle."""
     from practical_path_guiding_lab_amd.scene import veach_ajar
     _guided_lifecycle_bit_exact(veach_ajar(64, 36), True)
-    _guided_lifecycle_bit_exact(veach_ajar(64, 36), True, guide_kernel=True)  # the SD-tree calls as k_wave_guide
+    _guided_lifecycle_bit_exact(veach_ajar(64, 36), True, stages=1)  # k_wave_shade_a with the SD-tree calls | k_wave_cast | k_wave_shade_b
+    _guided_lifecycle_bit_exact(veach_ajar(64, 36), True, stages=2)  # ... and the SD-tree calls as k_wave_guide
 
 
-def test_veach_ajar_deep_split_bounces_bit_exact():
+@pytest.mark.parametrize("stages", [0, 1, 2])
+def test_veach_ajar_deep_split_bounces_bit_exact(stages):
     """veach-ajar at 320x180 with 8 spp per pass: 460 800 paths, more than the tail launch takes over,
-    so the deep bounces run through the five split kernels too (the live list, the workspace planes and
-    the record list at every depth); radiance and accumulators against the oracle over three iterations."""
+    so the deep bounces run through the per-bounce kernels too (the live list, the records of the sorted bounces, the
+    workspace planes and the record list at every depth) -- in each of the three forms of pg_render_stages; radiance and
+    accumulators against the oracle over three iterations."""
     import torch
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
@@ -177,7 +181,7 @@ def test_veach_ajar_deep_split_bounces_bit_exact():
     o.setup(bmin, bmax, 20, 20, True)
     g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
     g.setup(npix, bmin, bmax, 20, 20, True, 0.5)
-    ws = WavefrontScene(sc)
+    ws = WavefrontScene(sc, stages=stages)
     for k in range(3):
         g.setIteration(k, False)
         Lo, vo = po.render_pass(o, sc, sc.camera, 13, 8, k, False, 77 + k, 8, True, 0.5)
@@ -221,9 +225,9 @@ def test_lifecycle_parity_at_larger_sizes(which):
     _guided_lifecycle_bit_exact(sc, True)
 
 
-def _guided_lifecycle_bit_exact(sc, nee, bbox=None, guide_kernel=False):
-    """bbox: the SD-tree's root box when it is not the scene's own (main.py:55-59); guide_kernel: the SD-tree calls of a
-    mesh scene's bounce as k_wave_guide (pg_render_guide_kernel) instead of the tail of k_wave_shade_a."""
+def _guided_lifecycle_bit_exact(sc, nee, bbox=None, stages=0):
+    """bbox: the SD-tree's root box when it is not the scene's own (main.py:55-59); stages: pg_render_stages -- a mesh
+    scene's bounce as one shading kernel (0), three (1) or four with k_wave_guide on its own (2)."""
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
@@ -238,7 +242,7 @@ def _guided_lifecycle_bit_exact(sc, nee, bbox=None, guide_kernel=False):
     o_sumL2 = np.zeros((3, npix), np.float32)
     g = PathGuidingIntegrator({"max_depth": D, "rr_depth": RR})
     g.setup(npix, bmin, bmax, sdTreeMaxDepth=20, quadTreeMaxDepth=20, isStoreNEERadiance=nee, bsdfSamplingFraction=0.5)
-    ws = WavefrontScene(sc, guide_kernel=guide_kernel)
+    ws = WavefrontScene(sc, stages=stages)
     cumm = 0
     for k in range(4):
         final = k == 3
@@ -485,7 +489,7 @@ def test_fused_kernel_and_split_pipeline_are_two_implementations_of_one_bounce(w
             g.refineAndPrepareSDTreeForNextIteration()
         kt = g.sdTree.readKernelTiming()
         assert (kt.trace_launches > 0) == split   # really the other kernels (k_wave_trace runs in the split pipeline only)
-        assert kt.guide_launches == 0             # (the SD-tree calls are the tail of k_wave_shade_a unless pg_render_guide_kernel asks)
+        assert kt.guide_launches == 0             # (k_wave_guide runs on request only: pg_render_stages(2))
         runs.append((last.clone(), g.sumL.clone(), g.sumL2.clone(), g.sdTree.export()))
         del g, ws
         torch.cuda.empty_cache()
@@ -512,10 +516,10 @@ def test_two_passes_in_flight_equal_one_at_a_time(which):
     npix = sc.camera.width * sc.camera.height
     bmin, bmax = sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4)
 
-    def run(in_flight, overlap, sort=False, guide_kernel=False, split=False):
+    def run(in_flight, overlap, sort=False, stages=0, split=False):
         g = PathGuidingIntegrator({"max_depth": sc.max_depth, "rr_depth": sc.rr_depth})
         g.setup(npix, bmin, bmax, 20, 20, True, 0.5)
-        ws = WavefrontScene(sc, in_flight=in_flight, overlap=overlap, sort=sort, guide_kernel=guide_kernel, split_pipeline=split)
+        ws = WavefrontScene(sc, in_flight=in_flight, overlap=overlap, sort=sort, stages=stages, split_pipeline=split)
         g.sdTree.enableKernelTiming(True)
         out = []
         cumm = 0
@@ -537,7 +541,7 @@ def test_two_passes_in_flight_equal_one_at_a_time(which):
                 out.append(g.sdTree.export())
         kt = g.sdTree.readKernelTiming()
         if kt.trace_launches:  # the split pipeline ran: k_wave_guide exactly when asked for (or implied by the overlap)
-            assert (kt.guide_launches > 0) == bool(guide_kernel or overlap)
+            assert (kt.guide_launches > 0) == bool(stages == 2 or overlap)
         return out
 
     def same(a, b):
@@ -559,7 +563,7 @@ def test_two_passes_in_flight_equal_one_at_a_time(which):
     # pg_render_sort: the bounces below rr_depth in a global spatial order (mesh scenes; a no-op for the fused kernels)
     same(ref, run(1, 0, sort=True))
     same(ref, run(2, 0, sort=True))
-    # pg_render_guide_kernel: the SD-tree calls of a bounce as k_wave_guide instead of the tail of k_wave_shade_a
-    same(ref, run(1, 0, sort=True, guide_kernel=True, split=True))
-    same(ref, run(1, 0, sort=False, guide_kernel=True, split=True))
-    same(ref, run(1, 0, sort=True, guide_kernel=False, split=True))
+    # pg_render_stages: one shading kernel per bounce, three, or four with the SD-tree calls as k_wave_guide
+    for st in (0, 1, 2):
+        same(ref, run(1, 0, sort=True, stages=st, split=True))
+        same(ref, run(2, 0, sort=False, stages=st, split=True))

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): the scheduling switches change no result, at a size where races would show -- veach-ajar 960x540,
-six iterations of 16-spp passes: list order one pass at a time vs sorted bounces with two passes in flight and the
-guide kernel beside the shadow rays.  Per-pixel sums and the refined trees must be identical.
+six iterations of 16-spp passes: list order one pass at a time (one shading kernel per bounce) vs sorted bounces, two passes
+in flight, the guide kernel beside the shadow rays, and the three- and four-kernel forms of pg_render_stages.  Per-pixel sums and the refined trees must be identical.
     python tools/stress_schedules.py"""
 import os
 import sys
@@ -38,7 +38,8 @@ def run(**kw):
 
 
 a_s, a_t = run(sort=0, in_flight=1, overlap=0)
-for kw in (dict(sort=1, in_flight=2, overlap=1), dict(sort=1, in_flight=1, overlap=0), dict(sort=0, in_flight=2, overlap=0)):
+for kw in (dict(sort=1, in_flight=2, overlap=1), dict(sort=1, in_flight=1, overlap=0), dict(sort=0, in_flight=2, overlap=0),
+           dict(sort=1, in_flight=2, overlap=0, stages=1), dict(sort=1, in_flight=1, overlap=0, stages=2), dict(sort=0, in_flight=1, overlap=0, stages=1)):
     b_s, b_t = run(**kw)
     for k, (x, y) in enumerate(zip(a_s, b_s)):
         assert (x[0].view(np.uint32) == y[0].view(np.uint32)).all() and (x[1].view(np.uint32) == y[1].view(np.uint32)).all(), (kw, k)

@@ -13,9 +13,9 @@ import sys
 src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 BOUNCES = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # k_bounce launches per pass = max_depth
 os.makedirs(dst, exist_ok=True)
-KERNELS = ("k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_tail", "k_bounce", "k_splat_list",
-           "k_process_and_splat", "k_finish")  # k_wave_cast = the persistent any-hit kernel of the shadow rays
-PER_BOUNCE = ("k_bounce", "k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b")
+KERNELS = ("k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_shade", "k_wave_tail", "k_bounce", "k_splat_list",
+           "k_process_and_splat", "k_finish")  # (k_wave_shade after _a and _b: the first name found in a kernel's name counts)  # k_wave_cast = the persistent any-hit kernel of the shadow rays
+PER_BOUNCE = ("k_bounce", "k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_shade")
 
 
 def short(name):
@@ -42,14 +42,19 @@ for r in csv.DictReader(open(trace)):
     k = short(r["Kernel_Name"])
     if k:
         dur[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-# bench.py times two regions: the default build of the pipeline (the SD-tree calls at the end of k_wave_shade_a), then the
-# same passes with pg_render_guide_kernel(1), k_wave_guide's only launches.  Every kernel but k_wave_guide is summarised over
+# bench.py times two regions: the default form of the pipeline (one shading kernel per bounce, k_wave_shade), then the
+# same passes with pg_render_stages(2), k_wave_guide's only launches.  Every kernel but k_wave_guide is summarised over
 # the FIRST region: the launches before the first k_wave_guide.
 t_split = min((t for t, _ in dur.get("k_wave_guide", [])), default=None)
+second_region = {"k_wave_guide"}  # kernels summarised over the second region: those that run there only
 if t_split is not None:
     for k in list(dur):
         if k != "k_wave_guide":
-            dur[k] = [(t, d) for t, d in dur[k] if t < t_split]
+            first = [(t, d) for t, d in dur[k] if t < t_split]
+            if first:
+                dur[k] = first
+            else:
+                second_region.add(k)
 trace_summary = {}
 for k, v in dur.items():
     v.sort()
@@ -59,6 +64,8 @@ for k, v in dur.items():
     last = [d for _, d in v[-10 * per_pass:]]
     trace_summary[k] = {"launches_in_timed_region": len(last), "avg_us": round(sum(last) / len(last) / 1e3, 2),
                         "min_us": round(min(last) / 1e3, 2), "max_us": round(max(last) / 1e3, 2)}
+    if t_split is not None and k in second_region:
+        trace_summary[k]["region"] = "roofline (pg_render_stages 2)"
 
 
 PMC_STEPS = 3  # tools/profile_bench.sh runs the counter passes with --steps 3
@@ -72,8 +79,9 @@ def agg(sub):
     if fs:
         rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
         first_guide = min((int(r["Dispatch_Id"]) for r in rows if short(r["Kernel_Name"]) == "k_wave_guide"), default=None)
-        if first_guide is not None:  # (see above: the other kernels over the first region only)
-            rows = [r for r in rows if short(r["Kernel_Name"]) == "k_wave_guide" or int(r["Dispatch_Id"]) < first_guide]
+        if first_guide is not None:  # (see above: the other kernels over the first region only, unless they run in the second only)
+            in_first = {short(r["Kernel_Name"]) for r in rows if int(r["Dispatch_Id"]) < first_guide}
+            rows = [r for r in rows if short(r["Kernel_Name"]) not in in_first or int(r["Dispatch_Id"]) < first_guide]
         for r in rows:
             k = short(r["Kernel_Name"])
             if k:
