@@ -723,7 +723,8 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 }
 
 // The survivors of a workgroup go to the next live list with their state (k_wave_shade_b, k_wave_shade): every thread of
-// the workgroup calls this.  s_rec: kRBlock * 8 entries of LDS when the next bounce is sorted (a.carry_out), else unused.
+// the workgroup calls this.  s_rec: kStage * 8 entries of LDS when the next bounce is sorted (a.carry_out), else unused.
+template <int kStage>
 __device__ __forceinline__ void append_survivors(const RenderArgs &a, bool cont, v3 ray_o, v3 ray_d, v3 thr, float ior, bool delta, v3 p_here,
                                                  float prev_pdf, v3 L, uint64_t lane, const Pcg32 &rng, uint32_t *s_wave, uint32_t &s_base,
                                                  uint32_t (*s_oct)[8], uint4 *s_rec)
@@ -750,40 +751,45 @@ __device__ __forceinline__ void append_survivors(const RenderArgs &a, bool cont,
 		s_base = tot ? atomicAdd(&a.live_count[a.bounce], tot) : 0u;
 	}
 	__syncthreads();
-	if (cont) { // the survivor's state goes to its place in the next list (whole lines: a wave's survivors are neighbours)
-		uint32_t off = s_base + rank_in_bin;
+	uint32_t off = s_base + rank_in_bin; // the survivor's place in the next list (whole lines: a wave's survivors are neighbours)
+	if (cont) {
 		for (unsigned k = 0; k < oct; ++k)
 			for (unsigned w = 0; w < kRBlock / 64; ++w) off += s_oct[w][k]; // (every earlier bin of the workgroup)
 		for (unsigned w = 0; w < wv; ++w) off += s_oct[w][oct];           // (this bin, the earlier waves)
-		if (a.carry_out) {
-			// the next bounce is sorted: the state goes into ONE 128-byte record per path and nowhere else -- k_wave_shade_a,
-			// the only kernel that looks through the permutation, reads it as one cache line; k_wave_trace takes the ray from
-			// it and adds the hit.  The records are written as WHOLE lines, all 128 bytes of each, by consecutive threads
-			// (through LDS, below): 96 of the 128 bytes -- by the lanes themselves or through LDS alike -- cost
-			// k_wave_shade_b 13.6 -> 18.4 ms per step.  A line written in part is read, merged and written back.
-			uint4 *rec = s_rec + (off - s_base) * 8u;
-			rec[0] = make_uint4(__float_as_uint(ray_o.x), __float_as_uint(ray_o.y), __float_as_uint(ray_o.z), (uint32_t)rng.state);
-			rec[1] = make_uint4(__float_as_uint(ray_d.x), __float_as_uint(ray_d.y), __float_as_uint(ray_d.z), (uint32_t)(rng.state >> 32));
-			rec[2] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), st_pack_ior(ior, delta));
-			rec[3] = make_uint4(__float_as_uint(p_here.x), __float_as_uint(p_here.y), __float_as_uint(p_here.z), __float_as_uint(prev_pdf));
-			rec[4] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), (uint32_t)lane);
-			rec[5] = make_uint4((uint32_t)rng.inc, (uint32_t)(rng.inc >> 32), 0u, 0u);
-			rec[6] = make_uint4(0u, 0u, 0u, 0u); rec[7] = make_uint4(0u, 0u, 0u, 0u); // (the hit: k_wave_trace; spare)
-		} else {
-			st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
-			st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
-			st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
-			st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
-			st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
-			a.inc_out[off] = rng.inc;
-		}
 	}
-	if (a.carry_out) { // the workgroup's records leave through LDS as WHOLE 128-byte lines (see above)
-		__syncthreads();
+	if (a.carry_out) {
+		// the next bounce is sorted: the state goes into ONE 128-byte record per path and nowhere else -- the kernel that
+		// looks through the permutation reads it as one cache line; k_wave_trace takes the ray from it and adds the hit.
+		// The records are written as WHOLE lines, all 128 bytes of each, by consecutive threads, through LDS, kStage
+		// records at a time: 96 of the 128 bytes -- by the lanes themselves or through LDS alike -- cost k_wave_shade_b
+		// 13.6 -> 18.4 ms per step.  A line written in part is read, merged and written back.
 		uint32_t tot = 0;
 		for (int w = 0; w < kRBlock / 64; ++w) tot += s_wave[w];
+		const uint32_t idx = cont ? off - s_base : 0xffffffffu;
 		uint4 *dst = a.carry_out + (uint64_t)s_base * 8;
-		for (uint32_t j = threadIdx.x; j < tot * 8u; j += kRBlock) dst[j] = s_rec[j];
+		for (uint32_t h = 0; h < tot; h += (uint32_t)kStage) { // (uniform over the workgroup)
+			if (h) __syncthreads(); // (the round before has been copied out)
+			if (idx >= h && idx < h + (uint32_t)kStage) {
+				uint4 *rec = s_rec + (idx - h) * 8u;
+				rec[0] = make_uint4(__float_as_uint(ray_o.x), __float_as_uint(ray_o.y), __float_as_uint(ray_o.z), (uint32_t)rng.state);
+				rec[1] = make_uint4(__float_as_uint(ray_d.x), __float_as_uint(ray_d.y), __float_as_uint(ray_d.z), (uint32_t)(rng.state >> 32));
+				rec[2] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), st_pack_ior(ior, delta));
+				rec[3] = make_uint4(__float_as_uint(p_here.x), __float_as_uint(p_here.y), __float_as_uint(p_here.z), __float_as_uint(prev_pdf));
+				rec[4] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), (uint32_t)lane);
+				rec[5] = make_uint4((uint32_t)rng.inc, (uint32_t)(rng.inc >> 32), 0u, 0u);
+				rec[6] = make_uint4(0u, 0u, 0u, 0u); rec[7] = make_uint4(0u, 0u, 0u, 0u); // (the hit: k_wave_trace; spare)
+			}
+			__syncthreads();
+			const uint32_t n = tot - h < (uint32_t)kStage ? tot - h : (uint32_t)kStage;
+			for (uint32_t j = threadIdx.x; j < n * 8u; j += kRBlock) dst[(uint64_t)h * 8 + j] = s_rec[j];
+		}
+	} else if (cont) {
+		st_store(a.st_out, a, 0, off, ray_o, (uint32_t)rng.state);
+		st_store(a.st_out, a, 1, off, ray_d, (uint32_t)(rng.state >> 32));
+		st_store(a.st_out, a, 2, off, thr, st_pack_ior(ior, delta));
+		st_store(a.st_out, a, 3, off, p_here, __float_as_uint(prev_pdf));
+		st_store(a.st_out, a, 4, off, L, (uint32_t)lane);
+		a.inc_out[off] = rng.inc;
 	}
 }
 
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
 		if (!cont) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here: its radiance (:431), written once -- one 16-byte store (k_finish lays the output column out)
 	}
-	append_survivors(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_rec);
+	append_survivors<kRBlock>(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_rec);
 }
 
 // ---- :189-381 in one kernel: everything of a bounce but the closest hit ----
@@ -873,7 +879,14 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 // rays as in k_wave_cast), and the tree walks run at the occupancy the shading's registers leave.  LDS: the walk's stacks
 // and the hottest BVH nodes, and -- over the same bytes, once every walk of the workgroup is done -- the survivors'
 // records of a sorted next bounce.
-constexpr int kShadeLdsQuads = kRBlock * 8; // 32 KB: the records; the stacks (16 KB) and the BVH top (6 KB) fit below that
+#ifndef PG_SHADE_STAGE
+#define PG_SHADE_STAGE 256
+#endif
+constexpr int kShadeStage = PG_SHADE_STAGE; // survivors' records staged in LDS at a time
+constexpr int kShadeLdsQuads = kShadeStage * 8 > kLdsStack * kRBlock / 2 + kBvhTopNodes * 8 ? kShadeStage * 8 : kLdsStack * kRBlock / 2 + kBvhTopNodes * 8;
+// (122 vector registers, four waves per SIMD, which is also what 33 KB of LDS per workgroup allow.  Measured: staging the
+// records 128 at a time -- 23 KB -- changes nothing by itself, and compiled for five waves on top of that the kernel spills
+// 31 registers: 35.2 -> 37.6 ms per step.)
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 {
@@ -882,7 +895,6 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 	__shared__ uint32_t s_base;
 	__shared__ uint32_t s_oct[kRBlock / 64][8];
 	extern __shared__ uint4 s_dyn[]; // kShadeLdsQuads entries: [stacks kLdsStack * kRBlock * 8 B][BVH top][...], later the records
-	static_assert(kLdsStack * kRBlock * 8 + kBvhTopNodes * 128 <= kShadeLdsQuads * 16, "the stacks and the BVH top lie inside the record area");
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
@@ -956,7 +968,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 		if (!cont) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here
 	}
 	// (append_survivors' first barrier comes after every walk of the workgroup: from there on the stacks' bytes hold records)
-	append_survivors(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_dyn);
+	append_survivors<kShadeStage>(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_dyn);
 }
 
 // See tail_checkpoint (pg_render_dev.hpp): launched before the launches of bounce a.bounce with a grid
