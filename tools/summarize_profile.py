@@ -45,16 +45,13 @@ for r in csv.DictReader(open(trace)):
 # bench.py times two regions: the default form of the pipeline (one shading kernel per bounce, k_wave_shade), then the
 # same passes with pg_render_stages(2), k_wave_guide's only launches.  Every kernel but k_wave_guide is summarised over
 # the FIRST region: the launches before the first k_wave_guide.
-t_split = min((t for t, _ in dur.get("k_wave_guide", [])), default=None)
-second_region = {"k_wave_guide"}  # kernels summarised over the second region: those that run there only
+SPLIT_ONLY = ("k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b")
+second_region = set(SPLIT_ONLY) if "k_wave_shade" in dur else {"k_wave_guide"}  # kernels that run in the second region only
+t_split = min((t for k in second_region for t, _ in dur.get(k, [])), default=None)
 if t_split is not None:
     for k in list(dur):
-        if k != "k_wave_guide":
-            first = [(t, d) for t, d in dur[k] if t < t_split]
-            if first:
-                dur[k] = first
-            else:
-                second_region.add(k)
+        if k not in second_region:
+            dur[k] = [(t, d) for t, d in dur[k] if t < t_split]
 trace_summary = {}
 for k, v in dur.items():
     v.sort()
@@ -78,10 +75,11 @@ def agg(sub):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     if fs:
         rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
-        first_guide = min((int(r["Dispatch_Id"]) for r in rows if short(r["Kernel_Name"]) == "k_wave_guide"), default=None)
-        if first_guide is not None:  # (see above: the other kernels over the first region only, unless they run in the second only)
-            in_first = {short(r["Kernel_Name"]) for r in rows if int(r["Dispatch_Id"]) < first_guide}
-            rows = [r for r in rows if short(r["Kernel_Name"]) not in in_first or int(r["Dispatch_Id"]) < first_guide]
+        names = {short(r["Kernel_Name"]) for r in rows}
+        second = set(SPLIT_ONLY) if "k_wave_shade" in names else {"k_wave_guide"}
+        first_second = min((int(r["Dispatch_Id"]) for r in rows if short(r["Kernel_Name"]) in second), default=None)
+        if first_second is not None:  # (see above: the other kernels over the first region only)
+            rows = [r for r in rows if short(r["Kernel_Name"]) in second or int(r["Dispatch_Id"]) < first_second]
         for r in rows:
             k = short(r["Kernel_Name"])
             if k:
