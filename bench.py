@@ -624,7 +624,7 @@ def run_render(args):
                              "traffic null: no PMC figures of this configuration taken of THIS code are committed (profiles/pmc_traffic.json "
                              "records the hash of the sources it was taken of; a mismatch is refused rather than paired with new timings)"),
             "region": ("the timed region of `value`" if kt_roof is None else
-                       f"steps {args.steps + 1}-{2 * args.steps} of the run: the passes of `value`'s region again with pg_render_guide_kernel(1) -- the "
+                       f"steps {args.steps + 1}-{2 * args.steps} of the run: the passes of `value`'s region again with pg_render_stages(2) -- the "
                        "SD-tree calls of a bounce as k_wave_guide (four kernels behind the closest hits) instead of inside the one shading kernel of the default, where they "
                        f"cannot be timed apart; that region ran at {1e3 * elapsed_roof / args.steps:.2f} ms per step against {step_ms:.2f} of the default"),
             "slowest_kernel_of_step": slowest,
