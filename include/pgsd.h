@@ -442,9 +442,11 @@ int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, flo
 typedef struct pg_kernel_timing {
 	double bounce_ms, splat_ms, generate_ms, finish_ms, compact_ms;
 	uint64_t bounce_launches, splat_launches, passes;
-	/* mesh scenes run a bounce as five kernels (ray casting, shading before and after the SD-tree
-	 * queries, shadow rays, the SD-tree queries): their shares of bounce_ms; bounce_launches then counts
-	 * bounces.  shade_ms = both shading kernels; tail_ms = the launch that finishes the last paths. */
+	/* mesh scenes run a bounce as two to five kernels (pg_render_stages: closest hits; then one shading kernel,
+	 * or shading before and after the shadow rays with the SD-tree calls in the first, or those calls as a kernel
+	 * of their own): their shares of bounce_ms; bounce_launches then counts bounces.  shade_ms = the shading
+	 * kernels (pg_render_stages(0): the one, with shadow_ms = guide_ms = shade_b_ms = 0); tail_ms = the launch
+	 * that finishes the last paths. */
 	double trace_ms, shade_ms, shadow_ms, guide_ms, tail_ms;
 	uint64_t trace_launches, guide_launches;
 	double shade_a_ms, shade_b_ms; /* the two shading kernels of shade_ms, each on its own */

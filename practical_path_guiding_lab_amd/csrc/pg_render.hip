@@ -981,7 +981,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 		a.last = it + 1 == D ? 1 : 0;
 		a.order_in = b.order[it & 1].p;
 		a.order_out = b.order[(it + 1) & 1].p;
-		if (wave) { // pg_render_wave.hip: five kernels per bounce, each timed on its own (kinds 5-9; 10 = tail)
+		if (wave) { // pg_render_wave.hip: the kernels of a bounce (pg_render_stages), each timed on its own (kinds 5-9; 10 = tail; k_wave_shade: kind 6)
 			// the state set this bounce reads and the one its survivors are written to; the camera rays of the first
 			// launch go to the set the first bounce reads
 			a.st_in = b.st[it & 1].p; a.inc_in = b.inc[it & 1].p;

@@ -1,31 +1,36 @@
 // pg_render_wave.hip -- the bounce of PathGuidingIntegrator.sample() (src/path_guiding_integrator.py:
-// 179-381) for scenes with triangle meshes (scenes/veach-ajar, scenes/torus), as a wavefront pipeline
-// of five small kernels per bounce instead of one big one:
+// 179-381) for scenes with triangle meshes (scenes/veach-ajar, scenes/torus), as a wavefront pipeline.
+// The stages of a bounce are device functions -- stage_a, stage_guide, stage_b, the BVH walks of
+// pg_render_dev.hpp -- and pg_render_stages chooses how many kernels they are cut into behind the closest hits:
 //
-//   k_wave_trace    :185   scene.ray_intersect: closest hit of every live ray (BVH walk, stack in LDS);
-//                          the first launch also makes the camera rays
-//   k_wave_shade_a  :189-220, 272-297   surface and textures at the hit, emitted radiance and its MIS
+//   k_wave_trace    :185   scene.ray_intersect: closest hit of every live ray (BVH walk; stacks and the hottest
+//                          nodes in LDS); the first launch also makes the camera rays.  Between it and what
+//                          follows the live list of a sorted bounce is put in spatial order (pg_sort.hip).
+//   k_wave_shade    :189-381   (the default) everything else of the bounce on one lane's registers: stage_a,
+//                          stage_guide, the shadow ray as an inline any-hit walk, stage_b, the survivors' append
+// or, handing their results on through the planes of `ws` (indexed by the lane's place in the live list):
+//   k_wave_shade_a  :189-220, 272-297   stage_a: surface and textures at the hit, emitted radiance and its MIS
 //                          weight, one emitter sample (a shadow ray to trace), the BSDF towards it, the
-//                          BSDF sample, the lane's class (delta | bsdf | bsdf-mis | sdtree-mis)
+//                          BSDF sample, the lane's class (delta | bsdf | bsdf-mis | sdtree-mis) -- and stage_guide
+//                          unless that runs as
+//   k_wave_guide    :244, 301, 307   stage_guide alone: the three SD-tree calls of the bounce and nothing else --
+//                          one KD descent, the pdf of the emitter direction, sample-or-pdf of the continuation
+//                          direction, the canonical coordinates and accumulators the record needs -- the kernel
+//                          the HBM roofline of the hot path is measured on
 //   k_wave_cast     :213   test_visibility: any-hit walk of the shadow rays, a persistent kernel (a lane whose
 //                          ray is done takes the next one: shadow rays end after very different numbers of steps)
-//   k_wave_guide    :244, 301, 307   the three SD-tree calls of the bounce and nothing else: one KD
-//                          descent, the pdf of the emitter direction, sample-or-pdf of the continuation
-//                          direction, the canonical coordinates the record needs -- the kernel the
-//                          HBM roofline of the hot path is measured on
-//   k_wave_shade_b  :247-261, 302-381   mixture pdfs and MIS weights, radiance, the path-vertex record,
+//   k_wave_shade_b  :247-261, 302-381   stage_b: mixture pdfs and MIS weights, radiance, the path-vertex record,
 //                          throughput, Russian roulette, the next ray; survivors are appended to the
 //                          next live list (one atomic per workgroup)
+//   k_wave_tail     all stages in sequence for the last few thousand paths of a long pass (see tail_checkpoint)
 //
-// Why split: the fused kernel of this scene class needed 153 vector registers (three waves per SIMD)
-// and kept its 64-entry BVH stack in scratch memory; a walk is a chain of dependent loads that wants
-// many waves to hide them, the shading wants registers.  Between the kernels a lane's intermediate
-// results travel through `ws`, planes indexed by the lane's position in the live list, so every
-// load and store of them is coalesced; what a path carries from bounce to bounce stays in the
-// per-lane state arrays.  The stages are device functions (stage_a, stage_guide, stage_b): the split
-// kernels load their inputs, call one, store its outputs; k_wave_tail calls all of them in sequence for
-// the last few thousand paths of a long pass (see tail_checkpoint).  Arithmetic and sampler draw order
-// are those of oracle/pg_oracle_render.c, operation by operation.
+// History in one paragraph (DESIGN.md 5.2 has the measurements): round 1's single kernel per bounce needed 153
+// vector registers and kept its BVH stack in scratch memory; rounds 2 and 3 split it into the five kernels above,
+// which is how each stage's bound was found -- address path for the walks, HBM for the planes between the shading
+// kernels -- and round 3 put the stages that only handed each other numbers back into one kernel, with the closest
+// hits and the sort still on their own.  What a path carries from bounce to bounce travels with its place in the
+// live list (st_load below).  Arithmetic and sampler draw order are those of oracle/pg_oracle_render.c, operation
+// by operation, in every form.
 #define PG_RENDER_INLINE_ALL
 #include "pg_render_dev.hpp"
 
