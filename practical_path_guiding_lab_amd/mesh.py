@@ -28,7 +28,7 @@ BVH_HOT_NODES = 96  # numbered first, by box area (see build_bvh)
 BVH_WIDTH = 4
 LEAF_FLAG = 0x80000000
 EMPTY_CHILD = 0xFFFFFFFF
-MAX_LEAF = 2  # triangles per leaf at most (measured on veach-ajar: 2 -> 33 ms of ray casting per pass, 3 -> 43, 4 -> 46, 8 -> 55; 1 is too deep for the walk's stack)
+MAX_LEAF = 2  # triangles per leaf at most (measured on veach-ajar: 2 -> 33 ms of ray casting per pass, 3 -> 43, 4 -> 46, 8 -> 55; 1 is too deep for the walk's stack; again with round 3's walks: 2 -> 59.0 ms per step, 3 -> 64.9, 4 -> 66.4)
 
 
 def read_obj(path: str, attributes: bool = False):
