@@ -51,6 +51,13 @@ def test_calls_before_setup_and_bad_arguments(ctx):
     assert bool(torch.isfinite(out).all())
     # NULL context
     assert L.pg_pdf(None, 8, x.data_ptr(), x.data_ptr(), None, out.data_ptr(), None) < 0
+    # the scheduling switches take the values the header names and nothing else
+    assert L.pg_render_stages(h, 3) < 0 and "pg_render_stages" in _msg(L, h)
+    assert L.pg_render_stages(h, -1) < 0
+    assert L.pg_render_overlap(h, 2) < 0 and "pg_render_overlap" in _msg(L, h)
+    for mode in (2, 1, 0):
+        assert L.pg_render_stages(h, mode) == 0
+    assert L.pg_render_stages(None, 0) < 0
 
 
 def test_scene_and_render_pass_misuse(ctx):
