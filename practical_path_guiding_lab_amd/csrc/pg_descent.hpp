@@ -234,13 +234,32 @@ constexpr uint32_t kSlotRoot = 0x80000000u; // the tree's root is the leaf: its 
 //                                             anything else: rec * 4 + child, the accumulator of a leaf below record `rec`
 __device__ __forceinline__ bool in_unit_square(float cx, float cy) { return cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f; }
 
+// The jump-table entry of a pdf walk, fetched AHEAD of the walk: the gather needs only the tree's number and the
+// direction, so a caller that knows both issues it together with the gather of the tree's head -- one round trip to
+// memory for the two -- instead of behind it (quad_pdf_pre looks at the head first, as the reference does).
+struct JumpPre {
+	uint4 e;
+	float jx, jy;
+	bool hit; // the direction lies strictly inside a cell of the table and the entry was fetched
+};
+__device__ __forceinline__ JumpPre jump_prefetch(const QuadJump *jump, uint32_t tree, float cx, float cy, bool wanted)
+{
+	JumpPre p;
+	p.e = make_uint4(0u, 0u, 0u, 0u);
+	p.jx = 0.0f; p.jy = 0.0f;
+	uint32_t cell = 0;
+	p.hit = wanted && jump != nullptr && jump_cell(cx, cy, cell, p.jx, p.jy);
+	if (p.hit) p.e = gather16(jump + (size_t)tree * kJumpCells + cell);
+	return p;
+}
+
 // QuadTree.pdfQuadTree (quadtree.py:1001-1101) for canonical position (cx,cy) in [0,1]^2.
-// jump/tree: the quadtree's jump table (nullptr: every level is walked).
+// pre: the entry of the quadtree's jump table for (cx,cy), if there is one (jump_prefetch; else every level is walked).
 // kSlot: also the accumulator slot of the leaf that holds (cx,cy) -- the walk then goes on to the leaf where the
 // pdf alone would stop (a 0/0 on the way, quadtree.py:1090-1092); the pdf is the same value either way.
 template <bool kSlot>
-__device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
-                                            float cx, float cy, uint32_t &levels, uint32_t &slot)
+__device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head, float cx, float cy, const JumpPre &pre,
+                                              uint32_t &levels, uint32_t &slot)
 {
 	float pdf = 1.0f;
 	levels = 0;
@@ -254,11 +273,10 @@ __device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *
 	float node_irr = head.root_irr;
 	float lox = 0.0f, loy = 0.0f, h = 0.5f;
 	int it0 = 0;
-	uint32_t cell;
-	float jx, jy;
 	bool dead = false; // (kSlot) the product met a 0/0: the value is 0, the walk goes on for the slot
-	if (jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) {
-		const uint4 e = gather16(jump + (size_t)tree * kJumpCells + cell);
+	if (pre.hit) {
+		const uint4 e = pre.e;
+		const float jx = pre.jx, jy = pre.jy;
 		const bool undefined = ((e.w >> 30) & 1u) != 0u; // the product is not defined along this path: the loop finds out where
 		if (!undefined || kSlot) {
 			levels = (e.w >> 26) & 15u;
@@ -302,6 +320,14 @@ __device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *
 		r = c;
 	}
 	return dead ? 0.0f : pdf;
+}
+
+// the same with the table's entry fetched here, behind the head (a tree whose root is a leaf has nothing to fetch)
+template <bool kSlot>
+__device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+                                            float cx, float cy, uint32_t &levels, uint32_t &slot)
+{
+	return quad_pdf_pre<kSlot>(rec, head, cx, cy, jump_prefetch(jump, tree, cx, cy, head.root_rec != kNoRecord), levels, slot);
 }
 
 __device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,

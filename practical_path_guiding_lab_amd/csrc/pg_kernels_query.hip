@@ -98,11 +98,15 @@ __global__ __launch_bounds__(kBlock) void k_pdf(TreeView t, uint64_t n, const fl
 		float pdf = 1.0f;
 		if (act) {
 			const float x = p[i], y = p[n + i], z = p[2 * n + i];
-			KdNode leaf;
-			kd_descend_grid(t, s_planes, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			float cx, cy;
 			dir_to_canonical(dir[i], dir[n + i], dir[2 * n + i], cx, cy);
-			pdf = quad_pdf(t.rec, t.jump, leaf.tree, load_head(t.head, leaf.tree), cx, cy, q_lv);
+			KdNode leaf;
+			kd_descend_grid(t, s_planes, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
+			// (the tree's head and the walk's jump-table entry need the leaf's tree number only: two gathers in flight at once)
+			const TreeHead head = load_head(t.head, leaf.tree);
+			const JumpPre pre = jump_prefetch(t.jump, leaf.tree, cx, cy, true);
+			uint32_t slot;
+			pdf = quad_pdf_pre<false>(t.rec, head, cx, cy, pre, q_lv, slot);
 			did = 1;
 		}
 		pdf_out[i] = pdf;
@@ -145,15 +149,20 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 		float pdf_nee = 1.0f, pdf = 1.0f;
 		if (nee || sel != 0) {
 			const float x = p[i], y = p[n + i], z = p[2 * n + i];
+			// (the canonical forms first: the tree's head and the jump-table entries of the two pdf walks then need the leaf's
+			// tree number only and leave together, three gathers in flight at once)
+			float ncx = 0.0f, ncy = 0.0f, wcx = 0.0f, wcy = 0.0f;
+			if (nee) dir_to_canonical(dir_nee[i], dir_nee[n + i], dir_nee[2 * n + i], ncx, ncy);
+			if (sel == 1) dir_to_canonical(dir_io[i], dir_io[n + i], dir_io[2 * n + i], wcx, wcy);
 			KdNode leaf;
 			kd_descend_grid(t, s_planes, x, y, z, inside_root(t, x, y, z), leaf, kd_lv);
 			kd_q = 1;
 			const TreeHead head = load_head(t.head, leaf.tree);
+			const JumpPre pre_nee = jump_prefetch(t.jump, leaf.tree, ncx, ncy, nee);
+			const JumpPre pre_wo = jump_prefetch(t.jump, leaf.tree, wcx, wcy, sel == 1);
 			if (nee) {
-				float cx, cy;
-				uint32_t lv;
-				dir_to_canonical(dir_nee[i], dir_nee[n + i], dir_nee[2 * n + i], cx, cy);
-				pdf_nee = quad_pdf(t.rec, t.jump, leaf.tree, head, cx, cy, lv);
+				uint32_t lv, slot;
+				pdf_nee = quad_pdf_pre<false>(t.rec, head, ncx, ncy, pre_nee, lv, slot);
 				q_lv += lv;
 				++q_q;
 			}
@@ -169,10 +178,8 @@ __global__ __launch_bounds__(kBlock) void k_guide_bounce(TreeView t, uint64_t n,
 				q_lv += lv;
 				++q_q;
 			} else if (sel == 1) {
-				float cx, cy;
-				uint32_t lv;
-				dir_to_canonical(dir_io[i], dir_io[n + i], dir_io[2 * n + i], cx, cy);
-				pdf = quad_pdf(t.rec, t.jump, leaf.tree, head, cx, cy, lv);
+				uint32_t lv, slot;
+				pdf = quad_pdf_pre<false>(t.rec, head, wcx, wcy, pre_wo, lv, slot);
 				q_lv += lv;
 				++q_q;
 			}
