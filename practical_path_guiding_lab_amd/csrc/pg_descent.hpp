@@ -431,8 +431,8 @@ struct LeafCursor {
 	bool walking, found, is_root;
 };
 
-__device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t tree, TreeHead head, float cx, float cy,
-                                                  bool enable)
+// pre: the jump-table entry for (cx,cy) fetched ahead (jump_prefetch, with `wanted` at least where this cursor walks)
+__device__ __forceinline__ LeafCursor leaf_cursor_pre(TreeHead head, float cx, float cy, bool enable, const JumpPre &pre)
 {
 	LeafCursor c;
 	c.r = head.root_rec;
@@ -444,10 +444,8 @@ __device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t
 	c.is_root = head.root_rec == kNoRecord;
 	c.found = inside && c.is_root;
 	c.walking = inside && !c.is_root;
-	uint32_t cell;
-	float jx, jy;
-	if (c.walking && jump != nullptr && jump_cell(cx, cy, cell, jx, jy)) { // skip the levels the table covers
-		const uint4 e = gather16(jump + (size_t)tree * kJumpCells + cell);
+	if (c.walking && pre.hit) { // skip the levels the table covers
+		const uint4 e = pre.e;
 		c.levels = (e.w >> 26) & 15u;
 		if (e.x == kNoRecord) {
 			c.slot = e.w & kJumpSlotMask;
@@ -455,11 +453,19 @@ __device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t
 			c.walking = false;
 		} else {
 			c.r = e.x;
-			c.lox = jx; c.loy = jy;
+			c.lox = pre.jx; c.loy = pre.jy;
 			c.h = 0.5f / (float)(1 << kJumpBits);
 		}
 	}
 	return c;
+}
+
+// the same with the table's entry fetched here, behind the head (and only where the cursor walks)
+__device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t tree, TreeHead head, float cx, float cy,
+                                                  bool enable)
+{
+	const bool walks = enable && cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f && head.root_rec != kNoRecord;
+	return leaf_cursor_pre(head, cx, cy, enable, jump_prefetch(jump, tree, cx, cy, walks));
 }
 
 __device__ __forceinline__ void leaf_step(LeafCursor &c, uint4 ch)

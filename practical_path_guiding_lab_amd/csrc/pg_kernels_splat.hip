@@ -61,10 +61,14 @@ __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &
 #endif
 	kd_lv = lv;
 	const uint32_t tree = leaf.tree; // outside the bbox: node 0's (stale) tree (kdtree.py:224)
+	// (the tree's head and the jump-table entries of the record's two directions need the tree's number only: three
+	// gathers in flight at once instead of the entries behind the head)
 	const TreeHead head = load_head_s(t.head, tree);
+	const JumpPre pre_p = jump_prefetch(t.jump, tree, dx, dy, in_unit_square(dx, dy));
+	const JumpPre pre_n = jump_prefetch(t.jump, tree, nx, ny, store_nee != 0 && in_unit_square(nx, ny));
 	const float w = wo_pdf > 0.0f ? radiance / wo_pdf : 0.0f;   // quadtree.py:451
 	const float wn = wo_pdf > 0.0f ? nee_lum / wo_pdf : 0.0f;   // quadtree.py:462
-	LeafCursor cp = leaf_cursor(t.jump, tree, head, dx, dy, true), cn = leaf_cursor(t.jump, tree, head, nx, ny, store_nee != 0);
+	LeafCursor cp = leaf_cursor_pre(head, dx, dy, true, pre_p), cn = leaf_cursor_pre(head, nx, ny, store_nee != 0, pre_n);
 	quad_find_leaf_slots2(t.rec, cp, cn);
 	path = plan_dir(a, tree, cp, w, inside ? 1 : 0);
 	q_lv += cp.levels;
