@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define PGSD_ABI_VERSION 2
+/* 3 (round 3): pg_pass_params gained `slot`, pg_kernel_timing gained shade_a_ms / shade_b_ms / sort_ms, pg_scene_desc's
+ * BVH is limited to 2^25 nodes; new entry points pg_film_stripes, pg_render_overlap, pg_render_sort, pg_render_stages.
+ * A caller compiled against version 2 must be rebuilt (the two structs changed size): check pg_abi_version(). */
+#define PGSD_ABI_VERSION 3
 
 typedef struct pg_context pg_context;
 

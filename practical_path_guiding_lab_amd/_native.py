@@ -104,6 +104,8 @@ class pg_depth_counters(C.Structure):
 
 
 # every symbol include/pgsd.h declares (checked by tests/test_abi.py)
+ABI_VERSION = 3  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
+
 EXPORTS = (
     "pg_create", "pg_destroy", "pg_last_error", "pg_abi_version", "pg_setup", "pg_set_iteration",
     "pg_get_leaf_node_index", "pg_sample", "pg_pdf", "pg_guide_bounce", "pg_compact_lanes", "pg_rng_seed", "pg_splat",
@@ -163,6 +165,9 @@ def lib() -> C.CDLL:
     L.pg_last_error.restype = C.c_char_p
     L.pg_last_error.argtypes = [V]
     L.pg_abi_version.restype = C.c_int
+    if L.pg_abi_version() != ABI_VERSION:  # (a library left over from an older build: its structs have other layouts)
+        raise ImportError(f"{LIB_PATH} has ABI version {L.pg_abi_version()}, these bindings are written for {ABI_VERSION}: "
+                          "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
     L.pg_create.argtypes = [C.POINTER(V), C.c_int]
     L.pg_destroy.argtypes = [V]
     L.pg_setup.argtypes = [V, V, V, U64, I32, I32, I32, I32, C.c_float]

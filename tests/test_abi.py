@@ -30,7 +30,9 @@ def test_header_symbols_are_exported(native):
 
 def test_abi_version_and_loud_failure_without_gpu(native):
     L = native.lib()
-    assert L.pg_abi_version() == 2
+    hdr = open(os.path.join(ROOT, "include", "pgsd.h")).read()
+    declared = int(re.search(r"^#define PGSD_ABI_VERSION (\d+)", hdr, flags=re.M).group(1))
+    assert L.pg_abi_version() == declared == native.ABI_VERSION == 3   # header, library and bindings agree
     import torch
 
     if torch.cuda.is_available():
