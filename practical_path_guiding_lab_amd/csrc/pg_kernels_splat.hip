@@ -356,7 +356,10 @@ __global__ __launch_bounds__(kBlock) void k_splat_list(TreeView t, AccumView a, 
 		const uint64_t g = base + threadIdx.x;
 		SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
 		if (g < total) {
-			const uint32_t ray = r.ray_of[g];
+			// (the list is read once, front to back: streaming loads keep it from pushing the accumulators out of L2 --
+			// 8.0 -> 7.65 ms per step)
+#define PG_LD(p) __builtin_nontemporal_load(p)
+			const uint32_t ray = PG_LD(r.ray_of + g);
 			if (ray != kNoRay) {
 				float in[3], lf[3];
 				if (l_final_q) { // (the split pipeline keeps a path's final radiance as one 16-byte entry: one gather)
@@ -367,20 +370,21 @@ __global__ __launch_bounds__(kBlock) void k_splat_list(TreeView t, AccumView a, 
 				}
 #pragma unroll
 				for (int ch = 0; ch < 3; ++ch) {
-					float out = (lf[ch] - r.throughput_radiance[ch * S + g]) / r.throughput_bsdf[ch * S + g];
+					float out = (lf[ch] - PG_LD(r.throughput_radiance + ch * S + g)) / PG_LD(r.throughput_bsdf + ch * S + g);
 					if (out != out) out = 0.0f;                         // :444
-					float q = out / r.bsdf[ch * S + g];
+					float q = out / PG_LD(r.bsdf + ch * S + g);
 					if (q != q) q = 0.0f;                               // :449
 					in[ch] = q;
 				}
 				float radiance = luminance(in[0], in[1], in[2]);       // :452
 				if (radiance != radiance) radiance = 0.0f;             // :466
-				const float nee_lum = r.nee_lum[g];
-				const float wp = r.wo_pdf[g];
+				const float nee_lum = PG_LD(r.nee_lum + g);
+				const float wp = PG_LD(r.wo_pdf + g);
 				const bool both_zero = (radiance == 0.0f) && (nee_lum == 0.0f); // :470-472
 				if (!both_zero && !(wp == 0.0f) && !(wp != wp)) {      // :475-478
 					const uint2 sl = r.slot[g];
-					const uint32_t tf = r.tree[g], tree = tf & 0x7fffffffu;
+					const uint32_t tf = PG_LD(r.tree + g), tree = tf & 0x7fffffffu;
+#undef PG_LD
 					const bool inside = (tf >> 31) != 0u;
 					const float w = wp > 0.0f ? radiance / wp : 0.0f;  // quadtree.py:451
 					const float wn = wp > 0.0f ? nee_lum / wp : 0.0f;  // quadtree.py:462
