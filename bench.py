@@ -616,7 +616,7 @@ def run_render(args):
             "frac_counter_hi": None if (tr_dom is None or dom_sec <= 0) else round(tr_dom["hi"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
             "model_note": (f"`frac` is SURVEY 8d's ALGORITHMIC model (16 B per KD level + 20 B per quadtree level walked by the reference's "
                            f"descents), not a bandwidth measurement: {100 * kd_share:.0f} % of those bytes are KD levels ({dc.kd_levels / max(dc.kd_queries, 1):.1f} per "
-                           "query) that the KD jump grid replaces by ONE 16-byte gather for most queries, and the top four quadtree levels of "
+                           "query) that the KD jump grid replaces by ONE 16-byte gather for most queries, and the top six quadtree levels of "
                            "a pdf walk are one 16-byte jump-table gather: the kernel moves far fewer bytes than the model prices -- read "
                            "frac_counter_lo / frac_counter_hi for what it moves, and `limiter` for what it waits on"),
             "traffic_note": ("traffic / frac_counter_*: PMC figures of this configuration taken of exactly this code (source hash checked)"

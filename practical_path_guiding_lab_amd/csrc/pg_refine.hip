@@ -637,8 +637,11 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 			f.kd_grid_valid = true;
 		}
 	}
-	// accumulator slots are packed into 26 bits of an entry; forests beyond that walk every level
-	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask) return PG_OK;
+	// accumulator slots are packed into 26 bits of an entry; forests beyond that walk every level -- and so do forests
+	// whose table would not be worth its memory (64 KB per quadtree: 1.4 GB for the 21 000 trees of the veach-ajar bench)
+	constexpr uint64_t kJumpTableMaxBytes = 32ull << 30;
+	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask ||
+	    (uint64_t)f.n_trees * kJumpCells * sizeof(QuadJump) > kJumpTableMaxBytes) return PG_OK;
 	PG_HIP(ctx, f.jump.ensure((size_t)f.n_trees * kJumpCells, 1.25));
 	TreeView t = ctx->view();
 	launch_build_jump(t, f.jump.p, s);
