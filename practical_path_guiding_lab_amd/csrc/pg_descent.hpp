@@ -265,23 +265,23 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 	levels = 0;
 	slot = kSlotNone;
 	const bool inside = in_unit_square(cx, cy);
-	if (head.root_rec == kNoRecord) {
-		if (kSlot && inside) slot = kSlotRoot;
-		return pdf * kInvFourPiF;
-	}
-	uint32_t r = head.root_rec;
-	float node_irr = head.root_irr;
+	// The table first: its entries say everything about the levels they cover -- also that a tree's root is a leaf (bit 31,
+	// k_build_jump) -- so a walk that hits the table reads the tree's head only if it has to go on below it, and the
+	// entry's gather does not wait for the head's.
+	uint32_t r = kNoRecord;
+	float node_irr = 0.0f;
 	float lox = 0.0f, loy = 0.0f, h = 0.5f;
 	int it0 = 0;
 	bool dead = false; // (kSlot) the product met a 0/0: the value is 0, the walk goes on for the slot
+	bool from_table = false;
 	if (pre.hit) {
 		const uint4 e = pre.e;
 		const float jx = pre.jx, jy = pre.jy;
 		const bool undefined = ((e.w >> 30) & 1u) != 0u; // the product is not defined along this path: the loop finds out where
 		if (!undefined || kSlot) {
 			levels = (e.w >> 26) & 15u;
-			if (e.x == kNoRecord) { // a leaf within the table: the final value
-				if (kSlot) slot = e.w & kJumpSlotMask;
+			if (e.x == kNoRecord) { // a leaf within the table (the root itself: bit 31): the final value
+				if (kSlot) slot = (e.w >> 31) ? kSlotRoot : (e.w & kJumpSlotMask);
 				return undefined ? 0.0f : __uint_as_float(e.y);
 			}
 			r = e.x;
@@ -291,7 +291,16 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 			lox = jx; loy = jy;
 			h = 0.5f / (float)(1 << kJumpBits);
 			it0 = kJumpBits;
+			from_table = true;
 		}
+	}
+	if (!from_table) { // from the root (quadtree.py:1011-1019)
+		if (head.root_rec == kNoRecord) {
+			if (kSlot && inside) slot = kSlotRoot;
+			return pdf * kInvFourPiF;
+		}
+		r = head.root_rec;
+		node_irr = head.root_irr;
 	}
 	for (int it = it0; it < kMaxLevels; ++it) {
 		const QuadLoad q = load_rec(rec, r);
@@ -322,12 +331,12 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 	return dead ? 0.0f : pdf;
 }
 
-// the same with the table's entry fetched here, behind the head (a tree whose root is a leaf has nothing to fetch)
+// the same with the table's entry fetched here (it does not wait for the head)
 template <bool kSlot>
 __device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
                                             float cx, float cy, uint32_t &levels, uint32_t &slot)
 {
-	return quad_pdf_pre<kSlot>(rec, head, cx, cy, jump_prefetch(jump, tree, cx, cy, head.root_rec != kNoRecord), levels, slot);
+	return quad_pdf_pre<kSlot>(rec, head, cx, cy, jump_prefetch(jump, tree, cx, cy, true), levels, slot);
 }
 
 __device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
@@ -464,7 +473,7 @@ __device__ __forceinline__ LeafCursor leaf_cursor_pre(TreeHead head, float cx, f
 __device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t tree, TreeHead head, float cx, float cy,
                                                   bool enable)
 {
-	const bool walks = enable && cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f && head.root_rec != kNoRecord;
+	const bool walks = enable && cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f; // (not a question to the head: the two gathers overlap)
 	return leaf_cursor_pre(head, cx, cy, enable, jump_prefetch(jump, tree, cx, cy, walks));
 }
 

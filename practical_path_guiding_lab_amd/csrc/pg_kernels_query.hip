@@ -288,9 +288,9 @@ __global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__r
 	const TreeHead head = load_head(t.head, tree);
 	QuadJump e;
 	e.next = kNoRecord;
-	e.pdf = kInvFourPiF; // 1.0f * 1/(4 pi): the root is a leaf (never read: such trees return before the table)
-	e.irr = head.root_irr;
-	e.info = 0;
+	e.pdf = kInvFourPiF; // 1.0f * 1/(4 pi): the root is a leaf -- the walk ends in the table like any other leaf within it,
+	e.irr = head.root_irr; // with the ROOT's accumulator for a slot (bit 31): a pdf walk that hits the table never needs the head
+	e.info = 0x80000000u;
 	if (head.root_rec != kNoRecord) {
 		uint32_t r = head.root_rec, levels = 0, slot = 0;
 		float pdf = 1.0f, node_irr = head.root_irr, lox = 0.0f, loy = 0.0f, h = 0.5f;
