@@ -79,7 +79,8 @@ struct alignas(16) QuadJump {
 	float pdf;      // product of 4*child/node over the levels taken (final value incl. 1/(4 pi) when ended)
 	float irr;      // energy of the node reached (the next level's denominator)
 	uint32_t info;  // bits 0-25 accumulator slot of the leaf (when ended), 26-29 levels taken, 30 pdf undefined
-	                // (a 0/0 on the way: take the loop), 31 unused
+	                // (a 0/0 on the way: take the loop), 31 the tree's ROOT is the leaf (every entry of such a tree: the
+	                // slot is the root's accumulator; a walk that hits the table never needs the tree's head)
 };
 constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
 
