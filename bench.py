@@ -178,40 +178,64 @@ def spawn_ranks(cmd, n, env=None, relay=sys.stdout, grace_s=10.0):
     base = dict(os.environ if env is None else env)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-    procs = []
-    for r in range(n):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import signal
     import threading
-    lines = []
+    procs, lines = [], []
 
-    def pump():
-        for line in procs[0].stdout:
-            lines.append(line)
+    def end_all(grace):
+        """terminate, wait the grace period, kill -- every child still alive, by its own process id"""
+        alive = [q for q in procs if q.poll() is None]
+        for q in alive:
+            q.terminate()
+        t_end = time.time() + grace
+        for q in alive:
+            try:
+                q.wait(max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
 
-    th = threading.Thread(target=pump, daemon=True)
-    th.start()
+    def on_signal(signum, frame):  # the harness's timeout, Ctrl-C: do not leave ranks behind holding the GPUs
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            old_handlers[sg] = signal.signal(sg, on_signal)
     rc = 0
-    pending = set(range(n))
-    while pending:
-        for r in sorted(pending):
-            c = procs[r].poll()
-            if c is None:
-                continue
-            pending.discard(r)
-            if c != 0 and rc == 0:
-                rc = c
-                print(f"[bench] rank {r} exited with code {c}; ending the other ranks", file=sys.stderr)
-                for q in pending:
-                    procs[q].terminate()
-                t_end = time.time() + grace_s
-                for q in pending:
-                    try:
-                        procs[q].wait(max(0.1, t_end - time.time()))
-                    except subprocess.TimeoutExpired:
-                        procs[q].kill()
-        time.sleep(0.05)
-    th.join(5.0)
+    th = None
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+
+        def pump():
+            for line in procs[0].stdout:
+                lines.append(line)
+
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                pending.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+                    print(f"[bench] rank {r} exited with code {c}; ending the other ranks", file=sys.stderr)
+                    end_all(grace_s)
+            time.sleep(0.05)
+    except KeyboardInterrupt as e:
+        print(f"[bench] interrupted ({e}); ending the ranks", file=sys.stderr)
+        rc = rc or 130
+    finally:
+        end_all(grace_s)  # (a no-op when every rank has exited)
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+    if th is not None:
+        th.join(5.0)
     for line in lines:  # rank 0's JSON line goes on; anything else a library wrote to its stdout is diagnostics
         (relay if line.lstrip().startswith("{") else sys.stderr).write(line)
     relay.flush()

@@ -31,7 +31,9 @@ extern "C" {
 /* 3 (round 3): pg_pass_params gained `slot`, pg_kernel_timing gained shade_a_ms / shade_b_ms / sort_ms, pg_scene_desc's
  * BVH is limited to 2^25 nodes; new entry points pg_film_stripes, pg_render_overlap, pg_render_sort, pg_render_stages.
  * A caller compiled against version 2 must be rebuilt (the two structs changed size): check pg_abi_version(). */
-#define PGSD_ABI_VERSION 3
+/* 4 (round 4): pg_depth_counters gained layout_bytes, pg_stats gained bytes_jump_tables / jump_bits / kd_grid_bits,
+ * pg_pass_params.reserved2 became `batched` (same size); new entry point pg_film_batched. */
+#define PGSD_ABI_VERSION 4
 
 typedef struct pg_context pg_context;
 
@@ -341,7 +343,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *scene, const pg_camera
 
 typedef struct pg_pass_params {
 	uint32_t seed;    /* sampler seed of the pass (main.py:218: initial_seed + cumm_spp) */
-	int32_t spp;      /* samples per pixel traced by this pass; lane = pixel*spp + s (:414-417) */
+	int32_t spp;      /* samples per pixel traced by this pass; lane = pixel*spp + s (:414-417); see `batched` */
 	int32_t rr_depth; /* Russian roulette from this depth on (:39, 375) */
 	/* 0 or 1: the set of pass buffers this pass uses.  The passes of an iteration are independent (main.py:208-218 seeds
 	 * each with initial_seed + cumm_spp), so two may be on the device at once: issue them alternately with slot 0 on one
@@ -359,7 +361,15 @@ typedef struct pg_pass_params {
 	 * round-robin -- in ascending order; pixel_begin must be 0 and pixel_count the number of pixels of
 	 * those rows (or 0).  The tile-local pixel i of L_out / valid_out is column i % width of the
 	 * (i / width)-th owned row.  stripe_count 0 or 1: the contiguous range above. */
-	uint32_t stripe_rows, stripe_index, stripe_count, reserved2;
+	uint32_t stripe_rows, stripe_index, stripe_count;
+	/* 0: one pass of `spp` samples per pixel, lane = pixel*spp + s, sampler stream = lane of `seed` (mi.render(spp=spp, seed)).
+	 * 1: the call stands for `spp` consecutive ONE-sample passes with the seeds seed, seed + 1, ... seed + spp - 1 -- the
+	 *    reference's training passes (main.py:192 renders them with spp 1, :218 seeds them initial_seed + cumm_spp) --
+	 *    traced together in one wavefront: sample s of a pixel is the sample pass seed + s gives that pixel (stream =
+	 *    pixel of seed + s).  Radiance per sample, the per-pixel sums (added in pass order), sdTree_current and -- with
+	 *    pg_film_batched -- the developed images are those of the spp separate calls, bit for bit; only the number of
+	 *    kernel launches differs.  L_out keeps the lane order pixel*spp + s. */
+	uint32_t batched;
 } pg_pass_params;
 
 /* One call of PathGuidingIntegrator.sample() for all width*height*spp lanes
@@ -434,6 +444,12 @@ int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const f
 int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out,
                     uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream);
 
+/* The film of a batched call (pg_pass_params.batched = 1): n_passes images, image s = what pg_film_stripes develops for the
+ * one-sample pass seed + s alone, from L as the batched pg_render_pass wrote it (lane = pixel*n_passes + s).
+ * images_out: n_passes x Color3f[W*H] planar, image-major. */
+int pg_film_batched(pg_context *ctx, int32_t filter, uint32_t seed, int32_t n_passes, const float *L, float *images_out,
+                    uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream);
+
 /* Element-wise evaluation of the library's own fp32 transcendental functions (fixed
  * sequences of double operations, no vendor math library), so that a caller -- the parity tests --
  * can compare them with another implementation of the same contract.
@@ -470,6 +486,12 @@ typedef struct pg_stats {
 	double mean_quad_leaf_depth; /* over quadtree leaves of all trees        */
 	uint32_t max_kd_depth, max_quad_depth;
 	uint64_t bytes_kd, bytes_quad_records, bytes_accumulators;
+	/* the tables that stand in for the top levels of the descents (not in the reference): the quadtree jump tables
+	 * (4^jump_bits entries of 16 bytes per quadtree; 0 bits: none -- the forest is too big for its memory budget,
+	 * $PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB and at most a quarter of the free device memory) and the KD jump grid
+	 * (8^kd_grid_bits cells of 16 bytes) */
+	uint64_t bytes_jump_tables;
+	uint32_t jump_bits, kd_grid_bits;
 } pg_stats;
 int pg_get_stats(pg_context *ctx, pg_stats *out);
 
@@ -478,6 +500,11 @@ int pg_get_stats(pg_context *ctx, pg_stats *out);
 typedef struct pg_depth_counters {
 	uint64_t kd_levels, kd_queries;     /* sum of KD leaf depths, number of descents  */
 	uint64_t quad_levels, quad_queries; /* sum of quadtree leaf depths, descents      */
+	/* bytes the lanes of those descents gathered from the tables of the BUILT layout, nothing credited for lanes
+	 * that share a cache line: 16 per KD grid entry and per KD node below it, 16 per jump-table entry, 32 per quadtree
+	 * record of a pdf or sampling walk, 16 per record of a leaf walk (the 8-byte tree heads not included: add 8 per
+	 * KD descent that is followed by a quadtree walk) */
+	uint64_t layout_bytes;
 } pg_depth_counters;
 int pg_enable_depth_counters(pg_context *ctx, int32_t on);
 int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t reset);

@@ -65,6 +65,7 @@ class pg_stats(C.Structure):
         ("mean_kd_leaf_depth", C.c_double), ("mean_quad_leaf_depth", C.c_double),
         ("max_kd_depth", C.c_uint32), ("max_quad_depth", C.c_uint32),
         ("bytes_kd", C.c_uint64), ("bytes_quad_records", C.c_uint64), ("bytes_accumulators", C.c_uint64),
+        ("bytes_jump_tables", C.c_uint64), ("jump_bits", C.c_uint32), ("kd_grid_bits", C.c_uint32),
     ]
 
 
@@ -85,7 +86,7 @@ class pg_scene_desc(C.Structure):
 class pg_pass_params(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("spp", C.c_int32), ("rr_depth", C.c_int32), ("slot", C.c_int32),
                 ("pixel_begin", C.c_uint64), ("pixel_count", C.c_uint64),
-                ("stripe_rows", C.c_uint32), ("stripe_index", C.c_uint32), ("stripe_count", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("stripe_rows", C.c_uint32), ("stripe_index", C.c_uint32), ("stripe_count", C.c_uint32), ("batched", C.c_uint32)]
 
 
 class pg_kernel_timing(C.Structure):
@@ -100,11 +101,11 @@ class pg_kernel_timing(C.Structure):
 
 class pg_depth_counters(C.Structure):
     _fields_ = [("kd_levels", C.c_uint64), ("kd_queries", C.c_uint64),
-                ("quad_levels", C.c_uint64), ("quad_queries", C.c_uint64)]
+                ("quad_levels", C.c_uint64), ("quad_queries", C.c_uint64), ("layout_bytes", C.c_uint64)]
 
 
 # every symbol include/pgsd.h declares (checked by tests/test_abi.py)
-ABI_VERSION = 3  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
+ABI_VERSION = 4  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
 
 EXPORTS = (
     "pg_create", "pg_destroy", "pg_last_error", "pg_abi_version", "pg_setup", "pg_set_iteration",
@@ -113,7 +114,7 @@ EXPORTS = (
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
-    "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
+    "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_film_batched", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
     "pg_render_split_pipeline",
 )
@@ -198,6 +199,7 @@ def lib() -> C.CDLL:
     L.pg_film_tent.argtypes = [V, U32, I32, V, V, V]
     L.pg_film.argtypes = [V, I32, U32, I32, V, V, V]
     L.pg_film_stripes.argtypes = [V, I32, U32, I32, V, V, U32, U32, U32, V]
+    L.pg_film_batched.argtypes = [V, I32, U32, I32, V, V, U32, U32, U32, V]
     L.pg_render_overlap.argtypes = [V, I32]
     L.pg_render_sort.argtypes = [V, I32]
     L.pg_render_stages.argtypes = [V, I32]

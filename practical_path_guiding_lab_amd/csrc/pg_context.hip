@@ -4,6 +4,7 @@
 #include "pg_context.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <limits>
@@ -119,6 +120,11 @@ int pg_create(pg_context **out, int device_ordinal)
 	if (!ctx) return fail(nullptr, PG_ERR_NOMEM, "pg_create: out of host memory");
 	ctx->device = device_ordinal;
 	if (prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
+	if (const char *b = getenv("PGSD_JUMP_TABLE_MAX_BYTES")) { // memory budget of the quadtree jump tables (pg_refine.hip: rebuild_jump)
+		char *end = nullptr;
+		const unsigned long long v = strtoull(b, &end, 10);
+		if (end != b) ctx->jump_budget = v;
+	}
 	e = hipMalloc((void **)&ctx->dc, sizeof(DepthCounters));
 	if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipMalloc(depth counters)"); }
 	(void)hipMemset(ctx->dc, 0, sizeof(DepthCounters));
@@ -360,6 +366,7 @@ int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t rese
 	out->kd_queries = h.kd_queries;
 	out->quad_levels = h.quad_levels;
 	out->quad_queries = h.quad_queries;
+	out->layout_bytes = h.layout_bytes;
 	if (reset) PG_HIP(ctx, hipMemset(ctx->dc, 0, sizeof(DepthCounters)));
 	return PG_OK;
 }
@@ -676,6 +683,9 @@ int pg_get_stats(pg_context *ctx, pg_stats *out)
 	out->bytes_kd = (uint64_t)f.n_kd * sizeof(KdNode);
 	out->bytes_quad_records = (uint64_t)f.n_rec * sizeof(QuadRec) + (uint64_t)f.n_trees * sizeof(TreeHead);
 	out->bytes_accumulators = f.acc_count() * sizeof(long long);
+	out->jump_bits = f.jump_valid ? (uint32_t)f.jump_bits : 0u;
+	out->bytes_jump_tables = f.jump_valid ? (((uint64_t)f.n_trees * sizeof(QuadJump)) << (2 * f.jump_bits)) : 0ull;
+	out->kd_grid_bits = f.kd_grid_valid ? (uint32_t)f.kd_grid_bits : 0u;
 	return PG_OK;
 }
 

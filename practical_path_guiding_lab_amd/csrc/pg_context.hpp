@@ -9,11 +9,15 @@
 
 #include "../../include/pgsd.h"
 #include "pg_kernels.hpp"
+#include "pg_math.hpp"
 #include "pg_tree.hpp"
 
 namespace pg {
 
-// Growable device array.  ensure() discards contents when it has to reallocate.
+// Growable device array.  ensure() discards contents when it has to reallocate.  Growth is geometric where the caller
+// asks for slack: a hipFree synchronises the whole device and a fresh hipMalloc of a gigabyte maps pages for tens of
+// milliseconds, so a buffer that follows a growing tree must not be reallocated every time the tree grows a little
+// (round 3's refine spent 20-190 ms per iteration there).
 template <class T> struct DevBuf {
 	T *p = nullptr;
 	size_t cap = 0;
@@ -62,8 +66,9 @@ struct Forest {
 	DevBuf<TreeHead> head;
 	DevBuf<float> tree_thr;          // refinementThreshold of each tree (export only)
 	uint32_t n_trees = 0;
-	DevBuf<QuadJump> jump;           // n_trees * kJumpCells entries, rebuilt whenever rec/head change
+	DevBuf<QuadJump> jump;           // n_trees << (2 * jump_bits) entries, rebuilt whenever rec/head change
 	bool jump_valid = false;
+	int jump_bits = 0;               // levels the tables of this forest cover (<= kJumpBits; what fits the memory budget)
 	DevBuf<KdGridEntry> kd_grid;     // 8^kd_grid_bits cells + kKdGridRootEntries, rebuilt whenever the KD tree changes
 	DevBuf<float> kd_planes;         // 3 * kKdGridPlanes cell boundaries (they follow the root box)
 	bool kd_grid_valid = false;
@@ -74,6 +79,19 @@ struct Forest {
 	{
 		return (uint64_t)n_rec * 4 * kAccWords + (uint64_t)n_trees * kAccWords + n_trees;
 	}
+	// what a refine needs besides the forest itself: kept between refines (pg_refine.hip) so that a refine of a tree that
+	// did not outgrow them allocates nothing
+	struct RefineScratch {
+		DevBuf<I128> tot;
+		DevBuf<float> slot_irr, root_irr, new_thr;
+		DevBuf<unsigned long long> kd_cnt, cnt_tot, tree_count, plan;
+		DevBuf<uint32_t> tree_src, counts, cnt, pos, scan_sums, scan_total;
+		DevBuf<TreeHead> new_head;
+		DevBuf<QuadRec> new_rec;
+		DevBuf<unsigned char> pend_a, pend_b; // (Pending entries: the type lives in pg_refine.hip)
+		void *pinned = nullptr;             // 64 bytes of page-locked host memory for the counters a refine reads back
+		~RefineScratch() { if (pinned) (void)hipHostFree(pinned); }
+	} scratch;
 	AccumView accum_view()
 	{
 		AccumView a;
@@ -103,6 +121,9 @@ struct pg_context {
 	pg::Forest f;
 	pg::DepthCounters *dc = nullptr; // device
 	bool dc_on = false;
+	// memory budget of the quadtree jump tables (bytes): $PGSD_JUMP_TABLE_MAX_BYTES at pg_create, default 2 GiB, and never
+	// more than a quarter of the device memory that is free when they are built
+	uint64_t jump_budget = 2ull << 30;
 	void *comm = nullptr;            // ncclComm_t of the multi-GPU exchange (pg_comm.hip)
 	bool comm_owned = false;         // made by pg_comm_init (destroyed with the context) or attached by the caller
 	int comm_ranks = 0;
@@ -113,7 +134,8 @@ struct pg_context {
 		t.kd = f.kd.p;
 		t.rec = f.rec.p;
 		t.head = f.head.p;
-		t.jump = f.jump_valid ? f.jump.p : nullptr;
+		t.jump.p = f.jump_valid ? f.jump.p : nullptr;
+		t.jump.bits = f.jump_valid ? f.jump_bits : 0;
 		t.kd_grid = f.kd_grid_valid ? f.kd_grid.p : nullptr;
 		t.kd_planes = f.kd_planes.p;
 		for (int a = 0; a < 3; ++a) {

@@ -7,6 +7,17 @@
 
 namespace pg {
 
+// ---- walk statistics ----
+// Every walk reports ONE word, `levels`: bits 0-7 the levels of the reference's descent it stands for (what SURVEY 8d's
+// algorithmic model prices), bits 8.. the BYTES this lane gathered from the tables of the built layout to get there (16 per
+// KD grid entry or node, 16 per jump-table entry, 32 per quadtree record of a pdf or sampling walk, 16 per record of a
+// leaf walk) -- nothing credited for lanes that share a line.  Callers sum the words of a lane's walks (at most three
+// quadtree walks of at most 32 levels: the low byte cannot carry) and unpack them where the counters are added, in
+// instrumented launches only (stat_levels / stat_bytes).
+__device__ __forceinline__ uint32_t stat_word(uint32_t levels, uint32_t bytes) { return levels | (bytes << 8); }
+__device__ __forceinline__ uint32_t stat_levels(uint32_t w) { return w & 0xffu; }
+__device__ __forceinline__ uint32_t stat_bytes(uint32_t w) { return w >> 8; }
+
 __device__ __forceinline__ KdNode load_kd(const KdNode *kd, uint32_t i)
 {
 	const uint4 v = gather16(kd + i);
@@ -44,6 +55,7 @@ __device__ __forceinline__ uint32_t kd_descend(const KdNode *kd, float x, float 
 			++levels;
 		}
 	}
+	levels = stat_word(levels, 16u * (levels + 1u)); // the root and one node per level
 	leaf = nd;
 	return node;
 }
@@ -92,6 +104,7 @@ __device__ __forceinline__ uint32_t kd_descend_lds(const KdNode *kd, const uint4
 			}
 		}
 	}
+	levels = stat_word(levels, 16u * levels); // (an A/B form: the nodes read from LDS are priced like the others)
 	leaf.child = v.x;
 	leaf.split = __uint_as_float(v.y);
 	leaf.axis_depth = v.z;
@@ -153,6 +166,7 @@ __device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const flo
 	const uint4 e = gather16(t.kd_grid + (in_cell ? cell : root_entry));
 	uint32_t node = e.x;
 	levels = e.y >> 16;
+	const uint32_t from_grid = levels;
 	KdNode nd;
 	nd.child = e.z;
 	nd.axis_depth = e.y & 0xffffu;
@@ -168,6 +182,7 @@ __device__ __forceinline__ uint32_t kd_descend_grid(const TreeView &t, const flo
 		}
 		if (nd.child != 0) nd = load_kd(t.kd, node); // (kMaxLevels deep without a leaf: not a tree this library holds)
 	}
+	levels = stat_word(levels, 16u + 16u * (levels - from_grid)); // the grid entry and one node per level below it
 	leaf = nd;
 	return node;
 }
@@ -209,18 +224,18 @@ __device__ __forceinline__ void quadrant(float cx, float cy, float mx, float my,
 	last = t3 ? 3 : (t2 ? 2 : (t1 ? 1 : (t0 ? 0 : -1)));
 }
 
-// The cell of the jump table a canonical position falls strictly inside of, or false (on a cell
-// boundary, outside the unit square, NaN): 2^kJumpBits * c is exact in fp32.
-__device__ __forceinline__ bool jump_cell(float cx, float cy, uint32_t &cell, float &lox, float &loy)
+// The cell of a 2^bits x 2^bits jump table a canonical position falls strictly inside of, or false (on a cell
+// boundary, outside the unit square, NaN): 2^bits * c is exact in fp32, and so is every product with 2^-bits.
+__device__ __forceinline__ bool jump_cell(int bits, float cx, float cy, uint32_t &cell, float &lox, float &loy)
 {
-	constexpr float S = (float)(1 << kJumpBits);
+	const float S = (float)(1 << bits), inv = 1.0f / S; // (uniform; a power of two: the reciprocal is exact)
 	const float fx = cx * S, fy = cy * S;
 	if (!(fx > 0.0f && fx < S && fy > 0.0f && fy < S)) return false;
 	const float ix = __builtin_floorf(fx), iy = __builtin_floorf(fy);
 	if (fx == ix || fy == iy) return false;
-	cell = ((uint32_t)iy << kJumpBits) | (uint32_t)ix;
-	lox = ix * (1.0f / S);
-	loy = iy * (1.0f / S);
+	cell = ((uint32_t)iy << bits) | (uint32_t)ix;
+	lox = ix * inv;
+	loy = iy * inv;
 	return true;
 }
 
@@ -240,16 +255,18 @@ __device__ __forceinline__ bool in_unit_square(float cx, float cy) { return cx >
 struct JumpPre {
 	uint4 e;
 	float jx, jy;
+	int bits; // levels the table covers (uniform)
 	bool hit; // the direction lies strictly inside a cell of the table and the entry was fetched
 };
-__device__ __forceinline__ JumpPre jump_prefetch(const QuadJump *jump, uint32_t tree, float cx, float cy, bool wanted)
+__device__ __forceinline__ JumpPre jump_prefetch(JumpRef jump, uint32_t tree, float cx, float cy, bool wanted)
 {
 	JumpPre p;
 	p.e = make_uint4(0u, 0u, 0u, 0u);
 	p.jx = 0.0f; p.jy = 0.0f;
+	p.bits = jump.bits;
 	uint32_t cell = 0;
-	p.hit = wanted && jump != nullptr && jump_cell(cx, cy, cell, p.jx, p.jy);
-	if (p.hit) p.e = gather16(jump + (size_t)tree * kJumpCells + cell);
+	p.hit = wanted && jump.p != nullptr && jump_cell(jump.bits, cx, cy, cell, p.jx, p.jy);
+	if (p.hit) p.e = gather16(jump.p + (((size_t)tree << (2 * jump.bits)) + cell));
 	return p;
 }
 
@@ -264,6 +281,7 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 	float pdf = 1.0f;
 	levels = 0;
 	slot = kSlotNone;
+	const uint32_t tab_bytes = pre.hit ? 16u : 0u; // (the entry was gathered whether or not the walk can use it)
 	const bool inside = in_unit_square(cx, cy);
 	// The table first: its entries say everything about the levels they cover -- also that a tree's root is a leaf (bit 31,
 	// k_build_jump) -- so a walk that hits the table reads the tree's head only if it has to go on below it, and the
@@ -282,6 +300,7 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 			levels = (e.w >> 26) & 15u;
 			if (e.x == kNoRecord) { // a leaf within the table (the root itself: bit 31): the final value
 				if (kSlot) slot = (e.w >> 31) ? kSlotRoot : (e.w & kJumpSlotMask);
+				levels = stat_word(levels, tab_bytes);
 				return undefined ? 0.0f : __uint_as_float(e.y);
 			}
 			r = e.x;
@@ -289,19 +308,21 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 			node_irr = __uint_as_float(e.z);
 			dead = undefined;
 			lox = jx; loy = jy;
-			h = 0.5f / (float)(1 << kJumpBits);
-			it0 = kJumpBits;
+			h = 0.5f / (float)(1 << pre.bits);
+			it0 = pre.bits;
 			from_table = true;
 		}
 	}
 	if (!from_table) { // from the root (quadtree.py:1011-1019)
 		if (head.root_rec == kNoRecord) {
 			if (kSlot && inside) slot = kSlotRoot;
+			levels = stat_word(0u, tab_bytes);
 			return pdf * kInvFourPiF;
 		}
 		r = head.root_rec;
 		node_irr = head.root_irr;
 	}
+	// (bytes: 32 per record loaded = per pass of the loop, it - it0 + 1 when leaving from inside it)
 	for (int it = it0; it < kMaxLevels; ++it) {
 		const QuadLoad q = load_rec(rec, r);
 		const float mx = lox + h, my = loy + h;
@@ -311,11 +332,14 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 			const float child_irr = first < 0 ? 0.0f : sel4f(first, q.i0, q.i1, q.i2, q.i3);
 			pdf = pdf * ((4.0f * child_irr) / node_irr);
 			if (pdf != pdf) {                     // quadtree.py:1090-1092
-				if (!kSlot) return 0.0f;
+				if (!kSlot) { levels = stat_word(levels, tab_bytes + 32u * (uint32_t)(it - it0 + 1)); return 0.0f; }
 				dead = true;
 			}
 		}
-		if (last < 0) return dead ? 0.0f : pdf;  // outside every child: the reference would spin
+		if (last < 0) { // outside every child: the reference would spin
+			levels = stat_word(levels, tab_bytes + 32u * (uint32_t)(it - it0 + 1));
+			return dead ? 0.0f : pdf;
+		}
 		++levels;
 		node_irr = sel4f(last, q.i0, q.i1, q.i2, q.i3);
 		const uint32_t c = sel4u(last, q.c0, q.c1, q.c2, q.c3);
@@ -324,22 +348,24 @@ __device__ __forceinline__ float quad_pdf_pre(const QuadRec *rec, TreeHead head,
 		h *= 0.5f;
 		if (c == 0) { // child is a leaf (quadtree.py:1025-1030)
 			if (kSlot && inside) slot = r * 4u + (uint32_t)last;
+			levels = stat_word(levels, tab_bytes + 32u * (uint32_t)(it - it0 + 1));
 			return dead ? 0.0f : pdf * kInvFourPiF;
 		}
 		r = c;
 	}
+	levels = stat_word(levels, tab_bytes + 32u * (uint32_t)(kMaxLevels - it0));
 	return dead ? 0.0f : pdf;
 }
 
 // the same with the table's entry fetched here (it does not wait for the head)
 template <bool kSlot>
-__device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+__device__ __forceinline__ float quad_pdf_t(const QuadRec *rec, JumpRef jump, uint32_t tree, TreeHead head,
                                             float cx, float cy, uint32_t &levels, uint32_t &slot)
 {
 	return quad_pdf_pre<kSlot>(rec, head, cx, cy, jump_prefetch(jump, tree, cx, cy, true), levels, slot);
 }
 
-__device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+__device__ __forceinline__ float quad_pdf(const QuadRec *rec, JumpRef jump, uint32_t tree, TreeHead head,
                                           float cx, float cy, uint32_t &levels)
 {
 	uint32_t slot;
@@ -353,7 +379,7 @@ __device__ __forceinline__ float quad_pdf(const QuadRec *rec, const QuadJump *ju
 // the sampled leaf cell, otherwise the literal second descent is taken.
 // kSlot: also the accumulator slot of the leaf that holds the canonical form of the sampled direction.
 template <bool kSlot>
-__device__ __forceinline__ void quad_sample_t(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+__device__ __forceinline__ void quad_sample_t(const QuadRec *rec, JumpRef jump, uint32_t tree, TreeHead head,
                                               Pcg32 &rng, float &dx, float &dy, float &dz, float &pdf_out,
                                               uint32_t &levels, uint32_t &slot)
 {
@@ -411,16 +437,18 @@ __device__ __forceinline__ void quad_sample_t(const QuadRec *rec, const QuadJump
 	float qx, qy;
 	dir_to_canonical(dx, dy, dz, qx, qy);
 	const bool strictly_inside = reached_leaf && qx > lox && qx < lox + size && qy > loy && qy < loy + size;
+	levels = stat_word(levels, 32u * levels); // one record per level sampled
 	if (strictly_inside) {
 		pdf_out = dead ? 0.0f : pdf * kInvFourPiF;
 		slot = leaf_slot;
 	} else {
 		uint32_t lv;
 		pdf_out = quad_pdf_t<kSlot>(rec, jump, tree, head, qx, qy, lv, slot);
+		levels += stat_word(0u, stat_bytes(lv)); // (the literal second descent: its bytes, not its levels)
 	}
 }
 
-__device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *jump, uint32_t tree, TreeHead head,
+__device__ __forceinline__ void quad_sample(const QuadRec *rec, JumpRef jump, uint32_t tree, TreeHead head,
                                             Pcg32 &rng, float &dx, float &dy, float &dz, float &pdf_out,
                                             uint32_t &levels)
 {
@@ -435,7 +463,7 @@ __device__ __forceinline__ void quad_sample(const QuadRec *rec, const QuadJump *
 // direction fall into the same quadtree, quadtree.py:443-464), advanced in lock step so that the two
 // dependent gather chains overlap instead of running one after the other.
 struct LeafCursor {
-	uint32_t r, slot, levels;
+	uint32_t r, slot, levels; // (levels: a statistics word, see stat_word)
 	float lox, loy, h, cx, cy;
 	bool walking, found, is_root;
 };
@@ -453,9 +481,10 @@ __device__ __forceinline__ LeafCursor leaf_cursor_pre(TreeHead head, float cx, f
 	c.is_root = head.root_rec == kNoRecord;
 	c.found = inside && c.is_root;
 	c.walking = inside && !c.is_root;
+	if (pre.hit) c.levels = stat_word(0u, 16u); // (gathered, used or not)
 	if (c.walking && pre.hit) { // skip the levels the table covers
 		const uint4 e = pre.e;
-		c.levels = (e.w >> 26) & 15u;
+		c.levels += (e.w >> 26) & 15u;
 		if (e.x == kNoRecord) {
 			c.slot = e.w & kJumpSlotMask;
 			c.found = true;
@@ -463,14 +492,14 @@ __device__ __forceinline__ LeafCursor leaf_cursor_pre(TreeHead head, float cx, f
 		} else {
 			c.r = e.x;
 			c.lox = pre.jx; c.loy = pre.jy;
-			c.h = 0.5f / (float)(1 << kJumpBits);
+			c.h = 0.5f / (float)(1 << pre.bits);
 		}
 	}
 	return c;
 }
 
 // the same with the table's entry fetched here, behind the head (and only where the cursor walks)
-__device__ __forceinline__ LeafCursor leaf_cursor(const QuadJump *jump, uint32_t tree, TreeHead head, float cx, float cy,
+__device__ __forceinline__ LeafCursor leaf_cursor(JumpRef jump, uint32_t tree, TreeHead head, float cx, float cy,
                                                   bool enable)
 {
 	const bool walks = enable && cx >= 0.0f && cx <= 1.0f && cy >= 0.0f && cy <= 1.0f; // (not a question to the head: the two gathers overlap)
@@ -482,7 +511,7 @@ __device__ __forceinline__ void leaf_step(LeafCursor &c, uint4 ch)
 	const float mx = c.lox + c.h, my = c.loy + c.h;
 	int first, last;
 	quadrant(c.cx, c.cy, mx, my, first, last);
-	++c.levels;
+	c.levels += stat_word(1u, 16u); // (the child words of one record)
 	const uint32_t child = sel4u(last, ch.x, ch.y, ch.z, ch.w);
 	if (child == 0) {
 		c.slot = c.r * 4u + (uint32_t)last;

@@ -11,6 +11,7 @@ namespace pg {
 
 struct DepthCounters { // device-resident, optional
 	unsigned long long kd_levels, kd_queries, quad_levels, quad_queries;
+	unsigned long long layout_bytes; // bytes the lanes gathered from the built tables (stat_word, pg_descent.hpp); tree heads not included
 };
 
 // ---- queries (pg_kernels_query.hip) ----
@@ -31,8 +32,8 @@ void launch_compact_lanes(uint64_t n, const uint8_t *select, const uint8_t *nee_
 void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state, uint64_t *inc,
                      hipStream_t s);
 
-// (re)builds the quadtree jump table of `t` into out[t.n_trees * kJumpCells] (t.jump is not read)
-void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s);
+// (re)builds the quadtree jump tables of `t`, 4^bits entries per tree, into out[t.n_trees << (2 * bits)] (t.jump is not read)
+void launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s);
 // (re)builds the KD jump grid of `t` into out[8^t.grid_bits + kKdGridRootEntries] (t.kd_grid is not read; t.grid_bits, kd_planes and grid_inv are)
 void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s);
 

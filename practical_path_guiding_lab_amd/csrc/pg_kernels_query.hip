@@ -20,12 +20,15 @@ __device__ __forceinline__ void count_depths(DepthCounters *dc, unsigned kd_lv, 
                                              unsigned q_lv, unsigned q_q)
 {
 	if (dc == nullptr) return; // wave-uniform
-	const unsigned long long a = wave_sum(kd_lv), b = wave_sum(kd_q), c = wave_sum(q_lv), d = wave_sum(q_q);
+	// (kd_lv, q_lv: sums of statistics words, pg_descent.hpp)
+	const unsigned long long a = wave_sum(stat_levels(kd_lv)), b = wave_sum(kd_q), c = wave_sum(stat_levels(q_lv)), d = wave_sum(q_q);
+	const unsigned long long e = wave_sum(stat_bytes(kd_lv) + stat_bytes(q_lv));
 	if ((threadIdx.x & 63) == 0) {
 		atomicAdd(&dc->kd_levels, a);
 		atomicAdd(&dc->kd_queries, b);
 		atomicAdd(&dc->quad_levels, c);
 		atomicAdd(&dc->quad_queries, d);
+		atomicAdd(&dc->layout_bytes, e);
 	}
 }
 
@@ -275,54 +278,76 @@ __global__ __launch_bounds__(kBlock) void k_rng_seed(uint64_t n, uint32_t seed, 
 	inc[i] = r.inc;
 }
 
-// Jump-table entry of (tree, cell): the state of pdfQuadTree's loop (quadtree.py:1020-1098) and of
-// addIrradiancePropagate's walk (quadtree.py:398-441) after the kJumpBits levels a point strictly
-// inside the cell passes through, computed by that very loop for the cell's centre.
-__global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__restrict__ out)
+// The jump table of one quadtree per workgroup, built TOP-DOWN in LDS: the entry of a cell of the 2^l x 2^l grid is the
+// state of pdfQuadTree's loop (quadtree.py:1020-1098) and of addIrradiancePropagate's walk (quadtree.py:398-441) after the l
+// levels a point strictly inside the cell passes through; the four cells it splits into at level l + 1 follow from it and ONE
+// read of the node's record, by the very operations of that loop in its order (so a table built this way equals, bit for
+// bit, the one round 3 built by running the loop from the root for every cell's centre -- 4096 six-level descents per tree,
+// 87 M dependent gather chains for the veach-ajar bench forest; here a tree's records are read once each, at most 1365 of
+// them, and the 64 KB leave as whole lines).  A level-l entry lives at the table position of its cell's lowest corner, so
+// the expansion is in place: a thread reads its parent, then overwrites it with child 3 (the quadrant at the cell's own
+// corner) and writes the three others to positions no level-l entry occupies.
+// Quadrants (quadtree.py:153-175; `quadrant` in pg_descent.hpp): child 0 = (x >= mid, y >= mid), 1 = (x <= mid, y >= mid),
+// 2 = (x <= mid, y <= mid), 3 = (x >= mid, y <= mid).
+__global__ __launch_bounds__(kBlock) void k_build_jump(TreeView t, QuadJump *__restrict__ out, int bits)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= (uint64_t)t.n_trees * kJumpCells) return;
-	const uint32_t tree = (uint32_t)(i / kJumpCells), cell = (uint32_t)(i % kJumpCells);
-	constexpr float S = (float)(1 << kJumpBits);
-	const float cx = ((float)(cell & ((1u << kJumpBits) - 1u)) + 0.5f) / S, cy = ((float)(cell >> kJumpBits) + 0.5f) / S;
-	const TreeHead head = load_head(t.head, tree);
-	QuadJump e;
-	e.next = kNoRecord;
-	e.pdf = kInvFourPiF; // 1.0f * 1/(4 pi): the root is a leaf -- the walk ends in the table like any other leaf within it,
-	e.irr = head.root_irr; // with the ROOT's accumulator for a slot (bit 31): a pdf walk that hits the table never needs the head
-	e.info = 0x80000000u;
-	if (head.root_rec != kNoRecord) {
-		uint32_t r = head.root_rec, levels = 0, slot = 0;
-		float pdf = 1.0f, node_irr = head.root_irr, lox = 0.0f, loy = 0.0f, h = 0.5f;
-		bool dead = false, ended = false;
-		for (int it = 0; it < kJumpBits; ++it) {
-			const QuadLoad q = load_rec(t.rec, r);
-			const float mx = lox + h, my = loy + h;
-			int first, last;
-			quadrant(cx, cy, mx, my, first, last); // first == last: the centre lies on no boundary
-			const float child_irr = sel4f(first, q.i0, q.i1, q.i2, q.i3);
-			pdf = pdf * ((4.0f * child_irr) / node_irr);
-			if (pdf != pdf) dead = true; // quadtree.py:1090-1092 ends the pdf loop here; the splat's walk goes on
-			++levels;
-			node_irr = sel4f(last, q.i0, q.i1, q.i2, q.i3);
-			const uint32_t c = sel4u(last, q.c0, q.c1, q.c2, q.c3);
-			if (last == 0 || last == 3) lox = mx;
-			if (last == 0 || last == 1) loy = my;
-			h *= 0.5f;
-			if (c == 0) { // the child is a leaf
-				slot = r * 4u + (uint32_t)last;
-				pdf = pdf * kInvFourPiF;
-				ended = true;
-				break;
-			}
-			r = c;
+	extern __shared__ u32x4_t s_tab[]; // 4^bits entries
+	const uint32_t tree = blockIdx.x;
+	const uint32_t cells = 1u << (2 * bits);
+	if (threadIdx.x == 0) {
+		const TreeHead head = load_head(t.head, tree);
+		u32x4_t e;
+		if (head.root_rec == kNoRecord) {
+			// the root is a leaf: the walk ends in the table like at any other leaf within it, with the ROOT's accumulator
+			// for a slot (bit 31) -- a pdf walk that hits the table never needs the tree's head
+			e.x = kNoRecord; e.y = __float_as_uint(kInvFourPiF); e.z = __float_as_uint(head.root_irr); e.w = 0x80000000u;
+		} else {
+			e.x = head.root_rec; e.y = __float_as_uint(1.0f); e.z = __float_as_uint(head.root_irr); e.w = 0u;
 		}
-		e.next = ended ? kNoRecord : r;
-		e.pdf = pdf;
-		e.irr = node_irr;
-		e.info = (ended ? (slot & kJumpSlotMask) : 0u) | (levels << 26) | (dead ? (1u << 30) : 0u);
+		s_tab[0] = e;
 	}
-	out[i] = e;
+	__syncthreads();
+	for (int l = 0; l < bits; ++l) {
+		const uint32_t n_par = 1u << (2 * l);
+		const int shift = bits - l;            // a level-l cell spans 2^shift table cells per axis
+		const uint32_t half = 1u << (shift - 1);
+		for (uint32_t p = threadIdx.x; p < n_par; p += kBlock) {
+			const uint32_t iy = p >> l, ix = p & ((1u << l) - 1u);
+			const uint32_t pos = ((iy << shift) << bits) | (ix << shift);
+			const u32x4_t e = s_tab[pos];
+			u32x4_t c[4] = {e, e, e, e}; // (a walk that has ended: its entry covers the whole cell)
+			if (e.x != kNoRecord) {
+				const QuadLoad q = load_rec(t.rec, e.x);
+				const float pdf = __uint_as_float(e.y), node_irr = __uint_as_float(e.z);
+				const uint32_t levels = ((e.w >> 26) & 15u) + 1u;
+				const bool was_dead = ((e.w >> 30) & 1u) != 0u;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const float child_irr = sel4f(k, q.i0, q.i1, q.i2, q.i3);
+					float pk = pdf * ((4.0f * child_irr) / node_irr);
+					const bool dead = was_dead || pk != pk; // quadtree.py:1090-1092 ends the pdf loop here; the splat's walk goes on
+					const uint32_t ch = sel4u(k, q.c0, q.c1, q.c2, q.c3);
+					uint32_t slot = 0;
+					if (ch == 0) { // the child is a leaf
+						slot = (e.x * 4u + (uint32_t)k) & kJumpSlotMask;
+						pk = pk * kInvFourPiF;
+					}
+					c[k].x = ch == 0 ? kNoRecord : ch;
+					c[k].y = __float_as_uint(pk);
+					c[k].z = __float_as_uint(child_irr);
+					c[k].w = slot | (levels << 26) | (dead ? (1u << 30) : 0u);
+				}
+			}
+			// (dx, dy) of child k: 0 -> (1, 1), 1 -> (0, 1), 2 -> (0, 0), 3 -> (1, 0)
+			s_tab[pos + (half << bits) + half] = c[0];
+			s_tab[pos + (half << bits)] = c[1];
+			s_tab[pos + half] = c[3];
+			s_tab[pos] = c[2];
+		}
+		__syncthreads();
+	}
+	u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + ((size_t)tree << (2 * bits)));
+	for (uint32_t i = threadIdx.x; i < cells; i += kBlock) dst[i] = s_tab[i];
 }
 
 // One thread per cell of the KD jump grid: descend with the cell's interval for as long as every point
@@ -371,11 +396,16 @@ void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s)
 	hipLaunchKernelGGL(k_build_kd_grid, grid_for((1ull << (3 * t.grid_bits)) + kKdGridRootEntries), dim3(kBlock), 0, s, t, out);
 }
 
-void launch_build_jump(const TreeView &t, QuadJump *out, hipStream_t s)
+void launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s)
 {
-	const uint64_t n = (uint64_t)t.n_trees * kJumpCells;
-	if (n == 0) return;
-	hipLaunchKernelGGL(k_build_jump, grid_for(n), dim3(kBlock), 0, s, t, out);
+	if (t.n_trees == 0) return;
+	const size_t lds = sizeof(QuadJump) << (2 * bits); // 64 KB for the finest table
+	static bool raised = false;
+	if (!raised && lds > 48 * 1024) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		raised = true;
+	}
+	hipLaunchKernelGGL(k_build_jump, dim3(t.n_trees), dim3(kBlock), lds, s, t, out, bits);
 }
 
 void launch_leaf_index(const TreeView &t, uint64_t n, const float *p, const uint8_t *active,

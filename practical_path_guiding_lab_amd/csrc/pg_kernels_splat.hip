@@ -49,7 +49,7 @@ __device__ __forceinline__ SlotAdd plan_dir(const AccumView &a, uint32_t tree, c
 __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &a, const uint4 *s_kd, int store_nee,
                                             float x, float y, float z, float dx, float dy, float radiance,
                                             float wo_pdf, float nx, float ny, float nee_lum, SlotAdd &path,
-                                            SlotAdd &nee, unsigned &kd_lv, unsigned &q_lv, unsigned &q_q)
+                                            SlotAdd &nee, unsigned &kd_lv, unsigned &q_lv, unsigned &q_q, unsigned &bytes)
 {
 	const bool inside = inside_root(t, x, y, z);
 	KdNode leaf;
@@ -59,7 +59,8 @@ __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &
 #else
 	kd_descend_grid(t, reinterpret_cast<const float *>(s_kd), x, y, z, inside, leaf, lv);
 #endif
-	kd_lv = lv;
+	kd_lv += stat_levels(lv); // (statistics words, pg_descent.hpp: a thread may plan many records, so they are unpacked here)
+	bytes += stat_bytes(lv);
 	const uint32_t tree = leaf.tree; // outside the bbox: node 0's (stale) tree (kdtree.py:224)
 	// (the tree's head and the jump-table entries of the record's two directions need the tree's number only: three
 	// gathers in flight at once instead of the entries behind the head)
@@ -71,13 +72,15 @@ __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &
 	LeafCursor cp = leaf_cursor_pre(head, dx, dy, true, pre_p), cn = leaf_cursor_pre(head, nx, ny, store_nee != 0, pre_n);
 	quad_find_leaf_slots2(t.rec, cp, cn);
 	path = plan_dir(a, tree, cp, w, inside ? 1 : 0);
-	q_lv += cp.levels;
+	q_lv += stat_levels(cp.levels);
+	bytes += stat_bytes(cp.levels);
 	++q_q;
 	// a counted record whose direction reaches no leaf (outside the unit square): fallback counter
 	if (inside && path.ptr == nullptr) atomicAdd(a.leaf_count + tree, 1ull);
 	nee = plan_dir(a, tree, cn, wn, 0);
 	if (store_nee) {
-		q_lv += cn.levels;
+		q_lv += stat_levels(cn.levels);
+		bytes += stat_bytes(cn.levels);
 		++q_q;
 	}
 }
@@ -144,15 +147,17 @@ __device__ __forceinline__ unsigned long long wave_sum_s(unsigned long long v)
 }
 
 __device__ __forceinline__ void count_depths_s(DepthCounters *dc, unsigned kd_lv, unsigned kd_q,
-                                               unsigned q_lv, unsigned q_q)
+                                               unsigned q_lv, unsigned q_q, unsigned bytes)
 {
 	if (dc == nullptr) return;
 	const unsigned long long a = wave_sum_s(kd_lv), b = wave_sum_s(kd_q), c = wave_sum_s(q_lv), d = wave_sum_s(q_q);
+	const unsigned long long e = wave_sum_s(bytes);
 	if ((threadIdx.x & 63) == 0) {
 		atomicAdd(&dc->kd_levels, a);
 		atomicAdd(&dc->kd_queries, b);
 		atomicAdd(&dc->quad_levels, c);
 		atomicAdd(&dc->quad_queries, d);
+		atomicAdd(&dc->layout_bytes, e);
 	}
 }
 
@@ -179,18 +184,18 @@ __global__ __launch_bounds__(kBlock) void k_splat(TreeView t, AccumView a, int s
 #endif
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	const uint64_t valid = d_count ? (uint64_t)*d_count : m; // plane stride stays m
-	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
+	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0, st_bytes = 0;
 	SlotAdd path = {nullptr, 0, 0, 0, 0}, nee = {nullptr, 0, 0, 0, 0};
 	if (i < valid && i < m) {
 		const float nx = store_nee ? dir_nee[i] : 0.0f, ny = store_nee ? dir_nee[m + i] : 0.0f;
 		const float nl = store_nee ? nee_lum[i] : 0.0f;
 		plan_record(t, a, s_kd, store_nee, pos[i], pos[m + i], pos[2 * m + i], dir[i], dir[m + i], radiance[i],
-		            wo_pdf[i], nx, ny, nl, path, nee, kd_lv, q_lv, q_q);
+		            wo_pdf[i], nx, ny, nl, path, nee, kd_lv, q_lv, q_q, st_bytes);
 		did = 1;
 	}
 	coop_add(path, s_val, s_ptr);
 	if (store_nee) coop_add(nee, s_val, s_ptr);
-	count_depths_s(dc, kd_lv, did, q_lv, q_q);
+	count_depths_s(dc, kd_lv, did, q_lv, q_q, st_bytes);
 }
 
 // processPathData + scatterDataIntoSDTree's filter for dense slot g
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 	// sum inside the workgroup and send four atomics per workgroup instead of two per record.
 	const bool single = t.n_rec == 0 && t.n_trees == 1;
 	long long v[4] = {0, 0, 0, 0};
-	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0;
+	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0, st_bytes = 0;
 	for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += (uint64_t)gridDim.x * kBlock) {
 		const uint64_t g = base + threadIdx.x;
 		float radiance = 0.0f, nee_lum = 0.0f, wp = 0.0f;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 		if (keep) {
 			plan_record(t, a, s_kd, store_nee, r.position[g], r.position[S + g], r.position[2 * S + g], r.direction[g],
 			            r.direction[S + g], radiance, wp, r.direction_nee[g], r.direction_nee[S + g], nee_lum, path, nee,
-			            kd_lv, q_lv, q_q);
+			            kd_lv, q_lv, q_q, st_bytes);
 			++did;
 		}
 		if (single) {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
 			if (tot) atomicAdd(reinterpret_cast<unsigned long long *>(a.root_acc + threadIdx.x), tot);
 		}
 	}
-	count_depths_s(dc, kd_lv, did, q_lv, q_q);
+	count_depths_s(dc, kd_lv, did, q_lv, q_q, st_bytes);
 }
 
 // The split render pipeline's list (pg_list_records): processPathData + the filter of scatterDataIntoSDTree

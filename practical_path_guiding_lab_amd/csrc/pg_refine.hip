@@ -22,7 +22,11 @@
 
 #include <math.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
+#include <chrono>
 
 #include "pg_math.hpp"
 
@@ -427,22 +431,30 @@ __global__ __launch_bounds__(kBlk) void k_iota(uint32_t *p, uint32_t n)
 // ---------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlk - 1) / kBlk)); }
 
+// Growth policy of everything that follows the tree: twice what is needed now.  The tree roughly doubles per training
+// iteration (2^(k+2) spp), so doubling leaves room for the next refine; what matters more is that NOTHING is allocated or
+// freed by a refine whose tree fits what the last one left (hipFree synchronises the device, a hipMalloc of a gigabyte
+// takes tens of milliseconds: round 3's refine spent 20-190 ms there).
+constexpr double kGrow = 2.0;
+
 struct Scanner {
-	DevBuf<uint32_t> sums, total;
+	DevBuf<uint32_t> &sums, &total;
+	uint32_t *h_total; // page-locked
 	// out[i] = sum(in[0..i)), returns grand total (synchronises the stream)
 	int run(pg_context *ctx, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t &tot, hipStream_t s)
 	{
 		tot = 0;
 		if (n == 0) return PG_OK;
 		const uint32_t nb = (n + kScanTile - 1) / kScanTile;
-		PG_HIP(ctx, sums.ensure(nb, 1.5));
+		PG_HIP(ctx, sums.ensure(nb, kGrow));
 		PG_HIP(ctx, total.ensure(1));
 		hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kBlk), 0, s, in, n, sums.p);
 		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums.p, nb, total.p);
 		hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kBlk), 0, s, in, n, sums.p, out);
 		PG_HIP(ctx, hipGetLastError());
-		PG_HIP(ctx, hipMemcpyAsync(&tot, total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		PG_HIP(ctx, hipMemcpyAsync(h_total, total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		PG_HIP(ctx, hipStreamSynchronize(s));
+		tot = *h_total;
 		return PG_OK;
 	}
 };
@@ -451,7 +463,7 @@ template <class T> static hipError_t grow_preserve(DevBuf<T> &b, size_t keep, si
 {
 	if (need <= b.cap) return hipSuccess;
 	DevBuf<T> n;
-	hipError_t e = n.ensure(need, 1.5);
+	hipError_t e = n.ensure(need, kGrow);
 	if (e != hipSuccess) return e;
 	if (keep) {
 		e = hipMemcpyAsync(n.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
@@ -463,47 +475,65 @@ template <class T> static hipError_t grow_preserve(DevBuf<T> &b, size_t keep, si
 	return hipSuccess;
 }
 
+// PGSD_TRACE_REFINE=1: wall time of every phase of a refine on stderr (each mark synchronises the stream: diagnosis only)
+struct PhaseTrace {
+	bool on;
+	hipStream_t s;
+	std::chrono::steady_clock::time_point t0;
+	PhaseTrace(hipStream_t s_) : on(getenv("PGSD_TRACE_REFINE") != nullptr), s(s_), t0(std::chrono::steady_clock::now()) {}
+	void mark(const char *what)
+	{
+		if (!on) return;
+		(void)hipStreamSynchronize(s);
+		const auto t1 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[pgsd refine] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		t0 = t1;
+	}
+};
+
 int refine_and_swap(pg_context *ctx, hipStream_t s)
 {
+	PhaseTrace tr(s);
 	Forest &f = ctx->f;
+	Forest::RefineScratch &w = f.scratch;
 	const AccumView av = f.accum_view();
 	const uint32_t L = (uint32_t)f.level_off.size() - 1;
+	if (!w.pinned) PG_HIP(ctx, hipHostMalloc(&w.pinned, 64, hipHostMallocDefault));
+	unsigned long long *h_plan = static_cast<unsigned long long *>(w.pinned);       // [2]
+	uint32_t *h_counts = reinterpret_cast<uint32_t *>(h_plan + 2);                   // [2]
+	uint32_t *h_total = h_counts + 2;                                                // [1]
 
 	// ---- 1. resolve --------------------------------------------------------------------------
-	DevBuf<I128> tot;
-	DevBuf<float> slot_irr, root_irr;
-	DevBuf<unsigned long long> kd_cnt, cnt_tot, tree_count;
-	PG_HIP(ctx, tot.ensure(f.n_rec));
-	PG_HIP(ctx, cnt_tot.ensure(f.n_rec));
-	PG_HIP(ctx, slot_irr.ensure((size_t)f.n_rec * 4));
-	PG_HIP(ctx, root_irr.ensure(f.n_trees));
-	PG_HIP(ctx, tree_count.ensure(f.n_trees));
+	PG_HIP(ctx, w.tot.ensure(f.n_rec, kGrow));
+	PG_HIP(ctx, w.cnt_tot.ensure(f.n_rec, kGrow));
+	PG_HIP(ctx, w.slot_irr.ensure((size_t)f.n_rec * 4, kGrow));
+	PG_HIP(ctx, w.root_irr.ensure(f.n_trees, kGrow));
+	PG_HIP(ctx, w.tree_count.ensure(f.n_trees, kGrow));
 	for (int l = (int)L - 1; l >= 0; --l) {
 		const uint32_t b = f.level_off[l], e = f.level_off[l + 1];
 		if (e > b)
-			hipLaunchKernelGGL(k_resolve_level, grid_for(e - b), dim3(kBlk), 0, s, f.rec.p, av.rec_acc, tot.p,
-			                   cnt_tot.p, slot_irr.p, b, e);
+			hipLaunchKernelGGL(k_resolve_level, grid_for(e - b), dim3(kBlk), 0, s, f.rec.p, av.rec_acc, w.tot.p,
+			                   w.cnt_tot.p, w.slot_irr.p, b, e);
 	}
-	hipLaunchKernelGGL(k_resolve_roots, grid_for(f.n_trees), dim3(kBlk), 0, s, f.head.p, av.root_acc, tot.p,
-	                   cnt_tot.p, av.leaf_count, root_irr.p, tree_count.p, f.n_trees);
-	PG_HIP(ctx, kd_cnt.ensure(f.n_kd));
-	hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, tree_count.p, kd_cnt.p, 0, 1);
+	hipLaunchKernelGGL(k_resolve_roots, grid_for(f.n_trees), dim3(kBlk), 0, s, f.head.p, av.root_acc, w.tot.p,
+	                   w.cnt_tot.p, av.leaf_count, w.root_irr.p, w.tree_count.p, f.n_trees);
+	PG_HIP(ctx, w.kd_cnt.ensure(f.n_kd, kGrow));
+	hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, w.tree_count.p, w.kd_cnt.p, 0, 1);
 	for (int d = ctx->kd_max_depth - 1; d >= 0; --d)
-		hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, tree_count.p, kd_cnt.p, d, 0);
-	hipLaunchKernelGGL(k_kd_vcount, grid_for(f.n_kd), dim3(kBlk), 0, s, kd_cnt.p, f.kd_vcount.p, f.n_kd);
+		hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, w.tree_count.p, w.kd_cnt.p, d, 0);
+	hipLaunchKernelGGL(k_kd_vcount, grid_for(f.n_kd), dim3(kBlk), 0, s, w.kd_cnt.p, f.kd_vcount.p, f.n_kd);
 	PG_HIP(ctx, hipGetLastError());
 
+	tr.mark("resolve");
 	// ---- 2. KD refine ------------------------------------------------------------------------
 	ctx->kd_max_leaf_size = 12000.0 * sqrt(pow(2.0, (double)ctx->iteration)); // kdtree.py:327-330
 	const float kd_thr = (float)ctx->kd_max_leaf_size;
-	DevBuf<unsigned long long> plan;
-	PG_HIP(ctx, plan.ensure(2));
-	PG_HIP(ctx, hipMemsetAsync(plan.p, 0, 2 * sizeof(unsigned long long), s));
+	PG_HIP(ctx, w.plan.ensure(2));
+	PG_HIP(ctx, hipMemsetAsync(w.plan.p, 0, 2 * sizeof(unsigned long long), s));
 	hipLaunchKernelGGL(k_kd_plan, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, f.kd_vcount.p, kd_thr,
-	                   ctx->kd_max_depth, plan.p);
+	                   ctx->kd_max_depth, w.plan.p);
 	PG_HIP(ctx, hipGetLastError());
-	unsigned long long h_plan[2];
-	PG_HIP(ctx, hipMemcpyAsync(h_plan, plan.p, sizeof(h_plan), hipMemcpyDeviceToHost, s));
+	PG_HIP(ctx, hipMemcpyAsync(h_plan, w.plan.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	PG_HIP(ctx, hipStreamSynchronize(s));
 	const uint64_t want_kd = (uint64_t)f.n_kd + h_plan[0], want_trees = (uint64_t)f.n_trees + h_plan[1];
 	if (want_kd > 0x7fffffffull) return fail(ctx, PG_ERR_NOMEM, "refine: KD tree would exceed 2^31 nodes");
@@ -511,20 +541,18 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 	PG_HIP(ctx, grow_preserve(f.kd_bmin, (size_t)f.n_kd * 3, want_kd * 3, s));
 	PG_HIP(ctx, grow_preserve(f.kd_bmax, (size_t)f.n_kd * 3, want_kd * 3, s));
 	PG_HIP(ctx, grow_preserve(f.kd_vcount, f.n_kd, want_kd, s));
-	DevBuf<uint32_t> tree_src, counts;
-	PG_HIP(ctx, tree_src.ensure(want_trees));
-	PG_HIP(ctx, counts.ensure(2));
-	hipLaunchKernelGGL(k_iota, grid_for(f.n_trees), dim3(kBlk), 0, s, tree_src.p, f.n_trees);
+	PG_HIP(ctx, w.tree_src.ensure(want_trees, kGrow));
+	PG_HIP(ctx, w.counts.ensure(2));
+	hipLaunchKernelGGL(k_iota, grid_for(f.n_trees), dim3(kBlk), 0, s, w.tree_src.p, f.n_trees);
 	uint32_t n_kd_new = f.n_kd, n_trees_new = f.n_trees;
 	if (h_plan[0]) {
 		KdRefineArgs a;
 		a.kd = f.kd.p; a.bmin = f.kd_bmin.p; a.bmax = f.kd_bmax.p; a.vc = f.kd_vcount.p;
-		a.tree_src = tree_src.p; a.n_kd = f.n_kd; a.n_trees = f.n_trees; a.thr = kd_thr;
-		a.max_depth = ctx->kd_max_depth; a.out_counts = counts.p;
+		a.tree_src = w.tree_src.p; a.n_kd = f.n_kd; a.n_trees = f.n_trees; a.thr = kd_thr;
+		a.max_depth = ctx->kd_max_depth; a.out_counts = w.counts.p;
 		hipLaunchKernelGGL(k_kd_refine, dim3(1), dim3(1024), 0, s, a);
 		PG_HIP(ctx, hipGetLastError());
-		uint32_t h_counts[2];
-		PG_HIP(ctx, hipMemcpyAsync(h_counts, counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, s));
+		PG_HIP(ctx, hipMemcpyAsync(h_counts, w.counts.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		PG_HIP(ctx, hipStreamSynchronize(s));
 		n_kd_new = h_counts[0];
 		n_trees_new = h_counts[1];
@@ -532,70 +560,72 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 			return fail(ctx, PG_ERR_INVALID, "refine: KD plan and KD split rounds disagree (internal error)");
 	}
 
+	tr.mark("kd refine");
 	// ---- 3. quadtree rebuild -----------------------------------------------------------------
 	const int qmax = ctx->quad_max_depth;
-	DevBuf<TreeHead> new_head;
-	DevBuf<float> new_thr;
-	DevBuf<QuadRec> new_rec;
-	DevBuf<uint32_t> cnt, pos;
-	DevBuf<Pending> pend_a, pend_b;
-	Scanner scan;
-	PG_HIP(ctx, new_head.ensure(n_trees_new, 1.5));
-	PG_HIP(ctx, new_thr.ensure(n_trees_new, 1.5));
-	PG_HIP(ctx, cnt.ensure(n_trees_new));
-	PG_HIP(ctx, pos.ensure(n_trees_new));
-	hipLaunchKernelGGL(k_roots_plan, grid_for(n_trees_new), dim3(kBlk), 0, s, tree_src.p, f.head.p, root_irr.p,
-	                   n_trees_new, qmax, new_head.p, new_thr.p, cnt.p);
+	Scanner scan{w.scan_sums, w.scan_total, h_total};
+	PG_HIP(ctx, w.new_head.ensure(n_trees_new, kGrow));
+	PG_HIP(ctx, w.new_thr.ensure(n_trees_new, kGrow));
+	PG_HIP(ctx, w.cnt.ensure(n_trees_new, kGrow));
+	PG_HIP(ctx, w.pos.ensure(n_trees_new, kGrow));
+	hipLaunchKernelGGL(k_roots_plan, grid_for(n_trees_new), dim3(kBlk), 0, s, w.tree_src.p, f.head.p, w.root_irr.p,
+	                   n_trees_new, qmax, w.new_head.p, w.new_thr.p, w.cnt.p);
 	PG_HIP(ctx, hipGetLastError());
 	uint32_t n_level = 0;
-	int rc = scan.run(ctx, cnt.p, n_trees_new, pos.p, n_level, s);
+	int rc = scan.run(ctx, w.cnt.p, n_trees_new, w.pos.p, n_level, s);
 	if (rc != PG_OK) return rc;
-	PG_HIP(ctx, pend_a.ensure(n_level, 1.25));
+	PG_HIP(ctx, w.pend_a.ensure((size_t)n_level * sizeof(Pending), kGrow));
 	if (n_level)
-		hipLaunchKernelGGL(k_roots_emit, grid_for(n_trees_new), dim3(kBlk), 0, s, tree_src.p, f.head.p, n_trees_new,
-		                   cnt.p, pos.p, new_head.p, pend_a.p);
+		hipLaunchKernelGGL(k_roots_emit, grid_for(n_trees_new), dim3(kBlk), 0, s, w.tree_src.p, f.head.p, n_trees_new,
+		                   w.cnt.p, w.pos.p, w.new_head.p, reinterpret_cast<Pending *>(w.pend_a.p));
 	PG_HIP(ctx, hipGetLastError());
 	std::vector<uint32_t> new_level_off(1, 0u);
 	uint64_t off = 0;
 	int level = 0;
+	// (the new forest is rarely smaller than the old one: start the record buffer there, so that it grows at most once or twice)
+	PG_HIP(ctx, w.new_rec.ensure(f.n_rec, kGrow));
 	while (n_level) {
 		if (level >= kMaxLevels - 2) return fail(ctx, PG_ERR_INVALID, "refine: quadtree deeper than supported");
 		if (off + n_level > 0xfffffff0ull) return fail(ctx, PG_ERR_NOMEM, "refine: more than 2^32 quadtree records");
-		PG_HIP(ctx, grow_preserve(new_rec, (size_t)off, (size_t)off + n_level, s));
-		PG_HIP(ctx, cnt.ensure(n_level, 1.25));
-		PG_HIP(ctx, pos.ensure(n_level, 1.25));
-		hipLaunchKernelGGL(k_level_plan, grid_for(n_level), dim3(kBlk), 0, s, pend_a.p, n_level, f.rec.p, slot_irr.p,
-		                   new_thr.p, level + 1, qmax, cnt.p);
+		PG_HIP(ctx, grow_preserve(w.new_rec, (size_t)off, (size_t)off + n_level, s));
+		PG_HIP(ctx, w.cnt.ensure(n_level, kGrow));
+		PG_HIP(ctx, w.pos.ensure(n_level, kGrow));
+		Pending *pa = reinterpret_cast<Pending *>(w.pend_a.p);
+		hipLaunchKernelGGL(k_level_plan, grid_for(n_level), dim3(kBlk), 0, s, pa, n_level, f.rec.p, w.slot_irr.p,
+		                   w.new_thr.p, level + 1, qmax, w.cnt.p);
 		PG_HIP(ctx, hipGetLastError());
 		uint32_t n_next = 0;
-		rc = scan.run(ctx, cnt.p, n_level, pos.p, n_next, s);
+		rc = scan.run(ctx, w.cnt.p, n_level, w.pos.p, n_next, s);
 		if (rc != PG_OK) return rc;
-		PG_HIP(ctx, pend_b.ensure(n_next, 1.25));
-		hipLaunchKernelGGL(k_level_emit, grid_for(n_level), dim3(kBlk), 0, s, pend_a.p, n_level, f.rec.p, slot_irr.p,
-		                   new_thr.p, level + 1, qmax, pos.p, (uint32_t)off, (uint32_t)(off + n_level), new_rec.p,
-		                   pend_b.p);
+		PG_HIP(ctx, w.pend_b.ensure((size_t)n_next * sizeof(Pending), kGrow));
+		hipLaunchKernelGGL(k_level_emit, grid_for(n_level), dim3(kBlk), 0, s, pa, n_level, f.rec.p, w.slot_irr.p,
+		                   w.new_thr.p, level + 1, qmax, w.pos.p, (uint32_t)off, (uint32_t)(off + n_level), w.new_rec.p,
+		                   reinterpret_cast<Pending *>(w.pend_b.p));
 		PG_HIP(ctx, hipGetLastError());
 		off += n_level;
 		new_level_off.push_back((uint32_t)off);
-		pend_a.swap(pend_b);
+		w.pend_a.swap(w.pend_b);
 		n_level = n_next;
 		++level;
 	}
 
+	tr.mark("quadtree rebuild");
 	// ---- 4. swap + reset ---------------------------------------------------------------------
 	PG_HIP(ctx, hipStreamSynchronize(s));
-	f.rec.swap(new_rec);
-	f.head.swap(new_head);
-	f.tree_thr.swap(new_thr);
+	f.rec.swap(w.new_rec);     // (the old forest's buffers become the next refine's scratch)
+	f.head.swap(w.new_head);
+	f.tree_thr.swap(w.new_thr);
 	f.n_rec = (uint32_t)off;
 	f.n_trees = n_trees_new;
 	f.n_kd = n_kd_new;
 	f.level_off = new_level_off;
-	PG_HIP(ctx, f.acc.ensure(f.acc_count(), 1.25));
+	PG_HIP(ctx, f.acc.ensure(f.acc_count(), kGrow));
 	PG_HIP(ctx, hipMemsetAsync(f.acc.p, 0, f.acc_count() * sizeof(long long), s));
+	tr.mark("swap + accumulators");
 	const int rc_jump = rebuild_jump(ctx, s);
 	if (rc_jump != PG_OK) return rc_jump;
 	PG_HIP(ctx, hipStreamSynchronize(s));
+	tr.mark("jump tables");
 	return PG_OK;
 }
 
@@ -627,7 +657,7 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 		TreeView tg = ctx->view();
 		ok = ok && tg.grid_inv[0] < 3.0e38f && tg.grid_inv[1] < 3.0e38f && tg.grid_inv[2] < 3.0e38f;
 		if (ok) {
-			PG_HIP(ctx, f.kd_grid.ensure(((size_t)1 << (3 * bits)) + kKdGridRootEntries));
+			PG_HIP(ctx, f.kd_grid.ensure((size_t)kKdGridCells + kKdGridRootEntries)); // (the finest grid, 4 MB, once: the resolution follows the tree)
 			PG_HIP(ctx, f.kd_planes.ensure(3 * kKdGridPlanes));
 			PG_HIP(ctx, hipMemcpyAsync(f.kd_planes.p, planes, sizeof planes, hipMemcpyHostToDevice, s));
 			PG_HIP(ctx, hipStreamSynchronize(s)); // (planes[] is on this stack frame)
@@ -637,15 +667,40 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 			f.kd_grid_valid = true;
 		}
 	}
-	// accumulator slots are packed into 26 bits of an entry; forests beyond that walk every level -- and so do forests
-	// whose table would not be worth its memory (64 KB per quadtree: 1.4 GB for the 21 000 trees of the veach-ajar bench)
-	constexpr uint64_t kJumpTableMaxBytes = 32ull << 30;
-	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask ||
-	    (uint64_t)f.n_trees * kJumpCells * sizeof(QuadJump) > kJumpTableMaxBytes) return PG_OK;
-	PG_HIP(ctx, f.jump.ensure((size_t)f.n_trees * kJumpCells, 1.25));
+	// The quadtree jump tables.  Accumulator slots are packed into 26 bits of an entry: forests beyond that walk every
+	// level.  Memory: 16 B << 2 * bits per quadtree (64 KB with six bits: 1.4 GB for the 21 000 trees of the veach-ajar
+	// bench) against a budget -- $PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB, and at most a quarter of the device memory
+	// that is free right now: a forest too big for six bits gets five (a quarter of the memory; measured on the veach-ajar
+	// bench, ms per step: 6 bits 56.3, 5 bits 56.4, 4 bits 56.9, 3 bits 57.5), then four, ... and a forest that cannot have
+	// a table at all, or whose table cannot be allocated, walks every level from the root: every consumer handles that
+	// (round 3's cap was 32 GB, and a failed allocation failed the refine).
+	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask) return PG_OK;
+	uint64_t budget = ctx->jump_budget;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+		const uint64_t avail = (uint64_t)free_b + (uint64_t)f.jump.cap * sizeof(QuadJump); // (the table we already hold counts as free)
+		if (avail / 4 < budget) budget = avail / 4;
+	} else (void)hipGetLastError();
+	int bits = kJumpBits;
+	while (bits >= 2 && (((uint64_t)f.n_trees * sizeof(QuadJump)) << (2 * bits)) > budget) --bits;
+	if (bits < 2) return PG_OK; // (a 2 x 2 table saves one level: below that nothing)
+	const size_t need = (size_t)f.n_trees << (2 * bits);
+	if (need > f.jump.cap) {
+		// room for the forest to double, as long as that stays within the budget
+		size_t want = need * 2;
+		if ((uint64_t)want * sizeof(QuadJump) > budget) want = need;
+		if (f.jump.ensure(want) != hipSuccess) {
+			(void)hipGetLastError(); // (not sticky) -- no table: the walks take every level
+			if (f.jump.ensure(need) != hipSuccess) {
+				(void)hipGetLastError();
+				return PG_OK;
+			}
+		}
+	}
 	TreeView t = ctx->view();
-	launch_build_jump(t, f.jump.p, s);
+	launch_build_jump(t, f.jump.p, bits, s);
 	PG_HIP(ctx, hipGetLastError());
+	f.jump_bits = bits;
 	f.jump_valid = true;
 	return PG_OK;
 }

@@ -40,10 +40,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const float ior = 1.0f;         // every BSDF of these scenes has eta 1: the running product stays exactly 1
 	static_assert(kGeneral < 2, "mesh scenes run the split pipeline of pg_render_wave.hip");
 	if (kFirst) {
-		// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples
-		// the full-frame pass would, whatever the number of ranks
 		const uint64_t pixel = global_pixel(a, lane / (uint64_t)a.spp);
-		rng = pcg32_seed(a.seed, (uint32_t)(pixel * (uint64_t)a.spp + lane % (uint64_t)a.spp));
+		rng = lane_stream(a.seed, a.spp, a.batched, pixel, (uint32_t)(lane % (uint64_t)a.spp));
 		const int W = a.cam.width, H = a.cam.height;
 		const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
 		const float jx = rng.next_f32(), jy = rng.next_f32();
@@ -210,10 +208,11 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		}
 	}
 	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
-		atomicAdd(&a.dc->kd_levels, (unsigned long long)c_kd);
+		atomicAdd(&a.dc->kd_levels, (unsigned long long)stat_levels(c_kd)); // (c_kd, c_q: sums of statistics words, pg_descent.hpp)
 		atomicAdd(&a.dc->kd_queries, (unsigned long long)c_kdq);
-		atomicAdd(&a.dc->quad_levels, (unsigned long long)c_q);
+		atomicAdd(&a.dc->quad_levels, (unsigned long long)stat_levels(c_q));
 		atomicAdd(&a.dc->quad_queries, (unsigned long long)c_qq);
+		atomicAdd(&a.dc->layout_bytes, (unsigned long long)(stat_bytes(c_kd) + stat_bytes(c_q)));
 	}
 	if (do_mis) { // :310-311
 		woPdf = f * bsdf_pdf + (1.0f - f) * sdtree_pdf;
@@ -454,7 +453,10 @@ __device__ __forceinline__ float gauss1(float d)
 	return a > 0.0f ? a : 0.0f;
 }
 
-template <int kFilter> // 0 tent (3x3 neighbourhood), 1 gaussian (5x5)
+// kBatched (pg_film_batched): L holds spp one-sample passes traced together (pg_pass_params.batched); the film is
+// developed for each of them by itself -- image s from the samples s of the neighbourhood, exactly what pg_film gives
+// for the pass seed + s alone -- into out[s][3][W * H].
+template <int kFilter, bool kBatched> // kFilter: 0 tent (3x3 neighbourhood), 1 gaussian (5x5)
 __global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W, int H,
                                                   const float *__restrict__ L, float *__restrict__ out,
                                                   uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count)
@@ -467,27 +469,30 @@ __global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W,
 	// (pg_film_stripes: the pixels of this rank's bands only; the others keep what `out` held)
 	if (stripe_count > 1u && ((uint32_t)y / stripe_rows) % stripe_count != stripe_index) return;
 	const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
-	float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;
-	for (int ny = y - R; ny <= y + R; ++ny)
-		for (int nx = x - R; nx <= x + R; ++nx) {
-			if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-			const uint64_t pix = (uint64_t)ny * (uint64_t)W + (uint64_t)nx;
-			for (int s = 0; s < spp; ++s) {
-				const uint64_t lane = pix * (uint64_t)spp + (uint64_t)s;
-				Pcg32 rng = pcg32_seed(seed, (uint32_t)lane);
-				const float jx = rng.next_f32(), jy = rng.next_f32();
-				const float ddx = cx - ((float)nx + jx), ddy = cy - ((float)ny + jy);
-				const float w = kFilter == 1 ? gauss1(ddx) * gauss1(ddy) : tent1(ddx) * tent1(ddy);
-				a0 = a0 + w * L[lane];
-				a1 = a1 + w * L[N + lane];
-				a2 = a2 + w * L[2 * N + lane];
-				wsum = wsum + w;
+	for (int img = 0; img < (kBatched ? spp : 1); ++img) {
+		float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;
+		for (int ny = y - R; ny <= y + R; ++ny)
+			for (int nx = x - R; nx <= x + R; ++nx) {
+				if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+				const uint64_t pix = (uint64_t)ny * (uint64_t)W + (uint64_t)nx;
+				for (int s = kBatched ? img : 0; s < (kBatched ? img + 1 : spp); ++s) {
+					const uint64_t lane = pix * (uint64_t)spp + (uint64_t)s;
+					Pcg32 rng = lane_stream(seed, spp, kBatched ? 1 : 0, pix, (uint32_t)s);
+					const float jx = rng.next_f32(), jy = rng.next_f32();
+					const float ddx = cx - ((float)nx + jx), ddy = cy - ((float)ny + jy);
+					const float w = kFilter == 1 ? gauss1(ddx) * gauss1(ddy) : tent1(ddx) * tent1(ddy);
+					a0 = a0 + w * L[lane];
+					a1 = a1 + w * L[N + lane];
+					a2 = a2 + w * L[2 * N + lane];
+					wsum = wsum + w;
+				}
 			}
-		}
-	const bool ok = wsum > 0.0f;
-	out[o] = ok ? a0 / wsum : 0.0f;
-	out[npix + o] = ok ? a1 / wsum : 0.0f;
-	out[2 * npix + o] = ok ? a2 / wsum : 0.0f;
+		const bool ok = wsum > 0.0f;
+		float *dst = out + (uint64_t)img * 3u * npix;
+		dst[o] = ok ? a0 / wsum : 0.0f;
+		dst[npix + o] = ok ? a1 / wsum : 0.0f;
+		dst[2 * npix + o] = ok ? a2 / wsum : 0.0f;
+	}
 }
 
 } // namespace pg
@@ -962,6 +967,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.store_nee = ctx->store_nee;
 	a.frac = ctx->bsdf_fraction;
 	a.seed = prm->seed;
+	a.batched = prm->batched ? 1 : 0;
 	a.dc = ctx->dc_on ? ctx->dc : nullptr;
 	a.ray_d = b.ray_d.p; a.thr = b.thr.p; a.L = L_out; a.prev_p = b.prev_p.p;
 	a.prev_pdf = b.prev_pdf.p; a.prev_quad = b.prev_quad.p; a.hit0 = b.hit0.p;
@@ -1196,8 +1202,8 @@ int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const f
 	return pg_film_stripes(ctx, filter, seed, spp, L, image_out, 0, 0, 0, stream);
 }
 
-int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out,
-                    uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
+static int film_launch(pg_context *ctx, int32_t filter, bool batched, uint32_t seed, int32_t spp, const float *L, float *image_out,
+                       uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
 {
 	if (!ctx) return PG_ERR_INVALID;
 	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_film: call pg_scene_set first");
@@ -1207,15 +1213,26 @@ int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp,
 	PG_HIP(ctx, hipSetDevice(ctx->device));
 	const pg_camera &cam = ctx->render->cam;
 	const uint64_t npix = (uint64_t)cam.width * (uint64_t)cam.height;
-	const dim3 grid((unsigned)((npix + kRBlock - 1) / kRBlock));
-	if (filter == PG_FILTER_GAUSSIAN)
-		hipLaunchKernelGGL(k_film<1>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out,
-		                   stripe_rows, stripe_index, stripe_count);
-	else
-		hipLaunchKernelGGL(k_film<0>, grid, dim3(kRBlock), 0, (hipStream_t)stream, seed, spp, cam.width, cam.height, L, image_out,
-		                   stripe_rows, stripe_index, stripe_count);
+	const dim3 grid((unsigned)((npix + kRBlock - 1) / kRBlock)), block(kRBlock);
+	hipStream_t st = (hipStream_t)stream;
+#define PG_FILM(F, B) hipLaunchKernelGGL((k_film<F, B>), grid, block, 0, st, seed, spp, cam.width, cam.height, L, image_out, stripe_rows, stripe_index, stripe_count)
+	if (filter == PG_FILTER_GAUSSIAN) { if (batched) PG_FILM(1, true); else PG_FILM(1, false); }
+	else { if (batched) PG_FILM(0, true); else PG_FILM(0, false); }
+#undef PG_FILM
 	PG_HIP(ctx, hipGetLastError());
 	return PG_OK;
+}
+
+int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const float *L, float *image_out,
+                    uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
+{
+	return film_launch(ctx, filter, false, seed, spp, L, image_out, stripe_rows, stripe_index, stripe_count, stream);
+}
+
+int pg_film_batched(pg_context *ctx, int32_t filter, uint32_t seed, int32_t n_passes, const float *L, float *images_out,
+                    uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
+{
+	return film_launch(ctx, filter, true, seed, n_passes, L, images_out, stripe_rows, stripe_index, stripe_count, stream);
 }
 
 int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, float *out, void *stream)

@@ -1152,6 +1152,7 @@ struct RenderArgs {
 	int spp, max_depth, rr_depth, guided, record, store_nee;
 	float frac;
 	uint32_t seed;
+	int batched;               // pg_pass_params.batched: the spp samples of a pixel are spp one-sample passes seed, seed + 1, ...
 	DepthCounters *dc;
 	int bounce, last;          // index of this launch = path depth of every live lane; last launch of the pass
 	int fuse_guide;            // split pipeline: k_wave_shade_a also makes the SD-tree calls, no k_wave_guide launch
@@ -1232,6 +1233,16 @@ __device__ __forceinline__ bool tail_took_over(const RenderArgs &a, int bounce)
 	return false;
 }
 
+
+// The sampler stream of sample s of film pixel `pixel` (Mitsuba's `independent` sampler: one PCG32 stream per lane of the
+// wavefront, lane = pixel * spp + s, path_guiding_integrator.py:414-417; keyed by the GLOBAL pixel, so a tile renders
+// exactly the samples the full-frame pass would).  A batched call stands for spp consecutive ONE-sample passes with the
+// seeds seed, seed + 1, ... (main.py:192, 218: a training pass is one sample per pixel, seeded initial_seed + cumm_spp):
+// its sample s IS the sample pass seed + s gives the pixel -- lane `pixel` of that pass's wavefront.
+__device__ __forceinline__ Pcg32 lane_stream(uint32_t seed, int spp, int batched, uint64_t pixel, uint32_t s)
+{
+	return batched ? pcg32_seed(seed + s, (uint32_t)pixel) : pcg32_seed(seed, (uint32_t)(pixel * (uint64_t)spp + s));
+}
 
 // film pixel of the tile-local pixel i (pg_pass_params: a contiguous range, or bands of rows dealt round-robin)
 __device__ __forceinline__ uint64_t global_pixel(const RenderArgs &a, uint64_t i)

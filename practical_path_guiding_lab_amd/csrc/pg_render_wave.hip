@@ -242,10 +242,11 @@ __device__ __forceinline__ void stage_guide(const RenderArgs &a, const float *s_
 		if (walk_nee) { g.slot_nee = cursor_slot(cn); c_q += cn.levels; ++c_qq; }
 	}
 	if (a.dc && c_kdq) { // instrumented passes only (pg_enable_depth_counters)
-		atomicAdd(&a.dc->kd_levels, (unsigned long long)c_kd);
+		atomicAdd(&a.dc->kd_levels, (unsigned long long)stat_levels(c_kd)); // (c_kd, c_q: sums of statistics words, pg_descent.hpp)
 		atomicAdd(&a.dc->kd_queries, (unsigned long long)c_kdq);
-		atomicAdd(&a.dc->quad_levels, (unsigned long long)c_q);
+		atomicAdd(&a.dc->quad_levels, (unsigned long long)stat_levels(c_q));
 		atomicAdd(&a.dc->quad_queries, (unsigned long long)c_qq);
+		atomicAdd(&a.dc->layout_bytes, (unsigned long long)(stat_bytes(c_kd) + stat_bytes(c_q)));
 	}
 }
 
@@ -368,10 +369,8 @@ __device__ __forceinline__ void wsput3(const RenderArgs &a, int plane, uint64_t 
 // the camera ray of a lane (mi.render's sensor.sample_ray_differential: one 2-D jitter draw per sample)
 __device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, Pcg32 &rng, v3 &ray_o, v3 &ray_d)
 {
-	// streams are keyed by the GLOBAL lane id (pixel*spp + s): a tile renders exactly the samples the
-	// full-frame pass would, whatever the number of ranks
 	const uint64_t pixel = global_pixel(a, lane / (uint64_t)a.spp);
-	rng = pcg32_seed(a.seed, (uint32_t)(pixel * (uint64_t)a.spp + lane % (uint64_t)a.spp));
+	rng = lane_stream(a.seed, a.spp, a.batched, pixel, (uint32_t)(lane % (uint64_t)a.spp));
 	const int W = a.cam.width, H = a.cam.height;
 	const float px = (float)(pixel % (uint64_t)W), py = (float)(pixel / (uint64_t)W);
 	const float jx = rng.next_f32(), jy = rng.next_f32();

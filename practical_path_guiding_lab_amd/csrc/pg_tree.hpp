@@ -72,8 +72,10 @@ struct alignas(8) TreeHead {
 #ifndef PG_JUMP_BITS
 #define PG_JUMP_BITS 6
 #endif
-constexpr int kJumpBits = PG_JUMP_BITS;
-constexpr uint32_t kJumpCells = 1u << (2 * kJumpBits); // entries per tree
+constexpr int kJumpBits = PG_JUMP_BITS; // the finest table.  A forest takes fewer bits when its tables would not fit their
+                                        // memory budget (pg_refine.hip: rebuild_jump): 4^bits entries per tree, the same for
+                                        // every tree of a forest, a number the kernels read from the view (uniform)
+constexpr uint32_t kJumpCells = 1u << (2 * kJumpBits); // entries per tree of the finest table
 struct alignas(16) QuadJump {
 	uint32_t next;  // record to continue from; kNoRecord: the walk ended in a leaf within the table
 	float pdf;      // product of 4*child/node over the levels taken (final value incl. 1/(4 pi) when ended)
@@ -83,6 +85,11 @@ struct alignas(16) QuadJump {
 	                // slot is the root's accumulator; a walk that hits the table never needs the tree's head)
 };
 constexpr uint32_t kJumpSlotMask = (1u << 26) - 1u;
+// what a kernel holds of a forest's tables: 4^bits entries per tree, tree-major; p == nullptr: none (every level is walked)
+struct JumpRef {
+	const QuadJump *p;
+	int bits;
+};
 
 // Jump grid over the top of the KD tree: the root box cut into 2^kKdGridBits cells per axis; entry
 // (iz, iy, ix) holds the node every point strictly inside that cell reaches from the root before a
@@ -125,7 +132,7 @@ struct TreeView {
 	const KdNode *kd;
 	const QuadRec *rec;
 	const TreeHead *head;
-	const QuadJump *jump; // n_trees * kJumpCells entries, or nullptr
+	JumpRef jump;         // n_trees << (2 * jump.bits) entries, or {nullptr, 0}
 	const KdGridEntry *kd_grid; // 8^grid_bits cell entries + kKdGridRootEntries, or nullptr
 	const float *kd_planes;     // 3 * kKdGridPlanes cell boundaries of the grid (x planes, y planes, z planes), ascending
 	float bmin[3], bmax[3]; // root bounding box (kdtree.py:138)

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .integrator import PathGuidingIntegrator
-from .render import WavefrontScene, render
+from .render import WavefrontScene, render, render_batched
 
 
 class PerformanceData:
@@ -94,8 +94,14 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                       stable_variance_spp_threshold: int = 256, train_stop_cumm_spp: int = 1000,
                       record_in_iteration: bool = False, out_dir: Optional[str] = None,
                       all_reduce: Optional[Callable[[torch.Tensor], None]] = None,
-                      log: Callable[[str], None] = print, shard=None, gt_mask=None) -> Dict:
+                      log: Callable[[str], None] = print, shard=None, gt_mask=None,
+                      training_passes_per_launch: int = 1) -> Dict:
     """Runs the whole training + rendering schedule; returns the final image, logs and timings.
+
+    training_passes_per_launch = B > 1 (with training_spp_per_pass = 1, the reference's value): B consecutive training
+    passes are traced as ONE device pass (pg_pass_params.batched: sample s of the launch is the sample pass seed + s gives
+    the pixel) and developed by one film launch -- images, sums, logs and SD-tree are those of B separate one-sample
+    passes, bit for bit (tests/test_gpu_render.py); the schedule stays main.py's, only the number of launches changes.
 
     Multi-GPU (one process per GPU, torch.distributed initialised): shard = (rank, world[, stripe_rows
     [, group]]) makes this rank trace its interleaved bands of the film only (WavefrontScene.set_shard);
@@ -117,15 +123,24 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         if all_reduce is None:
             all_reduce = lambda acc: all_reduce_accumulators(acc, group)  # noqa: E731
     whole = gather.reduce_image if hasattr(gather, "reduce_image") else (lambda img: img)
+    # Files are written by ONE rank of a sharded run (every rank ends with the same image, tree and logs): the lowest rank
+    # that was given an out_dir.  Whether anyone was is agreed on once, here, so that the collectives below never depend on a
+    # per-rank argument.
+    save_dir, want_blends = out_dir, bool(out_dir)
+    if gather is not None:
+        from .parallel import lowest_rank_with
+        writer = lowest_rank_with(bool(out_dir), group)
+        want_blends = writer >= 0
+        save_dir = out_dir if writer == rank else None
     bmin, bmax = scene.bbox()
     eps = np.float32(1e-4)  # main.py:55-59
     integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
                      quadTreeMaxDepth=quadTreeMaxDepth, isStoreNEERadiance=isStoreNEERadiance,
                      bsdfSamplingFraction=bsdfSamplingFraction)
     integrator.setGroundTruthMask(gt_mask)  # (the pixels a comparison with the ground truth counts; None: all)
-    scene.reserve(integrator, max(batch_spp, training_spp_per_pass))  # (:93: the record arrays are allocated in setup())
-    if out_dir:
-        os.makedirs(out_dir, exist_ok=True)
+    scene.reserve(integrator, max(batch_spp, training_spp_per_pass, int(training_passes_per_launch)))  # (:93: the record arrays are allocated in setup())
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
     rec = {k: PerformanceData() for k in ("variance_inIter", "variance_groundTruth_inIter", "mse_groundTruth_inIter",
                                           "variance_endIter", "variance_groundTruth_endIter", "mse_groundTruth_endIter",
                                           "variance_estimated_final")}
@@ -158,9 +173,19 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         curr_iter_image = None
         curr_iter_acc = None
         log(f"Iteration {k}: SPP {iter_spp}, cumm_SPP {cumm_spp}, remaining {budget_spp - cumm_spp}, final {is_final}")
+        launch = 1  # one-sample training passes traced per device launch
+        if not is_final and spp_per_pass == 1 and not record_in_iteration:
+            launch = max(1, int(training_passes_per_launch))
+        queued: List[torch.Tensor] = []
         for p in range(n_pass):
             cur = min(spp_per_pass, iter_spp - done)
-            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp, gather=gather)  # main.py:218
+            if launch > 1:
+                if not queued:  # the next `launch` passes in one go; their images are then consumed one per turn of this loop
+                    nb = min(launch, n_pass - p)
+                    queued = list(render_batched(scene, integrator, nb, seed=initial_seed + cumm_spp, gather=gather))
+                img = queued.pop(0)
+            else:
+                img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp, gather=gather)  # main.py:218
             wimg = img * float(cur / iter_spp)
             curr_iter_image = wimg if curr_iter_image is None else curr_iter_image + wimg
             if is_final:
@@ -177,11 +202,15 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                                                               variance=integrator.computeVariance(image_spp, ground_truth, sums))
                     rec["mse_groundTruth_inIter"].append(el, image_spp, cumm_spp, k,
                                                          mse=integrator.computeMSE(image_spp, ground_truth, sums))
-            if is_final and cumm_spp in possible and prev_iter_image is not None and out_dir:
+            # main.py:267-291, the intermediate image of a long final iteration.  `whole` is a collective when the film is
+            # sharded, so whether it is issued may depend only on values every rank holds alike (`want_blends`, not this rank's
+            # out_dir: a rank without one would leave the others waiting in the all-reduce)
+            if is_final and cumm_spp in possible and prev_iter_image is not None and want_blends:
                 cur_cnt = cumm_spp - cumm_spp_prev
                 acc_now = whole(curr_iter_acc)
-                blend = (acc_now / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
-                save_image(os.path.join(out_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), blend)
+                if save_dir:
+                    blend = (acc_now / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
+                    save_image(os.path.join(save_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), blend)
         curr_iter_image = whole(curr_iter_image)  # (sharded with a halo exchange: the ranks' rows become the film, once)
         torch.cuda.synchronize()
         t_render = time.perf_counter() - t_iter
@@ -231,121 +260,16 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         torch.cuda.synchronize()
         cumm_time += time.perf_counter() - t_iter
         per_iter.append({"iteration": k, "spp": iter_spp, "render_s": t_render, "refine_s": t_ref})
-        if out_dir:
-            save_image(os.path.join(out_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), image)
-            integrator.saveSDTreeToFile(os.path.join(out_dir, f"sdtree_iter-{k}.npz"))
-            integrator.saveSDTreeOBJ(os.path.join(out_dir, f"kdtree_iter-{k}.obj"))
+        if save_dir:
+            save_image(os.path.join(save_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), image)
+            integrator.saveSDTreeToFile(os.path.join(save_dir, f"sdtree_iter-{k}.npz"))
+            integrator.saveSDTreeOBJ(os.path.join(save_dir, f"kdtree_iter-{k}.obj"))
         variance_prev = variance_current
         k += 1
         cumm_spp_prev = cumm_spp
-    if out_dir:
+    if save_dir:
         for name, r in rec.items():
             if r.rows:
-                r.saveToFile(os.path.join(out_dir, name + ".csv"))
+                r.saveToFile(os.path.join(save_dir, name + ".csv"))
     return {"image": image, "records": rec, "iterations": per_iter, "cumm_spp": cumm_spp, "time_s": cumm_time,
             "guided_samples": guided_samples, "guided_time_s": guided_time}
-
-
-def repeat_high_spp(scene: WavefrontScene, integrator: PathGuidingIntegrator, tree_dir: str, start_iteration: int,
-                    end_iteration: int, max_tree_iteration: int, iter_spp: int, batch_spp: int = 4, initial_seed: int = 0,
-                    ground_truth: Optional[torch.Tensor] = None, sdTreeMaxDepth: int = 20, quadTreeMaxDepth: int = 20,
-                    isStoreNEERadiance: bool = True, bsdfSamplingFraction: float = 0.5, out_dir: Optional[str] = None,
-                    sim_iter: int = 0, gt_mask=None, log: Callable[[str], None] = print) -> Dict:
-    """repeat_high_spp_renderer.py:26-215 (doFullSimulation): every iteration's SD-tree, frozen, rendered with
-    the same `iter_spp` samples -- what each iteration's tree is worth at equal cost.  Iteration k renders as
-    a final iteration (nothing is recorded) with the tree saved after iteration k - 1
-    (`tree_dir`/sdtree_iter-{k-1}.npz, as run_guided_render leaves them; iterations 0 and 1 are unguided,
-    path_guiding_integrator.py:223), passes of `batch_spp`, seeds initial_seed + cumulative spp.  Returns
-    and (with out_dir) writes the reference's records: variance / variance_groundTruth / mse_groundTruth
-    `_endIter_high_spp_sim-{sim_iter}.csv`, and the image of every iteration."""
-    w, h = scene.film_size
-    bmin, bmax = scene.bbox()
-    eps = np.float32(1e-4)
-    integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps, sdTreeMaxDepth=sdTreeMaxDepth,
-                     quadTreeMaxDepth=quadTreeMaxDepth, isStoreNEERadiance=isStoreNEERadiance,
-                     bsdfSamplingFraction=bsdfSamplingFraction)
-    integrator.setGroundTruthMask(gt_mask)
-    scene.reserve(integrator, batch_spp)
-    if out_dir:
-        os.makedirs(out_dir, exist_ok=True)
-    rec = {k: PerformanceData() for k in ("variance_endIter", "variance_groundTruth_endIter", "mse_groundTruth_endIter")}
-    theo_cumm_iter_spp = cumm_spp = 0
-    elapsed = 0.0
-    images = {}
-    for k in range(start_iteration, end_iteration + 1):
-        integrator.resetVarianceCounter()
-        theo_cumm_iter_spp += 2 ** (k + 1) if k > 0 else 0  # :80-84: 0 4 12 28 ...
-        if 0 < k <= max_tree_iteration:  # :87-89
-            integrator.loadSDTreeFromFile(os.path.join(tree_dir, f"sdtree_iter-{k - 1}.npz"))
-        integrator.setIteration(k, True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        image, done = None, 0
-        while done < iter_spp:
-            cur = min(batch_spp, iter_spp - done)
-            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp)  # :122
-            wimg = img * float(cur / iter_spp)
-            image = wimg if image is None else image + wimg
-            done += cur
-            cumm_spp += cur
-        torch.cuda.synchronize()
-        elapsed += time.perf_counter() - t0
-        variance = integrator.computeVariance(done)
-        variance_gt = integrator.computeVariance(done, ground_truth) if ground_truth is not None else 0.0
-        mse_gt = integrator.computeMSE(done, ground_truth) if ground_truth is not None else 0.0
-        rec["variance_endIter"].append(elapsed, done, theo_cumm_iter_spp + done, k, variance=variance)
-        rec["variance_groundTruth_endIter"].append(elapsed, done, theo_cumm_iter_spp + done, k, variance=variance_gt)
-        rec["mse_groundTruth_endIter"].append(elapsed, done, theo_cumm_iter_spp + done, k, mse=mse_gt)
-        log(f"Iteration {k} (frozen tree, {done} spp): variance {variance:.6g}  variance_gt {variance_gt:.6g}  mse_gt {mse_gt:.6g}")
-        images[k] = image
-        if out_dir:
-            save_image(os.path.join(out_dir, f"high_spp_iter-{k}_spp-{done}"), image)
-    if out_dir:
-        for name, r in rec.items():
-            r.saveToFile(os.path.join(out_dir, f"{name}_high_spp_sim-{sim_iter}.csv"))
-    return {"records": rec, "images": images, "time_s": elapsed}
-
-
-def run_path_tracing(scene: WavefrontScene, integrator: PathGuidingIntegrator, target_spp: Optional[int] = None,
-                     time_budget_s: Optional[float] = None, chunk_spp: int = 4, initial_seed: int = 0,
-                     ground_truth: Optional[torch.Tensor] = None, out_dir: Optional[str] = None, gt_mask=None,
-                     log: Callable[[str], None] = print) -> Dict:
-    """path_tracing_render.py:24-165, the reference's benchmark renderer: the same sample() without the
-    SD-tree -- here the integrator held at iteration 0 as a final iteration (guiding needs iteration > 1,
-    path_guiding_integrator.py:223; nothing is recorded) -- in chunks of `chunk_spp` with seeds
-    initial_seed + pass number, until `target_spp` samples or `time_budget_s` seconds (which overrides).
-    Records (time, spp, variance vs ground truth, MSE) after every chunk: what guiding has to beat."""
-    if (target_spp is None) == (time_budget_s is None):
-        raise ValueError("give target_spp or time_budget_s")
-    w, h = scene.film_size
-    bmin, bmax = scene.bbox()
-    eps = np.float32(1e-4)
-    integrator.setup(numRays=w * h, bbox_min=bmin - eps, bbox_max=bmax + eps)
-    integrator.setGroundTruthMask(gt_mask)
-    integrator.setIteration(0, True)
-    integrator.resetVarianceCounter()
-    scene.reserve(integrator, chunk_spp)
-    rec = PerformanceData()
-    image_acc, used, passes = None, 0, 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    elapsed = 0.0
-    while (used < target_spp) if time_budget_s is None else (elapsed < time_budget_s):
-        cur = chunk_spp if time_budget_s is not None else min(chunk_spp, target_spp - used)
-        img = render(scene, integrator, spp=cur, seed=initial_seed + passes)  # :88, 128
-        image_acc = img * cur if image_acc is None else image_acc + img * cur
-        used += cur
-        passes += 1
-        mse = integrator.computeMSE(used, ground_truth) if ground_truth is not None else 0.0
-        var = integrator.computeVariance(used, ground_truth) if ground_truth is not None else integrator.computeVariance(used)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        rec.append(elapsed, used, used, 0, variance=var, mse=mse)
-    image = image_acc / float(used)
-    log(f"path tracing: {used} spp in {elapsed:.2f} s = {w * h * used / max(elapsed, 1e-9) / 1e6:.1f} Msamples/s; "
-        f"variance {rec.rows[-1][4]:.6g}  mse_gt {rec.rows[-1][5]:.6g}")
-    if out_dir:
-        os.makedirs(out_dir, exist_ok=True)
-        save_image(os.path.join(out_dir, f"path_tracing-{used}"), image)
-        rec.saveToFile(os.path.join(out_dir, "variance_groundTruth_path_tracing.csv"))
-    return {"image": image, "record": rec, "spp": used, "time_s": elapsed}

@@ -156,23 +156,46 @@ class HaloExchange:
     of its own bands (pg_film_stripes) and fetches only the filter's reach beyond them from its two ring
     neighbours -- per pass and neighbour `reach` rows x width x spp x 12 bytes per band, instead of the
     all-reduce of the whole film's samples LaneGather does.  The developed images of the ranks (zero outside
-    their own rows) are summed once per iteration (reduce_image; x + 0 is exact)."""
+    their own rows) are summed once per iteration (reduce_image; x + 0 is exact).
+
+    Message order.  A rank issues, in this order: send to next, send to previous, receive from previous, receive
+    from next.  With two ranks both neighbours are the same peer, and a backend that ignores tags (NCCL does)
+    pairs the messages of one peer in issue order: the peer's FIRST send (its send_next) must be what this rank
+    receives FIRST (recv_prev), its second send (send_prev) what it receives second (recv_next).  halo_plan makes
+    send_next of rank r equal recv_prev of rank r + 1 row for row, so the pairing holds; _plan() checks that
+    equality against the neighbours' own plans once per plan.  (This path has run over gloo only -- with 2, 3
+    and 8 ranks, tests/test_multi_rank.py; no multi-GPU hardware is reachable from where it was written.)"""
 
     def __init__(self, group=None):
         self.group = group
         self._full = None
         self._plans = {}
 
-    def _plan(self, scene, reach):
-        key = (scene.film_size, scene.stripe, reach)
+    def _peer(self, r: int) -> int:
+        """dist.P2POp addresses GLOBAL ranks: band-ring index r of `group` -> the global rank."""
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def _plan(self, scene, reach, device):
+        key = (scene.film_size, scene.stripe, reach, str(device))
         if key not in self._plans:
             rows, index, count = scene.stripe
-            self._plans[key] = halo_plan(scene.film_size[1], rows, index, count, reach)
-        return self._plans[key]
+            h = scene.film_size[1]
+            plan = halo_plan(h, rows, index, count, reach)
+            send_next, send_prev, recv_prev, recv_next = plan
+            # the same message at both ends (and, for two ranks, the issue order the pairing relies on)
+            assert send_next == halo_plan(h, rows, (index + 1) % count, count, reach)[2]
+            assert send_prev == halo_plan(h, rows, (index - 1) % count, count, reach)[3]
+            own = [y for y in range(h) if (y // rows) % count == index]
 
-    def _local_row(self, scene, y: int) -> int:
-        rows, _, count = scene.stripe
-        return (y // rows // count) * rows + y % rows
+            def idx(ys):
+                return torch.as_tensor(ys, dtype=torch.long, device=device)
+
+            def local(ys):
+                return idx([(y // rows // count) * rows + y % rows for y in ys])
+
+            self._plans[key] = {"rows": plan, "own": idx(own), "n_own": len(own), "send_next": local(send_next),
+                                "send_prev": local(send_prev), "recv_prev": idx(recv_prev), "recv_next": idx(recv_next)}
+        return self._plans[key]
 
     def __call__(self, L: torch.Tensor, scene, spp: int, reach: int) -> torch.Tensor:
         """(3, pixels * spp) in full-frame lane order, valid on this rank's rows and `reach` rows around its bands."""
@@ -184,43 +207,56 @@ class HaloExchange:
         if self._full is None or self._full.numel() != n or self._full.device != L.device:
             self._full = torch.zeros((3, h, w * spp), dtype=L.dtype, device=L.device)
         full = self._full
-        own = [y for y in range(h) if (y // rows) % count == index]
-        Lr = L.reshape(3, len(own), w * spp)
-        full[:, torch.as_tensor(own, device=L.device)] = Lr
-        send_next, send_prev, recv_prev, recv_next = self._plan(scene, reach)
-        nxt, prv = (index + 1) % count, (index - 1) % count
+        pl = self._plan(scene, reach, L.device)
+        Lr = L.reshape(3, pl["n_own"], w * spp)
+        full[:, pl["own"]] = Lr
+        nxt, prv = self._peer((index + 1) % count), self._peer((index - 1) % count)
         host = dist.get_backend(self.group) == "gloo" and L.is_cuda  # (gloo moves host memory)
 
-        def pick(ys):
-            t = Lr[:, torch.as_tensor([self._local_row(scene, y) for y in ys], dtype=torch.long, device=L.device)].contiguous()
+        def pick(ix):
+            t = Lr[:, ix].contiguous()
             return t.cpu() if host else t
 
-        def room(ys):
-            return torch.empty((3, len(ys), w * spp), dtype=L.dtype, device="cpu" if host else L.device)
+        def room(ix):
+            return torch.empty((3, ix.numel(), w * spp), dtype=L.dtype, device="cpu" if host else L.device)
 
         ops, got = [], []
-        # tags keep the two messages apart when both neighbours are the same rank (two ranks)
-        if send_next:
-            ops.append(dist.P2POp(dist.isend, pick(send_next), nxt, self.group, 0))
-        if send_prev:
-            ops.append(dist.P2POp(dist.isend, pick(send_prev), prv, self.group, 1))
-        if recv_prev:
-            got.append((recv_prev, room(recv_prev)))
+        # (tags keep the two messages of one peer apart where the backend honours them; where it does not, the issue order
+        # documented above does)
+        if pl["send_next"].numel():
+            ops.append(dist.P2POp(dist.isend, pick(pl["send_next"]), nxt, self.group, 0))
+        if pl["send_prev"].numel():
+            ops.append(dist.P2POp(dist.isend, pick(pl["send_prev"]), prv, self.group, 1))
+        if pl["recv_prev"].numel():
+            got.append((pl["recv_prev"], room(pl["recv_prev"])))
             ops.append(dist.P2POp(dist.irecv, got[-1][1], prv, self.group, 0))
-        if recv_next:
-            got.append((recv_next, room(recv_next)))
+        if pl["recv_next"].numel():
+            got.append((pl["recv_next"], room(pl["recv_next"])))
             ops.append(dist.P2POp(dist.irecv, got[-1][1], nxt, self.group, 1))
         self.bytes_last_pass = sum(op.tensor.numel() * 4 for op in ops if op.op is dist.isend)
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for ys, buf in got:
-            full[:, torch.as_tensor(ys, device=L.device)] = buf.to(L.device)
+        for ix, buf in got:
+            full[:, ix] = buf.to(L.device)
         return full.reshape(3, h * w * spp)
 
     def reduce_image(self, image: torch.Tensor) -> torch.Tensor:
         """The film of all ranks from the images they developed for their own rows (zero elsewhere)."""
         return _all_reduce_sum(image.clone(), self.group)
+
+
+def lowest_rank_with(flag: bool, group: Optional[dist.ProcessGroup] = None) -> int:
+    """The lowest rank of `group` whose `flag` is set, or -1 when none is -- the same number on every rank (one MIN
+    all-reduce): how the ranks of a sharded render agree on who writes files, so that no collective depends on a
+    per-rank argument."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0 if flag else -1
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    t = torch.tensor([rank if flag else world], dtype=torch.int64, device=_flag_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    r = int(t.item())
+    return r if r < world else -1
 
 
 def min_max_over_ranks(value: float, group: Optional[dist.ProcessGroup] = None):

@@ -23,9 +23,13 @@ class IndependentSampler:
     """What the driver uses of mi.Sampler: `sample_count()` and a seed (PCG32 streams are derived
     per lane on the device: pcg32_seed(seed, lane))."""
 
-    def __init__(self, sample_count: int = 1, seed: int = 0):
+    def __init__(self, sample_count: int = 1, seed: int = 0, batched: bool = False):
+        """batched: the `sample_count` samples of a pixel are that many consecutive ONE-sample passes with the seeds
+        seed, seed + 1, ... traced in one wavefront (pg_pass_params.batched) -- the reference's training passes
+        (main.py:192, 218), bit for bit, in one launch instead of sample_count."""
         self._spp = int(sample_count)
         self._seed = int(seed)
+        self.batched = bool(batched)
 
     def sample_count(self) -> int:
         return self._spp
@@ -224,7 +228,7 @@ class WavefrontScene:
             if n == 0:
                 return L, valid, spp
             p = N.pg_pass_params(sampler.seed_value & 0xFFFFFFFF, spp, int(integrator.rr_depth), slot, begin, count,
-                                 stripe[0], stripe[1], stripe[2], 0)
+                                 stripe[0], stripe[1], stripe[2], 1 if getattr(sampler, "batched", False) else 0)
             sl = integrator.sumL.data_ptr() if accumulate else None
             sl2 = integrator.sumL2.data_ptr() if accumulate else None
             N.check(tree._h, tree._lib.pg_render_pass(tree._h, C.byref(p), L.data_ptr(), valid.data_ptr(), sl, sl2,
@@ -234,6 +238,42 @@ class WavefrontScene:
             L.record_stream(torch.cuda.current_stream())
             valid.record_stream(torch.cuda.current_stream())
         return L, valid, spp
+
+
+def render_batched(scene: WavefrontScene, integrator, n_passes: int, seed: int, gather=None) -> torch.Tensor:
+    """[render(scene, integrator, 1, seed + s) for s in range(n_passes)] -- the reference's one-sample training passes
+    (main.py:192, 218) -- as ONE device pass (pg_pass_params.batched) and one film launch (pg_film_batched): returns the
+    n_passes images, (n_passes, H, W, 3), each bit-identical to the image of the separate call; the integrator's sums and
+    sdTree_current end as after the separate calls.  Box filter: the image of a one-sample pass is its samples."""
+    sampler = IndependentSampler(n_passes, seed, batched=True)
+    L, _, _ = integrator.sample(scene, sampler)
+    scene.join()
+    w, h = scene.film_size
+    tree = integrator.sdTree
+    filt = scene.scene.rfilter
+    stripes = (0, 0, 0)
+    partial = False
+    if scene.sharded:
+        if gather is None:
+            return L.reshape(3, -1, n_passes).permute(2, 1, 0).reshape(n_passes, -1, 1, 3).contiguous()
+        if hasattr(gather, "reduce_image"):
+            partial = True
+            stripes = scene.stripe
+            if filt in ("tent", "gaussian"):
+                L = gather(L, scene, n_passes, 1 if filt == "tent" else 2)
+        else:
+            L = gather(L, scene, n_passes)
+    if filt in ("tent", "gaussian"):
+        img = (torch.zeros if partial else torch.empty)((n_passes, 3, h * w), dtype=torch.float32, device=tree.device)
+        N.check(tree._h, tree._lib.pg_film_batched(tree._h, ("tent", "gaussian").index(filt), seed & 0xFFFFFFFF, n_passes,
+                                                   L.data_ptr(), img.data_ptr(), stripes[0], stripes[1], stripes[2],
+                                                   torch.cuda.current_stream().cuda_stream))
+        return img.reshape(n_passes, 3, h, w).permute(0, 2, 3, 1).contiguous()
+    if partial:
+        img = torch.zeros((n_passes, 3, h * w), dtype=torch.float32, device=tree.device)
+        img[:, :, torch.from_numpy(scene.local_pixels()).to(tree.device)] = L.reshape(3, -1, n_passes).permute(2, 0, 1)
+        return img.reshape(n_passes, 3, h, w).permute(0, 2, 3, 1).contiguous()
+    return L.reshape(3, h, w, n_passes).permute(3, 1, 2, 0).contiguous()
 
 
 def render(scene: WavefrontScene, integrator, spp: int, seed: int, gather=None) -> torch.Tensor:

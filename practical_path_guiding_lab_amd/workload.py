@@ -209,3 +209,206 @@ def bounce_bytes(kd_levels, kd_queries, quad_levels, quad_queries) -> float:
 def splat_bytes(kd_levels, records, quad_levels, quad_descents) -> float:
     """B_rec summed over a launch: 16*D_kd + 4 + (4+8)*D_q per descent + 48 B record."""
     return 16.0 * kd_levels + 4.0 * records + 12.0 * quad_levels + 48.0 * records
+
+
+# ================================================================================================
+# SURVEY.md 8(d)'s kernel-level synthetic inputs S1 / S2 / S3, generated by the package itself with torch
+# (on the GPU in bench.py, where 2^25 records take milliseconds; on the CPU in the tests, which hand the very same
+# arrays to the CPU oracle).  Streams are Mitsuba's `independent` sampler -- PCG32 seeded through TEA, the
+# published algorithms, in 64-bit integer arithmetic (two's-complement int64 stands in for uint64: products and
+# sums wrap alike, right shifts are masked) -- so the inputs are the ones the round-1..3 tools took from the
+# oracle's generator (tests/test_host_logic.py compares them bit for bit).
+# ================================================================================================
+import numpy as np  # noqa: E402
+
+S_BBOX = (0.0, 100.0)          # kdtree.py:700 builds its test tree over [0, 100]^3
+S1_KD_DEPTH, S1_QUAD_DEPTH = 12, 5
+S_QUERIES = 1 << 22
+S2_RECORDS = 1 << 24
+S2_ITERATIONS = 6
+_M32 = 0xFFFFFFFF
+
+
+def _tea64(v0: torch.Tensor, v1: torch.Tensor) -> torch.Tensor:
+    """Tiny Encryption Algorithm, 4 rounds, on uint32 pairs held in int64 (masked after every step)."""
+    v0, v1 = v0.clone(), v1.clone()
+    s = 0
+    for _ in range(4):
+        s = (s + 0x9E3779B9) & _M32
+        v0 = (v0 + ((((v1 << 4) & _M32) + 0xA341316C) ^ (v1 + s) ^ ((v1 >> 5) + 0xC8013EA4))) & _M32
+        v1 = (v1 + ((((v0 << 4) & _M32) + 0xAD90777D) ^ (v0 + s) ^ ((v0 >> 5) + 0x7E95761E))) & _M32
+    return (v0 << 32) | v1   # (bit 63 may be set: the int64 is the uint64's bit pattern)
+
+
+def _lsr(x: torch.Tensor, k: int) -> torch.Tensor:
+    """logical right shift of the uint64 bit pattern held in an int64"""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+class Pcg32Lanes:
+    """n PCG32 streams seeded like Mitsuba's independent sampler: lane i = stream (seed, lane0 + i)."""
+
+    MULT = 0x5851F42D4C957F2D
+
+    def __init__(self, n: int, seed: int, lane0: int = 0, device="cpu"):
+        lane = (torch.arange(n, dtype=torch.int64, device=device) + int(lane0)) & _M32
+        sd = torch.full((n,), seed & _M32, dtype=torch.int64, device=device)
+        initstate, initseq = _tea64(sd, lane), _tea64(lane, sd)
+        self.inc = (initseq << 1) | 1
+        self.state = torch.zeros(n, dtype=torch.int64, device=device)
+        self.next_u32()
+        self.state = self.state + initstate
+        self.next_u32()
+
+    def next_u32(self) -> torch.Tensor:
+        old = self.state
+        self.state = old * self.MULT + self.inc
+        x = _lsr(_lsr(old, 18) ^ old, 27) & _M32
+        rot = _lsr(old, 59)
+        return ((x >> rot) | (x << ((32 - rot) & 31))) & _M32
+
+    def next_f32(self) -> torch.Tensor:
+        bits = (self.next_u32() >> 9) | 0x3F800000
+        return bits.to(torch.int32).view(torch.float32) - 1.0
+
+
+def s_uniform(n: int, seed: int, draws: int = 1, lane0: int = 0, device="cpu") -> torch.Tensor:
+    """(draws, n) fp32 uniforms in [0, 1): lane i draws from stream (seed, lane0 + i)."""
+    r = Pcg32Lanes(n, seed, lane0, device)
+    return torch.stack([r.next_f32() for _ in range(draws)])
+
+
+def s_positions_uniform(n: int, seed: int, bbox=S_BBOX, device="cpu") -> torch.Tensor:
+    u = s_uniform(n, seed, 3, device=device)
+    return (bbox[0] + u * (bbox[1] - bbox[0])).contiguous()
+
+
+def s_directions_uniform(n: int, seed: int, device="cpu") -> torch.Tensor:
+    """Directions uniform on the sphere: canonicalToDir (common.py:100-121) of uniform canonical points, in double (an
+    INPUT generator: product and oracle are both handed its result)."""
+    u = s_uniform(n, seed, 2, device=device).to(torch.float64)
+    cos_t = 2.0 * u[1] - 1.0
+    sin_t = torch.sqrt(torch.clamp(1.0 - cos_t * cos_t, min=0.0))
+    phi = 2.0 * math.pi * u[0]
+    return torch.stack([sin_t * torch.cos(phi), sin_t * torch.sin(phi), cos_t]).to(torch.float32).contiguous()
+
+
+def s_positions_clustered(n, seed, bbox=S_BBOX, power=3, device="cpu"):
+    u = s_uniform(n, seed, 3 * power + 3, device=device)
+    t = torch.ones((3, n), dtype=torch.float32, device=device)
+    for k in range(power):
+        t = t * u[3 * k: 3 * k + 3]
+    sgn = torch.where(u[3 * power: 3 * power + 3] < 0.5, -1.0, 1.0).to(torch.float32)
+    c = 0.5 + (0.5 * sgn) * t
+    return (bbox[0] + c * (bbox[1] - bbox[0])).contiguous()
+
+
+def s_canonical_lobes(n, seed, shift=0, device="cpu"):
+    u = s_uniform(n, seed, 5, device=device)
+    centres = np.array([[0.125, 0.75], [0.625, 0.25], [0.375, 0.375], [0.875, 0.875]], np.float32)
+    centres = ((centres + np.float32(shift) * np.float32(0.0625)) % np.float32(1.0)).astype(np.float32)
+    centres = torch.from_numpy(centres).to(device)
+    k = torch.clamp((u[0] * 5.0).to(torch.int64), max=4)
+    bg = k == 4
+    kk = torch.where(bg, 0, k)
+    out = []
+    for a in range(2):
+        lob = centres[kk, a] + (u[1 + a] * u[3 + a] - 0.25) * 0.0625
+        out.append(torch.where(bg, u[1 + a], lob))
+    return torch.clamp(torch.stack(out), 0.0, 1.0).contiguous()
+
+
+def s_records(m: int, seed: int, bbox=S_BBOX, shift: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """A record stream shaped like scatterDataIntoSDTree's output (path_guiding_integrator.py:485-497): positions dense
+    near the centre of the box, canonical directions in four tight lobes over a uniform background, heavy-tailed
+    radiance 2^(8u-4) u', woPdf in [0.05, 1)."""
+    u = s_uniform(m, seed + 3, 4, device=device)
+    e = torch.floor(u[0] * 8.0).to(torch.int32) - 4
+    return {
+        "position": s_positions_clustered(m, seed, bbox, device=device), "direction": s_canonical_lobes(m, seed + 1, shift, device),
+        "radiance": torch.ldexp(u[1], e), "woPdf": 0.05 + 0.95 * u[2],
+        "direction_nee": s_canonical_lobes(m, seed + 2, shift, device),
+        "radiance_nee_lum": torch.where(u[3] < 0.25, 0.0, torch.ldexp(u[3], e)).to(torch.float32),
+    }
+
+
+def s2_record_stream(k: int, device="cpu") -> Dict[str, torch.Tensor]:
+    """Records of iteration k of S2's six splat + refine iterations: 2^19 ... 2^24 of them."""
+    return s_records(S2_RECORDS >> (S2_ITERATIONS - 1 - k), 77 + 10 * k, device=device)
+
+
+def s1_balanced_tree(kd_depth: int = S1_KD_DEPTH, quad_depth: int = S1_QUAD_DEPTH, seed: int = 1234, bbox=S_BBOX) -> dict:
+    """S1 in the reference's 23-key schema (kdtree.py:575-602), built directly: a KD tree complete to `kd_depth` over
+    bbox^3 in the reference's node numbering (round r splits the 2^r leaves of depth r in ascending order, children
+    appended at old + 2 i, old + 2 i + 1; the left child keeps its parent's quadtree, the right one gets tree 2^r + i:
+    kdtree.py:243-245, 316-323), every leaf owning a complete quadtree of `quad_depth` in the canonical arena (roots,
+    then level by level, four consecutive children per node in quadrant order 1..4, quadtree.py:110-175, 695-851);
+    leaf irradiance 1 - u (PCG32 stream = node index, seed 1234), inner nodes c1 + c2 + c3 + c4 in fp32, that order."""
+    lo, hi = np.float32(bbox[0]), np.float32(bbox[1])
+    n_kd = (1 << (kd_depth + 1)) - 1
+    bmin = np.zeros((n_kd, 3), np.float32)
+    bmax = np.zeros((n_kd, 3), np.float32)
+    depth = np.zeros(n_kd, np.uint32)
+    left = np.zeros(n_kd, np.uint32)
+    right = np.zeros(n_kd, np.uint32)
+    qroot = np.zeros(n_kd, np.uint32)
+    bmin[0], bmax[0] = lo, hi
+    for d in range(kd_depth):
+        first, cnt = (1 << d) - 1, 1 << d
+        par = np.arange(first, first + cnt)
+        l = (first + cnt) + 2 * np.arange(cnt)
+        r = l + 1
+        axis = d % 3
+        mid = ((bmin[par, axis] + bmax[par, axis]) / np.float32(2.0)).astype(np.float32)
+        for ch in (l, r):
+            bmin[ch], bmax[ch], depth[ch] = bmin[par], bmax[par], d + 1
+        bmax[l, axis] = mid
+        bmin[r, axis] = mid
+        left[par], right[par] = l, r
+        qroot[l] = qroot[par]
+        qroot[r] = cnt + np.arange(cnt)
+    is_leaf = depth == kd_depth
+    R = 1 << kd_depth
+    per_tree = sum(4 ** l for l in range(quad_depth + 1))
+    n_q = R * per_tree
+    base = [R * sum(4 ** j for j in range(l)) for l in range(quad_depth + 2)]  # first node of level l
+    q_depth = np.zeros(n_q, np.uint32)
+    q_min = np.zeros((n_q, 2), np.float32)
+    q_max = np.ones((n_q, 2), np.float32)
+    q_child = np.zeros((4, n_q), np.uint32)
+    for l in range(quad_depth):
+        n_l = R * 4 ** l
+        par = base[l] + np.arange(n_l)
+        mid = ((q_min[par] + q_max[par]) / np.float32(2.0)).astype(np.float32)
+        for c in range(4):
+            ch = base[l + 1] + 4 * np.arange(n_l) + c
+            q_child[c, par] = ch
+            q_depth[ch] = l + 1
+            # quadtree.py:153-175: child 1 = [mid, max], 2 = x [min, mid] y [mid, max], 3 = [min, mid], 4 = x [mid, max] y [min, mid]
+            x_hi, y_hi = c in (0, 3), c in (0, 1)
+            q_min[ch, 0] = mid[:, 0] if x_hi else q_min[par, 0]
+            q_max[ch, 0] = q_max[par, 0] if x_hi else mid[:, 0]
+            q_min[ch, 1] = mid[:, 1] if y_hi else q_min[par, 1]
+            q_max[ch, 1] = q_max[par, 1] if y_hi else mid[:, 1]
+    q_leaf = q_depth == quad_depth
+    irr = np.zeros(n_q, np.float32)
+    u = s_uniform(n_q, seed, 1)[0].numpy()
+    irr[q_leaf] = (np.float32(1) - u[q_leaf]).astype(np.float32)
+    for l in range(quad_depth - 1, -1, -1):
+        par = base[l] + np.arange(R * 4 ** l)
+        s = irr[q_child[0, par]]
+        for c in (1, 2, 3):
+            s = (s + irr[q_child[c, par]]).astype(np.float32)
+        irr[par] = s
+    return {
+        "kdtree_maxLeafSize": np.float64(1.0), "kdtree_maxDepth": np.int64(max(kd_depth, 1)),
+        "kdtree_bbox_min": bmin, "kdtree_bbox_max": bmax, "kdtree_depth": depth,
+        "kdtree_vertCount": np.zeros(n_kd, np.float32), "kdtree_isLeaf": is_leaf,
+        "kdtree_quadTreeRootIndex": qroot, "kdtree_child_left_index": left, "kdtree_child_right_index": right,
+        "quadtree_maxDepth": np.int64(max(quad_depth, 1)), "quadtree_isStoreNEERadiance": np.bool_(True),
+        "quadtree_rootNodeIndex": np.arange(R, dtype=np.uint32), "quadtree_bbox_min": q_min, "quadtree_bbox_max": q_max,
+        "quadtree_depth": q_depth, "quadtree_irradiance": irr, "quadtree_isLeaf": q_leaf,
+        "quadtree_refinementThreshold": np.full(n_q, np.inf, np.float32),  # (the initial root's, copied by every split: quadtree.py:355-359, 133)
+        "quadtree_child_1_index": q_child[0], "quadtree_child_2_index": q_child[1],
+        "quadtree_child_3_index": q_child[2], "quadtree_child_4_index": q_child[3],
+    }

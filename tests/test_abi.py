@@ -32,7 +32,7 @@ def test_abi_version_and_loud_failure_without_gpu(native):
     L = native.lib()
     hdr = open(os.path.join(ROOT, "include", "pgsd.h")).read()
     declared = int(re.search(r"^#define PGSD_ABI_VERSION (\d+)", hdr, flags=re.M).group(1))
-    assert L.pg_abi_version() == declared == native.ABI_VERSION == 3   # header, library and bindings agree
+    assert L.pg_abi_version() == declared == native.ABI_VERSION == 4   # header, library and bindings agree
     import torch
 
     if torch.cuda.is_available():
@@ -53,5 +53,5 @@ def test_struct_layouts_match_header(native):
     assert ctypes.sizeof(native.pg_dense_records) == 9 * 8
     assert ctypes.sizeof(native.pg_tree_sizes) == 24
     assert ctypes.sizeof(native.pg_tree_columns) == 8 + 3 * 4 + 4 + 19 * 8
-    assert ctypes.sizeof(native.pg_stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8
-    assert ctypes.sizeof(native.pg_depth_counters) == 32
+    assert ctypes.sizeof(native.pg_stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 8 + 2 * 4
+    assert ctypes.sizeof(native.pg_depth_counters) == 40

@@ -109,43 +109,6 @@ def test_main_py_masks_the_teapots_of_veach_ajar_in_its_mse(tmp_path):
     assert abs(lum[m].mean() - masked) <= 1e-4 * masked
 
 
-def test_main_py_repeats_every_iterations_tree_at_equal_spp(tmp_path):
-    """--repeat-high-spp (repeat_high_spp_renderer.py): after the schedule every iteration's saved tree is
-    loaded again and rendered, frozen, with the same number of samples; one record per iteration."""
-    out = str(tmp_path / "rep")
-    gt = os.path.join(ROOT, "tests", "golden", "cornell_gt_256_f16.npy")   # box-filtered 4x to the 64-pixel film
-    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "cornell-box", "--width", "64", "--height", "64",
-           "--budget-spp", "60", "--ground-truth", gt, "--repeat-high-spp", "16", "--out", out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout.count("frozen tree, 16 spp") == 4
-    rows = open(os.path.join(out, "mse_groundTruth_endIter_high_spp_sim-0.csv")).read().splitlines()
-    assert rows[0] == "time,spp,cumm_spp,iteration,variance,mse" and len(rows) == 5
-    cols = [r_.split(",") for r_ in rows[1:]]
-    assert [int(c[3]) for c in cols] == [0, 1, 2, 3] and all(int(c[1]) == 16 for c in cols)
-    assert [int(c[2]) for c in cols] == [16, 4 + 16, 12 + 16, 28 + 16]            # theoretical cumulative spp + this render's
-    mse = [float(c[5]) for c in cols]
-    assert all(np.isfinite(m) and 0 < m < 1 for m in mse)
-    files = set(os.listdir(out))
-    assert all(f"high_spp_iter-{k}_spp-16.exr" in files for k in range(4))
-
-
-def test_main_py_path_tracing_baseline(tmp_path):
-    """--path-tracing (path_tracing_render.py): the unguided benchmark renderer, by sample count and by time."""
-    out = str(tmp_path / "pt")
-    gt = os.path.join(ROOT, "tests", "golden", "cornell_gt_256_f16.npy")
-    base = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "cornell-box", "--width", "64", "--height", "64",
-            "--ground-truth", gt, "--path-tracing", "--out", out]
-    r = subprocess.run(base + ["--budget-spp", "22", "--batch-spp", "8"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "path tracing: 22 spp" in r.stdout
-    rows = [x.split(",") for x in open(os.path.join(out, "variance_groundTruth_path_tracing.csv")).read().splitlines()[1:]]
-    assert [int(x[1]) for x in rows] == [8, 16, 22] and float(rows[-1][5]) < float(rows[0][5])   # MSE falls with spp
-    assert "path_tracing-22.exr" in os.listdir(out)
-    r = subprocess.run(base + ["--time-budget", "0.2", "--batch-spp", "4"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "path tracing:" in r.stdout
-
-
 def test_sdtree_file_round_trip(tmp_path):
     """saveSDTreeToFile -> loadSDTreeFromFile into a fresh integrator: the 23 keys, the same columns,
     and a tree that samples, evaluates and keeps training exactly like the one that was saved."""

@@ -567,3 +567,93 @@ def test_two_passes_in_flight_equal_one_at_a_time(which):
     for st in (0, 1, 2):
         same(ref, run(1, 0, sort=True, stages=st, split=True))
         same(ref, run(2, 0, sort=False, stages=st, split=True))
+
+
+@pytest.mark.parametrize("which", ["cornell-box", "veach-ajar", "torus"])
+def test_batched_launch_equals_separate_one_sample_passes(which):
+    """pg_pass_params.batched / pg_film_batched: B consecutive one-sample passes (the reference's training passes,
+    main.py:192, seeded initial_seed + cumm_spp, :218) traced as one wavefront are those B passes, bit for bit --
+    radiance per sample, the developed image of every pass, the per-pixel sums (added in pass order), the accumulators
+    of sdTree_current and the tree refined from them -- for the fused kernels (cornell-box, tent film), the wavefront
+    pipeline (veach-ajar) and the gaussian film (torus); unguided and guided iterations; a whole film and a band-sharded
+    tile."""
+    import torch
+    from practical_path_guiding_lab_amd import scene as S
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene, render, render_batched
+
+    sc = {"cornell-box": lambda: S.cornell_box(40, 28, 6, 3), "veach-ajar": lambda: S.veach_ajar(48, 27, 9),
+          "torus": lambda: S.torus(40, 30, 10)}[which]()
+    w, h = sc.camera.width, sc.camera.height
+    B = 5
+
+    def fresh():
+        g = PathGuidingIntegrator({"max_depth": sc.max_depth, "rr_depth": sc.rr_depth})
+        g.setup(w * h, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
+        return g, WavefrontScene(sc)
+
+    (ga, wa), (gb, wb) = fresh(), fresh()
+    seed = 1000
+    for k in range(4):  # iterations 2 and 3 are guided
+        for g in (ga, gb):
+            g.setIteration(k, False)
+            g.resetVarianceCounter()
+        n = 2 ** (k + 2)
+        imgs_a, imgs_b = [], []
+        for p in range(n):
+            imgs_a.append(render(wa, ga, 1, seed + p))
+        for p in range(0, n, B):
+            imgs_b += list(render_batched(wb, gb, min(B, n - p), seed + p))
+        seed += n
+        assert len(imgs_a) == len(imgs_b) == n
+        for ia, ib in zip(imgs_a, imgs_b):
+            assert ia.shape == ib.shape == (h, w, 3)
+            assert torch.equal(ia.view(torch.int32), ib.view(torch.int32)), "image of a pass, iteration %d" % k
+        assert torch.equal(ga.sumL.view(torch.int32), gb.sumL.view(torch.int32))
+        assert torch.equal(ga.sumL2.view(torch.int32), gb.sumL2.view(torch.int32))
+        assert torch.equal(ga.sdTree.accumulators(), gb.sdTree.accumulators())
+        for g in (ga, gb):
+            g.refineAndPrepareSDTreeForNextIteration()
+        _same_tree(ga.sdTree.export(), gb.sdTree.export())
+    # radiance per sample, and a band-sharded tile (its lanes are the corresponding lanes of the full-frame launch)
+    for g in (ga, gb):
+        g.setIteration(4, False)
+    Ls = [ga.sample(wa, IndependentSampler(1, 77 + s))[0] for s in range(B)]
+    Lb = gb.sample(wb, IndependentSampler(B, 77, batched=True))[0].reshape(3, w * h, B)
+    for s in range(B):
+        assert torch.equal(Ls[s].view(torch.int32), Lb[:, :, s].contiguous().view(torch.int32))
+    wb.set_shard(1, 3, 2)
+    px = torch.from_numpy(wb.local_pixels()).cuda()
+    Lt = gb.sample(wb, IndependentSampler(B, 77, batched=True))[0].reshape(3, -1, B)
+    assert torch.equal(Lt.view(torch.int32), Lb[:, px, :].contiguous().view(torch.int32))
+    # ... and it is NOT the B-sample pass of the same seed (a different, equally valid set of streams)
+    wb.set_shard(0, 1)
+    Lm = gb.sample(wb, IndependentSampler(B, 77))[0].reshape(3, w * h, B)
+    assert not torch.equal(Lm, Lb)
+
+
+def test_driver_with_batched_training_launches_equals_the_reference_schedule():
+    """run_guided_render(training_spp_per_pass=1), main.py's own schedule, with 1 and with 8 training passes per launch:
+    the same image, logs and SD-tree, bit for bit."""
+    from practical_path_guiding_lab_amd.driver import run_guided_render
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import WavefrontScene
+    from practical_path_guiding_lab_amd.scene import cornell_box
+    import torch
+
+    def run(launch):
+        sc = cornell_box(36, 36, 6, 8)
+        g = PathGuidingIntegrator({"max_depth": 6, "rr_depth": 8})
+        gt = torch.full((3, 36 * 36), 0.25, device="cuda")
+        res = run_guided_render(WavefrontScene(sc), g, budget_spp=124, initial_seed=9, ground_truth=gt, training_spp_per_pass=1,
+                                batch_spp=4, log=lambda s: None, training_passes_per_launch=launch)
+        rows = {k: np.array(v.rows, dtype=np.float64)[:, 1:] for k, v in res["records"].items() if v.rows}
+        return res["image"].cpu().numpy(), g.sdTree.export(), rows
+
+    img1, tree1, rows1 = run(1)
+    img8, tree8, rows8 = run(8)
+    np.testing.assert_array_equal(img1.view(np.uint32), img8.view(np.uint32))
+    _same_tree(tree1, tree8)
+    assert rows1.keys() == rows8.keys()
+    for k in rows1:
+        np.testing.assert_array_equal(rows1[k], rows8[k], err_msg=k)

@@ -337,7 +337,7 @@ def _worker_halo(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,port", [(2, 29617), (3, 29618)])
+@pytest.mark.parametrize("world,port", [(2, 29617), (3, 29618), (8, 29621)])
 def test_halo_exchange_moves_the_filters_reach_not_the_film(tmp_path, world, port):
     """parallel.HaloExchange over gloo (CPU tensors): after the exchange a rank holds its own rows and the rows its
     reconstruction filter reaches (one for the tent filter, two for the gaussian) exactly as a single rank traced
@@ -348,7 +348,49 @@ def test_halo_exchange_moves_the_filters_reach_not_the_film(tmp_path, world, por
     assert all(bool(np.load(out % r)[0]) for r in range(world))
 
 
-def _drive(shard_arg, out_dir=None):
+def _worker_subgroup(rank, world, port, out):
+    """Three processes, the band ring is the SUB-group of global ranks 1 and 2 (ring index 0 = global rank 1): dist.P2POp
+    addresses global ranks, so a ring index handed to it unchanged would talk to the wrong process."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from practical_path_guiding_lab_amd.parallel import HaloExchange, lowest_rank_with
+    from practical_path_guiding_lab_amd.render import WavefrontScene
+    from practical_path_guiding_lab_amd.scene import cornell_box
+
+    ring = dist.new_group([1, 2])
+    ok = True
+    # who writes files: the lowest rank that was given a directory, the same answer everywhere, -1 when nobody was
+    ok = ok and lowest_rank_with(rank == 2) == 2 and lowest_rank_with(rank >= 1) == 1 and lowest_rank_with(False) == -1
+    ok = ok and lowest_rank_with(True) == 0
+    if rank >= 1:
+        idx = rank - 1
+        ok = ok and lowest_rank_with(idx == 1, ring) == 1 and lowest_rank_with(False, ring) == -1
+        w, h, spp, rows, reach = 6, 13, 2, 2, 1
+        ws = WavefrontScene(cornell_box(w, h, 4, 8))
+        ws.set_shard(idx, 2, rows)
+        px = ws.local_pixels()
+        lanes = (px[:, None] * spp + np.arange(spp)[None, :]).reshape(-1)
+        full = np.arange(3 * w * h * spp, dtype=np.float32).reshape(3, -1) + 0.25
+        hx = HaloExchange(ring)
+        for _ in range(2):  # (the second pass runs on the cached plan)
+            got = hx(torch.from_numpy(full[:, lanes].copy()), ws, spp, reach).numpy().reshape(3, h, w * spp)
+            own = sorted({int(p) // w for p in px})
+            valid = sorted({y + d for y in own for d in range(-reach, reach + 1) if 0 <= y + d < h})
+            ok = ok and bool((got[:, valid] == full.reshape(3, h, w * spp)[:, valid]).all())
+        ok = ok and len(hx._plans) == 1
+    np.save(out % rank, np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_in_a_sub_group_and_the_writer_vote(tmp_path):
+    out = str(tmp_path / "s%d.npy")
+    mp.spawn(_worker_subgroup, args=(3, 29622, out), nprocs=3, join=True)
+    assert all(bool(np.load(out % r)[0]) for r in range(3))
+
+
+def _drive(shard_arg, out_dir=None, **kw):
     from practical_path_guiding_lab_amd.driver import run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import WavefrontScene
@@ -358,7 +400,7 @@ def _drive(shard_arg, out_dir=None):
     g = PathGuidingIntegrator({"max_depth": 6, "rr_depth": 8})
     gt = torch.full((3, RES * 20), 0.25, device="cuda")
     res = run_guided_render(WavefrontScene(sc), g, budget_spp=60, initial_seed=5, ground_truth=gt, training_spp_per_pass=2,
-                            batch_spp=4, log=lambda s: None, shard=shard_arg)
+                            batch_spp=4, log=lambda s: None, shard=shard_arg, out_dir=out_dir, **kw)
     rows = {k: np.array(v.rows, dtype=np.float64)[:, 1:] for k, v in res["records"].items() if v.rows}  # (all but the wall time)
     return res["image"].cpu().numpy(), g.sdTree.export(), rows
 
@@ -392,6 +434,41 @@ def test_two_rank_driver_in_tile_mode_equals_one_rank(tmp_path):
             np.testing.assert_array_equal(np.asarray(got[key]).astype(np.float64), np.asarray(tree[key]).astype(np.float64), err_msg=key)
         for key, v in rows.items():
             np.testing.assert_array_equal(got["rec_" + key], v, err_msg=key)
+
+
+def _worker_drive_files(rank, world, port, out, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # training stops after iteration 1 (12 spp >= 10): the remaining 48 spp are one final iteration of twelve 4-spp
+    # passes that crosses cumm_spp 28 -- an intermediate image (main.py:267-291), i.e. a collective inside the pass loop
+    img, tree, rows = _drive((rank, world, 4), out_dir if rank == 0 else None, train_stop_cumm_spp=10)
+    np.savez(out % rank, image=img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_driver_writes_files_on_the_rank_that_was_given_a_directory(tmp_path):
+    """out_dir is a per-rank argument.  Rank 0 alone passes one: the run must not hang in the collective
+    that assembles an intermediate image (every rank issues it, decided by values all ranks share), rank 0 writes the
+    files -- the intermediate blend at 28 spp too -- and both ranks end with the single-rank image."""
+    world = 2
+    out, out_dir = str(tmp_path / "f%d.npz"), str(tmp_path / "files")
+    mp.spawn(_worker_drive_files, args=(world, 29623, out, out_dir), nprocs=world, join=True)
+    one_dir = str(tmp_path / "one")
+    img, _, _ = _drive(None, one_dir, train_stop_cumm_spp=10)
+    for r in range(world):
+        np.testing.assert_array_equal(dict(np.load(out % r))["image"].view(np.uint32), img.view(np.uint32))
+    names = sorted(os.listdir(out_dir))
+    assert names == sorted(os.listdir(one_dir))
+    blends = [n for n in names if n.endswith("cumm_spp-28.npy")]
+    assert len(blends) == 1
+    for n in names:
+        if n.endswith(".npy"):
+            a, b = np.load(os.path.join(out_dir, n)), np.load(os.path.join(one_dir, n))
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=n)
 
 
 @pytest.mark.gpu
@@ -465,6 +542,37 @@ def test_spawn_ranks_ends_the_job_when_a_rank_fails():
     t0 = time.time()
     rc = b.spawn_ranks([sys.executable, "-c", child], 3, relay=relay, grace_s=5.0)
     assert rc == 7 and time.time() - t0 < 30 and relay.getvalue() == ""
+
+
+def test_spawn_ranks_ends_its_ranks_when_the_launcher_is_terminated(tmp_path):
+    """a harness timeout (SIGTERM to the launcher) must not orphan rank processes that hold GPUs: the launcher
+    ends every child by its process id and exits non-zero."""
+    import signal
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pidfile = str(tmp_path / "pid")
+    child = f"import os, time; open({pidfile!r} + os.environ['RANK'], 'w').write(str(os.getpid())); time.sleep(120)"
+    launcher = ("import sys, importlib.util\n"
+                f"spec = importlib.util.spec_from_file_location('b', {os.path.join(root, 'bench.py')!r})\n"
+                "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+                f"sys.exit(b.spawn_ranks([sys.executable, '-c', {child!r}], 3, grace_s=3.0))\n")
+    p = subprocess.Popen([sys.executable, "-c", launcher])
+    t0 = time.time()
+    while time.time() - t0 < 30 and not all(os.path.exists(pidfile + str(r)) and open(pidfile + str(r)).read() for r in range(3)):
+        time.sleep(0.1)
+    pids = [int(open(pidfile + str(r)).read()) for r in range(3)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(30) != 0
+    time.sleep(0.2)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+            # (a zombie of another parent cannot be: the launcher waited for its children)
+        except ProcessLookupError:
+            alive = False
+        assert not alive, pid
 
 
 def test_backend_is_decided_from_the_device_count_alone():
