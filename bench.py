@@ -85,8 +85,15 @@ def parse():
     ap.add_argument("--res", type=int, default=None, help="film width (height follows the scene's aspect)")
     ap.add_argument("--depth", type=int, default=None, help="max_depth")
     ap.add_argument("--spp-per-pass", type=int, default=16,
-                    help="samples per pixel traced by one pass (16: 33 M paths per step at 1920x1080, and still 4 M per GPU at N = 8; "
+                    help="samples per pixel traced by one step (16: 33 M paths per step at 1920x1080, and still 4 M per GPU at N = 8; "
                          "measured on one GPU with every rank's share in turn: 7.2x of 8 at 16 spp per pass, 6.8x at 8)")
+    ap.add_argument("--batched", type=int, default=1,
+                    help="1 (default): a step is --spp-per-pass consecutive ONE-sample passes -- the reference's training passes, "
+                         "main.py:192, seeded initial_seed + cumm_spp, :218 -- traced as one wavefront (pg_pass_params.batched: bit-identical "
+                         "to the separate passes, tests/test_gpu_render.py); 0: one pass of --spp-per-pass samples per pixel (mi.render(spp=N))")
+    ap.add_argument("--synthetic-kernels", type=int, default=None,
+                    help="1: time the stand-alone entry points on SURVEY 8(d)'s S1 / S2 / S3 at their stated sizes and put the figures into "
+                         "`roofline` (s1_*, s2_*, s3_*); default: 1 at N = 1, 0 otherwise")
     ap.add_argument("--train-iters", type=int, default=6, help="iterations rendered to train the SD-tree (the configs say 8/10/12)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"], help="N > 1: strong scaling by tiles (default) or weak by passes")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
@@ -121,6 +128,8 @@ def parse():
         args.depth = 8 if args.synthetic else d
     if args.full_schedule is None:
         args.full_schedule = 1 if (args.gpus == 1 and not args.synthetic) else 0
+    if args.synthetic_kernels is None:
+        args.synthetic_kernels = 1 if (args.gpus == 1 and not args.synthetic) else 0
     return args
 
 
@@ -394,6 +403,7 @@ def run_render(args):
             reduce_fn = lambda acc: all_reduce_accumulators(acc)  # noqa: E731
 
     # ---- train: really render iterations 0..train_iters-1 (2^(k+2) spp each, main.py:170) ----
+    batched = bool(args.batched)
     per_iter = []
     cumm = 0
     for k in range(args.train_iters):
@@ -407,12 +417,12 @@ def run_render(args):
         if tiles or world == 1:
             chunk = max(1, min(args.spp_per_pass, iter_spp))
             for i in range(iter_spp // chunk):
-                integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk))
+                integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk, batched=batched))
         else:  # passes: the passes of an iteration are independent (main.py:208-218), ranks take them in turn
             chunk = max(1, min(args.spp_per_pass, iter_spp // world))
             for i in range(iter_spp // chunk):
                 if i % world == rank:
-                    integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk))
+                    integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk, batched=batched))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         integ.refineAndPrepareSDTreeForNextIteration(reduce_fn)
@@ -438,7 +448,7 @@ def run_render(args):
     seed = [cumm + (0 if tiles else rank * args.spp_per_pass)]
 
     def step():
-        integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0]))
+        integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0], batched=batched))
         seed[0] += args.spp_per_pass * (1 if tiles else world)
 
     # one instrumented pass for the byte model (depth counters add atomics: not timed)
@@ -482,14 +492,21 @@ def run_render(args):
     tree.refineAndPrepare()
     torch.cuda.synchronize()
     t_refine = time.perf_counter() - t1
-    # ---- the reference's own training passes are 1 spp each (main.py:192): the same tree, passes of one sample ----
-    spp1 = None
+    # ---- the same passes one launch each (what `value`'s batched launch stands for, bit for bit), and one pass of
+    # spp_per_pass samples per pixel (mi.render(spp=N): other streams, the same amount of work) ----
+    spp1 = multi_spp = None
     if args.spp1 and (tiles or world == 1):
         def step1():
             integ.sample(ws, IndependentSampler(1, seed[0]))
             seed[0] += 1
         n1 = max(16, args.steps)
         spp1 = npix * n1 / timed_steps(step1, n1, 2, world) / 1e6
+
+        def step_multi():
+            integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0], batched=not batched))
+            seed[0] += args.spp_per_pass
+        nm = max(3, args.steps // 2)
+        multi_spp = npix * args.spp_per_pass * nm / timed_steps(step_multi, nm, 1, world) / 1e6
 
     # ---- two passes in flight (pg_pass_params.slot): the same passes, alternating between two buffer sets and streams ----
     two_in_flight = None
@@ -523,6 +540,10 @@ def run_render(args):
     # SD-tree queries: 16 B per KD level + 20 B per quadtree level; splat: per record 16*D_kd + 4 + 48 + 12 per quadtree
     # level and descent, priced with the measured mean depths over the records actually kept
     tree_bytes = 16.0 * dc.kd_levels + 20.0 * dc.quad_levels          # all bounces of one pass
+    # ... and the bytes the lanes of that pass GATHERED from the tables of the built layout (16 per KD grid entry / node below
+    # it, 8 per tree head, 16 per jump-table entry, 32 per quadtree record of a pdf or sampling walk, 16 per record of a
+    # leaf walk), nothing credited for lanes of a wave that share a line: pg_depth_counters.layout_bytes
+    layout_bytes = float(dc.layout_bytes) + 8.0 * dc.kd_queries
     d_kd = dc.kd_levels / max(dc.kd_queries, 1)
     d_q = dc.quad_levels / max(dc.quad_queries, 1)
     splat_bytes = records_per_pass * (16.0 * d_kd + 4.0 + 48.0 + 12.0 * 2.0 * d_q)
@@ -627,8 +648,16 @@ def run_render(args):
                     kernels[name]["atomic_ceiling_G_per_s"] = ATOMIC_CEILING_GPS
     dom_sec = kernels[dom]["avg_us"] * 1e-6
     kd_share = 16.0 * dc.kd_levels / max(tree_bytes, 1.0)
+    dom_launches_per_pass = max(kernels[dom]["launches"] / max((kt_roof.passes if (kt_roof is not None and dom == "k_wave_guide") else passes), 1), 1)
+    layout_per_launch = layout_bytes / dom_launches_per_pass
+    layout_gbps = layout_per_launch / max(dom_sec, 1e-12) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
+            # the creditable fraction: bytes the lanes gathered from the built tables (no cross-lane sharing credited) per
+            # launch / the launch time measured in this run / peak -- cannot exceed what the memory pipeline moved
+            "frac_layout": round(layout_gbps / HBM_PEAK_GBS, 5), "layout_bytes_per_launch": int(layout_per_launch),
+            "layout_GBps": round(layout_gbps, 2), "alg_bytes_per_launch": kernels[dom].get("alg_bytes_per_launch"),
+            "avg_launch_us": kernels[dom]["avg_us"],
             "traffic": traffic,
             # above 1 the algorithmic model is not a bandwidth at all: in a spatially sorted list (pg_render_sort) the lanes of a
             # wave walk the same KD leaves and quadtrees, their gathers meet in L1/L2 and the bytes the model prices per lane are
@@ -671,6 +700,13 @@ def run_render(args):
     mse_small = mse_small_cpu = None
     if args.cpu and world == 1:
         cpu, mse_small, mse_small_cpu = cpu_leg(args)
+    synth_detail = None
+    if args.synthetic_kernels and world == 1:
+        synth_flat, synth_detail = synthetic_kernels_leg(local_rank)
+        roof.update(synth_flat)  # s1_pg_sample_frac_layout, ... (flat: the driver's record keeps scalars)
+        roof["synthetic_note"] = ("s1_* / s2_* / s3_*: pg_pdf, pg_sample, pg_guide_bounce, pg_splat on SURVEY 8(d)'s S1 / S2 / S3 at their stated sizes "
+                                  "(2^22 queries, 2^24 records) in this run; `kernels_synthetic` has units, bytes and depths")
+    refine_ms_iters = [p["exchange_refine_ms"] for p in per_iter]
     out = {
         "metric": f"Msamples/s guided, {args.scene} {film} max_depth {args.depth}", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": args.n_devices, "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
@@ -683,10 +719,12 @@ def run_render(args):
         "full_schedule": full,
         "mse_vs_gt": mse_train, "mse_vs_gt_small": mse_small, "mse_vs_gt_cpu": mse_small_cpu,
         "mse_equal": None if mse_small is None else bool(mse_small == mse_small_cpu),
-        "config": {"workload": f"{args.scene} {film} (the whole film per step"
+        "config": {"workload": f"{args.scene} {film}, max_depth {args.depth}, " +
+                               (f"{args.spp_per_pass} one-sample training passes (main.py:192, 218) per step in one batched launch"
+                                if batched else f"one {args.spp_per_pass}-spp pass per step") + " (the whole film"
                                + (", sharded by interleaved 4-row bands over the ranks" if tiles else (", per GPU" if world > 1 else ""))
-                               + f"), max_depth {args.depth}, guided iteration {k} (SD-tree trained by rendering iterations 0-{k - 1}, "
-                               f"{cumm} spp), {args.spp_per_pass} spp per pass; full PathGuidingIntegrator.sample(): camera rays, NEE, "
+                               + f"), guided iteration {k} (SD-tree trained by rendering iterations 0-{k - 1}, "
+                               f"{cumm} spp); full PathGuidingIntegrator.sample(): camera rays, NEE, "
                                "BSDF/SD-tree MIS, record list, post-process + splat; " + what,
                    "pixels_this_rank": my_pixels, "pixels_per_rank_min": int(pix_min), "pixels_per_rank_max": int(pix_max),
                    "spp_per_pass": args.spp_per_pass,
@@ -694,8 +732,20 @@ def run_render(args):
                    "quad_records": stats.n_quad_records, "mean_kd_leaf_depth": round(stats.mean_kd_leaf_depth, 3),
                    "mean_quad_leaf_depth": round(stats.mean_quad_leaf_depth, 3),
                    "guided_tree_queries_per_pass": int(dc.quad_queries), "paths_alive_after_bounce": live,
-                   "measured_D_kd": round(d_kd, 3), "measured_D_quad": round(d_q, 3)},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+                   "measured_D_kd": round(d_kd, 3), "measured_D_quad": round(d_q, 3),
+                   # the schedule `value` is quoted on, and the same work launched the other ways (all in this run)
+                   "pass_spp": 1 if batched else args.spp_per_pass, "passes_per_launch": args.spp_per_pass if batched else 1,
+                   "value_one_launch_per_1spp_pass": None if spp1 is None else round(spp1, 3),
+                   ("value_one_%dspp_pass_per_step" % args.spp_per_pass if batched else "value_batched_1spp_passes"):
+                       None if multi_spp is None else round(multi_spp, 3),
+                   "value_full_schedule_12it": None if full is None else full["value"],
+                   "mse_vs_gt_full_schedule": None if full is None else full["mse_vs_gt"],
+                   "mse_equal_device_vs_cpu": None if mse_small is None else bool(mse_small == mse_small_cpu),
+                   "mse_vs_gt_device_320": mse_small, "mse_vs_gt_cpu_320": mse_small_cpu,
+                   "exchange_refine_ms_max_over_training": max(refine_ms_iters) if refine_ms_iters else None,
+                   "refine_ms_after_steps": round(1e3 * t_refine, 3), "jump_bits": int(stats.jump_bits),
+                   "bytes_jump_tables": int(stats.bytes_jump_tables)},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "kernels_synthetic": synth_detail,
         "schedule": {"note": "value_full_schedule = film pixels x spp of the trained iterations >= 2 / their wall time incl. "
                              "accumulator exchange and refine (main.py:159,394); mse_vs_gt = the last trained iteration's "
                              f"image ({last_spp} spp) vs the ground truth" + (": " + mse_note if mse_note else ""),
@@ -709,10 +759,150 @@ def run_render(args):
     return out
 
 
+def synthetic_kernels_leg(device):
+    """SURVEY.md 8(d)'s kernel-level inputs at their stated sizes through the stand-alone entry points of the C ABI (no
+    renderer, no oracle: the trees and streams are made by practical_path_guiding_lab_amd.workload):
+      S1 "balanced"  KD complete to depth 12 (4096 leaves) over [0,100]^3, every leaf a complete quadtree of depth 5
+                     (5.59 M quadtree nodes), leaf irradiance uniform (0,1]; 2^22 queries (positions uniform in the box,
+                     directions uniform on the sphere, PCG32 stream = lane id, seed 0)
+      S2 "skewed"    grown on the device by six splat + refine iterations of 2^19 ... 2^24 clustered records with lobed
+                     directions, reference thresholds; the same queries
+      S3 "splat"     the last S2 record stream (2^24 records) replayed into the S2 topology
+    Per kernel: ms per launch (HIP events around 20 back-to-back launches on the launch stream), and two byte models over
+    the 8 TB/s HBM peak -- `frac`: SURVEY 8d's algorithmic bytes (16 B per KD level + 20 B per quadtree level of the
+    REFERENCE's descents; per record 16 D_kd + 4 + 48 + 12 per quadtree level and descent) with the depths an
+    instrumented launch counted; `frac_layout`: the bytes the lanes of that launch gathered from the tables of the BUILT
+    layout (pg_depth_counters.layout_bytes + 8 per tree head; 48 B per record streamed + 32 B per accumulator updated for
+    the splat), nothing credited for lanes that share a line.  Where the tables serve whole descents from L2 `frac` exceeds 1
+    (not a bandwidth); `frac_layout` cannot: a launch moves at least those bytes per lane through the memory pipeline.
+    Full-size parity of exactly these inputs against the CPU oracle: tests/test_gpu_fullsize.py."""
+    import torch
+    from practical_path_guiding_lab_amd import workload as Wk
+    from practical_path_guiding_lab_amd.sdtree import PCG32Sampler, SDTree
+
+    dev = torch.device("cuda", device)
+    nq = Wk.S_QUERIES
+
+    def timed(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def counted(tree, fn):
+        tree.enableDepthCounters(True)
+        tree.readDepthCounters(reset=True)
+        fn()
+        torch.cuda.synchronize()
+        dc = tree.readDepthCounters(reset=True)
+        tree.enableDepthCounters(False)
+        return dc
+
+    flat, detail = {}, []
+
+    def put(key, name, n, ms, alg, layout, extra):
+        d = {"kernel": name, "units": int(n), "ms": round(ms, 4), "G_units_per_s": round(n / ms / 1e6, 2),
+             "alg_bytes_per_launch": int(alg), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+             "layout_bytes_per_launch": int(layout), "frac_layout": round(layout / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        d.update(extra)
+        detail.append(d)
+        flat[key + "_ms"] = d["ms"]
+        flat[key + "_frac"] = d["frac"]
+        flat[key + "_frac_layout"] = d["frac_layout"]
+
+    P = Wk.s_positions_uniform(nq, 3, device=dev)
+    D = Wk.s_directions_uniform(nq, 4, device=dev)
+
+    def query_suite(tag, tree):
+        smp = PCG32Sampler(tree, nq, seed=0)
+        st0 = smp.state.clone()
+        out_idx = None
+        ms = timed(lambda: tree.getLeafNodeIndex(P))
+        dc = counted(tree, lambda: tree.pdf(P, D))
+        d_kd, d_q = dc.kd_levels / max(dc.kd_queries, 1), dc.quad_levels / max(dc.quad_queries, 1)
+        lay_pdf = dc.layout_bytes + 8 * dc.kd_queries
+        # (a leaf lookup alone gathers the KD side of that launch: what pdf's walks add is 16 per table hit + 32 per record)
+        ms_pdf = timed(lambda: tree.pdf(P, D))
+        put(tag + "_pg_pdf", tag.upper() + " pg_pdf", nq, ms_pdf, nq * (16.0 * d_kd + 20.0 * d_q), lay_pdf,
+            {"D_kd": round(d_kd, 3), "D_quad": round(d_q, 3)})
+
+        def do_sample():
+            tree.sample(P, smp)
+        smp.state.copy_(st0)
+        dcs = counted(tree, do_sample)
+        ds_q = dcs.quad_levels / max(dcs.quad_queries, 1)
+        ms_s = timed(do_sample)
+        put(tag + "_pg_sample", tag.upper() + " pg_sample", nq, ms_s, nq * (16.0 * d_kd + 20.0 * ds_q), dcs.layout_bytes + 8 * dcs.kd_queries,
+            {"D_kd": round(d_kd, 3), "D_quad": round(ds_q, 3)})
+        detail.append({"kernel": tag.upper() + " pg_get_leaf_node_index", "units": nq, "ms": round(ms, 4), "G_units_per_s": round(nq / ms / 1e6, 2),
+                       "alg_bytes_per_launch": int(nq * 16.0 * d_kd), "frac": round(nq * 16.0 * d_kd / ms / 1e6 / HBM_PEAK_GBS, 4),
+                       "note": "one 16-byte gather per lane from the KD jump grid, served from L2: the model prices D_kd levels"})
+        # the three calls of a bounce: NEE pdf for every lane, half the lanes sample, half evaluate
+        nee = torch.ones(nq, dtype=torch.uint8, device=dev)
+        sel = (torch.arange(nq, device=dev) % 2 + 1).to(torch.uint8)
+        dio = D.clone()
+        run = tree.prepareGuideBounce(P, D, nee, sel, dio, smp)
+        smp.state.copy_(st0)
+        dcb = counted(tree, run)
+        dio.copy_(D)
+        ms_b = timed(run)
+        put(tag + "_pg_guide_bounce", tag.upper() + " pg_guide_bounce", nq, ms_b, 16.0 * dcb.kd_levels + 20.0 * dcb.quad_levels,
+            dcb.layout_bytes + 8 * dcb.kd_queries,
+            {"D_kd": round(dcb.kd_levels / max(dcb.kd_queries, 1), 3), "D_quad": round(dcb.quad_levels / max(dcb.quad_queries, 1), 3),
+             "quad_descents_per_lane": round(dcb.quad_queries / nq, 3)})
+
+    trees = {}
+    g1 = SDTree(device)
+    g1.load(Wk.s1_balanced_tree())
+    st = g1.stats()
+    trees["s1"] = {"kd_leaves": int(st.n_kd_leaves), "quad_nodes": int(st.n_quad_nodes), "jump_bits": int(st.jump_bits),
+                   "kd_grid_bits": int(st.kd_grid_bits)}
+    query_suite("s1", g1)
+    del g1
+    g2 = SDTree(device)
+    g2.setup([Wk.S_BBOX[0]] * 3, [Wk.S_BBOX[1]] * 3, 0, 0, 20, 20, True, 0.5)
+    rec = None
+    refine_ms = []
+    for k in range(Wk.S2_ITERATIONS):
+        g2.setIteration(k, False)
+        rec = Wk.s2_record_stream(k, device=dev)
+        g2.addDataPropagate(rec)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g2.refineAndPrepare()
+        torch.cuda.synchronize()
+        refine_ms.append(round(1e3 * (time.perf_counter() - t0), 3))
+    st = g2.stats()
+    trees["s2"] = {"kd_leaves": int(st.n_kd_leaves), "quad_nodes": int(st.n_quad_nodes), "mean_kd_leaf_depth": round(st.mean_kd_leaf_depth, 3),
+                   "mean_quad_leaf_depth": round(st.mean_quad_leaf_depth, 3), "max_quad_depth": int(st.max_quad_depth),
+                   "jump_bits": int(st.jump_bits), "kd_grid_bits": int(st.kd_grid_bits), "refine_ms_per_iteration": refine_ms}
+    query_suite("s2", g2)
+    # S3: the last record stream replayed into the S2 topology
+    g2.setIteration(Wk.S2_ITERATIONS, False)
+    m = int(rec["radiance"].shape[0])
+    dc = counted(g2, lambda: g2.addDataPropagate(rec))
+    d_kd, d_q = dc.kd_levels / max(dc.kd_queries, 1), dc.quad_levels / max(dc.quad_queries, 1)
+    ms = timed(lambda: g2.addDataPropagate(rec), reps=5)
+    b_rec = 16.0 * d_kd + 4.0 + 24.0 * d_q + 48.0
+    # built layout: the record streamed (48 B), the gathers of its walks, its tree head, and one 32-byte accumulator per direction
+    put("s3_pg_splat", "S3 pg_splat", m, ms, m * b_rec, 48 * m + dc.layout_bytes + 8 * dc.kd_queries + 32 * dc.quad_queries,
+        {"D_kd": round(d_kd, 3), "D_quad": round(d_q, 3), "B_rec": round(b_rec, 1),
+         "atomic_sector_updates_G_per_s": round(dc.quad_queries / ms / 1e6, 2), "atomic_ceiling_G_per_s": ATOMIC_CEILING_GPS})
+    del g2
+    torch.cuda.empty_cache()
+    return flat, {"trees": trees, "kernels": detail, "note": synthetic_kernels_leg.__doc__.split("\n\n")[0]}
+
+
 def full_schedule_leg(args, integ, ws, shard, reduce_fn, W, H):
     """BASELINE.json's configuration as the reference's main.py runs it: budget = 4 + 8 + ... over the config's
-    number of iterations (veach-ajar: 12 -> 16380 spp, main.py:92-99, 170), training passes of --spp-per-pass samples
-    (main.py:192 has 1: a pass is a batch, the tree does not depend on how an iteration is cut into passes), the
+    number of iterations (veach-ajar: 12 -> 16380 spp, main.py:92-99, 170), training passes of ONE sample per pixel seeded
+    initial_seed + cumm_spp (main.py:192, 218) -- --spp-per-pass of them traced per launch (pg_pass_params.batched: the
+    same passes bit for bit) --, final passes of --spp-per-pass samples (main.py:123 has 4), the
     stop-training rule of main.py:334-377 (training ends once the estimated final variance rises after 256 spp or at
     1000 spp; the rest of the budget is one final iteration), image blending, variance bookkeeping, exchange and
     refine -- everything driver.run_guided_render does -- inside one wall clock."""
@@ -724,8 +914,12 @@ def full_schedule_leg(args, integ, ws, shard, reduce_fn, W, H):
     lines = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = run_guided_render(ws, integ, budget, initial_seed=0, batch_spp=args.spp_per_pass, training_spp_per_pass=args.spp_per_pass,
-                            all_reduce=reduce_fn, shard=shard, log=lines.append)
+    if args.batched:  # main.py's own schedule: one-sample training passes, spp_per_pass of them per launch
+        kw = dict(training_spp_per_pass=1, training_passes_per_launch=args.spp_per_pass)
+    else:
+        kw = dict(training_spp_per_pass=args.spp_per_pass)
+    res = run_guided_render(ws, integ, budget, initial_seed=0, batch_spp=args.spp_per_pass, all_reduce=reduce_fn, shard=shard,
+                            log=lines.append, **kw)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     rows = res["records"]["variance_endIter"].rows
@@ -771,20 +965,23 @@ def cpu_leg(args, iters=4, width=320):
     pair = po.OracleSDTreePair()
     pair.setup(bmin, bmax, 20, 20, True)
     o_sumL, o_sumL2 = np.zeros((3, npix), np.float32), np.zeros((3, npix), np.float32)
-    cumm, t_guided, n_guided = 0, 0.0, 0
+    cumm, t_guided_1, n_guided_1 = 0, 0.0, 0
     for k in range(iters):
         spp = 2 ** (k + 2)
         g.setIteration(k, False)
         g.resetVarianceCounter()
         o_sumL[:] = 0
         o_sumL2[:] = 0
-        g.sample(ws, IndependentSampler(spp, cumm))
+        # the reference's schedule: 2^(k+2) one-sample passes seeded cumm, cumm + 1, ... (main.py:170, 192, 218) -- on the
+        # device one batched launch, on the oracle literally pass by pass
+        g.sample(ws, IndependentSampler(spp, cumm, batched=True))
         t0 = time.perf_counter()
-        po.render_pass(pair, sc, sc.camera, args.depth, 8, k, False, cumm, spp, True, 0.5, o_sumL, o_sumL2)
+        for p_ in range(spp):
+            po.render_pass(pair, sc, sc.camera, args.depth, 8, k, False, cumm + p_, 1, True, 0.5, o_sumL, o_sumL2)
         dt = time.perf_counter() - t0
         if k >= 2:
-            t_guided += dt
-            n_guided += npix * spp
+            t_guided_1 += dt
+            n_guided_1 += npix * spp
         cumm += spp
         if k + 1 < iters:
             g.refineAndPrepareSDTreeForNextIteration()
@@ -794,10 +991,31 @@ def cpu_leg(args, iters=4, width=320):
     same = bool((g_sum.view(np.uint32) == o_sumL.view(np.uint32)).all())
     mse_g, _ = image_mse(g_sum, last, W, H, args.scene)
     mse_c, _ = image_mse(o_sumL, last, W, H, args.scene)
+    # the timed sample: the same schedule with each iteration's samples in ONE oracle pass of 2^(k+2) samples per pixel -- the
+    # CPU's best form (57 600 lanes of a one-sample pass do not keep 256 threads busy, and every pass allocates its record
+    # arrays) -- guided iterations 2-3 timed.  Same estimator, other sampler streams than the parity leg above.
+    pair2 = po.OracleSDTreePair()
+    pair2.setup(bmin, bmax, 20, 20, True)
+    cumm, t_guided, n_guided = 0, 0.0, 0
+    for k in range(iters):
+        spp = 2 ** (k + 2)
+        t0 = time.perf_counter()
+        po.render_pass(pair2, sc, sc.camera, args.depth, 8, k, False, cumm, spp, True, 0.5)
+        dt = time.perf_counter() - t0
+        if k >= 2:
+            t_guided += dt
+            n_guided += npix * spp
+        cumm += spp
+        if k + 1 < iters:
+            pair2.refine_and_prepare(k)
     cpu = {"value": round(n_guided / t_guided / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
            "images_bit_identical_to_device": same,
+           "mse_vs_gt_device": mse_g, "mse_vs_gt_cpu": mse_c, "mse_equal": bool(mse_g == mse_c),
+           "value_one_sample_passes": round(n_guided_1 / t_guided_1 / 1e6, 4),
            "sample": f"the guided passes (iterations 2-3, 16 + 32 spp) of a 4-iteration schedule of the same scene on a {W}x{H} "
-                     f"film ({n_guided} paths), C oracle with OpenMP over the lanes on {cores} threads, {t_guided:.1f} s"}
+                     f"film ({n_guided} paths), C oracle with OpenMP over the lanes on {cores} threads, {t_guided:.1f} s; "
+                     f"value_one_sample_passes: the same samples as 48 separate one-sample passes ({t_guided_1:.1f} s), the leg the "
+                     "device's images are compared with"}
     return cpu, mse_g, mse_c
 
 

@@ -443,3 +443,32 @@ def test_wavefront_scene_checks_its_scheduling_switches():
             WavefrontScene(sc, stages=bad)
     with pytest.raises(ValueError):
         WavefrontScene(sc, in_flight=3)
+
+
+def test_package_generators_of_s1_s2_s3_equal_the_oracles_streams():
+    """practical_path_guiding_lab_amd.workload makes SURVEY 8(d)'s synthetic inputs for bench.py and for the full-size
+    parity tests without the oracle (PCG32 + TEA in 64-bit integer tensors): its streams, record sets and the S1 tree
+    equal what tests/synth.py derives from the oracle's own generator, bit for bit -- also for seeds and lanes near 2^32,
+    where the integer arithmetic wraps."""
+    import synth
+    from practical_path_guiding_lab_amd import workload as W
+
+    for n, seed, draws, lane0 in ((1000, 7, 3, 5), (257, 0xFFFFFFF0, 2, 0xFFFFFFF0), (1, 0, 1, 0)):
+        a, b = synth.uniform(n, seed, draws, lane0), W.s_uniform(n, seed, draws, lane0).numpy()
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    bb0, bb1 = [W.S_BBOX[0]] * 3, [W.S_BBOX[1]] * 3
+    ra, rb = synth.records(30000, 77, bb0, bb1), W.s_records(30000, 77)
+    assert set(ra) == set(rb)
+    for k in ra:
+        assert (ra[k].view(np.uint32) == rb[k].numpy().view(np.uint32)).all(), k
+    pa, pb = synth.positions_uniform(5000, 3, bb0, bb1), W.s_positions_uniform(5000, 3).numpy()
+    assert (pa.view(np.uint32) == pb.view(np.uint32)).all()
+    d = W.s_directions_uniform(5000, 4).numpy()
+    assert np.abs(np.linalg.norm(d, axis=0) - 1).max() < 1e-6 and abs(d.mean()) < 0.02
+    t, s1 = synth.build_balanced(4, 3).export(), W.s1_balanced_tree(4, 3)
+    assert set(t) == set(s1)
+    for k in t:
+        assert np.asarray(t[k]).shape == np.asarray(s1[k]).shape, k
+        assert (np.asarray(t[k]).astype(np.float64) == np.asarray(s1[k]).astype(np.float64)).all(), k
+    # the S2 schedule: 2^19 ... 2^24 records
+    assert [W.S2_RECORDS >> (W.S2_ITERATIONS - 1 - k) for k in range(W.S2_ITERATIONS)] == [1 << e for e in range(19, 25)]
