@@ -112,7 +112,9 @@ typedef __attribute__((address_space(3))) uint32_t LdsWord; // an LDS pointer st
 typedef __attribute__((address_space(3))) u32x4_t LdsQuad;
 struct BvhStack {
 	LdsWord *lds; // the two words of &s_stack[0][threadIdx.x]; level sp is 2 * kRBlock words further
-	uint2 *ovf;   // this lane's kOvfStack entries of the workspace
+	uint2 *ovf;   // the workspace of overflow strips (uniform) ...
+	uint32_t ovf_first; // ... and this lane's first entry in it, kOvfStack of them: an index, not a pointer -- one register
+	                    // instead of two alive through the whole walk (pg_render_pass keeps n_lanes * kOvfStack below 2^32)
 	const LdsQuad *top; // the first n_top nodes of the BVH, which the kernel has copied into LDS (stage_bvh_top); 0: none
 	uint32_t n_top;
 	__device__ __forceinline__ void push(int sp, uint32_t ref, float t) const
@@ -120,7 +122,7 @@ struct BvhStack {
 		if (sp < kLdsStack) {
 			lds[sp * (2 * kRBlock)] = ref;
 			lds[sp * (2 * kRBlock) + 1] = __float_as_uint(t);
-		} else ovf[sp - kLdsStack] = make_uint2(ref, __float_as_uint(t));
+		} else ovf[ovf_first + (uint32_t)(sp - kLdsStack)] = make_uint2(ref, __float_as_uint(t));
 	}
 	__device__ __forceinline__ uint2 at(int sp) const
 	{
@@ -128,15 +130,16 @@ struct BvhStack {
 		// loads in two branches get folded into one flat load of a selected address
 		const volatile LdsWord *w = lds + (sp < kLdsStack ? sp : kLdsStack - 1) * (2 * kRBlock);
 		uint2 e = make_uint2(w[0], w[1]);
-		if (sp >= kLdsStack) e = ovf[sp - kLdsStack];
+		if (sp >= kLdsStack) e = ovf[ovf_first + (uint32_t)(sp - kLdsStack)];
 		return e;
 	}
 };
-__device__ __forceinline__ BvhStack bvh_stack(uint2 *lds_column, uint2 *ovf)
+__device__ __forceinline__ BvhStack bvh_stack(uint2 *lds_column, uint2 *ovf, uint32_t ovf_first)
 {
 	BvhStack s;
 	s.lds = (LdsWord *)lds_column;
 	s.ovf = ovf;
+	s.ovf_first = ovf_first;
 	s.top = nullptr; s.n_top = 0;
 	return s;
 }
@@ -283,17 +286,24 @@ constexpr uint32_t kBvhNone = 0xffffffffu;
 struct BvhWalk {
 	v3 o, d, inv;
 	int row_nx, row_fx, row_ny, row_fy, row_nz, row_fz; // byte offsets of the rows of a node that hold the near / far planes for this ray
+	                                                    // (a kSlim walk does not keep them: bvh_rows)
 	float bt, bu, bv;
 	int best, sp, budget;
 	uint32_t next; // a node, a leaf (bit 31), or kBvhNone: take the next candidate from the stack
 };
+// the six offsets from the signs of the ray's direction (bvh_begin keeps them in six registers; a walk inside a kernel that is
+// short of registers -- k_wave_shade -- makes them again at every node: six selects against seven gathers)
+__device__ __forceinline__ void bvh_rows(v3 d, int &nx, int &fx, int &ny, int &fy, int &nz, int &fz)
+{
+	const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
+	nx = ngx ? 48 : 0; fx = ngx ? 0 : 48; ny = ngy ? 64 : 16; fy = ngy ? 16 : 64; nz = ngz ? 80 : 32; fz = ngz ? 32 : 80;
+}
 
 __device__ __forceinline__ void bvh_begin(BvhWalk &w, const Shapes &sh, v3 o, v3 d, float bt, int best)
 {
 	w.o = o; w.d = d;
 	w.inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-	const bool ngx = (__float_as_uint(d.x) >> 31) != 0u, ngy = (__float_as_uint(d.y) >> 31) != 0u, ngz = (__float_as_uint(d.z) >> 31) != 0u;
-	w.row_nx = ngx ? 48 : 0; w.row_fx = ngx ? 0 : 48; w.row_ny = ngy ? 64 : 16; w.row_fy = ngy ? 16 : 64; w.row_nz = ngz ? 80 : 32; w.row_fz = ngz ? 32 : 80;
+	bvh_rows(d, w.row_nx, w.row_fx, w.row_ny, w.row_fy, w.row_nz, w.row_fz);
 	w.bt = bt; w.bu = 0.0f; w.bv = 0.0f;
 	w.best = best; w.sp = 0;
 	w.budget = 8 * sh.n_bvh_nodes + 8;
@@ -301,9 +311,16 @@ __device__ __forceinline__ void bvh_begin(BvhWalk &w, const Shapes &sh, v3 o, v3
 }
 
 // w.next is a node: test its children, push the farther ones, go on in the nearest
+template <bool kSlim = false>
 __device__ __forceinline__ void bvh_node_step(BvhWalk &w, const Shapes &sh, const BvhStack &stk)
 {
 	const float kInf = __builtin_huge_valf();
+	int row_nx = w.row_nx, row_fx = w.row_fx, row_ny = w.row_ny, row_fy = w.row_fy, row_nz = w.row_nz, row_fz = w.row_fz;
+	if (kSlim) {
+		v3 d = w.d;
+		asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z)); // (made here, every time: not six values hoisted out of the walk's loop)
+		bvh_rows(d, row_nx, row_fx, row_ny, row_fy, row_nz, row_fz);
+	}
 	// a node's rows are lo_x lo_y lo_z hi_x hi_y hi_z (four children each): the row holding the planes
 	// the ray meets first on an axis is known from the sign of its direction, so the rows are
 	// loaded as (near, far) per axis -- per-ray offsets, no per-child selects
@@ -319,12 +336,12 @@ __device__ __forceinline__ void bvh_node_step(BvhWalk &w, const Shapes &sh, cons
 	if (w.next < stk.n_top) {
 		const LdsQuad *T = stk.top + w.next * 8u;
 #define PG_Q(r) ({ const u32x4_t q_ = T[r]; make_uint4(q_.x, q_.y, q_.z, q_.w); })
-		nx4 = PG_Q(w.row_nx >> 4); ny4 = PG_Q(w.row_ny >> 4); nz4 = PG_Q(w.row_nz >> 4);
-		fx4 = PG_Q(w.row_fx >> 4); fy4 = PG_Q(w.row_fy >> 4); fz4 = PG_Q(w.row_fz >> 4); rf = PG_Q(6);
+		nx4 = PG_Q(row_nx >> 4); ny4 = PG_Q(row_ny >> 4); nz4 = PG_Q(row_nz >> 4);
+		fx4 = PG_Q(row_fx >> 4); fy4 = PG_Q(row_fy >> 4); fz4 = PG_Q(row_fz >> 4); rf = PG_Q(6);
 #undef PG_Q
 	} else {
-		nx4 = gather16(B + (nb + (uint32_t)w.row_nx)); ny4 = gather16(B + (nb + (uint32_t)w.row_ny)); nz4 = gather16(B + (nb + (uint32_t)w.row_nz));
-		fx4 = gather16(B + (nb + (uint32_t)w.row_fx)); fy4 = gather16(B + (nb + (uint32_t)w.row_fy)); fz4 = gather16(B + (nb + (uint32_t)w.row_fz));
+		nx4 = gather16(B + (nb + (uint32_t)row_nx)); ny4 = gather16(B + (nb + (uint32_t)row_ny)); nz4 = gather16(B + (nb + (uint32_t)row_nz));
+		fx4 = gather16(B + (nb + (uint32_t)row_fx)); fy4 = gather16(B + (nb + (uint32_t)row_fy)); fz4 = gather16(B + (nb + (uint32_t)row_fz));
 		rf = gather16(B + (nb + 96u));
 	}
 	uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
@@ -392,7 +409,7 @@ __device__ __forceinline__ void bvh_pop(BvhWalk &w, const BvhStack &stk)
 }
 
 // stk: the walk's stack (mesh scenes only); bu, bv: barycentrics of the triangle hit (closest-hit walks).
-template <int kGeneral, bool kAny = false>
+template <int kGeneral, bool kAny = false, bool kSlim = false>
 __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out, const BvhStack &stk,
                                          float &bu, float &bv)
 {
@@ -408,7 +425,7 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 			// idling until the other lanes of its wave have found their leaves: closest hits 16.4 -> 15.6 ms per step,
 			// shadow rays 9.5 -> 8.6; the ray's own sequence of steps is the same)
 			while (!(w.next & 0x80000000u) && w.budget > 0) {
-				bvh_node_step(w, sh, stk);
+				bvh_node_step<kSlim>(w, sh, stk);
 				if (w.next == kBvhNone) bvh_pop(w, stk);
 			}
 			if (w.next != kBvhNone && (w.next & 0x80000000u)) {
@@ -430,7 +447,7 @@ template <int kGeneral, bool kAny = false>
 __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out)
 {
 	static_assert(kGeneral < 2, "mesh scenes pass their BVH stack");
-	const BvhStack none = bvh_stack(nullptr, nullptr);
+	const BvhStack none = bvh_stack(nullptr, nullptr, 0u);
 	float bu, bv;
 	return intersect<kGeneral, kAny>(sh, o, d, tmax, t_out, none, bu, bv);
 }

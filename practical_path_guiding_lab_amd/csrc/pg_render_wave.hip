@@ -32,6 +32,9 @@
 // live list (st_load below).  Arithmetic and sampler draw order are those of oracle/pg_oracle_render.c, operation
 // by operation, in every form.
 #define PG_RENDER_INLINE_ALL
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "pg_render_dev.hpp"
 
 namespace pg {
@@ -107,14 +110,17 @@ __device__ __forceinline__ Material material_of(const RenderArgs &a, int mat, v3
 	return m;
 }
 
-// ---- :185-220, 272-297 ----
+// ---- :185-220 ----
+// stage_a in two halves, so that a kernel can put something between them (k_wave_shade walks the shadow ray there, with
+// the BSDF sample not made yet and so not alive): stage_a1 -- the surface, emitted radiance and its MIS weight, the
+// emitter sample, the BSDF towards it, the shadow ray; stage_a2 -- the BSDF sample and the lane's class.  The sampler
+// draws keep their order (:214 before :272, 286); stage_a = the two in sequence.
 template <int kLevel>
-__device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_o, v3 ray_d, v3 thr, v3 prev_p,
-                                        float prev_bsdf_pdf, bool prev_delta, const HitRec &h, uint32_t depth, StageA &o)
+__device__ __forceinline__ void stage_a1(const RenderArgs &a, Pcg32 &rng, v3 ray_o, v3 ray_d, v3 thr, v3 prev_p,
+                                         float prev_bsdf_pdf, bool prev_delta, const HitRec &h, uint32_t depth, StageA &o)
 {
 	const Shapes &sh = a.shapes;
 	const int D = a.max_depth;
-	const float f = a.frac;
 	const bool valid = h.prim >= 0;
 	Surface sf;
 	sf.p = V(0, 0, 0); sf.n = V(0, 0, 1); sf.ng = V(0, 0, 1); sf.radiance = V(0, 0, 0); sf.is_em = false;
@@ -153,7 +159,24 @@ __device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_
 	const bool nee_live = active_em && !(o.bv_em.x == 0.0f && o.bv_em.y == 0.0f && o.bv_em.z == 0.0f && finite_f32(o.em_w.x) &&
 	                                     finite_f32(o.em_w.y) && finite_f32(o.em_w.z));
 	if (!nee_live) need_shadow = false;
-	// ---- :272-297 next direction ----
+	o.p = p; o.n = n; o.ng = sf.ng; o.wi = wi; o.refl = mt.refl;
+	o.mat = valid ? (int)((mt.M - a.mats) / kMaterialStride) : 0;
+	asm volatile("" : "+v"(o.mat)); // (the row's NUMBER from here on, one register: not the 64-bit pointer it was made of, kept for later)
+	o.flags = (valid ? F_VALID : 0u) | (active_next ? F_ACTIVE_NEXT : 0u) | (active_em ? F_ACTIVE_EM : 0u) |
+	          (need_shadow ? F_NEED_SHADOW : 0u) | (ds_delta ? F_DS_DELTA : 0u) | (nee_live ? F_NEE_LIVE : 0u) |
+	          ((__float_as_uint(o.Le.x) | __float_as_uint(o.Le.y) | __float_as_uint(o.Le.z)) != 0u ? F_HAS_LE : 0u);
+}
+
+// ---- :272-297 next direction (the surface comes back from what stage_a1 left in `o`: the Duff frame of the shading normal and
+// the material row are functions of o.n and o.mat) ----
+template <int kLevel>
+__device__ __forceinline__ void stage_a2(const RenderArgs &a, Pcg32 &rng, StageA &o)
+{
+	const float f = a.frac;
+	const bool active_next = (o.flags & F_ACTIVE_NEXT) != 0u;
+	Material mt = material_of(a, o.mat, o.refl, kLevel);
+	if (!(o.flags & F_VALID)) { mt.type = 0; mt.one_sided = false; } // (the ray left the scene: stage_a1's placeholder surface)
+	const Frame fr = make_frame(o.n);
 	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
 	if (active_next) { // next_1d (lobe choice: only the dielectrics read it), next_2d
 		if (kLevel >= 3) s1 = rng.next_f32();
@@ -163,20 +186,22 @@ __device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_
 	}
 	v3 wo_local;
 	bool delta;
-	bsdf_sample<kLevel>(mt, wi, s1, s2x, s2y, active_next, wo_local, o.bsdf_pdf, o.bsdf_w, o.eta, delta);
+	bsdf_sample<kLevel>(mt, o.wi, s1, s2x, s2y, active_next, wo_local, o.bsdf_pdf, o.bsdf_w, o.eta, delta);
 	o.wo = to_world(fr, wo_local);
 	const bool do_mis = active_next && !delta && a.guided; // :283
 	bool pick_tree = false;
 	if (active_next) pick_tree = rng.next_f32() > f; // :286
 	const bool smp_tree = pick_tree && do_mis;
 	const bool bsdf_mis = do_mis && !smp_tree;
-	o.p = p; o.n = n; o.ng = sf.ng; o.wi = wi; o.refl = mt.refl;
-	o.mat = valid ? (int)((mt.M - a.mats) / kMaterialStride) : 0;
-	o.flags = (valid ? F_VALID : 0u) | (active_next ? F_ACTIVE_NEXT : 0u) | (active_em ? F_ACTIVE_EM : 0u) |
-	          (need_shadow ? F_NEED_SHADOW : 0u) | (ds_delta ? F_DS_DELTA : 0u) | (delta ? F_DELTA : 0u) |
-	          (do_mis ? F_DO_MIS : 0u) | (smp_tree ? F_SMP_TREE : 0u) | (bsdf_mis ? F_BSDF_MIS : 0u) |
-	          (nee_live ? F_NEE_LIVE : 0u) |
-	          ((__float_as_uint(o.Le.x) | __float_as_uint(o.Le.y) | __float_as_uint(o.Le.z)) != 0u ? F_HAS_LE : 0u);
+	o.flags |= (delta ? F_DELTA : 0u) | (do_mis ? F_DO_MIS : 0u) | (smp_tree ? F_SMP_TREE : 0u) | (bsdf_mis ? F_BSDF_MIS : 0u);
+}
+
+template <int kLevel>
+__device__ __forceinline__ void stage_a(const RenderArgs &a, Pcg32 &rng, v3 ray_o, v3 ray_d, v3 thr, v3 prev_p,
+                                        float prev_bsdf_pdf, bool prev_delta, const HitRec &h, uint32_t depth, StageA &o)
+{
+	stage_a1<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_bsdf_pdf, prev_delta, h, depth, o);
+	stage_a2<kLevel>(a, rng, o);
 }
 
 // ---- :244, 301, 307: the SD-tree calls of a bounce (one KD descent) and the canonical coordinates of
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
-	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
+	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
 	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
 	if (!alive) return;
 	v3 ray_o, ray_d;
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(7))) vo
 	const unsigned wl = threadIdx.x & 63u;
 	const Shapes &sh = a.shapes;
 	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
-	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + (size_t)gtid * kOvfStack);
+	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, gtid * (uint32_t)kOvfStack);
 	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
 	const int tri_base = sh.n_quads + sh.n_spheres + 6 * sh.n_boxes;
 	BvhWalk w;
@@ -899,15 +924,28 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 // and the hottest BVH nodes, and -- over the same bytes, once every walk of the workgroup is done -- the survivors'
 // records of a sorted next bounce.
 #ifndef PG_SHADE_STAGE
-#define PG_SHADE_STAGE 256
+#define PG_SHADE_STAGE 128
 #endif
 constexpr int kShadeStage = PG_SHADE_STAGE; // survivors' records staged in LDS at a time
-constexpr int kShadeLdsQuads = kShadeStage * 8 > kLdsStack * kRBlock / 2 + kBvhTopNodes * 8 ? kShadeStage * 8 : kLdsStack * kRBlock / 2 + kBvhTopNodes * 8;
+#ifndef PG_SHADE_STASH
+#define PG_SHADE_STASH 1
+#endif
+#ifndef PG_SHADE_TOP
+#define PG_SHADE_TOP 40
+#endif
+constexpr int kShadeTopNodes = PG_SHADE_STASH ? PG_SHADE_TOP : kBvhTopNodes; // (with the stash: what five workgroups per compute unit leave)
+constexpr int kShadeWalkQuads = kLdsStack * kRBlock / 2 + kShadeTopNodes * 8 + (PG_SHADE_STASH ? 9 * kRBlock / 4 : 0);
+constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage * 8 : kShadeWalkQuads;
 // (122 vector registers, four waves per SIMD, which is also what 33 KB of LDS per workgroup allow.  Measured: staging the
 // records 128 at a time -- 23 KB -- changes nothing by itself, and compiled for five waves on top of that the kernel spills
 // 31 registers: 35.2 -> 37.6 ms per step.)
+#ifdef PG_SHADE1_WAVES
+#define PG_SHADE1_OCC __attribute__((amdgpu_waves_per_eu(PG_SHADE1_WAVES)))
+#else
+#define PG_SHADE1_OCC
+#endif
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs a)
 {
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	__shared__ uint32_t s_wave[kRBlock / 64];
@@ -920,8 +958,8 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 	stage_kd_planes(s_planes, a.tree);
 	uint2 *s_stack = reinterpret_cast<uint2 *>(s_dyn);
 	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kLdsStack * kRBlock / 2;
-	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf + tid * kOvfStack);
-	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
+	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
+	stage_bvh_top<kShadeTopNodes>(s_top, a, stk);
 	bool cont = false;
 	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(1, 1, 1), L = V(0, 0, 0), p_here = V(0, 0, 0), prev_p = V(0, 0, 0);
 	float ior = 1.0f, prev_pdf = 1.0f;
@@ -933,22 +971,30 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 	if (!kFirst) {
 		rec_base = a.n_lanes;
 		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+		// (the same number in every lane, but read by vector loads -- live_count is written by this very grid -- so the
+		// compiler keeps it in two vector registers through the whole kernel unless it is told that it is uniform)
+		rec_base = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec_base) |
+		           ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rec_base >> 32)) << 32);
 	}
 	if (alive) {
+		// What a path carries from bounce to bounce is READ TWICE: the ray, the sampler, the hit and the throughput (for the
+		// emitted radiance's share) now; the throughput again, the index of refraction, the radiance so far and the path's lane
+		// only where stage_b needs them, behind the two walks -- the second read comes from the cache line the first one
+		// fetched, and nine registers are not alive across the walks (PG_SHADE_RELOAD 0: kept in registers, as round 3 did).
 		HitRec h;
-		if (!kFirst && a.perm) { // a sorted bounce: the path's 128-byte record, through the permutation
-			const uint4 *rec = a.carry_in + (tid < (uint64_t)a.n_sort ? (uint64_t)a.perm[tid] : tid) * 8;
-			const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+		const bool from_rec = !kFirst && a.perm != nullptr; // a sorted bounce: the path's 128-byte record, through the permutation
+		uint32_t place = (uint32_t)tid; // (32-bit: a place in the live list; one register through the walks, not two)
+		if (from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
+		if (from_rec) {
+			const uint4 *rec = a.carry_in + (uint64_t)place * 8;
+			const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q5 = rec[5], q6 = rec[6];
 			rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
 			rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
 			ray_o = st_v3(q0); ray_d = st_v3(q1);
 			thr = st_v3(q2);
-			ior = __uint_as_float(q2.w & 0x7fffffffu);
 			prev_delta = (q2.w >> 31) != 0u;
 			prev_p = st_v3(q3);
 			prev_pdf = __uint_as_float(q3.w);
-			L = st_v3(q4);
-			lane = q4.w;
 			h.prim = (int)q6.x; h.t = __uint_as_float(q6.y); h.u = __uint_as_float(q6.z); h.v = __uint_as_float(q6.w);
 		} else {
 			const uint4 q0 = st_load(a.st_in, a, 0, tid), q1 = st_load(a.st_in, a, 1, tid);
@@ -956,30 +1002,61 @@ __global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 			rng.inc = a.inc_in[tid];
 			ray_o = st_v3(q0); ray_d = st_v3(q1);
 			if (!kFirst) {
-				const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid), q4 = st_load(a.st_in, a, 4, tid);
+				const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid);
 				thr = st_v3(q2);
-				ior = __uint_as_float(q2.w & 0x7fffffffu);
 				prev_delta = (q2.w >> 31) != 0u;
 				prev_p = st_v3(q3);
 				prev_pdf = __uint_as_float(q3.w);
-				L = st_v3(q4);
-				lane = q4.w;
 			}
 			h.prim = (int)wsu(a, WS_HIT_PRIM, tid);
 			h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
 		}
 		StageA A;
-		stage_a<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
+		stage_a1<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
+		// What stage_a1 leaves is PINNED here: every output is made now, so that its inputs die.  (Left alone the compiler
+		// sinks the last operations of a value that is only read behind the walk -- the emitted radiance's three products, the
+		// flag word's bits -- below the walk, and carries their more numerous inputs through it instead.)
+		asm volatile("" : "+v"(A.flags), "+v"(A.wi.x), "+v"(A.wi.y), "+v"(A.wi.z), "+v"(A.p.x), "+v"(A.p.y), "+v"(A.p.z),
+		                  "+v"(A.ng.x), "+v"(A.ng.y), "+v"(A.ng.z), "+v"(A.refl.x), "+v"(A.refl.y), "+v"(A.refl.z));
+		asm volatile("" : "+v"(A.ds_d.x), "+v"(A.ds_d.y), "+v"(A.ds_d.z), "+v"(A.ds_pdf), "+v"(A.bp_em), "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z));
+#if PG_SHADE_STASH
+		// nine values only stage_b reads wait in LDS while the two walks run (column threadIdx.x of a [9][kRBlock] array)
+		float *stash = reinterpret_cast<float *>(s_dyn) + (kLdsStack * kRBlock * 2 + kShadeTopNodes * 32) + threadIdx.x;
+		stash[0 * kRBlock] = A.Le.x; stash[1 * kRBlock] = A.Le.y; stash[2 * kRBlock] = A.Le.z;
+		stash[3 * kRBlock] = A.bv_em.x; stash[4 * kRBlock] = A.bv_em.y; stash[5 * kRBlock] = A.bv_em.z;
+		stash[6 * kRBlock] = A.em_w.x; stash[7 * kRBlock] = A.em_w.y; stash[8 * kRBlock] = A.em_w.z;
+#endif
+		// The shadow ray is walked HERE, between the two halves of stage_a: the BSDF sample is not made yet and the SD-tree
+		// calls have no results yet, so neither is alive across the walk -- the walk's 50 registers on top of everything a
+		// bounce keeps were this kernel's register peak (123 with the walk at the end).  The walk draws no
+		// sample, so the sampler's order is untouched.
+		bool occluded = false;
+		if (A.flags & F_NEED_SHADOW) { // :213 test_visibility
+			float th, bu, bv;
+			occluded = intersect<kLevel, true, true>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
+		}
+		stage_a2<kLevel>(a, rng, A);
 		GuideOut g;
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
 		g.wo = A.wo;
 		if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, (A.flags & F_SMP_TREE) ? V(0, 0, 0) : A.wo, A.flags, g);
 		if (a.record && (A.flags & F_VALID)) store_slots(a, rec_base + tid, g);
-		bool occluded = false;
-		if (A.flags & F_NEED_SHADOW) { // :213 test_visibility
-			float th, bu, bv;
-			occluded = intersect<kLevel, true>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
+#if PG_SHADE_STASH
+		A.Le = V(stash[0 * kRBlock], stash[1 * kRBlock], stash[2 * kRBlock]);
+		A.bv_em = V(stash[3 * kRBlock], stash[4 * kRBlock], stash[5 * kRBlock]);
+		A.em_w = V(stash[6 * kRBlock], stash[7 * kRBlock], stash[8 * kRBlock]);
+#endif
+		// the second read (see above): throughput, index of refraction, radiance so far, lane
+		if (!kFirst) {
+			asm volatile("" : "+v"(place)); // (not the first read's value kept in registers: a load of its own)
+			uint4 q2, q4;
+			if (from_rec) { const uint4 *rec = a.carry_in + (uint64_t)place * 8; q2 = rec[2]; q4 = rec[4]; }
+			else { q2 = st_load(a.st_in, a, 2, place); q4 = st_load(a.st_in, a, 4, place); }
+			thr = st_v3(q2);
+			ior = __uint_as_float(q2.w & 0x7fffffffu);
+			L = st_v3(q4);
+			lane = q4.w;
 		}
 		cont = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, rec_base + tid, (uint32_t)a.bounce, ray_o, ray_d, prev_pdf, delta);
 		p_here = A.p;
@@ -1014,7 +1091,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	const uint64_t tail_base = rec_base + live; // behind the entries of bounce a.bounce
 	uint64_t slot = rec_base + tid;
 	const unsigned wl = threadIdx.x & 63u;
-	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf + tid * kOvfStack);
+	const BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
 	Pcg32 rng;
 	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(0, 0, 0), L = V(0, 0, 0), prev_p = V(0, 0, 0);
 	float prev_pdf = 1.0f, ior = 1.0f;
@@ -1123,7 +1200,16 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		break;
 	}
 	case 6: {
-		const size_t lds = (size_t)kShadeLdsQuads * sizeof(uint4);
+		// (dev switch: $PGSD_SHADE_LDS_PAD bytes of extra dynamic LDS per workgroup, to see what one resident wave fewer costs)
+		static const size_t pad = getenv("PGSD_SHADE_LDS_PAD") ? (size_t)atol(getenv("PGSD_SHADE_LDS_PAD")) : 0;
+		const size_t lds = (size_t)kShadeLdsQuads * sizeof(uint4) + pad;
+		static bool told = false;
+		if (!told && getenv("PGSD_TRACE_OCC")) { // (dev switch: how many workgroups of this kernel a compute unit holds)
+			told = true;
+			int nb = 0;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wave_shade<kLevel, false>, kRBlock, lds);
+			fprintf(stderr, "[pgsd] k_wave_shade<%d>: %d workgroups of %d threads per compute unit with %zu bytes of dynamic LDS\n", kLevel, nb, kRBlock, lds);
+		}
 		if (first) hipLaunchKernelGGL((k_wave_shade<kLevel, true>), grid, block, lds, s, a);
 		else hipLaunchKernelGGL((k_wave_shade<kLevel, false>), grid, block, lds, s, a);
 		break;
