@@ -211,6 +211,10 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                 if save_dir:
                     blend = (acc_now / done * cur_cnt + prev_iter_image * (image_spp - cur_cnt)) / image_spp  # main.py:271-273
                     save_image(os.path.join(save_dir, f"iter-{k}_spp-{image_spp}_cumm_spp-{cumm_spp}"), blend)
+        if gather is not None and all_reduce is not None and not is_final:
+            # the accumulators start travelling now, beside the image sums and the variance below (is_final is the same
+            # on every rank; whether the refine then happens is decided from the whole film's sums, also the same everywhere)
+            integrator.beginAccumulatorExchange(all_reduce)
         curr_iter_image = whole(curr_iter_image)  # (sharded with a halo exchange: the ranks' rows become the film, once)
         torch.cuda.synchronize()
         t_render = time.perf_counter() - t_iter

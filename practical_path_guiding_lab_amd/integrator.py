@@ -54,6 +54,9 @@ class PathGuidingIntegrator:
         # stream wait for the passes before anything here reads what they write
         self._epoch = 0
         self._inflight_scene = None
+        # the multi-GPU exchange of an iteration, issued ahead of its refine on a stream of its own (beginAccumulatorExchange)
+        self._exchange_stream = None
+        self._exchange_pending = False
 
     # ---- path_guiding_integrator.py:77-105 ---------------------------------------------------
     def _join(self) -> None:
@@ -83,6 +86,9 @@ class PathGuidingIntegrator:
 
     def setIteration(self, iteration: int, isFinalIter: bool) -> None:  # :121-123
         self._join()
+        if self._exchange_pending:  # (an exchange whose refine never came: the next iteration must not race with it)
+            torch.cuda.current_stream().wait_stream(self._exchange_stream)
+            self._exchange_pending = False
         self.iteration = int(iteration)
         self.isFinalIter = bool(isFinalIter)
         self.sdTree.setIteration(self.iteration, self.isFinalIter)
@@ -151,11 +157,29 @@ class PathGuidingIntegrator:
         return v
 
     # ---- refinement (:553-586) ------------------------------------------------------------------
+    def beginAccumulatorExchange(self, all_reduce) -> None:
+        """Multi-GPU: issues the iteration's all-reduce of sdTree_current's accumulators NOW -- behind everything the passes
+        have queued, on a stream of its own -- so that the 300 MB it moves over xGMI travel while the current stream
+        develops the film, sums the images and computes the variance that decides whether the refine happens at all
+        (main.py:334-377).  refineAndPrepareSDTreeForNextIteration waits for it instead of exchanging again.  Every rank
+        must call it at the same point (the driver does so after the last pass of every iteration that is not final).  An
+        exchange whose refine never comes (training stops) costs its time and changes nothing anyone reads."""
+        self._join()
+        if self._exchange_stream is None:
+            self._exchange_stream = torch.cuda.Stream(device=self.device)
+        self._exchange_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._exchange_stream):
+            all_reduce(self.sdTree.accumulators())
+        self._exchange_pending = True
+
     def refineAndPrepareSDTreeForNextIteration(self, all_reduce=None) -> None:
         """all_reduce: optional callable(int64 tensor) -> None summing the accumulators over ranks
         (torch.distributed.all_reduce on the RCCL group) before the deterministic refine."""
         self._join()
-        if all_reduce is not None:
+        if self._exchange_pending:  # (already on its way: beginAccumulatorExchange)
+            torch.cuda.current_stream().wait_stream(self._exchange_stream)
+            self._exchange_pending = False
+        elif all_reduce is not None:
             all_reduce(self.sdTree.accumulators())
         self.sdTree.refineAndPrepare()
 

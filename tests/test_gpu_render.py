@@ -367,33 +367,42 @@ def test_veach_ajar_agrees_with_the_tungsten_ground_truth():
     ground truth (tests/golden/veach_ajar_gt_320x180_f16.npy from scenes/veach-ajar/TungstenRender.exr),
     outside the rectangle of the three teapots whose meshes the reference mount lacks: the MSE metric
     falls by two orders of magnitude over the iterations; the image mean agrees to 2.5 % and the
-    15x20 blocks to 4 % on average (measured with the full-resolution textures of round 3: blocks -2.6 % in
-    the mean, 3.9 % off on average, the worst 15.1 %; with round 2's reduced textures -1.6 %, 3.8 %; the scene
-    is lit through the gap of a door, still noisy at this sample count, and the teapots' share of the indirect
-    light is missing)."""
+    15x20 blocks to 4 % on average, the worst to 15 %.
+
+    The block bound is taken on the mean image of THREE independent runs (seeds 3, 4, 5).  Measured over six seeds
+    (tools/ajar_block_spread.py, profiles/r04/ajar_block_spread.txt): what the missing teapots' indirect light and the
+    720p ground truth filtered to this film leave is an offset of 3.7 % per block on average and 11.4 % at the worst
+    block -- the same blocks, the same sign, whatever the seed; on top of it a block of one run scatters by 1.3 % on
+    average and by up to 5.8 % (the scene is lit through the gap of a door), so the worst block of a single run lay
+    anywhere between 11.4 % and 15.1 % -- round 3 moved the bound from 0.15 to 0.18 when the run with seed 3 came out
+    at 0.1508.  Averaging three runs brings the scatter under 3.4 % and the bound back to 0.15."""
     import os
     from practical_path_guiding_lab_amd.driver import load_ground_truth, run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import WavefrontScene
     from practical_path_guiding_lab_amd.scene import veach_ajar, veach_ajar_mask
 
-    sc = veach_ajar(320, 180)
-    assert sc.max_depth == 13 and sc.rfilter == "tent" and len(sc.skipped) == 6
     gt_path = os.path.join(os.path.dirname(__file__), "golden", "veach_ajar_gt_320x180_f16.npy")
-    gt = load_ground_truth(gt_path, 320, 180)
-    g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
-    res = run_guided_render(WavefrontScene(sc), g, 1020, initial_seed=3, ground_truth=gt, training_spp_per_pass=4,
-                            log=lambda s: None)
-    mse = [r[5] for r in res["records"]["mse_groundTruth_endIter"].rows]
-    assert len(mse) == 8 and all(np.isfinite(mse)) and mse[-1] < 0.02 * mse[0]
     gtn = np.load(gt_path).astype(np.float64)
     mask = veach_ajar_mask(320, 180)
-    img = np.where(mask[..., None], res["image"].cpu().numpy().astype(np.float64), gtn)  # teapot pixels drop out
-    assert np.isfinite(img).all()
-    assert abs(img[mask].mean() / gtn[mask].mean() - 1) < 0.025
-    ratios = _block_ratios(img, gtn, 15, 20)
-    assert ratios.size >= 150
-    assert abs(ratios.mean() - 1) < 0.04 and np.abs(ratios - 1).mean() < 0.05 and np.abs(ratios - 1).max() < 0.18
+    imgs = []
+    for seed in (3, 4, 5):
+        sc = veach_ajar(320, 180)
+        assert sc.max_depth == 13 and sc.rfilter == "tent" and len(sc.skipped) == 6
+        gt = load_ground_truth(gt_path, 320, 180)
+        g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
+        res = run_guided_render(WavefrontScene(sc), g, 1020, initial_seed=seed, ground_truth=gt, training_spp_per_pass=4,
+                                log=lambda s: None)
+        mse = [r[5] for r in res["records"]["mse_groundTruth_endIter"].rows]
+        assert len(mse) == 8 and all(np.isfinite(mse)) and mse[-1] < 0.02 * mse[0]
+        img = np.where(mask[..., None], res["image"].cpu().numpy().astype(np.float64), gtn)  # teapot pixels drop out
+        assert np.isfinite(img).all()
+        assert abs(img[mask].mean() / gtn[mask].mean() - 1) < 0.025
+        one = _block_ratios(img, gtn, 15, 20)
+        assert one.size >= 150 and abs(one.mean() - 1) < 0.04 and np.abs(one - 1).mean() < 0.05
+        imgs.append(img)
+    ratios = _block_ratios(np.mean(imgs, axis=0), gtn, 15, 20)
+    assert np.abs(ratios - 1).max() < 0.15
 
 
 def test_tent_film_matches_the_oracle_bit_for_bit():

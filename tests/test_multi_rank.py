@@ -83,9 +83,12 @@ def test_shard_covers_everything():
         shard(10, 2, 2)
 
 
-def test_two_rank_allreduce_equals_single_process(tmp_path):
-    world, out = 2, str(tmp_path / "sum.npy")
-    mp.spawn(_worker_cpu, args=(world, 29611, out), nprocs=world, join=True)
+@pytest.mark.parametrize("world,port", [(2, 29611), (8, 29624)])
+def test_rank_allreduce_equals_single_process(tmp_path, world, port):
+    """2 and 8 ranks (the node the multi-GPU configurations name): every rank splats its share of the records, the
+    accumulators are summed over gloo in the device's limb format, and equal a single process's that saw all records."""
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_worker_cpu, args=(world, port, out), nprocs=world, join=True)
     got = np.load(out)
     ref = po.OracleTree()
     ref.load(_base_tree())
