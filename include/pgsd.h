@@ -32,7 +32,7 @@ extern "C" {
  * BVH is limited to 2^25 nodes; new entry points pg_film_stripes, pg_render_overlap, pg_render_sort, pg_render_stages.
  * A caller compiled against version 2 must be rebuilt (the two structs changed size): check pg_abi_version(). */
 /* 4 (round 4): pg_depth_counters gained layout_bytes, pg_stats gained bytes_jump_tables / jump_bits / kd_grid_bits,
- * pg_pass_params.reserved2 became `batched` (same size); new entry point pg_film_batched. */
+ * pg_pass_params.reserved2 became `batched` (same size); new entry points pg_film_batched, pg_film_batched_accumulate. */
 #define PGSD_ABI_VERSION 4
 
 typedef struct pg_context pg_context;
@@ -449,6 +449,15 @@ int pg_film_stripes(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp,
  * images_out: n_passes x Color3f[W*H] planar, image-major. */
 int pg_film_batched(pg_context *ctx, int32_t filter, uint32_t seed, int32_t n_passes, const float *L, float *images_out,
                     uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream);
+
+/* The same without the n_passes images: the running mean main.py keeps of an iteration's passes (:218-239: every pass's image
+ * times spp_of_pass / spp_of_iteration, summed in pass order).  acc_io (Color3f[W*H] planar) becomes
+ * ((acc + image_0 * scale) + image_1 * scale) + ... in fp32, each product and each sum rounded on its own -- what a host
+ * makes of the separate images; with acc_has_value 0 the first image is assigned, not added (acc_io may then be
+ * uninitialised on the developed pixels).  A striped call touches its own rows only. */
+int pg_film_batched_accumulate(pg_context *ctx, int32_t filter, uint32_t seed, int32_t n_passes, const float *L, float *acc_io,
+                               float scale, int32_t acc_has_value, uint32_t stripe_rows, uint32_t stripe_index,
+                               uint32_t stripe_count, void *stream);
 
 /* Element-wise evaluation of the library's own fp32 transcendental functions (fixed
  * sequences of double operations, no vendor math library), so that a caller -- the parity tests --

@@ -114,7 +114,7 @@ EXPORTS = (
     "pg_export_sizes", "pg_export", "pg_import", "pg_export_accumulators", "pg_get_stats",
     "pg_enable_depth_counters", "pg_read_depth_counters", "pg_scene_set", "pg_render_pass",
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
-    "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_film_batched", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
+    "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_film_batched", "pg_film_batched_accumulate", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
     "pg_render_split_pipeline",
 )
@@ -200,6 +200,7 @@ def lib() -> C.CDLL:
     L.pg_film.argtypes = [V, I32, U32, I32, V, V, V]
     L.pg_film_stripes.argtypes = [V, I32, U32, I32, V, V, U32, U32, U32, V]
     L.pg_film_batched.argtypes = [V, I32, U32, I32, V, V, U32, U32, U32, V]
+    L.pg_film_batched_accumulate.argtypes = [V, I32, U32, I32, V, V, C.c_float, I32, U32, U32, U32, V]
     L.pg_render_overlap.argtypes = [V, I32]
     L.pg_render_sort.argtypes = [V, I32]
     L.pg_render_stages.argtypes = [V, I32]

@@ -456,10 +456,14 @@ __device__ __forceinline__ float gauss1(float d)
 // kBatched (pg_film_batched): L holds spp one-sample passes traced together (pg_pass_params.batched); the film is
 // developed for each of them by itself -- image s from the samples s of the neighbourhood, exactly what pg_film gives
 // for the pass seed + s alone -- into out[s][3][W * H].
+// With `acc` (pg_film_batched's accumulating form) the images are not written: image s is scaled and added to acc in pass
+// order, acc = acc + image_s * scale in fp32 (the first one assigned when acc_set is 0) -- the running mean main.py keeps
+// of an iteration's passes (:218-239), the very operations the host would make on the separate images.
 template <int kFilter, bool kBatched> // kFilter: 0 tent (3x3 neighbourhood), 1 gaussian (5x5)
 __global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W, int H,
                                                   const float *__restrict__ L, float *__restrict__ out,
-                                                  uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count)
+                                                  uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count,
+                                                  float *__restrict__ acc, float scale, int acc_set)
 {
 	constexpr int R = kFilter == 1 ? 2 : 1;
 	const uint64_t npix = (uint64_t)W * (uint64_t)H, N = npix * (uint64_t)spp;
@@ -488,10 +492,17 @@ __global__ __launch_bounds__(kRBlock) void k_film(uint32_t seed, int spp, int W,
 				}
 			}
 		const bool ok = wsum > 0.0f;
-		float *dst = out + (uint64_t)img * 3u * npix;
-		dst[o] = ok ? a0 / wsum : 0.0f;
-		dst[npix + o] = ok ? a1 / wsum : 0.0f;
-		dst[2 * npix + o] = ok ? a2 / wsum : 0.0f;
+		const float r0 = ok ? a0 / wsum : 0.0f, r1 = ok ? a1 / wsum : 0.0f, r2 = ok ? a2 / wsum : 0.0f;
+		if (kBatched && acc) {
+			const float v0 = r0 * scale, v1 = r1 * scale, v2 = r2 * scale;
+			const bool first = img == 0 && !acc_set;
+			acc[o] = first ? v0 : acc[o] + v0;
+			acc[npix + o] = first ? v1 : acc[npix + o] + v1;
+			acc[2 * npix + o] = first ? v2 : acc[2 * npix + o] + v2;
+		} else {
+			float *dst = out + (uint64_t)img * 3u * npix;
+			dst[o] = r0; dst[npix + o] = r1; dst[2 * npix + o] = r2;
+		}
 	}
 }
 
@@ -1203,11 +1214,12 @@ int pg_film(pg_context *ctx, int32_t filter, uint32_t seed, int32_t spp, const f
 }
 
 static int film_launch(pg_context *ctx, int32_t filter, bool batched, uint32_t seed, int32_t spp, const float *L, float *image_out,
-                       uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
+                       uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream, float *acc = nullptr,
+                       float scale = 1.0f, int acc_set = 0)
 {
 	if (!ctx) return PG_ERR_INVALID;
 	if (!ctx->render || !ctx->render->have_scene) return fail(ctx, PG_ERR_INVALID, "pg_film: call pg_scene_set first");
-	if (!L || !image_out || spp <= 0) return fail(ctx, PG_ERR_INVALID, "pg_film: NULL pointer or spp <= 0");
+	if (!L || (!image_out && !acc) || spp <= 0) return fail(ctx, PG_ERR_INVALID, "pg_film: NULL pointer or spp <= 0");
 	if (stripe_count > 1 && (stripe_rows == 0 || stripe_index >= stripe_count)) return fail(ctx, PG_ERR_INVALID, "pg_film_stripes: bad stripe parameters");
 	if (filter != PG_FILTER_TENT && filter != PG_FILTER_GAUSSIAN) return fail(ctx, PG_ERR_INVALID, "pg_film: unknown filter");
 	PG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1215,7 +1227,7 @@ static int film_launch(pg_context *ctx, int32_t filter, bool batched, uint32_t s
 	const uint64_t npix = (uint64_t)cam.width * (uint64_t)cam.height;
 	const dim3 grid((unsigned)((npix + kRBlock - 1) / kRBlock)), block(kRBlock);
 	hipStream_t st = (hipStream_t)stream;
-#define PG_FILM(F, B) hipLaunchKernelGGL((k_film<F, B>), grid, block, 0, st, seed, spp, cam.width, cam.height, L, image_out, stripe_rows, stripe_index, stripe_count)
+#define PG_FILM(F, B) hipLaunchKernelGGL((k_film<F, B>), grid, block, 0, st, seed, spp, cam.width, cam.height, L, image_out, stripe_rows, stripe_index, stripe_count, acc, scale, acc_set)
 	if (filter == PG_FILTER_GAUSSIAN) { if (batched) PG_FILM(1, true); else PG_FILM(1, false); }
 	else { if (batched) PG_FILM(0, true); else PG_FILM(0, false); }
 #undef PG_FILM
@@ -1233,6 +1245,15 @@ int pg_film_batched(pg_context *ctx, int32_t filter, uint32_t seed, int32_t n_pa
                     uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_count, void *stream)
 {
 	return film_launch(ctx, filter, true, seed, n_passes, L, images_out, stripe_rows, stripe_index, stripe_count, stream);
+}
+
+int pg_film_batched_accumulate(pg_context *ctx, int32_t filter, uint32_t seed, int32_t n_passes, const float *L, float *acc_io,
+                               float scale, int32_t acc_has_value, uint32_t stripe_rows, uint32_t stripe_index,
+                               uint32_t stripe_count, void *stream)
+{
+	if (!acc_io) return fail(ctx, PG_ERR_INVALID, "pg_film_batched_accumulate: NULL accumulator");
+	return film_launch(ctx, filter, true, seed, n_passes, L, nullptr, stripe_rows, stripe_index, stripe_count, stream, acc_io, scale,
+	                   acc_has_value ? 1 : 0);
 }
 
 int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, float *out, void *stream)

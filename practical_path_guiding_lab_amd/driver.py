@@ -176,16 +176,23 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         launch = 1  # one-sample training passes traced per device launch
         if not is_final and spp_per_pass == 1 and not record_in_iteration:
             launch = max(1, int(training_passes_per_launch))
-        queued: List[torch.Tensor] = []
+        if launch > 1:
+            # `launch` consecutive one-sample passes per device pass; the film folds their images into the iteration's running
+            # mean itself (pg_film_batched_accumulate) -- the products and sums the loop below makes of separate images, in
+            # the same order, without writing the images
+            acc = None
+            scale = float(np.float32(1.0 / iter_spp))
+            for p in range(0, n_pass, launch):
+                nb = min(launch, n_pass - p)
+                acc = render_batched(scene, integrator, nb, seed=initial_seed + cumm_spp, gather=gather, mean_of=(acc, scale))
+                image_spp += nb
+                done += nb
+                cumm_spp += nb
+            curr_iter_image = acc.reshape(3, h, w).permute(1, 2, 0).contiguous()
+            n_pass = 0
         for p in range(n_pass):
             cur = min(spp_per_pass, iter_spp - done)
-            if launch > 1:
-                if not queued:  # the next `launch` passes in one go; their images are then consumed one per turn of this loop
-                    nb = min(launch, n_pass - p)
-                    queued = list(render_batched(scene, integrator, nb, seed=initial_seed + cumm_spp, gather=gather))
-                img = queued.pop(0)
-            else:
-                img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp, gather=gather)  # main.py:218
+            img = render(scene, integrator, spp=cur, seed=initial_seed + cumm_spp, gather=gather)  # main.py:218
             wimg = img * float(cur / iter_spp)
             curr_iter_image = wimg if curr_iter_image is None else curr_iter_image + wimg
             if is_final:

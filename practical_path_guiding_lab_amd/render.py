@@ -240,11 +240,16 @@ class WavefrontScene:
         return L, valid, spp
 
 
-def render_batched(scene: WavefrontScene, integrator, n_passes: int, seed: int, gather=None) -> torch.Tensor:
+def render_batched(scene: WavefrontScene, integrator, n_passes: int, seed: int, gather=None, mean_of=None):
     """[render(scene, integrator, 1, seed + s) for s in range(n_passes)] -- the reference's one-sample training passes
     (main.py:192, 218) -- as ONE device pass (pg_pass_params.batched) and one film launch (pg_film_batched): returns the
     n_passes images, (n_passes, H, W, 3), each bit-identical to the image of the separate call; the integrator's sums and
-    sdTree_current end as after the separate calls.  Box filter: the image of a one-sample pass is its samples."""
+    sdTree_current end as after the separate calls.  Box filter: the image of a one-sample pass is its samples.
+
+    mean_of = (acc, scale): instead of the images, the running mean main.py keeps of an iteration's passes (:218-239) --
+    acc (a planar (3, H*W) tensor, or None before the first pass) becomes ((acc + image_0 * scale) + image_1 * scale) + ...,
+    fp32, every product and sum rounded on its own, exactly what the host makes of the separate images
+    (pg_film_batched_accumulate: the n_passes images are never written); returns acc."""
     sampler = IndependentSampler(n_passes, seed, batched=True)
     L, _, _ = integrator.sample(scene, sampler)
     scene.join()
@@ -255,6 +260,8 @@ def render_batched(scene: WavefrontScene, integrator, n_passes: int, seed: int, 
     partial = False
     if scene.sharded:
         if gather is None:
+            if mean_of is not None:
+                raise ValueError("mean_of needs the whole film or a gather")
             return L.reshape(3, -1, n_passes).permute(2, 1, 0).reshape(n_passes, -1, 1, 3).contiguous()
         if hasattr(gather, "reduce_image"):
             partial = True
@@ -263,6 +270,26 @@ def render_batched(scene: WavefrontScene, integrator, n_passes: int, seed: int, 
                 L = gather(L, scene, n_passes, 1 if filt == "tent" else 2)
         else:
             L = gather(L, scene, n_passes)
+    if mean_of is not None:
+        acc, scale = mean_of
+        if filt in ("tent", "gaussian"):
+            has = acc is not None
+            if acc is None:  # (a band-sharded rank develops its own rows only: the others stay zero, as in the separate images)
+                acc = (torch.zeros if partial else torch.empty)((3, h * w), dtype=torch.float32, device=tree.device)
+            N.check(tree._h, tree._lib.pg_film_batched_accumulate(
+                tree._h, ("tent", "gaussian").index(filt), seed & 0xFFFFFFFF, n_passes, L.data_ptr(), acc.data_ptr(),
+                C.c_float(float(scale)), 1 if has else 0, stripes[0], stripes[1], stripes[2], torch.cuda.current_stream().cuda_stream))
+            return acc
+        # box filter: the image of a one-sample pass is its samples
+        if partial:
+            imgs = torch.zeros((n_passes, 3, h * w), dtype=torch.float32, device=tree.device)
+            imgs[:, :, torch.from_numpy(scene.local_pixels()).to(tree.device)] = L.reshape(3, -1, n_passes).permute(2, 0, 1)
+        else:
+            imgs = L.reshape(3, h * w, n_passes).permute(2, 0, 1)
+        for s in range(n_passes):
+            wimg = imgs[s] * float(scale)
+            acc = wimg if acc is None else acc + wimg
+        return acc
     if filt in ("tent", "gaussian"):
         img = (torch.zeros if partial else torch.empty)((n_passes, 3, h * w), dtype=torch.float32, device=tree.device)
         N.check(tree._h, tree._lib.pg_film_batched(tree._h, ("tent", "gaussian").index(filt), seed & 0xFFFFFFFF, n_passes,

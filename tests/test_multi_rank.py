@@ -393,7 +393,7 @@ def test_halo_exchange_in_a_sub_group_and_the_writer_vote(tmp_path):
     assert all(bool(np.load(out % r)[0]) for r in range(3))
 
 
-def _drive(shard_arg, out_dir=None, **kw):
+def _drive(shard_arg, out_dir=None, spp_per_pass=2, **kw):
     from practical_path_guiding_lab_amd.driver import run_guided_render
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
     from practical_path_guiding_lab_amd.render import WavefrontScene
@@ -402,7 +402,7 @@ def _drive(shard_arg, out_dir=None, **kw):
     sc = cornell_box(RES, 20, 6, 8)  # tent filter: a pixel needs its neighbours, which another rank traced
     g = PathGuidingIntegrator({"max_depth": 6, "rr_depth": 8})
     gt = torch.full((3, RES * 20), 0.25, device="cuda")
-    res = run_guided_render(WavefrontScene(sc), g, budget_spp=60, initial_seed=5, ground_truth=gt, training_spp_per_pass=2,
+    res = run_guided_render(WavefrontScene(sc), g, budget_spp=60, initial_seed=5, ground_truth=gt, training_spp_per_pass=spp_per_pass,
                             batch_spp=4, log=lambda s: None, shard=shard_arg, out_dir=out_dir, **kw)
     rows = {k: np.array(v.rows, dtype=np.float64)[:, 1:] for k, v in res["records"].items() if v.rows}  # (all but the wall time)
     return res["image"].cpu().numpy(), g.sdTree.export(), rows
@@ -417,6 +417,35 @@ def _worker_drive(rank, world, port, out):
     np.savez(out % rank, image=img, **{"rec_" + k: v for k, v in rows.items()}, **tree)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_drive_batched(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    img, tree, rows = _drive((rank, world, 4), spp_per_pass=1, training_passes_per_launch=5)
+    np.savez(out % rank, image=img, **{"rec_" + k: v for k, v in rows.items()}, **tree)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_driver_with_batched_launches_equals_the_reference_schedule_on_one_rank(tmp_path):
+    """main.py's schedule (one-sample training passes) on two ranks, five passes per device launch, the film folded into the
+    running mean by pg_film_batched_accumulate on each rank's own rows behind the halo exchange: the image, the tree and
+    the logs of ONE rank that launches every pass by itself, bit for bit."""
+    world = 2
+    out = str(tmp_path / "b%d.npz")
+    mp.spawn(_worker_drive_batched, args=(world, 29625, out), nprocs=world, join=True)
+    img, tree, rows = _drive(None, spp_per_pass=1)
+    for r in range(world):
+        got = dict(np.load(out % r))
+        np.testing.assert_array_equal(got["image"].view(np.uint32), img.view(np.uint32))
+        for key in tree:
+            np.testing.assert_array_equal(np.asarray(got[key]).astype(np.float64), np.asarray(tree[key]).astype(np.float64), err_msg=key)
+        for key, v in rows.items():
+            np.testing.assert_array_equal(got["rec_" + key], v, err_msg=key)
 
 
 @pytest.mark.gpu
