@@ -789,7 +789,7 @@ int pg_scene_set_ex(pg_context *ctx, const pg_scene_desc *sc, const pg_camera *c
 			for (int c = 0; c < 4; ++c) kids += N[24 + c] != 0xffffffffu;
 			if (kids == 0) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH node without children");
 			const int below = (int)waiting[i] + kids - 1; // its other children wait while the walk is in one of them
-			if (below > kLdsStack + kOvfStack) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH too deep for the walk's stack (32 waiting siblings)");
+			if (below > kMinLdsStack + kOvfStack) return fail(ctx, PG_ERR_INVALID, "pg_scene_set: BVH too deep for the walk's stack (32 waiting siblings)");
 			for (int c = 0; c < 4; ++c) {
 				const uint32_t ref = N[24 + c];
 				if (ref == 0xffffffffu) continue;

@@ -106,8 +106,9 @@ struct Shapes {
 // wave's accesses to one level hit 64 different banks); the rare deeper ones go to a per-lane strip
 // of a global workspace.  An entry is (reference, entry distance).  pg_scene_set_ex checks that no
 // walk can need more than kLdsStack + kOvfStack entries.
-constexpr int kLdsStack = 8;
-constexpr int kOvfStack = 24;
+constexpr int kLdsStack = 8;  // entries of a lane in LDS in the ray-casting kernels (k_wave_shade keeps fewer: BvhStack::n_lds)
+constexpr int kOvfStack = 28; // entries of a lane's overflow strip: 32 (what pg_scene_set_ex admits) minus the fewest any kernel keeps in LDS
+constexpr int kMinLdsStack = 4;
 typedef __attribute__((address_space(3))) uint32_t LdsWord; // an LDS pointer stays one: ds_read / ds_write, never flat
 typedef __attribute__((address_space(3))) u32x4_t LdsQuad;
 struct BvhStack {
@@ -117,26 +118,28 @@ struct BvhStack {
 	                    // instead of two alive through the whole walk (pg_render_pass keeps n_lanes * kOvfStack below 2^32)
 	const LdsQuad *top; // the first n_top nodes of the BVH, which the kernel has copied into LDS (stage_bvh_top); 0: none
 	uint32_t n_top;
+	int n_lds;          // entries of this lane that sit in LDS (a constant of the kernel: kLdsStack, or fewer where LDS is short)
 	__device__ __forceinline__ void push(int sp, uint32_t ref, float t) const
 	{
-		if (sp < kLdsStack) {
+		if (sp < n_lds) {
 			lds[sp * (2 * kRBlock)] = ref;
 			lds[sp * (2 * kRBlock) + 1] = __float_as_uint(t);
-		} else ovf[ovf_first + (uint32_t)(sp - kLdsStack)] = make_uint2(ref, __float_as_uint(t));
+		} else ovf[ovf_first + (uint32_t)(sp - n_lds)] = make_uint2(ref, __float_as_uint(t));
 	}
 	__device__ __forceinline__ uint2 at(int sp) const
 	{
 		// the LDS read is unconditional (of a clamped level) and volatile so that it stays a ds_read: two
 		// loads in two branches get folded into one flat load of a selected address
-		const volatile LdsWord *w = lds + (sp < kLdsStack ? sp : kLdsStack - 1) * (2 * kRBlock);
+		const volatile LdsWord *w = lds + (sp < n_lds ? sp : n_lds - 1) * (2 * kRBlock);
 		uint2 e = make_uint2(w[0], w[1]);
-		if (sp >= kLdsStack) e = ovf[ovf_first + (uint32_t)(sp - kLdsStack)];
+		if (sp >= n_lds) e = ovf[ovf_first + (uint32_t)(sp - n_lds)];
 		return e;
 	}
 };
-__device__ __forceinline__ BvhStack bvh_stack(uint2 *lds_column, uint2 *ovf, uint32_t ovf_first)
+__device__ __forceinline__ BvhStack bvh_stack(uint2 *lds_column, uint2 *ovf, uint32_t ovf_first, int n_lds = kLdsStack)
 {
 	BvhStack s;
+	s.n_lds = n_lds;
 	s.lds = (LdsWord *)lds_column;
 	s.ovf = ovf;
 	s.ovf_first = ovf_first;

@@ -930,11 +930,31 @@ constexpr int kShadeStage = PG_SHADE_STAGE; // survivors' records staged in LDS 
 #ifndef PG_SHADE_STASH
 #define PG_SHADE_STASH 1
 #endif
+// (A/B switches of the other register measures of k_wave_shade, each on by default: the second read of the path's state,
+// the walk that makes its row offsets at every node, the pinning of stage_a1's outputs)
+#ifndef PG_SHADE_RELOAD
+#define PG_SHADE_RELOAD 0
+#endif
+#ifndef PG_SHADE_SLIM
+#define PG_SHADE_SLIM 1
+#endif
+#ifndef PG_SHADE_PIN
+#define PG_SHADE_PIN 1
+#endif
 #ifndef PG_SHADE_TOP
 #define PG_SHADE_TOP 40
 #endif
 constexpr int kShadeTopNodes = PG_SHADE_STASH ? PG_SHADE_TOP : kBvhTopNodes; // (with the stash: what five workgroups per compute unit leave)
-constexpr int kShadeWalkQuads = kLdsStack * kRBlock / 2 + kShadeTopNodes * 8 + (PG_SHADE_STASH ? 9 * kRBlock / 4 : 0);
+// The walk's stack keeps kShadeStack entries per lane in LDS here (the ray-casting kernels keep kLdsStack = 8; deeper ones go
+// to the lane's overflow strip either way), which leaves room for the stash: kShadeStash values per lane that only stage_b
+// reads wait in LDS while the two walks run.
+#ifndef PG_SHADE_LDS_STACK
+#define PG_SHADE_LDS_STACK 4
+#endif
+constexpr int kShadeStack = PG_SHADE_LDS_STACK;
+static_assert(kShadeStack >= kMinLdsStack && kShadeStack <= kLdsStack, "k_wave_shade: LDS stack depth");
+constexpr int kShadeStash = PG_SHADE_STASH ? (PG_SHADE_RELOAD ? 9 : 17) : 0;
+constexpr int kShadeWalkQuads = kShadeStack * kRBlock / 2 + kShadeTopNodes * 8 + kShadeStash * kRBlock / 4;
 constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage * 8 : kShadeWalkQuads;
 // (122 vector registers, four waves per SIMD, which is also what 33 KB of LDS per workgroup allow.  Measured: staging the
 // records 128 at a time -- 23 KB -- changes nothing by itself, and compiled for five waves on top of that the kernel spills
@@ -957,8 +977,8 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	stage_kd_planes(s_planes, a.tree);
 	uint2 *s_stack = reinterpret_cast<uint2 *>(s_dyn);
-	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kLdsStack * kRBlock / 2;
-	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
+	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kShadeStack * kRBlock / 2;
+	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack, kShadeStack);
 	stage_bvh_top<kShadeTopNodes>(s_top, a, stk);
 	bool cont = false;
 	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(1, 1, 1), L = V(0, 0, 0), p_here = V(0, 0, 0), prev_p = V(0, 0, 0);
@@ -992,6 +1012,9 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 			rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
 			ray_o = st_v3(q0); ray_d = st_v3(q1);
 			thr = st_v3(q2);
+#if !PG_SHADE_RELOAD
+			{ const uint4 q4 = rec[4]; ior = __uint_as_float(q2.w & 0x7fffffffu); L = st_v3(q4); lane = q4.w; }
+#endif
 			prev_delta = (q2.w >> 31) != 0u;
 			prev_p = st_v3(q3);
 			prev_pdf = __uint_as_float(q3.w);
@@ -1004,6 +1027,9 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 			if (!kFirst) {
 				const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid);
 				thr = st_v3(q2);
+#if !PG_SHADE_RELOAD
+				{ const uint4 q4 = st_load(a.st_in, a, 4, tid); ior = __uint_as_float(q2.w & 0x7fffffffu); L = st_v3(q4); lane = q4.w; }
+#endif
 				prev_delta = (q2.w >> 31) != 0u;
 				prev_p = st_v3(q3);
 				prev_pdf = __uint_as_float(q3.w);
@@ -1016,15 +1042,25 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		// What stage_a1 leaves is PINNED here: every output is made now, so that its inputs die.  (Left alone the compiler
 		// sinks the last operations of a value that is only read behind the walk -- the emitted radiance's three products, the
 		// flag word's bits -- below the walk, and carries their more numerous inputs through it instead.)
+#if PG_SHADE_PIN
 		asm volatile("" : "+v"(A.flags), "+v"(A.wi.x), "+v"(A.wi.y), "+v"(A.wi.z), "+v"(A.p.x), "+v"(A.p.y), "+v"(A.p.z),
 		                  "+v"(A.ng.x), "+v"(A.ng.y), "+v"(A.ng.z), "+v"(A.refl.x), "+v"(A.refl.y), "+v"(A.refl.z));
 		asm volatile("" : "+v"(A.ds_d.x), "+v"(A.ds_d.y), "+v"(A.ds_d.z), "+v"(A.ds_pdf), "+v"(A.bp_em), "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z));
+#endif
 #if PG_SHADE_STASH
 		// nine values only stage_b reads wait in LDS while the two walks run (column threadIdx.x of a [9][kRBlock] array)
-		float *stash = reinterpret_cast<float *>(s_dyn) + (kLdsStack * kRBlock * 2 + kShadeTopNodes * 32) + threadIdx.x;
+		float *stash = reinterpret_cast<float *>(s_dyn) + (kShadeStack * kRBlock * 2 + kShadeTopNodes * 32) + threadIdx.x;
 		stash[0 * kRBlock] = A.Le.x; stash[1 * kRBlock] = A.Le.y; stash[2 * kRBlock] = A.Le.z;
 		stash[3 * kRBlock] = A.bv_em.x; stash[4 * kRBlock] = A.bv_em.y; stash[5 * kRBlock] = A.bv_em.z;
 		stash[6 * kRBlock] = A.em_w.x; stash[7 * kRBlock] = A.em_w.y; stash[8 * kRBlock] = A.em_w.z;
+#if !PG_SHADE_RELOAD
+		// ... and with them what the path carries that only stage_b needs: throughput, radiance so far, index of refraction, lane
+		// (round-4 measurement: reading these a second time from the path's record cost 1.25 ms per step -- two more 16-byte
+		// gathers per lane in a kernel whose time follows its gathers -- where eight LDS words cost nothing)
+		stash[9 * kRBlock] = thr.x; stash[10 * kRBlock] = thr.y; stash[11 * kRBlock] = thr.z;
+		stash[12 * kRBlock] = L.x; stash[13 * kRBlock] = L.y; stash[14 * kRBlock] = L.z;
+		stash[15 * kRBlock] = ior; stash[16 * kRBlock] = __uint_as_float((uint32_t)lane);
+#endif
 #endif
 		// The shadow ray is walked HERE, between the two halves of stage_a: the BSDF sample is not made yet and the SD-tree
 		// calls have no results yet, so neither is alive across the walk -- the walk's 50 registers on top of everything a
@@ -1033,7 +1069,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		bool occluded = false;
 		if (A.flags & F_NEED_SHADOW) { // :213 test_visibility
 			float th, bu, bv;
-			occluded = intersect<kLevel, true, true>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
+			occluded = intersect<kLevel, true, PG_SHADE_SLIM != 0>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
 		}
 		stage_a2<kLevel>(a, rng, A);
 		GuideOut g;
@@ -1046,9 +1082,15 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		A.Le = V(stash[0 * kRBlock], stash[1 * kRBlock], stash[2 * kRBlock]);
 		A.bv_em = V(stash[3 * kRBlock], stash[4 * kRBlock], stash[5 * kRBlock]);
 		A.em_w = V(stash[6 * kRBlock], stash[7 * kRBlock], stash[8 * kRBlock]);
+#if !PG_SHADE_RELOAD
+		thr = V(stash[9 * kRBlock], stash[10 * kRBlock], stash[11 * kRBlock]);
+		L = V(stash[12 * kRBlock], stash[13 * kRBlock], stash[14 * kRBlock]);
+		ior = stash[15 * kRBlock];
+		lane = (uint64_t)__float_as_uint(stash[16 * kRBlock]);
+#endif
 #endif
 		// the second read (see above): throughput, index of refraction, radiance so far, lane
-		if (!kFirst) {
+		if (PG_SHADE_RELOAD && !kFirst) {
 			asm volatile("" : "+v"(place)); // (not the first read's value kept in registers: a load of its own)
 			uint4 q2, q4;
 			if (from_rec) { const uint4 *rec = a.carry_in + (uint64_t)place * 8; q2 = rec[2]; q4 = rec[4]; }
