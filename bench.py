@@ -7,11 +7,15 @@ file's max_depth 13, the 2^(k+2) spp schedule (scenes/veach-ajar/scene.xml, main
   train   iterations 0 .. train_iters-1 are really rendered (4, 8, 16 ... spp; accumulators summed
           over the ranks and the SD-tree refined after each) and timed per iteration ->
           `value_full_schedule`: guided paths (iterations >= 2) per second INCLUDING exchange + refine.
-  steps   a *step* is one guided pass of iteration train_iters over the whole film (spp_per_pass
-          samples per pixel): camera rays, max_depth bounces with NEE and BSDF/SD-tree one-sample MIS,
-          the record list, then record post-processing and the splat into sdTree_current --
-          PathGuidingIntegrator.sample() of the reference, whole.  `value` = paths per second over
-          K steps, wall clock between barriers, max over ranks.  Everything is resident in HBM.
+  steps   a *step* is --spp-per-pass (16) consecutive ONE-sample training passes of iteration train_iters over the whole
+          film -- the reference's own schedule: main.py:192 renders training passes with spp 1, :218 seeds pass p with
+          initial_seed + cumm_spp -- traced as ONE wavefront (pg_pass_params.batched: bit-identical to the 16 separate
+          passes, tests/test_gpu_render.py::test_batched_launch_equals_separate_one_sample_passes): camera rays,
+          max_depth bounces with NEE and BSDF/SD-tree one-sample MIS, the record list, then record post-processing and
+          the splat into sdTree_current -- PathGuidingIntegrator.sample() of the reference, whole.  `value` = paths per
+          second over K steps, wall clock between barriers, max over ranks.  Everything is resident in HBM.
+          config.value_one_launch_per_1spp_pass = the same passes launched one by one; config.value_one_16spp_pass_per_step
+          = one pass of 16 samples per pixel (mi.render(spp=16): other sampler streams, the same work).
   N > 1   the film is sharded: rank r traces bands of 4 rows dealt round-robin (pg_pass_params
           stripes), no data-path collective inside a step; one int64 all-reduce of the accumulators
           per iteration (RCCL).  The film is fixed, so `scaling` is "strong".  `--shard passes` is the
@@ -19,16 +23,25 @@ file's max_depth 13, the 2^(k+2) spp schedule (scenes/veach-ajar/scene.xml, main
   mse     MSE of the last trained iteration's image against the reference's ground truth
           (path_guiding_integrator.py:503-517; teapot pixels masked, both images box-filtered to
           640x360), and -- at N = 1 -- the same schedule on a 320x180 film on the device and on the
-          CPU oracle: equal spp, equal seeds, the two MSEs must be equal (`mse_equal`).
-  cpu_baseline   the CPU oracle ("port") timed on the guided passes of that 320x180 run, all host cores.
+          CPU oracle: equal spp, equal seeds, the two MSEs must be equal (config.mse_equal_device_vs_cpu).
+  cpu_baseline   the CPU oracle ("port") timed on the guided passes of that 320x180 schedule, all host cores.
+  kernels_synthetic / roofline.s1_* s2_* s3_*   the stand-alone entry points (pg_pdf, pg_sample, pg_guide_bounce, pg_splat) on
+          SURVEY 8(d)'s S1 / S2 / S3 at their stated sizes (synthetic_kernels_leg).
 
 roofline = the SD-tree kernel (the fused k_bounce of quad scenes in the timed region; for mesh scenes k_wave_guide,
 timed in a SECOND region of K steps that follows the K steps of `value` at once: the same passes with
 pg_render_stages(2) -- by default a bounce's shading, SD-tree calls and shadow ray are ONE kernel, k_wave_shade, in which
-they cannot be timed apart; `roofline.region` says which region the figures are of): its algorithmic bytes (16 B per KD level + 20 B per quadtree level, levels
-counted by an instrumented pass) per launch / mean launch time (HIP events recorded by the library on
-the launch stream) vs the 8 TB/s HBM peak.  `kernels` lists every kernel of a step with its share and, from the
-committed PMC figures of the same configuration (profiles/pmc_traffic.json), its counter traffic per second.
+they cannot be timed apart; `roofline.region` says which region the figures are of).  Two byte models over its mean
+launch time (HIP events recorded by the library on the launch stream) and the 8 TB/s HBM peak:
+  frac         SURVEY.md 8d's ALGORITHMIC bytes: 16 B per KD level + 20 B per quadtree level of the REFERENCE's descents, levels
+               counted by an instrumented pass.  The jump grid and jump tables serve most of those levels with one gather
+               each, so this exceeds 1 on spatially sorted lists: not a bandwidth (model_applicable false).
+  frac_layout  the bytes the lanes of that pass GATHERED from the tables of the built layout (16 per KD grid entry / node below
+               it, 8 per tree head, 16 per jump-table entry, 32 per quadtree record of a pdf or sampling walk, 16 per record
+               of a leaf walk; pg_depth_counters.layout_bytes), nothing credited for lanes of a wave that share a line --
+               what the memory pipeline moves at least; <= 1 by construction.
+`traffic` = HBM bytes of the PMC counters per launch (profiles/pmc_traffic.json, refused unless taken of exactly this code).
+`kernels` lists every kernel of a step with its share and, from the committed PMC figures, its counter traffic per second.
 
 `--synthetic` runs the renderer-free hot-path workload instead (seeded synthetic surface points).
 Launch:  python bench.py [--gpus N]      (N > 1 without WORLD_SIZE in the environment: this process starts N fresh

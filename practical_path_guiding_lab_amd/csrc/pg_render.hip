@@ -652,7 +652,10 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 		}
 		PG_HIP(ctx, b.ws.ensure((size_t)wave_workspace_planes() * N));
 		PG_HIP(ctx, b.shadow_list.ensure(N));
-		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread
+		// one overflow strip of the BVH stack per list position (closest-hit launches) or walking thread; a lane names its strip
+		// by a 32-bit entry index (BvhStack::ovf_first)
+		if ((N > kTailPaths ? N : (uint64_t)kTailPaths) * (uint64_t)kOvfStack > 0xffffffffull)
+			return fail(ctx, PG_ERR_INVALID, "pg_render_pass: more lanes than the BVH stacks' overflow strips can be indexed for (2^32 / 28)");
 		PG_HIP(ctx, b.bvh_ovf.ensure((size_t)kOvfStack * (N > kTailPaths ? N : kTailPaths)));
 	}
 	PG_HIP(ctx, b.rng_inc.ensure(N));

@@ -40,6 +40,12 @@ def _mask(active: Optional[torch.Tensor], n: int):
     return active, active.data_ptr()
 
 
+# Debug switch (the parity tests of the stand-alone entry points set it): synchronise the device behind every library call, so
+# that a GPU fault is reported under the call that launched the faulting kernel and not under whatever synchronised next
+# (round 2's memory-aperture abort surfaced in exportAccumulators, three launches later: profiles/r03/kd_descend_isa/).
+SYNC_EVERY_CALL = False
+
+
 class PCG32Sampler:
     """Per-lane PCG32 streams laid out like Mitsuba's `independent` sampler (state/inc arrays)."""
 
@@ -74,6 +80,8 @@ class SDTree:
 
     def _ck(self, rc):
         N.check(self._h, rc)
+        if SYNC_EVERY_CALL:  # (a fault of an asynchronous kernel then surfaces HERE, under the call that launched it)
+            torch.cuda.synchronize(self.device)
 
     # ---- lifecycle -----------------------------------------------------------------------
     def setup(self, bbox_min, bbox_max, numRays=0, max_depth=0, sdTreeMaxDepth=10, quadTreeMaxDepth=30,

@@ -18,6 +18,15 @@ from test_gpu_parity import BB0, BB1, check_accumulators, dense_records, dev, gp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _synchronise_behind_every_call():
+    """A GPU fault then names the call that launched the faulting kernel (round 2's abort surfaced three launches late)."""
+    from practical_path_guiding_lab_amd import sdtree
+    sdtree.SYNC_EVERY_CALL = True
+    yield
+    sdtree.SYNC_EVERY_CALL = False
+
+
 def face_positions(n, seed):
     """(3, n) positions in and around [0,100]^3: every coordinate is, with probability 0.45, a plane of
     the finest (64^3) grid -- so also of every coarser one -- or one ulp beside one; the first columns

@@ -9,6 +9,15 @@ from oracle import pg_oracle as po
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _synchronise_behind_every_call():
+    """A GPU fault then names the call that launched the faulting kernel (round 2's abort surfaced three launches late)."""
+    from practical_path_guiding_lab_amd import sdtree
+    sdtree.SYNC_EVERY_CALL = True
+    yield
+    sdtree.SYNC_EVERY_CALL = False
+
 BB0, BB1 = [0.0] * 3, [100.0] * 3
 
 
