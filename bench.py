@@ -129,8 +129,11 @@ def parse():
                          "in a second region for the roofline), 1 k_wave_shade_a with the SD-tree calls | k_wave_cast | k_wave_shade_b, "
                          "2 those with k_wave_guide on its own")
     ap.add_argument("--sort", type=int, default=1, help="pg_render_sort: the live list of a mesh scene's bounce in a global spatial order (0: list order)")
-    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
-                    help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at once")
+    ap.add_argument("--in-flight", type=int, default=None, choices=[1, 2],
+                    help="2: consecutive passes alternate between two buffer sets and two streams (pg_pass_params.slot), two on the device at "
+                         "once.  Default: 1 on one GPU (the whole film fills the chip: 51.9 vs 52.9 ms per step), 2 when the film is sharded -- an "
+                         "eighth of it leaves gaps between its small launches that a second pass fills: 7.72 -> 7.08 ms per step of a rank's share, "
+                         "6.7x -> 7.3x of 8 by emulation on one GPU (tools/stripe_balance.py, profiles/r04/stripe_balance.txt)")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
@@ -143,6 +146,8 @@ def parse():
         args.full_schedule = 1 if (args.gpus == 1 and not args.synthetic) else 0
     if args.synthetic_kernels is None:
         args.synthetic_kernels = 1 if (args.gpus == 1 and not args.synthetic) else 0
+    if args.in_flight is None:
+        args.in_flight = 2 if (args.gpus > 1 and args.shard == "tiles" and not args.synthetic) else 1
     return args
 
 
