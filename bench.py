@@ -756,6 +756,7 @@ def run_render(args):
                    "value_one_launch_per_1spp_pass": None if spp1 is None else round(spp1, 3),
                    ("value_one_%dspp_pass_per_step" % args.spp_per_pass if batched else "value_batched_1spp_passes"):
                        None if multi_spp is None else round(multi_spp, 3),
+                   "value_two_passes_in_flight": None if two_in_flight is None else round(two_in_flight, 3),
                    "value_full_schedule_12it": None if full is None else full["value"],
                    "mse_vs_gt_full_schedule": None if full is None else full["mse_vs_gt"],
                    "mse_equal_device_vs_cpu": None if mse_small is None else bool(mse_small == mse_small_cpu),
@@ -793,7 +794,7 @@ def synthetic_kernels_leg(device):
     layout (pg_depth_counters.layout_bytes + 8 per tree head; 48 B per record streamed + 32 B per accumulator updated for
     the splat), nothing credited for lanes that share a line.  Where the tables serve whole descents from L2 `frac` exceeds 1
     (not a bandwidth); `frac_layout` cannot: a launch moves at least those bytes per lane through the memory pipeline.
-    Full-size parity of exactly these inputs against the CPU oracle: tests/test_gpu_fullsize.py."""
+    Full-size parity of exactly these inputs against the CPU oracle: tests/test_gpu_synthetic_fullsize.py."""
     import torch
     from practical_path_guiding_lab_amd import workload as Wk
     from practical_path_guiding_lab_amd.sdtree import PCG32Sampler, SDTree
