@@ -4,6 +4,7 @@
 #include "pg_context.hpp"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -367,6 +368,9 @@ int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t rese
 	out->quad_levels = h.quad_levels;
 	out->quad_queries = h.quad_queries;
 	out->layout_bytes = h.layout_bytes;
+	if (getenv("PGSD_TRACE_SHADOW") && h.body_waves)
+		fprintf(stderr, "[pgsd] k_wave_shade: %llu waves ran the body, %llu of them walked shadow rays with %llu lanes (%.1f of 64 per walking wave)\n",
+		        h.body_waves, h.shadow_waves, h.shadow_lanes, h.shadow_waves ? (double)h.shadow_lanes / (double)h.shadow_waves : 0.0);
 	if (reset) PG_HIP(ctx, hipMemset(ctx->dc, 0, sizeof(DepthCounters)));
 	return PG_OK;
 }

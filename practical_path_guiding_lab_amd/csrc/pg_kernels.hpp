@@ -12,6 +12,9 @@ namespace pg {
 struct DepthCounters { // device-resident, optional
 	unsigned long long kd_levels, kd_queries, quad_levels, quad_queries;
 	unsigned long long layout_bytes; // bytes the lanes gathered from the built tables (stat_word, pg_descent.hpp); tree heads not included
+	// (diagnostics of instrumented passes, printed by pg_read_depth_counters under $PGSD_TRACE_SHADOW: how full are the waves
+	// that walk shadow rays in k_wave_shade?)  waves that walked, their lanes with a ray, waves that ran the kernel's body
+	unsigned long long shadow_waves, shadow_lanes, body_waves;
 };
 
 // ---- queries (pg_kernels_query.hip) ----

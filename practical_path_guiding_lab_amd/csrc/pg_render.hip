@@ -412,12 +412,6 @@ __global__ __launch_bounds__(kRBlock) void k_finish(RenderArgs a, uint8_t *__res
 	}
 }
 
-__global__ __launch_bounds__(kRBlock) void k_iota(uint32_t *__restrict__ out, uint64_t n)
-{
-	const uint64_t i = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	if (i < n) out[i] = (uint32_t)i;
-}
-
 // element-wise evaluation of the library's deterministic fp32 functions (pg_math_eval)
 __global__ __launch_bounds__(kRBlock) void k_math_eval(int which, uint64_t n, const float *__restrict__ x,
                                                        float *__restrict__ out)
@@ -531,7 +525,8 @@ struct PassBuf {
 	DevBuf<float> r_bsdf, r_tb, r_tr, r_nee, r_wp;
 	// pg_render_sort: keys of the places (written by k_wave_trace), the sorted keys, the identity, the places in sorted
 	// order, rocPRIM's temporary storage
-	DevBuf<uint32_t> sort_key, sort_key_out, sort_iota, sort_perm;
+	DevBuf<uint16_t> sort_key, sort_key_out;
+	DevBuf<uint32_t> sort_perm;
 	DevBuf<uint4> carry[2]; // the paths' 128-byte records of a sorted bounce (RenderArgs::carry_in), two sets swapped per bounce:
 	                        // k_wave_shade reads the records of its bounce and writes the next bounce's in one launch
 	// which bounces are worth a sort is read off the PREVIOUS pass of this set: its live counts come back to the host
@@ -546,7 +541,6 @@ struct PassBuf {
 	DevBuf<uint4> Lq;    // the split pipeline's radiance by lane (RenderArgs::Lq)
 	DevBuf<char> sort_tmp;
 	size_t sort_tmp_bytes = 0;
-	uint64_t sort_iota_n = 0;
 	DevBuf<uint2> r_slot;   // the list names accumulators instead of positions and directions (pg_list_records)
 	DevBuf<uint32_t> r_tree;
 	// pg_render_overlap: k_wave_guide beside k_wave_cast on a library-owned stream
@@ -646,7 +640,7 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 		if (r->sort) { // pg_render_sort: keys, the sorted places, the paths' 128-byte records, rocPRIM's temporary storage
 			if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
 			PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
-			PG_HIP(ctx, b.sort_iota.ensure(N)); PG_HIP(ctx, b.carry[0].ensure(8 * N)); PG_HIP(ctx, b.carry[1].ensure(8 * N));
+			PG_HIP(ctx, b.carry[0].ensure(8 * N)); PG_HIP(ctx, b.carry[1].ensure(8 * N));
 			const size_t need = sort_pairs_temp_bytes((uint32_t)N);
 			if (need > b.sort_tmp_bytes) { PG_HIP(ctx, b.sort_tmp.ensure(need)); b.sort_tmp_bytes = need; }
 		}
@@ -946,10 +940,6 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 			b.live_known = true;
 		}
 		if (b.live_known && (b.live_prev_lanes != N || (int)b.live_prev.size() != D)) b.live_known = false; // (another pass size)
-		if (b.sort_iota_n < N) { // (the buffers themselves: ensure_pass_buffers)
-			hipLaunchKernelGGL(k_iota, dim3((unsigned)((N + kRBlock - 1) / kRBlock)), dim3(kRBlock), 0, s, b.sort_iota.p, N);
-			b.sort_iota_n = N;
-		}
 	}
 	a.ws = b.ws.p;
 	a.bvh_ovf = b.bvh_ovf.p;
@@ -1033,15 +1023,14 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 					if (n_sort > N) n_sort = N;
 				}
 				a.n_sort = (uint32_t)n_sort;
-				PG_HIP(ctx, hipMemsetAsync(b.sort_key.p, 0xff, n_sort * sizeof(uint32_t), s)); // (0xffff: a place without a path)
+				PG_HIP(ctx, hipMemsetAsync(b.sort_key.p, 0xff, n_sort * sizeof(uint16_t), s)); // (0xffff: a place without a path)
 				{
 					Timed t(r, s, 5);
 					launch_wave_stage(0, r->general, false, a, grid.x, (unsigned)ctx->n_cus, s);
 				}
 				{
 					Timed t(r, s, 11);
-					PG_HIP(ctx, sort_pairs16(b.sort_tmp.p, b.sort_tmp_bytes, b.sort_key.p, b.sort_key_out.p, b.sort_iota.p, b.sort_perm.p,
-					                         (uint32_t)n_sort, s));
+					PG_HIP(ctx, sort_places16(b.sort_tmp.p, b.sort_tmp_bytes, b.sort_key.p, b.sort_key_out.p, b.sort_perm.p, (uint32_t)n_sort, s));
 				}
 				a.perm = b.sort_perm.p;
 				if (joint) {

@@ -1207,7 +1207,7 @@ struct RenderArgs {
 	uint64_t *inc_out;
 	// pg_render_sort: sort_key (k_wave_trace writes the key of every place it serves; nullptr = this bounce is not sorted)
 	// and perm (the places in sorted order, read by k_wave_shade_a; nullptr = list order)
-	uint32_t *sort_key;
+	uint16_t *sort_key;
 	const uint32_t *perm;
 	uint32_t n_sort; // perm covers the places [0, n_sort); a live place beyond it is served in list order
 	// ... and the 128-byte records of the paths (8 entries of 16 bytes per place: the five state entries, the sampler

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
 	if (a.carry_in) { // a sorted bounce: the hit joins the path's 128-byte record, which k_wave_shade_a reads through the permutation
 		a.carry_in[tid * 8 + 6] = make_uint4((uint32_t)h.prim, __float_as_uint(h.t), __float_as_uint(h.u), __float_as_uint(h.v));
-		if (tid < (uint64_t)a.n_sort) a.sort_key[tid] = h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu;
+		if (tid < (uint64_t)a.n_sort) a.sort_key[tid] = (uint16_t)(h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu);
 		return;
 	}
 	wsputu(a, WS_HIT_PRIM, tid, (uint32_t)h.prim);
@@ -1067,6 +1067,13 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		// bounce keeps were this kernel's register peak (123 with the walk at the end).  The walk draws no
 		// sample, so the sampler's order is untouched.
 		bool occluded = false;
+		if (a.dc) { // (instrumented passes only: how full are the waves that walk?)
+			const unsigned long long m = __ballot((A.flags & F_NEED_SHADOW) != 0u);
+			if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) {
+				atomicAdd(&a.dc->body_waves, 1ull);
+				if (m) { atomicAdd(&a.dc->shadow_waves, 1ull); atomicAdd(&a.dc->shadow_lanes, (unsigned long long)__popcll(m)); }
+			}
+		}
 		if (A.flags & F_NEED_SHADOW) { // :213 test_visibility
 			float th, bu, bv;
 			occluded = intersect<kLevel, true, PG_SHADE_SLIM != 0>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
