@@ -25,9 +25,14 @@ namespace pg {
 // kFirst: the camera ray is generated here (mi.render's sensor.sample_ray_differential: one 2-D
 // jitter draw per sample, box reconstruction) instead of being read back from a generate kernel.
 // kGeneral: the scene has spheres or rough conductors; false compiles the all-diffuse quad scene only.
-template <bool kFirst, int kGeneral>
+// stash (k_bounce; nullptr in the tail kernel): column threadIdx.x of a [kBounceStash][kRBlock] array in LDS, where values
+// that only the code BEHIND an SD-tree walk reads wait while the walk runs -- this kernel leaves the LDS almost empty, and
+// the walks are where its registers peak (tools/vgpr_liveness.py).
+constexpr int kBounceStash = 17;
+typedef __attribute__((address_space(3))) float LdsFloat;
+template <bool kFirst, int kGeneral, bool kStash = false>
 __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_kd, const uint64_t lane,
-                                            const uint64_t rec_slot, const uint32_t depth)
+                                            const uint64_t rec_slot, const uint32_t depth, LdsFloat *stash = nullptr)
 {
 	const uint64_t N = a.n_lanes;
 	const int D = a.max_depth;
@@ -124,6 +129,14 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	uint32_t slot_path = kSlotNone, slot_nee = kSlotNone, tree_flags = 0u;
 	const bool nee_slot_wanted = do_record && a.store_nee && active_em;
 	if (active_sd_em || (do_record && a.store_nee)) dir_to_canonical(ds_d.x, ds_d.y, ds_d.z, nee_cx, nee_cy);
+	if (kStash) { // (what only the NEE term and the record read, behind the first walks)
+		stash[0 * kRBlock] = thr.x; stash[1 * kRBlock] = thr.y; stash[2 * kRBlock] = thr.z;
+		stash[3 * kRBlock] = L.x; stash[4 * kRBlock] = L.y; stash[5 * kRBlock] = L.z;
+		stash[6 * kRBlock] = Le.x; stash[7 * kRBlock] = Le.y; stash[8 * kRBlock] = Le.z;
+		stash[9 * kRBlock] = bsdf_value_em.x; stash[10 * kRBlock] = bsdf_value_em.y; stash[11 * kRBlock] = bsdf_value_em.z;
+		stash[12 * kRBlock] = em_weight.x; stash[13 * kRBlock] = em_weight.y; stash[14 * kRBlock] = em_weight.z;
+		stash[15 * kRBlock] = bsdf_pdf_em; stash[16 * kRBlock] = ds_pdf;
+	}
 	if (active_sd_em || do_record) {
 		KdNode leaf;
 		const bool inside = inside_root(a.tree, p.x, p.y, p.z);
@@ -144,11 +157,26 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		sdtree_pdf_em = quad_pdf_t<true>(a.tree.rec, a.tree.jump, tree_id, head, nee_cx, nee_cy, lv, slot_nee);
 		c_q += lv; ++c_qq;
 	}
-	float surface_pdf_em = f * bsdf_pdf_em + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
-	if (!a.guided) surface_pdf_em = bsdf_pdf_em;
-	const float mis_em = mis_weight(ds_pdf, surface_pdf_em); // :253 (no delta emitters in these scenes)
-	const v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em), em_weight);
-	L = vadd(L, vadd(Le, Lr_dir)); // :261
+	v3 Le_ = Le, bsdf_value_em_ = bsdf_value_em, em_weight_ = em_weight;
+	float bsdf_pdf_em_ = bsdf_pdf_em, ds_pdf_ = ds_pdf;
+	if (kStash) {
+		thr = V(stash[0 * kRBlock], stash[1 * kRBlock], stash[2 * kRBlock]);
+		L = V(stash[3 * kRBlock], stash[4 * kRBlock], stash[5 * kRBlock]);
+		Le_ = V(stash[6 * kRBlock], stash[7 * kRBlock], stash[8 * kRBlock]);
+		bsdf_value_em_ = V(stash[9 * kRBlock], stash[10 * kRBlock], stash[11 * kRBlock]);
+		em_weight_ = V(stash[12 * kRBlock], stash[13 * kRBlock], stash[14 * kRBlock]);
+		bsdf_pdf_em_ = stash[15 * kRBlock]; ds_pdf_ = stash[16 * kRBlock];
+	}
+	float surface_pdf_em = f * bsdf_pdf_em_ + ((1.0f - f) * sdtree_pdf_em) * pdf_diffuse;
+	if (!a.guided) surface_pdf_em = bsdf_pdf_em_;
+	const float mis_em = mis_weight(ds_pdf_, surface_pdf_em); // :253 (no delta emitters in these scenes)
+	v3 Lr_dir = vmul(vmul(vscale(thr, mis_em), bsdf_value_em_), em_weight_);
+	L = vadd(L, vadd(Le_, Lr_dir)); // :261
+	if (kStash) { // (what only the record and the next bounce's state read, behind the second walks)
+		stash[0 * kRBlock] = thr.x; stash[1 * kRBlock] = thr.y; stash[2 * kRBlock] = thr.z;
+		stash[3 * kRBlock] = L.x; stash[4 * kRBlock] = L.y; stash[5 * kRBlock] = L.z;
+		stash[6 * kRBlock] = Lr_dir.x; stash[7 * kRBlock] = Lr_dir.y; stash[8 * kRBlock] = Lr_dir.z;
+	}
 	// ---- :272-311 next direction ----
 	float s1 = 0.0f, s2x = 0.0f, s2y = 0.0f;
 	if (active_next) { // next_1d (lobe choice: only the dielectric reads it), next_2d
@@ -214,6 +242,11 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 		atomicAdd(&a.dc->quad_queries, (unsigned long long)c_qq);
 		atomicAdd(&a.dc->layout_bytes, (unsigned long long)(stat_bytes(c_kd) + stat_bytes(c_q)));
 	}
+	if (kStash) {
+		thr = V(stash[0 * kRBlock], stash[1 * kRBlock], stash[2 * kRBlock]);
+		L = V(stash[3 * kRBlock], stash[4 * kRBlock], stash[5 * kRBlock]);
+		Lr_dir = V(stash[6 * kRBlock], stash[7 * kRBlock], stash[8 * kRBlock]);
+	}
 	if (do_mis) { // :310-311
 		woPdf = f * bsdf_pdf + (1.0f - f) * sdtree_pdf;
 		bsdf_weight = vdivs(bsdf_value, woPdf);
@@ -261,16 +294,22 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	const bool rr_continue = rr < rr_prob;
 	active_next = active_next && (!rr_active || rr_continue);
 	// ---- state for the next bounce; a path that ends here leaves only its radiance ----
-	a.L[lane] = L.x; a.L[N + lane] = L.y; a.L[2 * N + lane] = L.z;
-	if (kFirst) a.hit0[lane] = valid ? 1 : 0;
+	// (The addresses are made HERE, from the lane's number taken as a new value: left alone the compiler keeps the sixteen
+	// 64-bit addresses it formed for the loads at the top -- the same planes -- alive through the whole bounce, 32 of this
+	// kernel's 122 vector registers: tools/vgpr_liveness.py)
+	uint32_t lane32 = (uint32_t)lane;
+	asm volatile("" : "+v"(lane32));
+	const uint64_t ln = lane32;
+	a.L[ln] = L.x; a.L[N + ln] = L.y; a.L[2 * N + ln] = L.z;
+	if (kFirst) a.hit0[ln] = valid ? 1 : 0;
 	if (active_next) {
-		a.rng_state[lane] = rng.state;
-		if (kFirst) a.rng_inc[lane] = rng.inc;
-		a.ray_d[lane] = wo_world.x; a.ray_d[N + lane] = wo_world.y; a.ray_d[2 * N + lane] = wo_world.z;
-		a.thr[lane] = thr.x; a.thr[N + lane] = thr.y; a.thr[2 * N + lane] = thr.z;
-		a.prev_p[lane] = p.x; a.prev_p[N + lane] = p.y; a.prev_p[2 * N + lane] = p.z;
-		a.prev_pdf[lane] = woPdf;
-		a.prev_quad[lane] = (uint32_t)q;
+		a.rng_state[ln] = rng.state;
+		if (kFirst) a.rng_inc[ln] = rng.inc;
+		a.ray_d[ln] = wo_world.x; a.ray_d[N + ln] = wo_world.y; a.ray_d[2 * N + ln] = wo_world.z;
+		a.thr[ln] = thr.x; a.thr[N + ln] = thr.y; a.thr[2 * N + ln] = thr.z;
+		a.prev_p[ln] = p.x; a.prev_p[N + ln] = p.y; a.prev_p[2 * N + ln] = p.z;
+		a.prev_pdf[ln] = woPdf;
+		a.prev_quad[ln] = (uint32_t)q;
 	}
 	return active_next;
 }
@@ -293,6 +332,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 #endif
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
+	__shared__ float s_stash[kBounceStash][kRBlock];
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
@@ -311,7 +351,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
 	}
 	bool cont = false;
-	if (alive) cont = bounce_lane<kFirst, kGeneral>(a, s_kd, lane, rec_base + tid, (uint32_t)a.bounce);
+	if (alive) cont = bounce_lane<kFirst, kGeneral, true>(a, s_kd, lane, rec_base + tid, (uint32_t)a.bounce, (LdsFloat *)&s_stash[0][threadIdx.x]);
 	if (a.last) return; // nothing survives the last bounce
 	const unsigned long long ballot = __ballot(cont);
 	const unsigned wl = threadIdx.x & 63u, wv = threadIdx.x >> 6;
