@@ -949,11 +949,15 @@ constexpr int kShadeTopNodes = PG_SHADE_STASH ? PG_SHADE_TOP : kBvhTopNodes; // 
 // to the lane's overflow strip either way), which leaves room for the stash: kShadeStash values per lane that only stage_b
 // reads wait in LDS while the two walks run.
 #ifndef PG_SHADE_LDS_STACK
-#define PG_SHADE_LDS_STACK 4
+#define PG_SHADE_LDS_STACK 6
 #endif
 constexpr int kShadeStack = PG_SHADE_LDS_STACK;
 static_assert(kShadeStack >= kMinLdsStack && kShadeStack <= kLdsStack, "k_wave_shade: LDS stack depth");
-constexpr int kShadeStash = PG_SHADE_STASH ? (PG_SHADE_RELOAD ? 9 : 17) : 0;
+// (A/B: PG_SHADE_KEEP 1 / 2 / 3 keeps {ior, lane} / + L / + thr in registers instead -- room for a deeper LDS stack)
+#ifndef PG_SHADE_KEEP
+#define PG_SHADE_KEEP 2
+#endif
+constexpr int kShadeStash = PG_SHADE_STASH ? (PG_SHADE_RELOAD ? 9 : (PG_SHADE_KEEP >= 3 ? 9 : PG_SHADE_KEEP == 2 ? 12 : PG_SHADE_KEEP == 1 ? 15 : 17)) : 0;
 constexpr int kShadeWalkQuads = kShadeStack * kRBlock / 2 + kShadeTopNodes * 8 + kShadeStash * kRBlock / 4;
 constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage * 8 : kShadeWalkQuads;
 // (122 vector registers, four waves per SIMD, which is also what 33 KB of LDS per workgroup allow.  Measured: staging the
@@ -1057,9 +1061,9 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		// ... and with them what the path carries that only stage_b needs: throughput, radiance so far, index of refraction, lane
 		// (round-4 measurement: reading these a second time from the path's record cost 1.25 ms per step -- two more 16-byte
 		// gathers per lane in a kernel whose time follows its gathers -- where eight LDS words cost nothing)
-		stash[9 * kRBlock] = thr.x; stash[10 * kRBlock] = thr.y; stash[11 * kRBlock] = thr.z;
-		stash[12 * kRBlock] = L.x; stash[13 * kRBlock] = L.y; stash[14 * kRBlock] = L.z;
-		stash[15 * kRBlock] = ior; stash[16 * kRBlock] = __uint_as_float((uint32_t)lane);
+		if (PG_SHADE_KEEP < 3) { stash[9 * kRBlock] = thr.x; stash[10 * kRBlock] = thr.y; stash[11 * kRBlock] = thr.z; }
+		if (PG_SHADE_KEEP < 2) { stash[12 * kRBlock] = L.x; stash[13 * kRBlock] = L.y; stash[14 * kRBlock] = L.z; }
+		if (PG_SHADE_KEEP < 1) { stash[15 * kRBlock] = ior; stash[16 * kRBlock] = __uint_as_float((uint32_t)lane); }
 #endif
 #endif
 		// The shadow ray is walked HERE, between the two halves of stage_a: the BSDF sample is not made yet and the SD-tree
@@ -1078,22 +1082,37 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 			float th, bu, bv;
 			occluded = intersect<kLevel, true, PG_SHADE_SLIM != 0>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
 		}
+#if PG_SHADE_PIN
+		// (the shading frame and the material row are functions of the normal and the material's number: made again from
+		// them behind the walk -- a dozen operations and two loads -- instead of being carried through it, which is what
+		// the compiler does unless it is told that these ARE new values)
+		asm volatile("" : "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z), "+v"(A.mat));
+#endif
 		stage_a2<kLevel>(a, rng, A);
+#if PG_SHADE_PIN
+		// (stage_a2's outputs pinned like stage_a1's: the nine products of to_world() were carried through the SD-tree walks
+		// instead of the three sums)
+		asm volatile("" : "+v"(A.wo.x), "+v"(A.wo.y), "+v"(A.wo.z), "+v"(A.bsdf_w.x), "+v"(A.bsdf_w.y), "+v"(A.bsdf_w.z),
+		                  "+v"(A.bsdf_pdf), "+v"(A.flags));
+		if (kLevel >= 3) asm volatile("" : "+v"(A.eta));
+#endif
 		GuideOut g;
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
 		g.wo = A.wo;
 		if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, (A.flags & F_SMP_TREE) ? V(0, 0, 0) : A.wo, A.flags, g);
 		if (a.record && (A.flags & F_VALID)) store_slots(a, rec_base + tid, g);
+#if PG_SHADE_PIN
+		asm volatile("" : "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z), "+v"(A.mat)); // (the same behind the SD-tree walks, for stage_b's second BSDF evaluation)
+#endif
 #if PG_SHADE_STASH
 		A.Le = V(stash[0 * kRBlock], stash[1 * kRBlock], stash[2 * kRBlock]);
 		A.bv_em = V(stash[3 * kRBlock], stash[4 * kRBlock], stash[5 * kRBlock]);
 		A.em_w = V(stash[6 * kRBlock], stash[7 * kRBlock], stash[8 * kRBlock]);
 #if !PG_SHADE_RELOAD
-		thr = V(stash[9 * kRBlock], stash[10 * kRBlock], stash[11 * kRBlock]);
-		L = V(stash[12 * kRBlock], stash[13 * kRBlock], stash[14 * kRBlock]);
-		ior = stash[15 * kRBlock];
-		lane = (uint64_t)__float_as_uint(stash[16 * kRBlock]);
+		if (PG_SHADE_KEEP < 3) thr = V(stash[9 * kRBlock], stash[10 * kRBlock], stash[11 * kRBlock]);
+		if (PG_SHADE_KEEP < 2) L = V(stash[12 * kRBlock], stash[13 * kRBlock], stash[14 * kRBlock]);
+		if (PG_SHADE_KEEP < 1) { ior = stash[15 * kRBlock]; lane = (uint64_t)__float_as_uint(stash[16 * kRBlock]); }
 #endif
 #endif
 		// the second read (see above): throughput, index of refraction, radiance so far, lane
