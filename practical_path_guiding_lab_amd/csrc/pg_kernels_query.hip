@@ -400,11 +400,9 @@ void launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s
 {
 	if (t.n_trees == 0) return;
 	const size_t lds = sizeof(QuadJump) << (2 * bits); // 64 KB for the finest table
-	static bool raised = false;
-	if (!raised && lds > 48 * 1024) {
+	// (more than the default 48 KB of dynamic LDS has to be asked for; per device, so it is asked every time -- once per refine)
+	if (lds > 48 * 1024)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		raised = true;
-	}
 	hipLaunchKernelGGL(k_build_jump, dim3(t.n_trees), dim3(kBlock), lds, s, t, out, bits);
 }
 
