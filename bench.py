@@ -714,6 +714,32 @@ def run_render(args):
                      "(16 B/KD level, 20 B/quadtree level, SURVEY 8d). ")
                     + "The splat is bound by scattered L2 atomics, not HBM (DESIGN.md 5). `traffic` is not measured in this run: it "
                       "is the PMC figure of the same configuration and code committed in profiles/pmc_traffic.json."}
+    # ---- the same two fractions for the kernel that holds the SD-tree calls in the region `value` is quoted on (k_wave_shade:
+    # also the slowest kernel of the step).  It runs every launch of a bounce in that region, so its launches see the same
+    # algorithmic and layout bytes as k_wave_guide's; its time also covers the surface, the BSDFs, the shadow ray and the
+    # survivors' records, which the byte model does not price -- a lower bound of what the kernel moves, flat scalars so that
+    # the driver's record keeps them ----
+    if wave and kt_roof is not None and "k_wave_shade" in kernels and kernels["k_wave_shade"]["avg_us"] > 0:
+        sh = kernels["k_wave_shade"]
+        sh_sec = sh["avg_us"] * 1e-6
+        sh_launches_per_pass = max(sh["launches"] / passes, 1)
+        sh_alg = tree_bytes / sh_launches_per_pass
+        sh_layout = layout_bytes / sh_launches_per_pass
+        tr_sh = traffic_for("k_wave_shade", cfg_key)
+        roof.update({
+            "value_region_kernel": "k_wave_shade", "value_region_avg_launch_us": sh["avg_us"],
+            "value_region_alg_bytes_per_launch": int(sh_alg), "value_region_frac": round(sh_alg / sh_sec / 1e9 / HBM_PEAK_GBS, 5),
+            "value_region_layout_bytes_per_launch": int(sh_layout),
+            "value_region_frac_layout": round(sh_layout / sh_sec / 1e9 / HBM_PEAK_GBS, 5),
+            "value_region_traffic": None if tr_sh is None else tr_sh["hi"],
+            "value_region_frac_counter_lo": None if (tr_sh is None or tr_sh["lo"] is None) else round(tr_sh["lo"] / sh_sec / 1e9 / HBM_PEAK_GBS, 4),
+            "value_region_frac_counter_hi": None if tr_sh is None else round(tr_sh["hi"] / sh_sec / 1e9 / HBM_PEAK_GBS, 4),
+            "value_region_note": ("value_region_*: the kernel that makes the SD-tree calls in the steps `value` is quoted on (k_wave_shade, one launch "
+                                  "per bounce, the slowest kernel of the step) priced with the same SURVEY 8(d) bytes (value_region_frac) and the "
+                                  "same gathered layout bytes (value_region_frac_layout) as k_wave_guide above, over ITS average launch in the "
+                                  "timed region of `value`; value_region_traffic / _frac_counter_* are its committed PMC figures")})
+        sh["alg_bytes_per_launch"] = int(sh_alg)
+        sh["alg_GBps"] = round(sh_alg / sh_sec / 1e9, 2)
     cpu = None
     mse_small = mse_small_cpu = None
     if args.cpu and world == 1:
