@@ -314,12 +314,16 @@ def init_dist(args):
     return world, rank, local_rank
 
 
-def timed_steps(step, steps, warmup, world):
+def timed_steps(step, steps, warmup, world, flush=None):
+    """`flush` (optional): called after the last warm-up step and after the last timed step, before the device is waited for --
+    for a `step` that only queues its passes and launches several steps' passes at once (run_render, sharded film)."""
     import torch
     import torch.distributed as dist
 
     for _ in range(warmup):
         step()
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -327,6 +331,8 @@ def timed_steps(step, steps, warmup, world):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -407,7 +413,12 @@ def run_render(args):
     npix_local = my_pixels
     from practical_path_guiding_lab_amd.parallel import min_max_over_ranks
     pix_min, pix_max = min_max_over_ranks(my_pixels)
-    ws.reserve(integ, args.spp_per_pass)  # the pass buffers, as the reference's setup() allocates its record arrays (:93)
+    # A rank of a sharded film launches the passes of `group` = world steps at once: its share of the film is 1 / world of the
+    # pixels, so that launch is as big as the one-GPU launch of the whole film (33 M lanes at the default) instead of 1 / world
+    # of it -- the same passes, bit for bit (pg_pass_params.batched), and the same number of them per step; small launches are
+    # what a rank's eighth of the film lost (tools/stripe_balance.py: 6.7x -> 7.7x of 8 by emulation on one GPU).
+    group = world if (tiles and bool(args.batched)) else 1
+    ws.reserve(integ, args.spp_per_pass * group)  # the pass buffers, as the reference's setup() allocates its record arrays (:93)
     # the exchange: libpgsd's own ncclAllReduce (pg_allreduce) when every rank has its GPU, else torch.distributed
     exchange = "none"
     reduce_fn = None
@@ -433,7 +444,7 @@ def run_render(args):
             dist.barrier()
         t0 = time.perf_counter()
         if tiles or world == 1:
-            chunk = max(1, min(args.spp_per_pass, iter_spp))
+            chunk = max(1, min(args.spp_per_pass * group, iter_spp))
             for i in range(iter_spp // chunk):
                 integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk, batched=batched))
         else:  # passes: the passes of an iteration are independent (main.py:208-218), ranks take them in turn
@@ -464,8 +475,21 @@ def run_render(args):
     integ.setIteration(k, False)
 
     seed = [cumm + (0 if tiles else rank * args.spp_per_pass)]
+    pending = [0]  # steps queued and not yet launched (group > 1)
+
+    def flush():
+        if pending[0]:
+            n = args.spp_per_pass * pending[0]
+            integ.sample(ws, IndependentSampler(n, seed[0], batched=batched))
+            seed[0] += n
+            pending[0] = 0
 
     def step():
+        if group > 1:  # (a sharded film: the passes of `group` steps leave as one launch)
+            pending[0] += 1
+            if pending[0] == group:
+                flush()
+            return
         integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0], batched=batched))
         seed[0] += args.spp_per_pass * (1 if tiles else world)
 
@@ -474,6 +498,7 @@ def run_render(args):
     tree.readDepthCounters(reset=True)
     rec_before = int(tree.exportAccumulators()[0][0])  # records counted at the KD root so far
     step()
+    flush()  # (one step's passes by themselves: the counters below are per step)
     dc = tree.readDepthCounters(reset=True)
     tree.enableDepthCounters(False)
     records_per_pass = int(tree.exportAccumulators()[0][0]) - rec_before
@@ -482,8 +507,9 @@ def run_render(args):
     tree.enableKernelTiming(True)
     for _ in range(args.warmup):
         step()
+    flush()
     tree.readKernelTiming(reset=True)
-    elapsed = timed_steps(step, args.steps, 0, world)
+    elapsed = timed_steps(step, args.steps, 0, world, flush)
     kt = tree.readKernelTiming(reset=True)
     # ---- the roofline region: the SAME passes again with the SD-tree calls of a bounce in a kernel of their own
     # (pg_render_stages(2): k_wave_guide; in the region above they are part of k_wave_shade, where they cannot be timed
@@ -493,8 +519,9 @@ def run_render(args):
         ws.set_stages(integ, 2)
         for _ in range(min(args.warmup, 2)):
             step()
+        flush()
         tree.readKernelTiming(reset=True)
-        elapsed_roof = timed_steps(step, args.steps, 0, world)
+        elapsed_roof = timed_steps(step, args.steps, 0, world, flush)
         kt_roof = tree.readKernelTiming(reset=True)
         ws.set_stages(integ, args.stages)
     tree.enableKernelTiming(False)
@@ -530,7 +557,7 @@ def run_render(args):
     two_in_flight = None
     if args.spp1 and args.in_flight == 1 and (tiles or world == 1):
         ws.in_flight = 2
-        two_in_flight = npix * args.spp_per_pass * args.steps / timed_steps(step, args.steps, 2, world) / 1e6
+        two_in_flight = npix * args.spp_per_pass * args.steps / timed_steps(step, args.steps, 2, world, flush) / 1e6
         ws.join()
         torch.cuda.synchronize()
         ws.in_flight = 1
@@ -565,7 +592,8 @@ def run_render(args):
     d_kd = dc.kd_levels / max(dc.kd_queries, 1)
     d_q = dc.quad_levels / max(dc.quad_queries, 1)
     splat_bytes = records_per_pass * (16.0 * d_kd + 4.0 + 48.0 + 12.0 * 2.0 * d_q)
-    passes = max(kt.passes, 1)
+    # (the kernel table is per STEP: with group > 1 a launch of pg_render_pass holds the passes of several steps)
+    passes = max(kt.passes, 1) if group == 1 else max(args.steps, 1)
     wave = kt.trace_launches > 0  # the split pipeline of pg_render_wave.hip ran (mesh scenes, or --split-pipeline)
     step_ms = 1e3 * elapsed / args.steps
 
@@ -574,7 +602,7 @@ def run_render(args):
         d = {"launches": int(launches), "avg_us": round(1e3 * ms / max(launches, 1), 2), "ms_per_step": round(ms / passes, 3),
              "share_of_step": round(ms / passes / step_ms, 3)}
         if alg_bytes_per_pass is not None and ms > 0:
-            d["alg_bytes_per_launch"] = round(alg_bytes_per_pass / max(per_pass, 1))
+            d["alg_bytes_per_launch"] = round(alg_bytes_per_pass / (per_pass if per_pass > 0 else 1))
             d["alg_GBps"] = round(alg_bytes_per_pass * passes / (ms * 1e-3) / 1e9, 2)
         return d
 
@@ -584,12 +612,12 @@ def run_render(args):
         if kt_roof is None:  # (--stages 2 / --overlap 1: the SD-tree calls ran as k_wave_guide in the timed region itself)
             kernels["k_wave_guide"] = kern(kt.guide_ms, kt.guide_launches, tree_bytes)
         else:
-            p2 = max(kt_roof.passes, 1)
+            p2 = max(kt_roof.passes, 1) if group == 1 else max(args.steps, 1)
             ms2 = kt_roof.guide_ms
             kernels["k_wave_guide"] = {
                 "launches": int(kt_roof.guide_launches), "avg_us": round(1e3 * ms2 / max(kt_roof.guide_launches, 1), 2),
                 "ms_per_step": round(ms2 / p2, 3), "region": "roofline",
-                "alg_bytes_per_launch": round(tree_bytes / max(kt_roof.guide_launches / p2, 1)),
+                "alg_bytes_per_launch": round(tree_bytes / max(kt_roof.guide_launches / p2, 1e-9)),
                 "alg_GBps": round(tree_bytes * p2 / (ms2 * 1e-3) / 1e9, 2) if ms2 > 0 else 0.0,
                 "note": "timed in the roofline region (roofline.region), where the SD-tree calls are a kernel of their own; in the region "
                         "`value` is quoted on they are part of k_wave_shade (--stages 1: of k_wave_shade_a) and their time is inside it",
@@ -666,7 +694,7 @@ def run_render(args):
                     kernels[name]["atomic_ceiling_G_per_s"] = ATOMIC_CEILING_GPS
     dom_sec = kernels[dom]["avg_us"] * 1e-6
     kd_share = 16.0 * dc.kd_levels / max(tree_bytes, 1.0)
-    dom_launches_per_pass = max(kernels[dom]["launches"] / max((kt_roof.passes if (kt_roof is not None and dom == "k_wave_guide") else passes), 1), 1)
+    dom_launches_per_pass = max(kernels[dom]["launches"] / max(((kt_roof.passes if group == 1 else args.steps) if (kt_roof is not None and dom == "k_wave_guide") else passes), 1), 1e-9)
     layout_per_launch = layout_bytes / dom_launches_per_pass
     layout_gbps = layout_per_launch / max(dom_sec, 1e-12) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
@@ -722,7 +750,7 @@ def run_render(args):
     if wave and kt_roof is not None and "k_wave_shade" in kernels and kernels["k_wave_shade"]["avg_us"] > 0:
         sh = kernels["k_wave_shade"]
         sh_sec = sh["avg_us"] * 1e-6
-        sh_launches_per_pass = max(sh["launches"] / passes, 1)
+        sh_launches_per_pass = max(sh["launches"] / passes, 1e-9)
         sh_alg = tree_bytes / sh_launches_per_pass
         sh_layout = layout_bytes / sh_launches_per_pass
         tr_sh = traffic_for("k_wave_shade", cfg_key)
@@ -778,7 +806,8 @@ def run_render(args):
                    "guided_tree_queries_per_pass": int(dc.quad_queries), "paths_alive_after_bounce": live,
                    "measured_D_kd": round(d_kd, 3), "measured_D_quad": round(d_q, 3),
                    # the schedule `value` is quoted on, and the same work launched the other ways (all in this run)
-                   "pass_spp": 1 if batched else args.spp_per_pass, "passes_per_launch": args.spp_per_pass if batched else 1,
+                   "pass_spp": 1 if batched else args.spp_per_pass, "passes_per_launch": (args.spp_per_pass if batched else 1) * group,
+                   "steps_per_launch": group,
                    "value_one_launch_per_1spp_pass": None if spp1 is None else round(spp1, 3),
                    ("value_one_%dspp_pass_per_step" % args.spp_per_pass if batched else "value_batched_1spp_passes"):
                        None if multi_spp is None else round(multi_spp, 3),
@@ -1152,6 +1181,9 @@ def run_synthetic(args):
 
 
 def main():
+    # (the pool's host driver supports dmabuf IPC only: RCCL and CUDA-tensor sharing across processes fail without this, and the
+    # HSA runtime reads it when it starts -- so it is set before anything here or in a rank can have touched the GPU)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing above has imported

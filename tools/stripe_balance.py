@@ -4,7 +4,9 @@ the N-GPU step takes as long as the slowest share.  A step is `spp` batched one-
 whole training iteration (128 spp = 8 such steps) with the per-rank FIXED costs that do not shrink with N -- the refine
 (measured here; every rank refines the same tree) and the accumulators' all-reduce (an ESTIMATE: bytes x 2 (N-1)/N over one
 153 GB/s xGMI link per direction of a ring -- no multi-GPU hardware is reachable from here).
-    python tools/stripe_balance.py [world] [rows] [spp] [passes in flight: 1 | 2]"""
+    python tools/stripe_balance.py [world] [rows] [spp] [passes in flight: 1 | 2] [passes per launch of a rank's share]
+The last argument (default: spp) is what bench.py --gpus N does since round 4: a rank launches spp x N of the iteration's
+one-sample passes at once, so that its launch is as big as the one-GPU launch of the whole film."""
 import os
 import sys
 import time
@@ -25,6 +27,7 @@ sc = S.veach_ajar(1920, 1080)
 g = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
 g.setup(1920 * 1080, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
 in_flight = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+share_spp = int(sys.argv[5]) if len(sys.argv) > 5 else spp
 ws = WavefrontScene(sc, in_flight=in_flight)
 cumm = 0
 for k in range(5):
@@ -37,24 +40,25 @@ for k in range(5):
 g.setIteration(5, False)
 
 
-def timed():
-    g.sample(ws, IndependentSampler(spp, 999, batched=True))
+def timed(n=spp):
+    """ms per `spp` passes, launched n at a time"""
+    g.sample(ws, IndependentSampler(n, 999, batched=True))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(6):
-        g.sample(ws, IndependentSampler(spp, 1000 + i * spp, batched=True))
+        g.sample(ws, IndependentSampler(n, 1000 + i * n, batched=True))
     ws.join()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 6 * 1e3
+    return (time.perf_counter() - t0) / 6 * 1e3 * spp / n
 
 
 full = timed()
 shares = []
 for r in range(world):
     ws.set_shard(r, world, rows)
-    shares.append(timed())
+    shares.append(timed(share_spp))
 ws.set_shard(0, 1)
-print(f"full film {full:.2f} ms; shares of {world} ranks ({rows}-row bands, {spp} spp): " + " ".join(f"{t:.2f}" for t in shares))
+print(f"full film {full:.2f} ms; shares of {world} ranks ({rows}-row bands, {spp} spp" + (f", launched {share_spp} passes at a time" if share_spp != spp else "") + "): " + " ".join(f"{t:.2f}" for t in shares))
 print(f"slowest share {max(shares):.2f} ms -> speed-up {full / max(shares):.2f}x of {world} (mean share {np.mean(shares):.2f} ms: "
       f"{full / np.mean(shares):.2f}x without imbalance)")
 
