@@ -449,7 +449,24 @@ __device__ __forceinline__ uint32_t spread5(uint32_t v) // bits 0-4 -> bits 0, 3
 {
 	return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }
-__device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p)
+// The key's LOWEST bit on a guided pass: the lane's CLASS at this bounce -- whether it will take its direction from the SD-tree
+// (:286 `next_1d() > bsdfSamplingFraction`) or from its BSDF.  The draw is the sixth of the bounce (:214 two, :272 three, :286),
+// so the closest-hit kernel, which holds the path's sampler state, can look it up ahead of time.  Inside a cell of the sort the
+// lanes then stand class by class and most waves hold ONE class: the sampling walk and the second BSDF evaluation run on full
+// waves of "tree" lanes, the pdf walk on full waves of "BSDF" lanes, instead of every wave making all three for half its lanes
+// each.  A hint, not a contract: where the guess is wrong (a delta lobe, :283) only the order differs, and the order is free.
+#ifndef PG_SORT_CLASS_BIT
+#define PG_SORT_CLASS_BIT 1
+#endif
+__device__ __forceinline__ uint32_t lane_class_ahead(uint64_t state, uint64_t inc, float frac)
+{
+	Pcg32 r;
+	r.state = state; r.inc = inc;
+	r.skip(); r.skip(); r.skip(); r.skip(); r.skip();
+	return r.next_f32() > frac ? 1u : 0u;
+}
+
+__device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p, int cls = -1)
 {
 	uint32_t c[3];
 	const float q[3] = {p.x, p.y, p.z};
@@ -462,7 +479,8 @@ __device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p)
 		if (f > 63.0f) f = 63.0f;
 		c[k] = (uint32_t)f;
 	}
-	const uint32_t half = (longest == 0 ? c[0] : (longest == 1 ? c[1] : c[2])) & 1u;
+	const uint32_t half = cls >= 0 ? (uint32_t)cls : ((longest == 0 ? c[0] : (longest == 1 ? c[1] : c[2])) & 1u);
+	// (measured: the class as the key's highest bit instead -- the list in two halves, each in cell order -- shades in the same time)
 	const uint32_t m = ((spread5(c[0] >> 1) | (spread5(c[1] >> 1) << 1) | (spread5(c[2] >> 1) << 2)) << 1) | half;
 	return m < 0xfffdu ? m : 0xfffdu; // (0xfffe and 0xffff mean something else)
 }
@@ -497,6 +515,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
 	if (!alive) return;
 	v3 ray_o, ray_d;
+	int cls_ahead = -1; // (a sorted, guided bounce: the lane's class, for the sort key)
 	if (kFirst) { // (place = lane in the first list)
 		Pcg32 rng;
 		camera_ray(a, tid, rng, ray_o, ray_d);
@@ -505,8 +524,15 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 		st_store(const_cast<uint4 *>(a.st_in), a, 0, tid, ray_o, (uint32_t)rng.state);
 		st_store(const_cast<uint4 *>(a.st_in), a, 1, tid, ray_d, (uint32_t)(rng.state >> 32));
 	} else if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
-		ray_o = st_v3(a.carry_in[tid * 8 + 0]);
-		ray_d = st_v3(a.carry_in[tid * 8 + 1]);
+		const uint4 q0 = a.carry_in[tid * 8 + 0], q1 = a.carry_in[tid * 8 + 1];
+		ray_o = st_v3(q0);
+		ray_d = st_v3(q1);
+		// (the class bit of the sort key is made HERE, ahead of the walk, from the sampler state in the two entries just read: one
+		// register through the walk instead of the state's four)
+		if (PG_SORT_CLASS_BIT && a.guided && a.bounce + 1 < a.max_depth && tid < (uint64_t)a.n_sort) {
+			const uint4 q5 = a.carry_in[tid * 8 + 5];
+			cls_ahead = (int)lane_class_ahead((uint64_t)q0.w | ((uint64_t)q1.w << 32), (uint64_t)q5.x | ((uint64_t)q5.y << 32), a.frac);
+		}
 	} else {
 		ray_o = st_v3(st_load(a.st_in, a, 0, tid));
 		ray_d = st_v3(st_load(a.st_in, a, 1, tid));
@@ -516,7 +542,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	h.prim = intersect<kLevel, false>(a.shapes, ray_o, ray_d, __builtin_huge_valf(), h.t, stk, h.u, h.v);
 	if (a.carry_in) { // a sorted bounce: the hit joins the path's 128-byte record, which k_wave_shade_a reads through the permutation
 		a.carry_in[tid * 8 + 6] = make_uint4((uint32_t)h.prim, __float_as_uint(h.t), __float_as_uint(h.u), __float_as_uint(h.v));
-		if (tid < (uint64_t)a.n_sort) a.sort_key[tid] = (uint16_t)(h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t))) : 0xfffeu);
+		if (tid < (uint64_t)a.n_sort) a.sort_key[tid] = (uint16_t)(h.prim >= 0 ? vertex_sort_key(a, vadd(ray_o, vscale(ray_d, h.t)), cls_ahead) : 0xfffeu);
 		return;
 	}
 	wsputu(a, WS_HIT_PRIM, tid, (uint32_t)h.prim);
