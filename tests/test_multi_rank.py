@@ -628,7 +628,8 @@ def test_bench_gpus_2_from_a_bare_command_line(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scene", "cornell-box", "--res", "96", "--steps", "2",
+    # (three steps: a rank launches the passes of world = 2 steps at once, the odd one leaves by itself when the region is flushed)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scene", "cornell-box", "--res", "96", "--steps", "3",
            "--warmup", "1", "--train-iters", "3", "--spp-per-pass", "4", "--cpu", "0", "--full-schedule", "0"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -644,6 +645,8 @@ def test_bench_gpus_2_from_a_bare_command_line(tmp_path):
         assert "RCCL" in out["extra"]["exchange"] or "nccl" in out["extra"]["exchange"]
     c = out["config"]
     assert c["pixels_per_rank_min"] + c["pixels_per_rank_max"] == 96 * 96 and c["pixels_per_rank_min"] > 0
+    assert c["steps_per_launch"] == 2 and c["passes_per_launch"] == 8 and out["steps"] == 3
+    assert c["paths_per_step"] == 96 * 96 * 4  # (a step is still spp_per_pass passes of the whole film)
 
 
 def _worker_nccl_one_rank(rank, world, port, out):
