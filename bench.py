@@ -120,6 +120,13 @@ def parse():
                          "report value_full_schedule_12it + the final image's MSE; default: 1 at N = 1, 0 otherwise")
     ap.add_argument("--spp1", type=int, default=1, help="0: skip the leg that times 1-spp passes (value_spp1)")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
+    ap.add_argument("--other-configs", type=int, default=None,
+                    help="1: also time BASELINE configs[1], [2], [4] (cornell-box 512x512, veach-mis 1280x720, torus 1920x1080 depth 32) for a "
+                         "few steps each and put the figures into `config` (c2_/c3_/c5_*); default: 1 at N = 1 on the default scene")
+    ap.add_argument("--exchange-overlap", type=int, default=0,
+                    help="N > 1, full-schedule leg: 1 lets the accumulators' all-reduce (libpgsd's RCCL communicator) travel beside the image "
+                         "collectives of torch.distributed's communicator; 0 (default) orders it ahead of them -- two communicators in flight at "
+                         "once has not run on hardware yet")
     ap.add_argument("--split-pipeline", action="store_true",
                     help="cornell-box / veach-mis: run the bounce as the split pipeline instead of the fused kernel (same results; the "
                          "roofline is then read off k_wave_guide, the SD-tree queries alone)")
@@ -146,6 +153,8 @@ def parse():
         args.full_schedule = 1 if (args.gpus == 1 and not args.synthetic) else 0
     if args.synthetic_kernels is None:
         args.synthetic_kernels = 1 if (args.gpus == 1 and not args.synthetic) else 0
+    if args.other_configs is None:
+        args.other_configs = 1 if (args.gpus == 1 and not args.synthetic and args.scene == "veach-ajar") else 0
     if args.in_flight is None:
         args.in_flight = 2 if (args.gpus > 1 and args.shard == "tiles" and not args.synthetic) else 1
     return args
@@ -697,12 +706,22 @@ def run_render(args):
     dom_launches_per_pass = max(kernels[dom]["launches"] / max(((kt_roof.passes if group == 1 else args.steps) if (kt_roof is not None and dom == "k_wave_guide") else passes), 1), 1e-9)
     layout_per_launch = layout_bytes / dom_launches_per_pass
     layout_gbps = layout_per_launch / max(dom_sec, 1e-12) / 1e9
-    roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom].get("alg_GBps", 0.0), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(kernels[dom].get("alg_GBps", 0.0) / HBM_PEAK_GBS, 5),
-            # the creditable fraction: bytes the lanes gathered from the built tables (no cross-lane sharing credited) per
-            # launch / the launch time measured in this run / peak -- cannot exceed what the memory pipeline moved
+    model_gbps = kernels[dom].get("alg_GBps", 0.0)
+    # `frac` / `achieved`: the bytes the lanes of an instrumented pass GATHERED from the tables of the built layout (no
+    # cross-lane sharing credited) per launch / the launch time measured in this run (HIP events on the launch stream) / the
+    # 8 TB/s peak -- what the memory pipeline moves at least, <= 1 by construction, recomputable from layout_bytes_per_launch
+    # and avg_launch_us (the committed rocprofv3 summary of the same command has the same average).  SURVEY 8(d)'s
+    # ALGORITHMIC model (the reference's levels priced one by one) is kept beside it as frac_model_8d: on spatially sorted
+    # lists it exceeds the peak (model_applicable false) and is not a bandwidth.
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(layout_gbps, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(layout_gbps / HBM_PEAK_GBS, 5),
+            "frac_basis": "bytes gathered from the built layout (16 per KD grid entry / node below it, 8 per tree head, 16 per jump-table "
+                          "entry, 32 per quadtree record of a pdf or sampling walk, 16 per record of a leaf walk), counted walk by walk by an "
+                          "instrumented pass (pg_depth_counters.layout_bytes), per launch / avg_launch_us / peak",
             "frac_layout": round(layout_gbps / HBM_PEAK_GBS, 5), "layout_bytes_per_launch": int(layout_per_launch),
-            "layout_GBps": round(layout_gbps, 2), "alg_bytes_per_launch": kernels[dom].get("alg_bytes_per_launch"),
+            "layout_GBps": round(layout_gbps, 2),
+            "frac_model_8d": round(model_gbps / HBM_PEAK_GBS, 5), "achieved_model_8d": model_gbps,
+            "alg_bytes_per_launch": kernels[dom].get("alg_bytes_per_launch"),
             "avg_launch_us": kernels[dom]["avg_us"],
             "traffic": traffic,
             # above 1 the algorithmic model is not a bandwidth at all: in a spatially sorted list (pg_render_sort) the lanes of a
@@ -713,7 +732,7 @@ def run_render(args):
             # lo as counted, hi with the guide's x2 FETCH correction (an upper bound for scattered reads)
             "frac_counter_lo": None if (tr_dom is None or tr_dom["lo"] is None or dom_sec <= 0) else round(tr_dom["lo"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
             "frac_counter_hi": None if (tr_dom is None or dom_sec <= 0) else round(tr_dom["hi"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
-            "model_note": (f"`frac` is SURVEY 8d's ALGORITHMIC model (16 B per KD level + 20 B per quadtree level walked by the reference's "
+            "model_note": (f"`frac_model_8d` is SURVEY 8d's ALGORITHMIC model (16 B per KD level + 20 B per quadtree level walked by the reference's "
                            f"descents), not a bandwidth measurement: {100 * kd_share:.0f} % of those bytes are KD levels ({dc.kd_levels / max(dc.kd_queries, 1):.1f} per "
                            "query) that the KD jump grid replaces by ONE 16-byte gather for most queries, and the top six quadtree levels of "
                            "a pdf walk are one 16-byte jump-table gather: the kernel moves far fewer bytes than the model prices -- read "
@@ -756,15 +775,16 @@ def run_render(args):
         tr_sh = traffic_for("k_wave_shade", cfg_key)
         roof.update({
             "value_region_kernel": "k_wave_shade", "value_region_avg_launch_us": sh["avg_us"],
-            "value_region_alg_bytes_per_launch": int(sh_alg), "value_region_frac": round(sh_alg / sh_sec / 1e9 / HBM_PEAK_GBS, 5),
+            "value_region_alg_bytes_per_launch": int(sh_alg), "value_region_frac_model_8d": round(sh_alg / sh_sec / 1e9 / HBM_PEAK_GBS, 5),
             "value_region_layout_bytes_per_launch": int(sh_layout),
+            "value_region_frac": round(sh_layout / sh_sec / 1e9 / HBM_PEAK_GBS, 5),
             "value_region_frac_layout": round(sh_layout / sh_sec / 1e9 / HBM_PEAK_GBS, 5),
             "value_region_traffic": None if tr_sh is None else tr_sh["hi"],
             "value_region_frac_counter_lo": None if (tr_sh is None or tr_sh["lo"] is None) else round(tr_sh["lo"] / sh_sec / 1e9 / HBM_PEAK_GBS, 4),
             "value_region_frac_counter_hi": None if tr_sh is None else round(tr_sh["hi"] / sh_sec / 1e9 / HBM_PEAK_GBS, 4),
             "value_region_note": ("value_region_*: the kernel that makes the SD-tree calls in the steps `value` is quoted on (k_wave_shade, one launch "
-                                  "per bounce, the slowest kernel of the step) priced with the same SURVEY 8(d) bytes (value_region_frac) and the "
-                                  "same gathered layout bytes (value_region_frac_layout) as k_wave_guide above, over ITS average launch in the "
+                                  "per bounce, the slowest kernel of the step) priced with the same gathered layout bytes (value_region_frac) and the "
+                                  "same SURVEY 8(d) model bytes (value_region_frac_model_8d) as k_wave_guide above, over ITS average launch in the "
                                   "timed region of `value`; value_region_traffic / _frac_counter_* are its committed PMC figures")})
         sh["alg_bytes_per_launch"] = int(sh_alg)
         sh["alg_GBps"] = round(sh_alg / sh_sec / 1e9, 2)
@@ -774,10 +794,13 @@ def run_render(args):
         cpu, mse_small, mse_small_cpu = cpu_leg(args)
     synth_detail = None
     if args.synthetic_kernels and world == 1:
-        synth_flat, synth_detail = synthetic_kernels_leg(local_rank)
+        synth_flat, synth_detail = synthetic_kernels_leg(local_rank, cpu=bool(args.cpu))
         roof.update(synth_flat)  # s1_pg_sample_frac_layout, ... (flat: the driver's record keeps scalars)
         roof["synthetic_note"] = ("s1_* / s2_* / s3_*: pg_pdf, pg_sample, pg_guide_bounce, pg_splat on SURVEY 8(d)'s S1 / S2 / S3 at their stated sizes "
                                   "(2^22 queries, 2^24 records) in this run; `kernels_synthetic` has units, bytes and depths")
+    other = {}
+    if args.other_configs and world == 1:
+        other = other_configs_leg(local_rank)
     refine_ms_iters = [p["exchange_refine_ms"] for p in per_iter]
     out = {
         "metric": f"Msamples/s guided, {args.scene} {film} max_depth {args.depth}", "value": round(value, 3), "unit": "Msamples/s",
@@ -818,7 +841,7 @@ def run_render(args):
                    "mse_vs_gt_device_320": mse_small, "mse_vs_gt_cpu_320": mse_small_cpu,
                    "exchange_refine_ms_max_over_training": max(refine_ms_iters) if refine_ms_iters else None,
                    "refine_ms_after_steps": round(1e3 * t_refine, 3), "jump_bits": int(stats.jump_bits),
-                   "bytes_jump_tables": int(stats.bytes_jump_tables)},
+                   "kd_grid_bits": int(stats.kd_grid_bits), "bytes_jump_tables": int(stats.bytes_jump_tables), **other},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "kernels_synthetic": synth_detail,
         "schedule": {"note": "value_full_schedule = film pixels x spp of the trained iterations >= 2 / their wall time incl. "
                              "accumulator exchange and refine (main.py:159,394); mse_vs_gt = the last trained iteration's "
@@ -833,7 +856,7 @@ def run_render(args):
     return out
 
 
-def synthetic_kernels_leg(device):
+def synthetic_kernels_leg(device, cpu=False):
     """SURVEY.md 8(d)'s kernel-level inputs at their stated sizes through the stand-alone entry points of the C ABI (no
     renderer, no oracle: the trees and streams are made by practical_path_guiding_lab_amd.workload):
       S1 "balanced"  KD complete to depth 12 (4096 leaves) over [0,100]^3, every leaf a complete quadtree of depth 5
@@ -881,13 +904,14 @@ def synthetic_kernels_leg(device):
 
     def put(key, name, n, ms, alg, layout, extra):
         d = {"kernel": name, "units": int(n), "ms": round(ms, 4), "G_units_per_s": round(n / ms / 1e6, 2),
-             "alg_bytes_per_launch": int(alg), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
-             "layout_bytes_per_launch": int(layout), "frac_layout": round(layout / ms / 1e6 / HBM_PEAK_GBS, 4)}
+             "layout_bytes_per_launch": int(layout), "frac": round(layout / ms / 1e6 / HBM_PEAK_GBS, 4),
+             "frac_layout": round(layout / ms / 1e6 / HBM_PEAK_GBS, 4),
+             "alg_bytes_per_launch": int(alg), "frac_model_8d": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
         d.update(extra)
         detail.append(d)
         flat[key + "_ms"] = d["ms"]
         flat[key + "_frac"] = d["frac"]
-        flat[key + "_frac_layout"] = d["frac_layout"]
+        flat[key + "_frac_model_8d"] = d["frac_model_8d"]
 
     P = Wk.s_positions_uniform(nq, 3, device=dev)
     D = Wk.s_directions_uniform(nq, 4, device=dev)
@@ -914,7 +938,8 @@ def synthetic_kernels_leg(device):
         put(tag + "_pg_sample", tag.upper() + " pg_sample", nq, ms_s, nq * (16.0 * d_kd + 20.0 * ds_q), dcs.layout_bytes + 8 * dcs.kd_queries,
             {"D_kd": round(d_kd, 3), "D_quad": round(ds_q, 3)})
         detail.append({"kernel": tag.upper() + " pg_get_leaf_node_index", "units": nq, "ms": round(ms, 4), "G_units_per_s": round(nq / ms / 1e6, 2),
-                       "alg_bytes_per_launch": int(nq * 16.0 * d_kd), "frac": round(nq * 16.0 * d_kd / ms / 1e6 / HBM_PEAK_GBS, 4),
+                       "layout_bytes_per_launch": int(nq * 16), "frac": round(nq * 16.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                       "alg_bytes_per_launch": int(nq * 16.0 * d_kd), "frac_model_8d": round(nq * 16.0 * d_kd / ms / 1e6 / HBM_PEAK_GBS, 4),
                        "note": "one 16-byte gather per lane from the KD jump grid, served from L2: the model prices D_kd levels"})
         # the three calls of a bounce: NEE pdf for every lane, half the lanes sample, half evaluate
         nee = torch.ones(nq, dtype=torch.uint8, device=dev)
@@ -928,15 +953,33 @@ def synthetic_kernels_leg(device):
         put(tag + "_pg_guide_bounce", tag.upper() + " pg_guide_bounce", nq, ms_b, 16.0 * dcb.kd_levels + 20.0 * dcb.quad_levels,
             dcb.layout_bytes + 8 * dcb.kd_queries,
             {"D_kd": round(dcb.kd_levels / max(dcb.kd_queries, 1), 3), "D_quad": round(dcb.quad_levels / max(dcb.quad_queries, 1), 3),
-             "quad_descents_per_lane": round(dcb.quad_queries / nq, 3)})
+             "quad_descents_per_lane": round(dcb.quad_queries / nq, 3),
+             "classes": "interleaved lane by lane (lane % 2): every wave walks both ways -- the worst case, which the renderer no "
+                        "longer runs since the lane's class went into the sort key (DESIGN 5.9)"})
+        # ... and the same mix with class-uniform waves (wave w samples or evaluates as a whole: what a sorted bounce of the
+        # renderer looks like)
+        sel_u = ((torch.arange(nq, device=dev) // 64) % 2 + 1).to(torch.uint8)
+        dio.copy_(D)
+        run_u = tree.prepareGuideBounce(P, D, nee, sel_u, dio, smp)
+        smp.state.copy_(st0)
+        dcu = counted(tree, run_u)
+        dio.copy_(D)
+        ms_u = timed(run_u)
+        put(tag + "_pg_guide_bounce_uniform_waves", tag.upper() + " pg_guide_bounce (class-uniform waves)", nq, ms_u,
+            16.0 * dcu.kd_levels + 20.0 * dcu.quad_levels, dcu.layout_bytes + 8 * dcu.kd_queries,
+            {"D_kd": round(dcu.kd_levels / max(dcu.kd_queries, 1), 3), "D_quad": round(dcu.quad_levels / max(dcu.quad_queries, 1), 3),
+             "quad_descents_per_lane": round(dcu.quad_queries / nq, 3), "classes": "uniform per wave ((lane // 64) % 2)"})
 
     trees = {}
+    cpu_in = {}
     g1 = SDTree(device)
     g1.load(Wk.s1_balanced_tree())
     st = g1.stats()
     trees["s1"] = {"kd_leaves": int(st.n_kd_leaves), "quad_nodes": int(st.n_quad_nodes), "jump_bits": int(st.jump_bits),
                    "kd_grid_bits": int(st.kd_grid_bits)}
     query_suite("s1", g1)
+    if cpu:
+        cpu_in["s1"] = {"tree": Wk.s1_balanced_tree(), "pdf": g1.pdf(P, D).cpu().numpy(), "leaf": g1.getLeafNodeIndex(P).cpu().numpy()}
     del g1
     g2 = SDTree(device)
     g2.setup([Wk.S_BBOX[0]] * 3, [Wk.S_BBOX[1]] * 3, 0, 0, 20, 20, True, 0.5)
@@ -956,6 +999,9 @@ def synthetic_kernels_leg(device):
                    "mean_quad_leaf_depth": round(st.mean_quad_leaf_depth, 3), "max_quad_depth": int(st.max_quad_depth),
                    "jump_bits": int(st.jump_bits), "kd_grid_bits": int(st.kd_grid_bits), "refine_ms_per_iteration": refine_ms}
     query_suite("s2", g2)
+    if cpu:
+        cpu_in["s2"] = {"tree": g2.export(), "pdf": g2.pdf(P, D).cpu().numpy(), "leaf": g2.getLeafNodeIndex(P).cpu().numpy()}
+        cpu_in["s3"] = {k_: v.cpu().numpy() for k_, v in rec.items()}
     # S3: the last record stream replayed into the S2 topology
     g2.setIteration(Wk.S2_ITERATIONS, False)
     m = int(rec["radiance"].shape[0])
@@ -969,7 +1015,147 @@ def synthetic_kernels_leg(device):
          "atomic_sector_updates_G_per_s": round(dc.quad_queries / ms / 1e6, 2), "atomic_ceiling_G_per_s": ATOMIC_CEILING_GPS})
     del g2
     torch.cuda.empty_cache()
-    return flat, {"trees": trees, "kernels": detail, "note": synthetic_kernels_leg.__doc__.split("\n\n")[0]}
+    cpu_cols = None
+    if cpu:
+        cpu_cols = cpu_synthetic_columns(cpu_in, P.cpu().numpy(), D.cpu().numpy(), detail, flat)
+    return flat, {"trees": trees, "kernels": detail, "cpu": cpu_cols, "note": synthetic_kernels_leg.__doc__.split("\n\n")[0]}
+
+
+def cpu_synthetic_columns(cpu_in, P, D, detail, flat):
+    """Part of the cpu_baseline leg (the one place outside tests/ and smoke() that loads oracle/): the CPU restatement's
+    rate on the SAME S1 / S2 / S3 inputs as the device's kernels_synthetic entries ("CPU baseline ... same
+    inputs S1-S3 ..., OpenMP over all host cores"; the reference's own self-tests time exactly such streams,
+    kdtree.py:831-835, quadtree.py:1431-1436) -- pgo_get_leaf_node_index, pgo_pdf, pgo_sample over 2^22 lanes,
+    pgo_add_data_propagate over 2^24 records, on every host core (lanes are independent; the splat adds exact integers
+    with carry-correct atomic adds, so the result is the single-threaded one: tests/test_oracle_tree.py).  The S2 tree is
+    the device's own export loaded into the oracle (their equality at this size is tests/test_gpu_synthetic_fullsize.py);
+    as a cross-check the oracle's pdfs and leaf indices here are compared with the device's, bit for bit.  Adds
+    `cpu_G_units_per_s`, `cpu_cores`, `gpu_over_cpu` to the matching entries of `detail` (flat: s1_pg_pdf_cpu_G_per_s ...)."""
+    import numpy as np
+    from oracle import pg_oracle as po
+
+    po.build()
+    cores = po.set_threads(0)
+    by_name = {d["kernel"]: d for d in detail}
+    out = {"cores": cores, "label": "CPU restatement (oracle/pg_oracle.c, OpenMP over the lanes)", "equal_to_device": True}
+    n = P.shape[1]
+
+    def best(fn, reps=3):
+        t = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            t = min(t, time.perf_counter() - t0)
+        return t, r
+
+    def col(kernel, units, sec):
+        d = by_name.get(kernel)
+        g = units / sec / 1e9
+        if d is not None:
+            d["cpu_G_units_per_s"] = round(g, 5)
+            d["cpu_cores"] = cores
+            d["gpu_over_cpu"] = round(d["G_units_per_s"] / g, 1) if g > 0 else None
+        key = kernel.lower().replace(" ", "_")
+        flat[key + "_cpu_G_per_s"] = round(g, 5)
+        out[key + "_G_per_s"] = round(g, 5)
+
+    try:
+        for tag in ("s1", "s2"):
+            o = po.OracleTree()
+            o.load(cpu_in[tag]["tree"])
+            sec, leaf = best(lambda: o.get_leaf_node_index(P))
+            col(tag.upper() + " pg_get_leaf_node_index", n, sec)
+            sec, pdf = best(lambda: o.pdf(P, D))
+            col(tag.upper() + " pg_pdf", n, sec)
+            out["equal_to_device"] = bool(out["equal_to_device"]
+                                          and (leaf == cpu_in[tag]["leaf"].astype(np.uint32)).all()
+                                          and (pdf.view(np.uint32) == cpu_in[tag]["pdf"].view(np.uint32)).all())
+
+            def smp():
+                st, inc = po.rng_seed(n, 0)
+                t0 = time.perf_counter()
+                o.sample(P, st, inc)
+                return time.perf_counter() - t0
+            sec = min(smp() for _ in range(3))
+            col(tag.upper() + " pg_sample", n, sec)
+
+            # the three calls of a bounce as the reference makes them (path_guiding_integrator.py:244, 301, 307): a pdf for
+            # every lane, a sample for half the lanes, a pdf for the other half
+            sel = (np.arange(n) % 2 + 1).astype(np.uint8)
+
+            def bounce():
+                st, inc = po.rng_seed(n, 0)
+                t0 = time.perf_counter()
+                o.pdf(P, D)
+                o.sample(P, st, inc, (sel == 2).astype(np.uint8))
+                o.pdf(P, D, (sel == 1).astype(np.uint8))
+                return time.perf_counter() - t0
+            sec = min(bounce() for _ in range(2))
+            col(tag.upper() + " pg_guide_bounce", n, sec)
+            if tag == "s2":
+                r = cpu_in["s3"]
+                m = int(r["radiance"].shape[0])
+                cur = po.OracleTree()
+                cur.copy_from(o)
+                cur.reset()
+                sec, _ = best(lambda: cur.add_data_propagate(r["position"], r["direction"], r["radiance"], r["woPdf"],
+                                                             r["direction_nee"], r["radiance_nee_lum"]), reps=2)
+                col("S3 pg_splat", m, sec)
+                out["s3_root_count_ok"] = bool(int(cur.kd_column("count")[0]) == 2 * m)  # (two timed replays)
+            del o
+    finally:
+        po.set_threads(1)
+    return out
+
+
+def other_configs_leg(device, steps=6, train_iters=6, spp_per_pass=8):
+    """The other BASELINE.json configurations that fit one GPU -- configs[1] cornell-box 512x512 max_depth 8, configs[2]
+    veach-mis 1280x720 max_depth 3, configs[4] torus 1920x1080 max_depth 32 -- each as `python bench.py --scene X
+    --spp-per-pass 8` measures it (the SD-tree trained by six really rendered iterations, then `steps` timed steps of eight
+    one-sample training passes in one batched launch, wall clock between device synchronisations), so that the default
+    line carries driver-timed figures for them.  Flat keys: c2_/c3_/c5_..._msamples_per_s, _ms_per_step."""
+    import numpy as np
+    import torch
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+
+    flat = {}
+    for key, name in (("c2_cornell_box_512x512_d8", "cornell-box"), ("c3_veach_mis_1280x720_d3", "veach-mis"),
+                      ("c5_torus_1920x1080_d32", "torus")):
+        width, _, depth = SCENES[name]
+        sc = make_scene(name, width, depth)
+        W, H = sc.camera.width, sc.camera.height
+        g = PathGuidingIntegrator({"max_depth": depth, "rr_depth": 8}, device=device)
+        g.setup(W * H, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
+        ws = WavefrontScene(sc)
+        ws.reserve(g, spp_per_pass)
+        cumm = 0
+        for k in range(train_iters):
+            g.setIteration(k, False)
+            g.resetVarianceCounter()
+            iter_spp = 2 ** (k + 2)
+            chunk = min(spp_per_pass, iter_spp)
+            for i in range(iter_spp // chunk):
+                g.sample(ws, IndependentSampler(chunk, cumm + i * chunk, batched=True))
+            cumm += iter_spp
+            g.refineAndPrepareSDTreeForNextIteration()
+        g.setIteration(train_iters, False)
+        seed = [cumm]
+
+        def step():
+            g.sample(ws, IndependentSampler(spp_per_pass, seed[0], batched=True))
+            seed[0] += spp_per_pass
+        el = timed_steps(step, steps, 2, 1)
+        st = g.sdTree.stats()
+        flat[key + "_msamples_per_s"] = round(W * H * spp_per_pass * steps / el / 1e6, 3)
+        flat[key + "_ms_per_step"] = round(1e3 * el / steps, 4)
+        flat[key + "_kd_leaves"] = int(st.n_kd_leaves)
+        del ws, g, sc
+        torch.cuda.empty_cache()
+    flat["other_configs_note"] = (f"c2_/c3_/c5_*: BASELINE configs[1], [2], [4] on this GPU in this run -- SD-tree trained by {train_iters} rendered "
+                                  f"iterations, then {steps} timed steps of {spp_per_pass} one-sample training passes in one batched launch (as "
+                                  "`bench.py --scene X --spp-per-pass 8`)")
+    return flat
 
 
 def full_schedule_leg(args, integ, ws, shard, reduce_fn, W, H):
@@ -993,7 +1179,7 @@ def full_schedule_leg(args, integ, ws, shard, reduce_fn, W, H):
     else:
         kw = dict(training_spp_per_pass=args.spp_per_pass)
     res = run_guided_render(ws, integ, budget, initial_seed=0, batch_spp=args.spp_per_pass, all_reduce=reduce_fn, shard=shard,
-                            log=lines.append, **kw)
+                            log=lines.append, exchange_overlap=bool(args.exchange_overlap), **kw)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     rows = res["records"]["variance_endIter"].rows
@@ -1083,6 +1269,8 @@ def cpu_leg(args, iters=4, width=320):
         if k + 1 < iters:
             pair2.refine_and_prepare(k)
     cpu = {"value": round(n_guided / t_guided / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "label": "CPU restatement: the build's own C restatement of the reference's Python (oracle/, OpenMP over the lanes), NOT the "
+                    "reference -- its Python / Dr.Jit path cannot run on this box (Mitsuba 3 and Dr.Jit are absent: SURVEY 8c)",
            "images_bit_identical_to_device": same,
            "mse_vs_gt_device": mse_g, "mse_vs_gt_cpu": mse_c, "mse_equal": bool(mse_g == mse_c),
            "value_one_sample_passes": round(n_guided_1 / t_guided_1 / 1e6, 4),

@@ -497,7 +497,8 @@ typedef struct pg_stats {
 	uint64_t bytes_kd, bytes_quad_records, bytes_accumulators;
 	/* the tables that stand in for the top levels of the descents (not in the reference): the quadtree jump tables
 	 * (4^jump_bits entries of 16 bytes per quadtree; 0 bits: none -- the forest is too big for its memory budget,
-	 * $PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB and at most a quarter of the free device memory) and the KD jump grid
+	 * $PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB: a function of the forest and the budget alone, so that every rank and
+	 * every run builds the same tables; coarser only when the table cannot be allocated) and the KD jump grid
 	 * (8^kd_grid_bits cells of 16 bytes) */
 	uint64_t bytes_jump_tables;
 	uint32_t jump_bits, kd_grid_bits;

@@ -23,7 +23,18 @@ def main():
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--budget-spp", type=int, default=252)       # main.py:99
     ap.add_argument("--batch-spp", type=int, default=4)          # main.py:123
-    ap.add_argument("--training-spp-per-pass", type=int, default=8)
+    ap.add_argument("--training-spp-per-pass", type=int, default=1,      # main.py:192: training passes trace ONE sample per pixel
+                    help="samples per pixel of a training pass (the reference: 1, seeded initial_seed + cumm_spp, main.py:218)")
+    ap.add_argument("--training-passes-per-launch", type=int, default=16,
+                    help="one-sample training passes traced per device launch (pg_pass_params.batched): images, logs and SD-tree are "
+                         "those of the separate passes, byte for byte (tests/test_gpu_cli.py); 1 = one launch per pass")
+    ap.add_argument("--path-tracing", action="store_true",
+                    help="the reference's benchmark renderer instead (path_tracing_render.py): no SD-tree, --budget-spp samples "
+                         "(or --time-budget seconds) in chunks of --batch-spp")
+    ap.add_argument("--time-budget", type=float, default=None, help="--path-tracing: seconds instead of a sample count")
+    ap.add_argument("--repeat-high-spp", type=int, default=0, metavar="SPP",
+                    help="after the run: render every iteration's saved SD-tree, frozen, with SPP samples each "
+                         "(repeat_high_spp_renderer.py): what each iteration's tree is worth at equal cost")
     ap.add_argument("--seed", type=int, default=0)               # main.py:66-67
     ap.add_argument("--out", default="debug/cornell-box")
     ap.add_argument("--ground-truth", default=None, help=".exr or .npy (H,W,3) linear ground truth for MSE, e.g. "
@@ -59,12 +70,22 @@ def main():
     if gt is not None and (args.scene == "veach-ajar" or ("veach-ajar" in args.scene and sc.skipped)):
         mask = S.veach_ajar_mask(sc.camera.width, sc.camera.height)
         print("MSE / variance against the ground truth leave out the teapot rectangle")
+    if args.path_tracing:
+        from practical_path_guiding_lab_amd.extras import run_path_tracing
+        run_path_tracing(WavefrontScene(sc), integ, None if args.time_budget else args.budget_spp, args.time_budget,
+                         chunk_spp=args.batch_spp, initial_seed=args.seed, ground_truth=gt, out_dir=args.out, gt_mask=mask)
+        return
     res = run_guided_render(WavefrontScene(sc), integ, args.budget_spp, initial_seed=args.seed, ground_truth=gt,
                             batch_spp=args.batch_spp, training_spp_per_pass=args.training_spp_per_pass, out_dir=args.out,
-                            gt_mask=mask)
+                            gt_mask=mask, training_passes_per_launch=args.training_passes_per_launch)
     n = sc.camera.width * sc.camera.height * res["cumm_spp"]
     print(f"done: {res['cumm_spp']} spp in {res['time_s']:.2f} s = {n / res['time_s'] / 1e6:.1f} Msamples/s overall; "
           f"guided passes {res['guided_samples'] / max(res['guided_time_s'], 1e-9) / 1e6:.1f} Msamples/s")
+    if args.repeat_high_spp > 0:
+        from practical_path_guiding_lab_amd.extras import repeat_high_spp
+        last = len(res["iterations"]) - 1
+        repeat_high_spp(WavefrontScene(sc), integ, args.out, 0, last, last, args.repeat_high_spp, batch_spp=args.batch_spp,
+                        initial_seed=args.seed + 1000003, ground_truth=gt, out_dir=args.out, gt_mask=mask)
 
 
 if __name__ == "__main__":

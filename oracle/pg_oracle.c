@@ -470,14 +470,32 @@ static void qt_clear_unused(QT *q)
 	*q = fresh;
 }
 
+/* An exact 128-bit add that several threads may make to one accumulator at once: the low half by a 64-bit
+ * fetch-and-add whose returned old value tells THIS add whether it wrapped, the wrap carried into the high half by a
+ * second one.  The sum of integers does not depend on the order of the adds, so the threaded stand-alone
+ * entry points below (bench.py's CPU columns for S1-S3) give the single-threaded result bit for bit. */
+typedef uint64_t __attribute__((may_alias)) u64_alias;
+typedef int64_t __attribute__((may_alias)) i64_alias;
+static inline void acc_add(i128 *a, i128 w, int mt)
+{
+	if (!mt) { *a += w; return; }
+	u64_alias *lo = (u64_alias *)a;            /* (little-endian: low half first) */
+	i64_alias *hi = (i64_alias *)a + 1;
+	uint64_t wlo = (uint64_t)(u128)w;
+	int64_t whi = (int64_t)(w >> 64);
+	uint64_t old = __atomic_fetch_add(lo, wlo, __ATOMIC_RELAXED);
+	int64_t up = whi + (int64_t)((uint64_t)(old + wlo) < old);
+	if (up) __atomic_fetch_add(hi, up, __ATOMIC_RELAXED);
+}
+
 /* quadtree.py:398-441 (one addIrradiancePropagate call, scalar lane) */
-static void qt_add_one(QT *q, uint32_t rootIndex, float x, float y, float w)
+static void qt_add_one_mt(QT *q, uint32_t rootIndex, float x, float y, float w, int mt)
 {
 	uint32_t node = q->root[rootIndex];
 	if (!q_contains(q, node, x, y)) return;
 	i128 wq = quantize(w);
 	for (int guard = 0; guard < 64; ++guard) {
-		q->acc[node] += wq;
+		acc_add(&q->acc[node], wq, mt);
 		if (q->isLeaf[node]) return;
 		uint32_t next = node;
 		for (int j = 0; j < 4; ++j) { /* sequential overwrite: highest containing child wins */
@@ -684,9 +702,19 @@ void pgo_tree_copy_from(pgo_tree *dst, const pgo_tree *src)
 	qt_copy_all(&dst->qt, &src->qt);
 }
 
+/* The stand-alone entry points below loop over independent lanes (every lane has its own sampler stream and outputs):
+ * they run on pgo_set_threads() threads -- 1 unless a caller asked for more -- without changing a bit of the result. */
+int pgo_threads_in_effect(void); /* pg_oracle_render.c */
+#ifdef _OPENMP
+#define PGO_LANES _Pragma("omp parallel for schedule(static) num_threads(pgo_threads_in_effect()) if (pgo_threads_in_effect() > 1)")
+#else
+#define PGO_LANES
+#endif
+
 void pgo_get_leaf_node_index(const pgo_tree *t, size_t n, const float *p, const uint8_t *active,
                              uint32_t *out)
 {
+	PGO_LANES
 	for (size_t i = 0; i < n; ++i) {
 		float q[3] = { p[i], p[n + i], p[2 * n + i] };
 		out[i] = kd_leaf_index(&t->kd, q, active ? active[i] : 1);
@@ -717,6 +745,7 @@ void pgo_pdf_quadtree(const pgo_tree *t, size_t n, const uint32_t *rootIndex, co
 void pgo_sample(const pgo_tree *t, size_t n, const float *p, uint64_t *st, uint64_t *inc,
                 const uint8_t *active, float *dir, float *pdf)
 {
+	PGO_LANES
 	for (size_t i = 0; i < n; ++i) {
 		int act = active ? active[i] : 1;
 		float q[3] = { p[i], p[n + i], p[2 * n + i] };
@@ -734,6 +763,7 @@ void pgo_sample(const pgo_tree *t, size_t n, const float *p, uint64_t *st, uint6
 void pgo_pdf(const pgo_tree *t, size_t n, const float *p, const float *dir, const uint8_t *active,
              float *pdf)
 {
+	PGO_LANES
 	for (size_t i = 0; i < n; ++i) {
 		int act = active ? active[i] : 1;
 		float q[3] = { p[i], p[n + i], p[2 * n + i] };
@@ -749,13 +779,20 @@ void pgo_add_data_propagate(pgo_tree *t, size_t m, const float *pos, const float
                             const float *radNeeLum)
 {
 	KD *k = &t->kd;
+	/* several threads: the counts are exact integers and the irradiance sums exact 128-bit integers (acc_add), so the
+	 * records may be added in any order by any number of threads */
+	const int mt = pgo_threads_in_effect() > 1 && m > 1024;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(pgo_threads_in_effect()) if (mt)
+#endif
 	for (size_t i = 0; i < m; ++i) {
 		float p[3] = { pos[i], pos[m + i], pos[2 * m + i] };
 		/* kdtree.py:185-217: vertCount += 1 on every visited node */
 		uint32_t node = 0;
 		int active = kd_contains(k, 0, p);
 		for (int guard = 0; active && guard < 64; ++guard) {
-			k->count[node] += 1;
+			if (mt) __atomic_fetch_add(&k->count[node], 1, __ATOMIC_RELAXED);
+			else k->count[node] += 1;
 			if (k->isLeaf[node]) break;
 			uint32_t l = k->left[node], r = k->right[node], next = node;
 			if (kd_contains(k, l, p)) next = l;
@@ -767,10 +804,10 @@ void pgo_add_data_propagate(pgo_tree *t, size_t m, const float *pos, const float
 		uint32_t root = k->qroot[node];
 		float wp = woPdf[i];
 		float w = wp > 0.0f ? radiance[i] / wp : 0.0f;            /* quadtree.py:451 */
-		qt_add_one(&t->qt, root, dir[i], dir[m + i], w);
+		qt_add_one_mt(&t->qt, root, dir[i], dir[m + i], w, mt);
 		if (t->qt.storeNEE) {
 			float wn = wp > 0.0f ? radNeeLum[i] / wp : 0.0f;      /* quadtree.py:461-462 */
-			qt_add_one(&t->qt, root, dirNee[i], dirNee[m + i], wn);
+			qt_add_one_mt(&t->qt, root, dirNee[i], dirNee[m + i], wn, mt);
 		}
 	}
 }

@@ -27,6 +27,8 @@ int pgo_set_threads(int n)
 	return g_threads;
 }
 
+int pgo_threads_in_effect(void) { return g_threads; }
+
 /* scalar hooks exported by pg_oracle.c */
 uint32_t pgo_i_quadtree_of(const pgo_tree *t, const float p[3], int active);
 void pgo_i_sample(const pgo_tree *t, uint32_t root, uint64_t *state, uint64_t inc, int active, float dir[3]);

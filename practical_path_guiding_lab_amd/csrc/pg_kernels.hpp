@@ -36,7 +36,7 @@ void launch_rng_seed(uint64_t n, uint32_t seed, uint32_t lane0, uint64_t *state,
                      hipStream_t s);
 
 // (re)builds the quadtree jump tables of `t`, 4^bits entries per tree, into out[t.n_trees << (2 * bits)] (t.jump is not read)
-void launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s);
+bool launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s);
 // (re)builds the KD jump grid of `t` into out[8^t.grid_bits + kKdGridRootEntries] (t.kd_grid is not read; t.grid_bits, kd_planes and grid_inv are)
 void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s);
 

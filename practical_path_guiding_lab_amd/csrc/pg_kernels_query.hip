@@ -396,14 +396,20 @@ void launch_build_kd_grid(const TreeView &t, KdGridEntry *out, hipStream_t s)
 	hipLaunchKernelGGL(k_build_kd_grid, grid_for((1ull << (3 * t.grid_bits)) + kKdGridRootEntries), dim3(kBlock), 0, s, t, out);
 }
 
-void launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s)
+// false: the device refuses the dynamic LDS a table of this resolution is built in (nothing was launched; the caller
+// takes a coarser table)
+bool launch_build_jump(const TreeView &t, QuadJump *out, int bits, hipStream_t s)
 {
-	if (t.n_trees == 0) return;
+	if (t.n_trees == 0) return true;
 	const size_t lds = sizeof(QuadJump) << (2 * bits); // 64 KB for the finest table
 	// (more than the default 48 KB of dynamic LDS has to be asked for; per device, so it is asked every time -- once per refine)
-	if (lds > 48 * 1024)
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (lds > 48 * 1024 &&
+	    hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_jump), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
 	hipLaunchKernelGGL(k_build_jump, dim3(t.n_trees), dim3(kBlock), lds, s, t, out, bits);
+	return true;
 }
 
 void launch_leaf_index(const TreeView &t, uint64_t n, const float *p, const uint8_t *active,

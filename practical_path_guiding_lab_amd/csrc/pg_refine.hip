@@ -669,39 +669,38 @@ int rebuild_jump(pg_context *ctx, hipStream_t s)
 	}
 	// The quadtree jump tables.  Accumulator slots are packed into 26 bits of an entry: forests beyond that walk every
 	// level.  Memory: 16 B << 2 * bits per quadtree (64 KB with six bits: 1.4 GB for the 21 000 trees of the veach-ajar
-	// bench) against a budget -- $PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB, and at most a quarter of the device memory
-	// that is free right now: a forest too big for six bits gets five (a quarter of the memory; measured on the veach-ajar
-	// bench, ms per step: 6 bits 56.3, 5 bits 56.4, 4 bits 56.9, 3 bits 57.5), then four, ... and a forest that cannot have
-	// a table at all, or whose table cannot be allocated, walks every level from the root: every consumer handles that
-	// (round 3's cap was 32 GB, and a failed allocation failed the refine).
+	// bench) against a budget -- $PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB: a forest too big for six bits gets five (a
+	// quarter of the memory; measured on the veach-ajar bench, ms per step: 6 bits 56.3, 5 bits 56.4, 4 bits 56.9, 3 bits
+	// 57.5), then four, ...  The resolution is a function of the FOREST and the budget alone, so that every rank of a
+	// sharded run, and every run of a bench, builds the same tables (round 4 also looked at the memory that happened to be
+	// free: results were the same bit for bit, timings and pg_stats were not -- ADVICE r4).  Only when the table cannot be
+	// ALLOCATED, or the device refuses the LDS its builder needs, does a forest get a coarser table than that, or none:
+	// it then walks every level from the root, which every consumer handles (a failed allocation never fails a refine).
 	if (f.n_trees == 0 || (uint64_t)f.n_rec * 4ull > (uint64_t)kJumpSlotMask) return PG_OK;
-	uint64_t budget = ctx->jump_budget;
-	size_t free_b = 0, total_b = 0;
-	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-		const uint64_t avail = (uint64_t)free_b + (uint64_t)f.jump.cap * sizeof(QuadJump); // (the table we already hold counts as free)
-		if (avail / 4 < budget) budget = avail / 4;
-	} else (void)hipGetLastError();
+	const uint64_t budget = ctx->jump_budget;
 	int bits = kJumpBits;
 	while (bits >= 2 && (((uint64_t)f.n_trees * sizeof(QuadJump)) << (2 * bits)) > budget) --bits;
-	if (bits < 2) return PG_OK; // (a 2 x 2 table saves one level: below that nothing)
-	const size_t need = (size_t)f.n_trees << (2 * bits);
-	if (need > f.jump.cap) {
-		// room for the forest to double, as long as that stays within the budget
-		size_t want = need * 2;
-		if ((uint64_t)want * sizeof(QuadJump) > budget) want = need;
-		if (f.jump.ensure(want) != hipSuccess) {
-			(void)hipGetLastError(); // (not sticky) -- no table: the walks take every level
-			if (f.jump.ensure(need) != hipSuccess) {
-				(void)hipGetLastError();
-				return PG_OK;
+	for (; bits >= 2; --bits) { // (a 2 x 2 table saves one level: below that nothing)
+		const size_t need = (size_t)f.n_trees << (2 * bits);
+		if (need > f.jump.cap) {
+			// room for the forest to double, as long as that stays within the budget
+			size_t want = need * 2;
+			if ((uint64_t)want * sizeof(QuadJump) > budget) want = need;
+			if (f.jump.ensure(want) != hipSuccess) {
+				(void)hipGetLastError(); // (not sticky)
+				if (f.jump.ensure(need) != hipSuccess) {
+					(void)hipGetLastError();
+					continue; // a quarter of the memory
+				}
 			}
 		}
+		TreeView t = ctx->view();
+		if (!launch_build_jump(t, f.jump.p, bits, s)) continue;
+		PG_HIP(ctx, hipGetLastError());
+		f.jump_bits = bits;
+		f.jump_valid = true;
+		break;
 	}
-	TreeView t = ctx->view();
-	launch_build_jump(t, f.jump.p, bits, s);
-	PG_HIP(ctx, hipGetLastError());
-	f.jump_bits = bits;
-	f.jump_valid = true;
 	return PG_OK;
 }
 

@@ -95,13 +95,19 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
                       record_in_iteration: bool = False, out_dir: Optional[str] = None,
                       all_reduce: Optional[Callable[[torch.Tensor], None]] = None,
                       log: Callable[[str], None] = print, shard=None, gt_mask=None,
-                      training_passes_per_launch: int = 1) -> Dict:
+                      training_passes_per_launch: int = 1, exchange_overlap: Optional[bool] = None) -> Dict:
     """Runs the whole training + rendering schedule; returns the final image, logs and timings.
 
     training_passes_per_launch = B > 1 (with training_spp_per_pass = 1, the reference's value): B consecutive training
     passes are traced as ONE device pass (pg_pass_params.batched: sample s of the launch is the sample pass seed + s gives
     the pixel) and developed by one film launch -- images, sums, logs and SD-tree are those of B separate one-sample
     passes, bit for bit (tests/test_gpu_render.py); the schedule stays main.py's, only the number of launches changes.
+
+    exchange_overlap: whether a sharded run lets the accumulators' all-reduce travel beside the image sums
+    (PathGuidingIntegrator.beginAccumulatorExchange).  None = only when `all_reduce` is the driver's own torch.distributed
+    collective, i.e. on the communicator the image sums use too; a caller-supplied `all_reduce` (libpgsd's RCCL
+    communicator) is issued at the same point but ORDERED ahead of the image collectives until the two-communicator overlap
+    has been validated on a multi-GPU node.
 
     Multi-GPU (one process per GPU, torch.distributed initialised): shard = (rank, world[, stripe_rows
     [, group]]) makes this rank trace its interleaved bands of the film only (WavefrontScene.set_shard);
@@ -122,6 +128,8 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         sums_of = lambda: all_reduce_sums(integrator.sumL, integrator.sumL2, group)  # noqa: E731
         if all_reduce is None:
             all_reduce = lambda acc: all_reduce_accumulators(acc, group)  # noqa: E731
+            if exchange_overlap is None:
+                exchange_overlap = True
     whole = gather.reduce_image if hasattr(gather, "reduce_image") else (lambda img: img)
     # Files are written by ONE rank of a sharded run (every rank ends with the same image, tree and logs): the lowest rank
     # that was given an out_dir.  Whether anyone was is agreed on once, here, so that the collectives below never depend on a
@@ -221,7 +229,7 @@ def run_guided_render(scene: WavefrontScene, integrator: PathGuidingIntegrator, 
         if gather is not None and all_reduce is not None and not is_final:
             # the accumulators start travelling now, beside the image sums and the variance below (is_final is the same
             # on every rank; whether the refine then happens is decided from the whole film's sums, also the same everywhere)
-            integrator.beginAccumulatorExchange(all_reduce)
+            integrator.beginAccumulatorExchange(all_reduce, overlap=bool(exchange_overlap))
         curr_iter_image = whole(curr_iter_image)  # (sharded with a halo exchange: the ranks' rows become the film, once)
         torch.cuda.synchronize()
         t_render = time.perf_counter() - t_iter

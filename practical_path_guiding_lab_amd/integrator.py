@@ -57,6 +57,7 @@ class PathGuidingIntegrator:
         # the multi-GPU exchange of an iteration, issued ahead of its refine on a stream of its own (beginAccumulatorExchange)
         self._exchange_stream = None
         self._exchange_pending = False
+        self._exchange_done = False
 
     # ---- path_guiding_integrator.py:77-105 ---------------------------------------------------
     def _join(self) -> None:
@@ -89,6 +90,7 @@ class PathGuidingIntegrator:
         if self._exchange_pending:  # (an exchange whose refine never came: the next iteration must not race with it)
             torch.cuda.current_stream().wait_stream(self._exchange_stream)
             self._exchange_pending = False
+        self._exchange_done = False
         self.iteration = int(iteration)
         self.isFinalIter = bool(isFinalIter)
         self.sdTree.setIteration(self.iteration, self.isFinalIter)
@@ -157,20 +159,33 @@ class PathGuidingIntegrator:
         return v
 
     # ---- refinement (:553-586) ------------------------------------------------------------------
-    def beginAccumulatorExchange(self, all_reduce) -> None:
+    def beginAccumulatorExchange(self, all_reduce, overlap: bool = False) -> None:
         """Multi-GPU: issues the iteration's all-reduce of sdTree_current's accumulators NOW -- behind everything the passes
         have queued, on a stream of its own -- so that the 300 MB it moves over xGMI travel while the current stream
         develops the film, sums the images and computes the variance that decides whether the refine happens at all
         (main.py:334-377).  refineAndPrepareSDTreeForNextIteration waits for it instead of exchanging again.  Every rank
         must call it at the same point (the driver does so after the last pass of every iteration that is not final).  An
-        exchange whose refine never comes (training stops) costs its time and changes nothing anyone reads."""
+        exchange whose refine never comes (training stops) costs its time and changes nothing anyone reads.
+
+        overlap = False (the default): the current stream waits for the exchange at once, so that whatever collective the
+        caller issues next (the image sum, the film's sums: torch.distributed's communicator) runs BEHIND this one on the
+        device.  `all_reduce` may be libpgsd's own RCCL communicator (SDTree.allReduce); two communicators with
+        collectives in flight at once and no order between them is a documented NCCL / RCCL deadlock hazard, and the
+        overlapped form has run over gloo only (no N > 1 hardware so far: DESIGN 7).  overlap = True is for an `all_reduce`
+        on the SAME communicator as the caller's other collectives (the driver's default, torch.distributed on one
+        group), where the backend orders them itself, or for a node on which the overlap has been validated
+        (bench.py --exchange-overlap 1)."""
         self._join()
         if self._exchange_stream is None:
             self._exchange_stream = torch.cuda.Stream(device=self.device)
         self._exchange_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._exchange_stream):
             all_reduce(self.sdTree.accumulators())
-        self._exchange_pending = True
+        if overlap:
+            self._exchange_pending = True
+        else:
+            torch.cuda.current_stream().wait_stream(self._exchange_stream)
+            self._exchange_done = True  # (refineAndPrepareSDTreeForNextIteration must not exchange a second time)
 
     def refineAndPrepareSDTreeForNextIteration(self, all_reduce=None) -> None:
         """all_reduce: optional callable(int64 tensor) -> None summing the accumulators over ranks
@@ -179,6 +194,8 @@ class PathGuidingIntegrator:
         if self._exchange_pending:  # (already on its way: beginAccumulatorExchange)
             torch.cuda.current_stream().wait_stream(self._exchange_stream)
             self._exchange_pending = False
+        elif self._exchange_done:  # (issued and already ordered ahead of the current stream: overlap = False)
+            self._exchange_done = False
         elif all_reduce is not None:
             all_reduce(self.sdTree.accumulators())
         self.sdTree.refineAndPrepare()

@@ -96,7 +96,7 @@ def test_main_py_masks_the_teapots_of_veach_ajar_in_its_mse(tmp_path):
     def schedule(mask):
         gi = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8})
         res = run_guided_render(WavefrontScene(S.veach_ajar(320, 180)), gi, 28, ground_truth=gtt, batch_spp=4,
-                                training_spp_per_pass=8, gt_mask=mask, log=lambda s_: None)
+                                training_spp_per_pass=1, training_passes_per_launch=16, gt_mask=mask, log=lambda s_: None)
         return res["records"]["mse_groundTruth_endIter"].rows[-1], gi
 
     row_m, gi = schedule(S.veach_ajar_mask(320, 180))
@@ -192,3 +192,79 @@ def test_register_with_mitsuba_through_a_stub_module(monkeypatch):
         registered["path_guiding_integrator"](Props(max_depth=-2))
     with pytest.raises(Exception, match="rr_depth"):
         registered["path_guiding_integrator"](Props(rr_depth=-1))
+
+
+def test_main_py_batched_training_launches_equal_one_launch_per_pass(tmp_path):
+    """main.py runs the reference's schedule -- one-sample training passes seeded initial_seed + cumm_spp (main.py:192,
+    218) -- and by default traces 16 of them per device launch (--training-passes-per-launch): every image file, every
+    log column but the wall-clock one and every saved SD-tree equal those of one launch per pass, byte for byte."""
+    outs = []
+    for launch in (16, 1):
+        out = str(tmp_path / f"launch{launch}")
+        cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "veach-ajar", "--width", "96", "--height", "54",
+               "--budget-spp", "60", "--training-passes-per-launch", str(launch), "--out", out]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "done: 60 spp" in r.stdout
+        outs.append(out)
+    a, b = outs
+    files = sorted(os.listdir(a))
+    assert files == sorted(os.listdir(b)) and sum(f.endswith(".npz") for f in files) == 4
+    for f in files:
+        pa, pb = os.path.join(a, f), os.path.join(b, f)
+        if f.endswith(".npz"):  # (a zip archive carries time stamps: the arrays are what has to be equal)
+            ta, tb = np.load(pa), np.load(pb)
+            assert set(ta.files) == NPZ_KEYS == set(tb.files)
+            for k in ta.files:
+                assert ta[k].dtype == tb[k].dtype and ta[k].tobytes() == tb[k].tobytes(), (f, k)
+        elif f.endswith(".csv"):
+            ra = [x.split(",")[1:] for x in open(pa).read().splitlines()]  # (column 0 is the wall clock)
+            rb = [x.split(",")[1:] for x in open(pb).read().splitlines()]
+            assert ra == rb, f
+        else:  # .png .exr .npy .obj
+            assert open(pa, "rb").read() == open(pb, "rb").read(), f
+    # the default IS the reference's schedule: no flag gives the same files as --training-spp-per-pass 1 --training-passes-per-launch 16
+    out = str(tmp_path / "default")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--scene", "veach-ajar", "--width", "96", "--height", "54",
+                        "--budget-spp", "60", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [f for f in files if f.endswith(".npy")][-1]
+    assert open(os.path.join(out, last), "rb").read() == open(os.path.join(a, last), "rb").read()
+
+
+def test_main_py_repeats_every_iterations_tree_at_equal_spp(tmp_path):
+    """--repeat-high-spp (repeat_high_spp_renderer.py): after the schedule every iteration's saved tree is
+    loaded again (loadSDTreeFromFile, path_guiding_integrator.py:597-608) and rendered, frozen, with the same number of
+    samples; one record per iteration."""
+    out = str(tmp_path / "rep")
+    gt = os.path.join(ROOT, "tests", "golden", "cornell_gt_256_f16.npy")   # box-filtered 4x to the 64-pixel film
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "cornell-box", "--width", "64", "--height", "64",
+           "--budget-spp", "60", "--ground-truth", gt, "--repeat-high-spp", "16", "--out", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("frozen tree, 16 spp") == 4
+    rows = open(os.path.join(out, "mse_groundTruth_endIter_high_spp_sim-0.csv")).read().splitlines()
+    assert rows[0] == "time,spp,cumm_spp,iteration,variance,mse" and len(rows) == 5
+    cols = [r_.split(",") for r_ in rows[1:]]
+    assert [int(c[3]) for c in cols] == [0, 1, 2, 3] and all(int(c[1]) == 16 for c in cols)
+    assert [int(c[2]) for c in cols] == [16, 4 + 16, 12 + 16, 28 + 16]            # theoretical cumulative spp + this render's
+    mse = [float(c[5]) for c in cols]
+    assert all(np.isfinite(m) and 0 < m < 1 for m in mse)
+    files = set(os.listdir(out))
+    assert all(f"high_spp_iter-{k}_spp-16.exr" in files for k in range(4))
+
+
+def test_main_py_path_tracing_baseline(tmp_path):
+    """--path-tracing (path_tracing_render.py): the unguided benchmark renderer, by sample count and by time."""
+    out = str(tmp_path / "pt")
+    gt = os.path.join(ROOT, "tests", "golden", "cornell_gt_256_f16.npy")
+    base = [sys.executable, os.path.join(ROOT, "main.py"), "--scene", "cornell-box", "--width", "64", "--height", "64",
+            "--ground-truth", gt, "--path-tracing", "--out", out]
+    r = subprocess.run(base + ["--budget-spp", "22", "--batch-spp", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "path tracing: 22 spp" in r.stdout
+    rows = [x.split(",") for x in open(os.path.join(out, "variance_groundTruth_path_tracing.csv")).read().splitlines()[1:]]
+    assert [int(x[1]) for x in rows] == [8, 16, 22] and float(rows[-1][5]) < float(rows[0][5])   # MSE falls with spp
+    assert "path_tracing-22.exr" in os.listdir(out)
+    r = subprocess.run(base + ["--time-budget", "0.2", "--batch-spp", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "path tracing:" in r.stdout

@@ -47,6 +47,48 @@ def _trained(name="cornell-box"):
     return g, ws
 
 
+@pytest.mark.parametrize("name", ["veach-ajar", "torus"])
+def test_guided_pass_at_full_size_equals_the_oracle(name):
+    """Device against ORACLE at BASELINE's full sizes, inside the suite (the lifecycle comparison at these sizes,
+    tools/soak_parity.py, takes two minutes per scene): the SD-tree is trained on the device (three iterations),
+    exported (pg_export) and loaded into the oracle -- sdTree_prev and, zeroed, sdTree_current -- and then ONE guided
+    one-sample training pass (main.py:192) of the whole 1920x1080 film is traced on both: veach-ajar at max_depth 13,
+    torus at max_depth 32 (path_guiding_integrator.py:126-431; 2 M paths, seconds on the box's host cores).  Radiance per
+    lane, the valid flags, the per-pixel sums, every KD count and every accumulator limb of every node: bit for bit."""
+    from oracle import pg_oracle as po
+    from practical_path_guiding_lab_amd.render import IndependentSampler
+
+    (w, h, depth, rr), _ = CONFIGS[name]
+    npix = w * h
+    g, ws = _trained(name)
+    tree = g.sdTree.export()
+    sc = ws.scene
+    pair = po.OracleSDTreePair()
+    pair.setup(sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True)
+    pair.prev.load(tree)
+    pair.current.load(tree)     # (same topology, path_guiding_integrator.py:582; a load leaves the accumulators at zero)
+    pair.current.reset()
+    g.setIteration(3, False)
+    g.resetVarianceCounter()
+    Lg, vg, _ = g.sample(ws, IndependentSampler(1, 31337))
+    o_sumL, o_sumL2 = np.zeros((3, npix), np.float32), np.zeros((3, npix), np.float32)
+    threads = po.set_threads(0)
+    try:
+        Lo, vo = po.render_pass(pair, sc, sc.camera, depth, rr, 3, False, 31337, 1, True, 0.5, o_sumL, o_sumL2)
+    finally:
+        po.set_threads(1)
+    assert threads >= 1 and Lo.shape == (3, npix) and np.isfinite(Lo).all() and Lo.mean() > 0
+    np.testing.assert_array_equal(Lg.cpu().numpy().view(np.uint32), Lo.view(np.uint32))
+    np.testing.assert_array_equal(vg.cpu().numpy(), vo)
+    np.testing.assert_array_equal(g.sumL.cpu().numpy().view(np.uint32), o_sumL.view(np.uint32))
+    np.testing.assert_array_equal(g.sumL2.cpu().numpy().view(np.uint32), o_sumL2.view(np.uint32))
+    kd, lo, hi = g.sdTree.exportAccumulators()
+    assert int(kd[0]) > npix // 4     # (a guided pass: most vertices leave a record)
+    np.testing.assert_array_equal(kd, pair.current.kd_column("count"))
+    np.testing.assert_array_equal(lo, pair.current.quad_column("acc_lo"))
+    np.testing.assert_array_equal(hi, pair.current.quad_column("acc_hi"))
+
+
 @pytest.mark.parametrize("name", ["veach-mis", "veach-ajar", "torus"])
 def test_other_bench_configs_reproducible_tile_invariant_and_conserving(name):
     """The three properties of the cornell-box tests below at the other bench sizes: veach-mis 1280x720

@@ -547,7 +547,7 @@ def test_jump_table_cell_boundaries_and_dead_trees(torch_mod, balanced, skewed):
 @pytest.mark.parametrize("budget,bits", [(None, 6), (64 * 16 * 4 ** 4, 4), (64 * 16 * 4 ** 2 + 100, 2), (1000, 0)])
 def test_jump_tables_follow_their_memory_budget(torch_mod, balanced, monkeypatch, budget, bits):
     """ADVICE r3 / VERDICT r3 item 5: the quadtree jump tables are capped by a memory budget ($PGSD_JUMP_TABLE_MAX_BYTES,
-    default 2 GiB, at most a quarter of the free device memory); a forest too big for 64 x 64 cells per tree gets 32 x 32,
+    default 2 GiB; the resolution depends on the forest and the budget only, not on the memory that happens to be free); a forest too big for 64 x 64 cells per tree gets 32 x 32,
     16 x 16 ... and one that fits nothing walks every level.  Whatever the table, every query, the splat and the refine
     give the oracle's results bit for bit (the 64 leaves of the balanced tree: 64 KB, 4 KB, 256 B per tree, none)."""
     torch = torch_mod

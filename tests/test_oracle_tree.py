@@ -427,3 +427,42 @@ def test_process_records_known_answers(oracle):
     rec["radiance_nee"][:, 0] = 1.0
     out = oracle.process_records(R, D, L, rec)
     assert out["radiance"].tolist() == [0.0] and out["radiance_nee_lum"][0] > 0.99
+
+
+def test_threaded_stand_alone_entry_points_equal_the_single_threaded_ones():
+    """bench.py's CPU columns for S1 / S2 / S3 run pgo_get_leaf_node_index, pgo_pdf, pgo_sample and
+    pgo_add_data_propagate on all host cores (pgo_set_threads): lanes are independent and the splat adds exact
+    integers (a 128-bit add made of two fetch-and-adds with the carry taken from the first one's old value), so every
+    output, every sampler state and every accumulator -- negative, huge and NaN weights included -- is the
+    single-threaded one, bit for bit."""
+    import synth
+    from oracle import pg_oracle as po
+
+    pair = synth.build_skewed(1 << 12, 4)
+    tree = pair.prev
+    n = 1 << 15
+    p = synth.positions_uniform(n, 5, [0.0] * 3, [100.0] * 3)
+    p[:, :7] = np.float32(1e9)     # outside the box
+    d = synth.directions_uniform(n, 6)
+    rec = synth.records(1 << 16, 99, [0.0] * 3, [100.0] * 3)
+    rec["radiance"][::7] *= np.float32(-1.0)          # negative weights borrow across the 64-bit halves
+    rec["radiance"][3::11] = np.float32(3e38)         # clamped to 2^48: the carries of the low half
+    rec["radiance"][5::13] = np.float32("nan")
+    rec["woPdf"][::17] = np.float32(1e-30)
+    out = {}
+    try:
+        for threads in (1, 7):
+            assert po.set_threads(threads) == threads
+            st, inc = po.rng_seed(n, 0)
+            dirs, pdfs = tree.sample(p, st, inc)
+            cur = po.OracleTree()
+            cur.copy_from(pair.current)
+            for _ in range(3):
+                synth.splat(cur, rec)
+            out[threads] = (tree.get_leaf_node_index(p), tree.pdf(p, d), dirs, pdfs, st.copy(),
+                            cur.kd_column("count"), cur.quad_column("acc_lo"), cur.quad_column("acc_hi"))
+    finally:
+        po.set_threads(1)
+    for a, b in zip(out[1], out[7]):
+        assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
+    assert out[1][5][0] == 3 * (1 << 16) and int(np.abs(out[1][7]).max()) > 0   # the high halves are in use
