@@ -278,6 +278,32 @@ def spawn_ranks(cmd, n, env=None, relay=sys.stdout, grace_s=10.0):
     return rc
 
 
+class StepQueue:
+    """The steps of a sharded film leave in groups: a rank's share is 1 / world of the pixels, so it launches the passes
+    of `group` = world steps at once (a launch as big as the one-GPU launch of the whole film); a step only queues its
+    passes, `flush` launches what is queued -- after the last warm-up step, after the last timed step (steps % group != 0
+    leaves a smaller last launch) and before anything waits for the device.  launch(n_passes, first_seed) traces n_passes
+    consecutive one-sample passes; seeds run on without gaps whatever the grouping."""
+
+    def __init__(self, launch, spp_per_step, group, first_seed, seed_stride=1):
+        self.launch, self.spp, self.group = launch, int(spp_per_step), max(1, int(group))
+        self.seed, self.stride, self.pending = int(first_seed), int(seed_stride), 0
+        self.launches = []  # (passes, first seed) of every launch, in order
+
+    def flush(self):
+        if self.pending:
+            n = self.spp * self.pending
+            self.launch(n, self.seed)
+            self.launches.append((n, self.seed))
+            self.seed += n * self.stride
+            self.pending = 0
+
+    def step(self):
+        self.pending += 1
+        if self.pending >= self.group:
+            self.flush()
+
+
 def pick_backend(args, world, ndev):
     """The torch.distributed backend, decided before anything is initialised and identically on every rank of
     the node: every rank sees the same device count."""
@@ -306,7 +332,13 @@ def init_dist(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = pick_backend(args, local_world, ndev)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # (a failure ends the run)
+            from datetime import timedelta
+            from practical_path_guiding_lab_amd.parallel import Watchdog, comm_init_timeout_s
+            # bounded: a rank whose peers never arrive exits non-zero (the launcher ends the job) instead of waiting for ever
+            with Watchdog(comm_init_timeout_s(), f"rank {rank}: init_process_group(nccl) + first barrier"):
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=timedelta(seconds=max(60.0, comm_init_timeout_s())))  # (a failure ends the run)
+                dist.barrier()
         else:
             # (the Gloo library prints a connection banner on STDOUT when its context comes up: stdout is for the one JSON
             # line, so file descriptor 1 points at stderr while the group is made and first used)
@@ -431,11 +463,14 @@ def run_render(args):
     # the exchange: libpgsd's own ncclAllReduce (pg_allreduce) when every rank has its GPU, else torch.distributed
     exchange = "none"
     reduce_fn = None
+    rccl_seen = None
     if world > 1:
         from practical_path_guiding_lab_amd.parallel import init_library_comm
         if init_library_comm(tree):  # (decided collectively: nccl backend and a GPU of its own for every rank)
             exchange = "pg_allreduce (RCCL ncclAllReduce int64 issued by libpgsd.so)"
             reduce_fn = lambda acc: tree.allReduce()  # noqa: E731
+            reduce_fn.exchanges_itself = True  # (pg_allreduce packs, sums and unpacks inside the library)
+            rccl_seen = tree.commInfo()  # RCCL's own word on the communicator: ncclCommCount, ncclCommUserRank
         else:
             exchange = f"torch.distributed all_reduce ({dist.get_backend()})"
             reduce_fn = lambda acc: all_reduce_accumulators(acc)  # noqa: E731
@@ -483,24 +518,11 @@ def run_render(args):
     k = args.train_iters
     integ.setIteration(k, False)
 
-    seed = [cumm + (0 if tiles else rank * args.spp_per_pass)]
-    pending = [0]  # steps queued and not yet launched (group > 1)
-
-    def flush():
-        if pending[0]:
-            n = args.spp_per_pass * pending[0]
-            integ.sample(ws, IndependentSampler(n, seed[0], batched=batched))
-            seed[0] += n
-            pending[0] = 0
-
-    def step():
-        if group > 1:  # (a sharded film: the passes of `group` steps leave as one launch)
-            pending[0] += 1
-            if pending[0] == group:
-                flush()
-            return
-        integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0], batched=batched))
-        seed[0] += args.spp_per_pass * (1 if tiles else world)
+    # (tiles: every rank traces the same passes of its own pixels; passes: rank r takes every world-th group of passes)
+    queue = StepQueue(lambda n, sd: integ.sample(ws, IndependentSampler(n, sd, batched=batched)), args.spp_per_pass, group,
+                      cumm + (0 if tiles else rank * args.spp_per_pass), 1 if (tiles or world == 1) else world)
+    step, flush = queue.step, queue.flush
+    seed = [0]  # (the later legs count their own seeds on from the queue's: set where they start)
 
     # one instrumented pass for the byte model (depth counters add atomics: not timed)
     tree.enableDepthCounters(True)
@@ -539,7 +561,7 @@ def run_render(args):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     if reduce_fn is not None:
-        reduce_fn(tree.accumulators())
+        integ._exchange(reduce_fn)
     torch.cuda.synchronize()
     t_allreduce = time.perf_counter() - t1
     t1 = time.perf_counter()
@@ -549,6 +571,8 @@ def run_render(args):
     # ---- the same passes one launch each (what `value`'s batched launch stands for, bit for bit), and one pass of
     # spp_per_pass samples per pixel (mi.render(spp=N): other streams, the same amount of work) ----
     spp1 = multi_spp = None
+    flush()
+    seed[0] = queue.seed
     if args.spp1 and (tiles or world == 1):
         def step1():
             integ.sample(ws, IndependentSampler(1, seed[0]))
@@ -566,6 +590,7 @@ def run_render(args):
     two_in_flight = None
     if args.spp1 and args.in_flight == 1 and (tiles or world == 1):
         ws.in_flight = 2
+        queue.seed = max(queue.seed, seed[0])
         two_in_flight = npix * args.spp_per_pass * args.steps / timed_steps(step, args.steps, 2, world, flush) / 1e6
         ws.join()
         torch.cuda.synchronize()
@@ -849,7 +874,10 @@ def run_render(args):
                      "iterations": per_iter, "trained_spp": cumm},
         "extra": {"library": os.path.relpath(N_LIB_PATH, ROOT), "source_hash": SRC_HASH,
                   "allreduce_ms": round(1e3 * t_allreduce, 3), "refine_ms": round(1e3 * t_refine, 3), "exchange": exchange,
-                  "accumulator_bytes": int(tree.accumulators().numel()) * 8},
+                  "accumulator_bytes": int(tree.accumulators().numel()) * 8,
+                  "exchange_bytes": int(tree.packAccumulators().numel()) * 8,
+                  "exchange_format": "24 B per accumulator (two 52-bit pieces + count<<24 | top: pgsd.h pg_exchange_pack) instead of the 32-byte device layout",
+                  "rccl_ranks": None if rccl_seen is None else rccl_seen[0], "rccl_rank": None if rccl_seen is None else rccl_seen[1]},
     }
     if world > 1:
         dist.destroy_process_group()

@@ -33,7 +33,9 @@ extern "C" {
  * A caller compiled against version 2 must be rebuilt (the two structs changed size): check pg_abi_version(). */
 /* 4 (round 4): pg_depth_counters gained layout_bytes, pg_stats gained bytes_jump_tables / jump_bits / kd_grid_bits,
  * pg_pass_params.reserved2 became `batched` (same size); new entry points pg_film_batched, pg_film_batched_accumulate. */
-#define PGSD_ABI_VERSION 4
+/* 5 (round 5): new entry points pg_comm_info, pg_exchange_pack, pg_exchange_unpack, pg_exchange_pack_words,
+ * pg_exchange_unpack_words; pg_allreduce moves the accumulators in the 24-byte exchange format (same sums).  No struct changed. */
+#define PGSD_ABI_VERSION 5
 
 typedef struct pg_context pg_context;
 
@@ -206,6 +208,26 @@ int pg_comm_init(pg_context *ctx, int32_t n_ranks, int32_t rank, const uint8_t *
 int pg_comm_attach(pg_context *ctx, void *nccl_comm, int32_t n_ranks);
 int pg_comm_destroy(pg_context *ctx);
 int pg_allreduce(pg_context *ctx, void *stream);
+/* What RCCL itself says about the context's communicator -- ncclCommCount and ncclCommUserRank read back, not the numbers
+ * the caller passed to pg_comm_init: a witness that the library's exchange really spans n ranks. */
+int pg_comm_info(pg_context *ctx, int32_t *n_ranks_out, int32_t *rank_out);
+
+/* The exchange format.  An accumulator is four int64 words on the device (three limbs of 32 payload bits + a record
+ * count: 32 bytes, cheap to add to with 64-bit atomics); what has to travel between GPUs is its VALUE, 24 bytes:
+ *     T = l0 + l1 2^32 + l2 2^64      p0 = T mod 2^52    p1 = (T >> 52) mod 2^52    p2 = (count << 24) + (T >> 104)
+ * (|T| < 2^119 and sum of counts < 2^31 per accumulator and iteration over all ranks -- the bounds the limbs rely on
+ * anyway).  Element-wise int64 sums of packed buffers over up to 2^11 ranks cannot overflow and decode to the exact sums.
+ *   pg_exchange_pack   : packs sdTree_current's accumulators into a library-owned device buffer of *count int64
+ *                        ([accumulators x 3 | per-tree fallback counters]) on `stream`; the accumulators stay as they are
+ *   pg_exchange_unpack : writes the (summed) packed buffer back into the accumulators on `stream`: same values, same counts
+ * A host with its own collective: pack, all-reduce *d_buffer (int64, sum), unpack, pg_refine_and_swap.  pg_allreduce does
+ * exactly that with RCCL.  Summing the raw pg_accumulators buffer stays valid (a third more bytes).
+ *   pg_exchange_pack_words / _unpack_words : the same arithmetic on HOST arrays of n_acc accumulators (4 words in, 3 out and
+ *                        back); no context, no device. */
+int pg_exchange_pack(pg_context *ctx, int64_t **d_buffer, uint64_t *count, void *stream);
+int pg_exchange_unpack(pg_context *ctx, void *stream);
+int pg_exchange_pack_words(const int64_t *h_acc, uint64_t n_acc, int64_t *h_out);
+int pg_exchange_unpack_words(const int64_t *h_in, uint64_t n_acc, int64_t *h_acc_out);
 
 /* ---- import / export in the reference's schema (kdtree.py:539-602) -------------------- */
 

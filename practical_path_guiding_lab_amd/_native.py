@@ -105,7 +105,7 @@ class pg_depth_counters(C.Structure):
 
 
 # every symbol include/pgsd.h declares (checked by tests/test_abi.py)
-ABI_VERSION = 4  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
+ABI_VERSION = 5  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
 
 EXPORTS = (
     "pg_create", "pg_destroy", "pg_last_error", "pg_abi_version", "pg_setup", "pg_set_iteration",
@@ -116,7 +116,8 @@ EXPORTS = (
     "pg_enable_kernel_timing", "pg_read_kernel_timing", "pg_render_live_counts", "pg_film_tent",
     "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_film_batched", "pg_film_batched_accumulate", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
-    "pg_render_split_pipeline",
+    "pg_render_split_pipeline", "pg_comm_info", "pg_exchange_pack", "pg_exchange_unpack", "pg_exchange_pack_words",
+    "pg_exchange_unpack_words",
 )
 
 
@@ -211,6 +212,11 @@ def lib() -> C.CDLL:
     L.pg_comm_attach.argtypes = [V, V, I32]
     L.pg_comm_destroy.argtypes = [V]
     L.pg_allreduce.argtypes = [V, V]
+    L.pg_comm_info.argtypes = [V, C.POINTER(I32), C.POINTER(I32)]
+    L.pg_exchange_pack.argtypes = [V, C.POINTER(V), C.POINTER(U64), V]
+    L.pg_exchange_unpack.argtypes = [V, V]
+    L.pg_exchange_pack_words.argtypes = [V, U64, V]
+    L.pg_exchange_unpack_words.argtypes = [V, U64, V]
     L.pg_render_reserve.argtypes = [V, U64]
     L.pg_render_split_pipeline.argtypes = [V, C.c_int32]
     for name in EXPORTS:

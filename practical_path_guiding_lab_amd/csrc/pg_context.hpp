@@ -75,6 +75,9 @@ struct Forest {
 	int kd_grid_bits = 0;            // cells per axis = 2^kd_grid_bits
 	// accumulators of the running iteration: [rec_acc | root_acc | leaf_count]
 	DevBuf<long long> acc;
+	DevBuf<long long> xchg;          // the accumulators in their 24-byte exchange format (pg_exchange_pack): what travels
+	uint64_t n_acc() const { return (uint64_t)n_rec * 4 + n_trees; }             // four-word accumulators
+	uint64_t xchg_count() const { return n_acc() * kXchgWords + n_trees; }       // [n_acc x 3 | fallback counters]
 	uint64_t acc_count() const
 	{
 		return (uint64_t)n_rec * 4 * kAccWords + (uint64_t)n_trees * kAccWords + n_trees;

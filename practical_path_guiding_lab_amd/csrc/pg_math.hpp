@@ -375,6 +375,45 @@ __device__ __host__ __forceinline__ I128 i128_add(I128 a, I128 b)
 	return r;
 }
 
+// ---- the exchange format of an accumulator: 24 bytes instead of 32 ------------------------------------
+// On the device an accumulator is four int64 words -- three limbs of 32 payload bits (cheap to add to with 64-bit
+// atomics) and a record count.  What travels between GPUs is its VALUE: T = l0 + l1 2^32 + l2 2^64 (|T| < 2^119: at
+// most 2^31 records of |q| <= 2^88 per accumulator and iteration over ALL ranks -- the bound the limbs already rely on)
+// cut into two unsigned pieces of 52 bits and a signed top, the count folded into the top word's upper bits:
+//     p0 = T mod 2^52          p1 = (T >> 52) mod 2^52          p2 = (count << 24) + (T >> 104)
+// Element-wise int64 sums of these words over R ranks cannot overflow (R 2^52 < 2^63 for R < 2^11; sum of counts < 2^31, so
+// p2 < 2^55 + |sum of tops|, the tops within +-(2^15 + R) of each other's sum: 24 bits with room) and decode to the exact
+// sums of T and of the counts, whatever R and whatever the order: unpack gives the limbs of the sum, same value,
+// same count -- the refine that follows cannot tell how the sum travelled.
+constexpr int kXchgWords = 3;
+constexpr int kXchgPieceBits = 52;
+constexpr int kXchgCountShift = 24;
+
+__device__ __host__ __forceinline__ void xchg_pack(const long long a[4], long long out[3])
+{
+	const I128 T = limbs_resolve(a[0], a[1], a[2]);
+	const uint64_t mask = (1ull << kXchgPieceBits) - 1ull;
+	out[0] = (long long)(T.lo & mask);
+	out[1] = (long long)(((T.lo >> kXchgPieceBits) | ((uint64_t)T.hi << (64 - kXchgPieceBits))) & mask);
+	const long long top = (long long)(T.hi >> (2 * kXchgPieceBits - 64)); // arithmetic: T >> 104, signed
+	out[2] = (long long)((unsigned long long)a[3] << kXchgCountShift) + top;
+}
+
+__device__ __host__ __forceinline__ void xchg_unpack(const long long p[3], long long a[4])
+{
+	// the top: the low 24 bits of p2 as a signed number; what is left above them is the count
+	const long long top = (long long)((unsigned long long)p[2] << (64 - kXchgCountShift)) >> (64 - kXchgCountShift);
+	const long long cnt = (p[2] - top) >> kXchgCountShift;
+	I128 T = {(uint64_t)p[0], 0};
+	const I128 mid = {(uint64_t)p[1] << kXchgPieceBits, (int64_t)((uint64_t)p[1] >> (64 - kXchgPieceBits))};
+	T = i128_add(T, mid);
+	T.hi += top * (1ll << (2 * kXchgPieceBits - 64));
+	a[0] = (long long)(T.lo & 0xffffffffull);
+	a[1] = (long long)(T.lo >> 32);
+	a[2] = (long long)T.hi;
+	a[3] = cnt;
+}
+
 // exact integer -> fp32 with one round-to-nearest-even, then the exact 2^-kFracBits scaling
 __device__ __host__ __forceinline__ float i128_to_f32(I128 v)
 {

@@ -180,12 +180,24 @@ class PathGuidingIntegrator:
             self._exchange_stream = torch.cuda.Stream(device=self.device)
         self._exchange_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._exchange_stream):
-            all_reduce(self.sdTree.accumulators())
+            self._exchange(all_reduce)
         if overlap:
             self._exchange_pending = True
         else:
             torch.cuda.current_stream().wait_stream(self._exchange_stream)
             self._exchange_done = True  # (refineAndPrepareSDTreeForNextIteration must not exchange a second time)
+
+    def _exchange(self, all_reduce) -> None:
+        """The iteration's one exchange on the current stream.  `all_reduce` sums an int64 tensor over the ranks in place; it
+        is handed sdTree_current's accumulators in their 24-byte exchange format (SDTree.packAccumulators: a quarter fewer
+        bytes than the 32-byte device layout, the same sums) and the result is unpacked into the accumulators.  A callable
+        with the attribute `exchanges_itself` (libpgsd's own RCCL communicator: SDTree.allReduce packs, sums and unpacks
+        inside the library) is called with None."""
+        if getattr(all_reduce, "exchanges_itself", False):
+            all_reduce(None)
+            return
+        all_reduce(self.sdTree.packAccumulators())
+        self.sdTree.unpackAccumulators()
 
     def refineAndPrepareSDTreeForNextIteration(self, all_reduce=None) -> None:
         """all_reduce: optional callable(int64 tensor) -> None summing the accumulators over ranks
@@ -197,7 +209,7 @@ class PathGuidingIntegrator:
         elif self._exchange_done:  # (issued and already ordered ahead of the current stream: overlap = False)
             self._exchange_done = False
         elif all_reduce is not None:
-            all_reduce(self.sdTree.accumulators())
+            self._exchange(all_reduce)
         self.sdTree.refineAndPrepare()
 
     # ---- files (:589-615) -----------------------------------------------------------------------

@@ -48,6 +48,48 @@ def _flag_device(group):
     return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
 
 
+class Watchdog:
+    """A bounded wait around a call that can hang for ever -- a rank joining a communicator whose other ranks never
+    come (ncclCommInitRank, the first collective of a process group).  When `seconds` pass before the block ends, the
+    process prints why and EXITS with `exit_code` (os._exit from a timer thread that touches nothing of the GPU): the
+    launcher sees a non-zero exit and ends the other ranks (bench.spawn_ranks, torch.distributed.run).  Nothing is
+    re-executed and nothing is retried: a process that has initialised the GPU must not be replaced by another program,
+    and a half-joined communicator cannot be joined again.  seconds <= 0: no limit."""
+
+    def __init__(self, seconds: float, what: str, exit_code: int = 75):
+        self.seconds, self.what, self.exit_code = float(seconds), what, int(exit_code)
+        self._timer = None
+
+    def _expire(self):
+        import os
+        import sys
+        sys.stderr.write(f"[pgsd] {self.what}: no progress after {self.seconds:.0f} s -- ending this rank with exit code {self.exit_code}\n")
+        sys.stderr.flush()
+        os._exit(self.exit_code)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+            self._timer = threading.Timer(self.seconds, self._expire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
+def comm_init_timeout_s() -> float:
+    """$PGSD_COMM_INIT_TIMEOUT_S (default 180): the bound on joining a communicator."""
+    import os
+    try:
+        return float(os.environ.get("PGSD_COMM_INIT_TIMEOUT_S", "180"))
+    except ValueError:
+        return 180.0
+
+
 def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
     """Gives `tree` (an SDTree) its own RCCL communicator over the ranks of `group` (pg_comm_init): rank
     0's ncclUniqueId travels through torch.distributed, then every rank joins -- on the calling thread.
@@ -83,7 +125,13 @@ def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
     dist.broadcast_object_list(ident, src=0, group=group)
     if ident[0] is None:
         return False
-    tree.commInit(world, rank, ident[0])  # ncclCommInitRank; raises on failure
+    # ncclCommInitRank blocks until every rank has joined: bounded (a rank whose peers never come exits non-zero and the
+    # launcher ends the job); raises on failure
+    with Watchdog(comm_init_timeout_s(), f"rank {rank}: ncclCommInitRank of libpgsd's communicator ({world} ranks)"):
+        tree.commInit(world, rank, ident[0])
+    n_seen, r_seen = tree.commInfo()  # what RCCL itself says (ncclCommCount / ncclCommUserRank)
+    if (n_seen, r_seen) != (world, rank):
+        raise RuntimeError(f"libpgsd communicator: RCCL reports {n_seen} ranks / rank {r_seen}, expected {world} / {rank}")
     return True
 
 

@@ -277,6 +277,24 @@ class SDTree:
         self._ck(self._lib.pg_accumulators(self._h, C.byref(p), C.byref(n)))
         return _wrap_device_i64(p.value, n.value, self.device)
 
+    def packAccumulators(self) -> torch.Tensor:
+        """sdTree_current's accumulators in the 24-byte exchange format (pg_exchange_pack, on the current stream): the int64
+        tensor a host-side collective sums instead of accumulators() -- a quarter fewer bytes; unpackAccumulators() writes
+        the sums back."""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._ck(self._lib.pg_exchange_pack(self._h, C.byref(p), C.byref(n), _stream_ptr()))
+        return _wrap_device_i64(p.value, n.value, self.device)
+
+    def unpackAccumulators(self) -> None:
+        self._ck(self._lib.pg_exchange_unpack(self._h, _stream_ptr()))
+
+    def commInfo(self):
+        """(ranks, rank) as RCCL reports them for this tree's communicator (ncclCommCount, ncclCommUserRank)."""
+        n, r = C.c_int32(-1), C.c_int32(-1)
+        self._ck(self._lib.pg_comm_info(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
     # ---- the library's own exchange (pg_comm_*, pg_allreduce: RCCL bound at run time) ----------
     def commUniqueId(self) -> bytes:
         buf = (C.c_uint8 * 128)()

@@ -102,6 +102,109 @@ def test_rank_allreduce_equals_single_process(tmp_path, world, port):
     np.testing.assert_array_equal(got[nq * 3:], ref.kd_column("count").astype(np.int64))
 
 
+def _worker_cpu_packed(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from practical_path_guiding_lab_amd import _native as N
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators
+
+    t = po.OracleTree()
+    t.load(_base_tree())
+    t.reset()
+    rec = _rank_records(rank, world)
+    rec["radiance"][::5] *= np.float32(-3.0)        # negative totals: the signed top word
+    rec["radiance"][1::9] = np.float32(3e38)         # clamped to 2^48: the biggest q a record can carry
+    synth.splat(t, rec)
+    limbs = _limbs(t.quad_column("acc_lo"), t.quad_column("acc_hi"))
+    nq = limbs.shape[0]
+    # the device's four-word accumulator: three limbs + a count (here: this rank's number of records, the same for every node)
+    acc = np.concatenate([limbs, np.full((nq, 1), rec["radiance"].shape[0], np.int64)], axis=1)
+    # limbs as the device leaves them after many adds: payloads beyond 32 bits, mixed signs, the same value
+    acc[:, 0] += np.int64(5) << np.int64(32)
+    acc[:, 1] -= np.int64(5)
+    acc[:, 1] += np.int64(-7) << np.int64(32)
+    acc[:, 2] -= np.int64(-7)
+    packed = np.zeros((nq, 3), np.int64)
+    L = N.lib()
+    assert L.pg_exchange_pack_words(acc.ctypes.data, nq, packed.ctypes.data) == 0
+    assert packed[:, :2].min() >= 0 and packed[:, :2].max() < (1 << 52)
+    buf = torch.from_numpy(packed.reshape(-1).copy())
+    all_reduce_accumulators(buf)
+    back = np.zeros((nq, 4), np.int64)
+    assert L.pg_exchange_unpack_words(buf.numpy().ctypes.data, nq, back.ctypes.data) == 0
+    if rank == 0:
+        np.save(out, back)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_exchange_format_with_eight_ranks(tmp_path):
+    """The 24-byte exchange format (pgsd.h pg_exchange_pack: two 52-bit pieces + count << 24 | top) through the LIBRARY's
+    own arithmetic on host arrays (pg_exchange_pack_words / _unpack_words: the functions the device kernels inline): eight
+    ranks pack their accumulators, gloo sums the packed words, the unpacked result is the single-process sum -- value and
+    count of every node -- with negative totals, clamped 2^88 weights and limbs that are not normalised."""
+    world = 8
+    out = str(tmp_path / "packed.npy")
+    mp.spawn(_worker_cpu_packed, args=(world, 29627, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = po.OracleTree()
+    ref.load(_base_tree())
+    ref.reset()
+    rec = synth.records(M, 4242, BB0, BB1)
+    from practical_path_guiding_lab_amd.parallel import shard
+    for r in range(world):   # (the per-rank edits, applied to the same records)
+        s0, c0 = shard(M, r, world)
+        rec["radiance"][s0:s0 + c0][::5] *= np.float32(-3.0)
+        rec["radiance"][s0:s0 + c0][1::9] = np.float32(3e38)
+    synth.splat(ref, rec)
+    exp = [((int(h) << 64) + int(l)) % (1 << 128) for l, h in zip(ref.quad_column("acc_lo"), ref.quad_column("acc_hi"))]
+    assert [v % (1 << 128) for v in _resolve(got[:, :3])] == exp
+    assert (got[:, 3] == M).all()
+    assert (got[:, 0] >= 0).all() and (got[:, 0] < (1 << 32)).all() and (got[:, 1] >= 0).all() and (got[:, 1] < (1 << 32)).all()
+    assert any(v >= (1 << 127) for v in exp) and max(abs(int(x)) for x in got[:, 2]) > 0   # negative totals, high limbs in use
+
+
+def test_packed_exchange_headroom_at_the_bounds():
+    """The bounds the format states: 2^31 records of |q| = 2^88 per accumulator over all ranks, any split over up to 2048
+    ranks -- the packed words of the ranks' extreme shares add without overflow and decode exactly."""
+    from practical_path_guiding_lab_amd import _native as N
+
+    L = N.lib()
+    for ranks in (1, 8, 2048):
+        per = (1 << 31) // ranks                       # records per rank
+        for sign in (1, -1):
+            T = sign * per * (1 << 88)                 # this rank's total
+            Tm = T % (1 << 128)
+            l0, l1 = Tm & 0xFFFFFFFF, (Tm >> 32) & 0xFFFFFFFF
+            l2 = (Tm >> 64) - (1 << 64) if (Tm >> 127) else (Tm >> 64)
+            acc = np.array([[l0, l1, l2, per]], np.int64)
+            p = np.zeros((1, 3), np.int64)
+            assert L.pg_exchange_pack_words(acc.ctypes.data, 1, p.ctypes.data) == 0
+            tot = [int(x) * ranks for x in p[0]]       # every rank the same share: the element-wise sums
+            assert all(-(1 << 63) <= x < (1 << 63) for x in tot)
+            q = np.array([tot], np.int64)
+            back = np.zeros((1, 4), np.int64)
+            assert L.pg_exchange_unpack_words(q.ctypes.data, 1, back.ctypes.data) == 0
+            assert _resolve(back[:, :3])[0] == T * ranks and int(back[0, 3]) == per * ranks
+
+
+def test_watchdog_ends_a_rank_that_waits_for_ever(tmp_path):
+    """parallel.Watchdog, the bound around ncclCommInitRank and the first barrier: a block that outlives its limit ends the
+    PROCESS with the given exit code (the launcher then ends the other ranks); a block that finishes in time is untouched."""
+    import subprocess
+    import time as _t
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from practical_path_guiding_lab_amd.parallel import Watchdog\n"
+            "with Watchdog(30, 'quick'):\n    pass\n"
+            "with Watchdog(0.5, 'a rank that never comes', exit_code=75):\n    time.sleep(60)\n"
+            "print('not reached')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = _t.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 75 and "not reached" not in r.stdout and "a rank that never comes" in r.stderr
+    assert _t.time() - t0 < 45
+
+
 def test_single_rank_is_a_noop():
     from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators
 
@@ -125,7 +228,16 @@ def _worker_gpu(rank, world, port, out):
     g.setIteration(3, False)
     rec = _rank_records(rank, world)
     g.addDataPropagate({k: torch.from_numpy(v).cuda() for k, v in rec.items()})
-    all_reduce_accumulators(g.accumulators())
+    # the exchange format: pack (24 B per accumulator) -> sum -> unpack, and beside it the raw 32-byte layout of the same
+    # per-rank accumulators summed the old way: the same value and count for every accumulator
+    raw = g.accumulators().clone()
+    all_reduce_accumulators(g.packAccumulators())
+    g.unpackAccumulators()
+    kd_p, lo_p, hi_p = g.exportAccumulators()
+    all_reduce_accumulators(raw)
+    g.accumulators().copy_(raw)
+    kd_r, lo_r, hi_r = g.exportAccumulators()
+    assert (kd_p == kd_r).all() and (lo_p == lo_r).all() and (hi_p == hi_r).all() and int(kd_p[0]) == M
     g.refineAndPrepare()
     e = g.export()
     np.savez(out % rank, **e)
@@ -519,12 +631,25 @@ def test_library_exchange_with_one_rank():
     rec = synth.records(5000, 11, BB0, BB1)
     g.addDataPropagate({k: torch.from_numpy(v).cuda() for k, v in rec.items()})
     before = g.accumulators().clone()
+    kd0, lo0, hi0 = g.exportAccumulators()
     ident = g.commUniqueId()
     assert len(ident) == 128 and any(ident)
+    with pytest.raises(PgError):
+        g.commInfo()
     g.commInit(1, 0, ident)
-    g.allReduce()
+    assert g.commInfo() == (1, 0)   # ncclCommCount / ncclCommUserRank read back from RCCL
+    g.allReduce()                   # pack (24 B per accumulator) -> ncclAllReduce -> unpack
     torch.cuda.synchronize()
-    assert torch.equal(g.accumulators(), before) and int(before.abs().sum()) > 0
+    kd1, lo1, hi1 = g.exportAccumulators()
+    # the same values and counts (the limbs come back normalised: the representation may differ, the sums may not)
+    np.testing.assert_array_equal(kd0, kd1)
+    np.testing.assert_array_equal(lo0, lo1)
+    np.testing.assert_array_equal(hi0, hi1)
+    assert int(before.abs().sum()) > 0 and int(kd0[0]) == 5000
+    a = g.accumulators().clone()
+    g.allReduce()                   # normalised limbs are a fixed point of pack -> unpack
+    torch.cuda.synchronize()
+    assert torch.equal(g.accumulators(), a)
     g.commDestroy()
     with pytest.raises(PgError):
         g.allReduce()
@@ -540,6 +665,28 @@ def _bench_module():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def test_step_queue_of_eight_ranks_with_steps_that_do_not_fill_the_last_group():
+    """bench.py --gpus 8 (tiles): a rank launches the passes of eight steps at once.  The queue that does it, by itself and
+    without a GPU: 5 warm-up + 13 timed steps of 16 passes on 8 ranks leave as launches of 5, 8 and 5 steps -- the warm-up
+    flushed by itself, the last group smaller -- with seeds that run on without a gap, so that the passes traced are
+    exactly those of 18 separate steps; `--shard passes` strides the seeds by the world size."""
+    B = _bench_module()
+    calls = []
+    q = B.StepQueue(lambda n, sd: calls.append((n, sd)), 16, 8, first_seed=252)
+    for _ in range(5):
+        q.step()
+    q.flush()
+    for _ in range(13):
+        q.step()
+    q.flush()
+    q.flush()  # (nothing queued: nothing launched)
+    assert calls == [(80, 252), (128, 332), (80, 460)] == q.launches
+    assert q.seed == 252 + 18 * 16 and sum(n for n, _ in calls) == 18 * 16
+    one = B.StepQueue(lambda n, sd: calls.append((n, sd)), 16, 1, first_seed=7, seed_stride=8)   # passes-sharded: group 1
+    one.step(); one.step()
+    assert one.launches == [(16, 7), (16, 7 + 16 * 8)]
 
 
 def test_spawn_ranks_gives_every_rank_its_environment_and_relays_rank_zero(tmp_path):
