@@ -1065,7 +1065,8 @@ def cpu_synthetic_columns(cpu_in, P, D, detail, flat):
     po.build()
     cores = po.set_threads(0)
     by_name = {d["kernel"]: d for d in detail}
-    out = {"cores": cores, "label": "CPU restatement (oracle/pg_oracle.c, OpenMP over the lanes)", "equal_to_device": True}
+    out = {"cores": cores, "host_cores_usable": po.usable_cores(), "label": "CPU restatement (oracle/pg_oracle.c, OpenMP over the lanes)",
+           "equal_to_device": True}
     n = P.shape[1]
 
     def best(fn, reps=3):
@@ -1242,7 +1243,8 @@ def cpu_leg(args, iters=4, width=320):
     from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
 
     po.build()
-    cores = po.set_threads(0)
+    cores = po.set_threads(0)  # (two threads per core of this process's CPU share: oracle.pg_oracle.default_threads)
+    usable = po.usable_cores()
     sc = make_scene(args.scene, width, args.depth)
     W, H = sc.camera.width, sc.camera.height
     npix = W * H
@@ -1296,14 +1298,16 @@ def cpu_leg(args, iters=4, width=320):
         cumm += spp
         if k + 1 < iters:
             pair2.refine_and_prepare(k)
-    cpu = {"value": round(n_guided / t_guided / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+    cpu = {"value": round(n_guided / t_guided / 1e6, 4), "unit": "Msamples/s", "cores": cores, "host_cores_usable": usable,
+           "host_cores_shown": os.cpu_count(), "kind": "port",
            "label": "CPU restatement: the build's own C restatement of the reference's Python (oracle/, OpenMP over the lanes), NOT the "
                     "reference -- its Python / Dr.Jit path cannot run on this box (Mitsuba 3 and Dr.Jit are absent: SURVEY 8c)",
            "images_bit_identical_to_device": same,
            "mse_vs_gt_device": mse_g, "mse_vs_gt_cpu": mse_c, "mse_equal": bool(mse_g == mse_c),
            "value_one_sample_passes": round(n_guided_1 / t_guided_1 / 1e6, 4),
            "sample": f"the guided passes (iterations 2-3, 16 + 32 spp) of a 4-iteration schedule of the same scene on a {W}x{H} "
-                     f"film ({n_guided} paths), C oracle with OpenMP over the lanes on {cores} threads, {t_guided:.1f} s; "
+                     f"film ({n_guided} paths), C oracle with OpenMP over the lanes on {cores} threads (this process may use {usable} of the box's "
+                     f"{os.cpu_count()} cores: its cgroup quota), {t_guided:.1f} s; "
                      f"value_one_sample_passes: the same samples as 48 separate one-sample passes ({t_guided_1:.1f} s), the leg the "
                      "device's images are compared with"}
     return cpu, mse_g, mse_c

@@ -994,6 +994,17 @@ constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage *
 #else
 #define PG_SHADE1_OCC
 #endif
+// The paths' 128-byte records of a sorted bounce are read THROUGH LDS by the wave as a whole (PG_SHADE_COOP): a lane that
+// gathers the seven 16-byte entries of its own record makes seven vector loads that each touch 64 different cache lines --
+// the compute unit's L1 looks up about one line per clock, so such a load holds the vector-memory path for 64 clocks however
+// few bytes it wants -- where eight lanes that read one record's eight entries side by side touch 8 lines per load: the same
+// 64 records in eight loads of 8 lines instead of seven of 64.  The entries cross to the lanes that own them through LDS
+// ([entry][thread] planes over the bytes the walks' stacks and the stash use later: one more workgroup barrier, ahead of the
+// staging of the BVH's top).
+#ifndef PG_SHADE_COOP
+#define PG_SHADE_COOP 1
+#endif
+static_assert(!PG_SHADE_COOP || 7 * kRBlock <= kShadeLdsQuads, "k_wave_shade: the records' seven entries per thread must fit the dynamic LDS");
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs a)
 {
@@ -1005,6 +1016,25 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	uint4 cq0 = make_uint4(0u, 0u, 0u, 0u), cq1 = cq0, cq2 = cq0, cq3 = cq0, cq4 = cq0, cq5 = cq0, cq6 = cq0;
+	uint32_t coop_place = (uint32_t)tid;
+	const bool coop = PG_SHADE_COOP && !kFirst && a.perm != nullptr; // (uniform)
+	if (coop) {
+		if (alive && tid < (uint64_t)a.n_sort) coop_place = a.perm[tid];
+		if (!alive) coop_place = 0u; // (a lane past the list still serves its wave's loads: any record that exists)
+		const uint32_t l = threadIdx.x & 63u, wbase = threadIdx.x & ~63u, q = l & 7u;
+#pragma unroll
+		for (uint32_t k = 0; k < 8u; ++k) {
+			const uint32_t j = k * 8u + (l >> 3);
+			const uint32_t pj = (uint32_t)__shfl((int)coop_place, (int)j, 64);
+			if (q < 7u) s_dyn[q * kRBlock + wbase + j] = gather16(a.carry_in + (uint64_t)pj * 8 + q); // (entry 7 of a record is unused)
+		}
+		// (written and read by the same wave, LDS operations of a wave complete in order: no barrier between the two)
+		cq0 = s_dyn[0 * kRBlock + threadIdx.x]; cq1 = s_dyn[1 * kRBlock + threadIdx.x]; cq2 = s_dyn[2 * kRBlock + threadIdx.x];
+		cq3 = s_dyn[3 * kRBlock + threadIdx.x]; cq4 = s_dyn[4 * kRBlock + threadIdx.x]; cq5 = s_dyn[5 * kRBlock + threadIdx.x];
+		cq6 = s_dyn[6 * kRBlock + threadIdx.x];
+		__syncthreads(); // every wave has its entries: the bytes become the BVH's top, the stacks and the stash
+	}
 	stage_kd_planes(s_planes, a.tree);
 	uint2 *s_stack = reinterpret_cast<uint2 *>(s_dyn);
 	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kShadeStack * kRBlock / 2;
@@ -1034,16 +1064,19 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		HitRec h;
 		const bool from_rec = !kFirst && a.perm != nullptr; // a sorted bounce: the path's 128-byte record, through the permutation
 		uint32_t place = (uint32_t)tid; // (32-bit: a place in the live list; one register through the walks, not two)
-		if (from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
+		if (coop) place = coop_place;
+		else if (from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
 		if (from_rec) {
 			const uint4 *rec = a.carry_in + (uint64_t)place * 8;
-			const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q5 = rec[5], q6 = rec[6];
+			uint4 q0, q1, q2, q3, q5, q6;
+			if (coop) { q0 = cq0; q1 = cq1; q2 = cq2; q3 = cq3; q5 = cq5; q6 = cq6; }
+			else { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q5 = rec[5]; q6 = rec[6]; }
 			rng.state = (uint64_t)q0.w | ((uint64_t)q1.w << 32);
 			rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
 			ray_o = st_v3(q0); ray_d = st_v3(q1);
 			thr = st_v3(q2);
 #if !PG_SHADE_RELOAD
-			{ const uint4 q4 = rec[4]; ior = __uint_as_float(q2.w & 0x7fffffffu); L = st_v3(q4); lane = q4.w; }
+			{ const uint4 q4 = coop ? cq4 : rec[4]; ior = __uint_as_float(q2.w & 0x7fffffffu); L = st_v3(q4); lane = q4.w; }
 #endif
 			prev_delta = (q2.w >> 31) != 0u;
 			prev_p = st_v3(q3);

@@ -812,13 +812,17 @@ def _worker_nccl_one_rank(rank, world, port, out):
     g.setIteration(3, False)
     rec = synth.records(5000, 11, BB0, BB1)
     g.addDataPropagate({k: torch.from_numpy(v).cuda() for k, v in rec.items()})
-    before = g.accumulators().clone()
-    ok = init_library_comm(g)            # the vote, rank 0's id through broadcast_object_list, ncclCommInitRank
+    before = g.exportAccumulators()
+    ok = init_library_comm(g)            # the vote, rank 0's id through broadcast_object_list, ncclCommInitRank, RCCL's own rank count
     if ok:
-        g.allReduce()                    # pg_allreduce: ncclAllReduce issued by libpgsd.so
+        ok = g.commInfo() == (1, 0)
+        g.allReduce()                    # pg_allreduce: pack -> ncclAllReduce issued by libpgsd.so -> unpack
     all_reduce_accumulators(g.accumulators())   # and the torch.distributed route (a no-op sum with one rank)
+    all_reduce_accumulators(g.packAccumulators())
+    g.unpackAccumulators()
     torch.cuda.synchronize()
-    same = bool(torch.equal(g.accumulators(), before))
+    # (values and counts: the limbs come back normalised from the exchange format)
+    same = all(bool((x == y).all()) for x, y in zip(g.exportAccumulators(), before))
     s1, s2 = all_reduce_sums(torch.ones(3, 8, device="cuda"), torch.full((3, 8), 2.0, device="cuda"))
     lo, hi = min_max_over_ranks(7.0)
     t = max_over_ranks(0.25, device="cuda")
