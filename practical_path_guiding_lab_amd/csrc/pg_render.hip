@@ -16,6 +16,10 @@
 //
 // Arithmetic mirrors oracle/pg_oracle_render.c operation by operation (fp32, no contraction), so
 // radiance, records and therefore the refined trees are bit-identical to the CPU restatement.
+// (The microfacet helpers are inlined here too since round 5: kept out of line, every call cost the level-1 kernels a 32-byte
+// stack frame in scratch memory; inlined, k_bounce<*, 1> is 87 / 89 registers at five waves per SIMD with no scratch at
+// all -- veach-mis 2.33 -> 2.32 ms per pass, profiles/r05/ab_fused_kernel_helpers_inlined.txt.)
+#define PG_RENDER_INLINE_ALL
 #include "pg_render_dev.hpp"
 
 namespace pg {

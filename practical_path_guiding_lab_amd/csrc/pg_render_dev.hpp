@@ -9,10 +9,10 @@
 #include "pg_descent.hpp"
 #include "pg_kernels.hpp"
 
-// The microfacet helpers are called from several places.  The fused kernel of pg_render.hip keeps
-// them out of line (its diffuse-only instantiation never references them, the general one stays
-// small); the split kernels of pg_render_wave.hip inline them: a call needs a stack frame in scratch
-// memory, and those kernels are to use none.
+// The microfacet helpers are called from several places.  Both render translation units inline them
+// (PG_RENDER_INLINE_ALL): a call needs a stack frame in scratch memory, and no kernel of the library is to use any.
+// (Rounds 1-4 kept them out of line in the fused kernel of pg_render.hip: 32 bytes of scratch per lane in its level-1
+// instantiations.)
 #ifdef PG_RENDER_INLINE_ALL
 #define PG_OUTLINE __forceinline__
 #else
@@ -517,6 +517,11 @@ __device__ __forceinline__ Surface surface_at(const Shapes &sh, const float *mat
 	Surface s;
 	const float *M;
 	if (kGeneral >= 2 && prim >= sh.n_quads + sh.n_spheres + 6 * sh.n_boxes) { // a mesh triangle
+		// (Measured and removed, round 5: ONE 128-byte line per triangle with everything this branch reads -- face normal +
+		// material, nine vertex normals, six texture coordinates: five 16-byte gathers of one line instead of seven or eight of
+		// three arrays.  k_wave_shade 28.0 -> 28.3 ms per step: the tightly packed arrays put two to five neighbouring
+		// triangles into a cache line, and the lanes of a spatially sorted wave hit neighbouring triangles.
+		// profiles/r05/ab_triangle_shading_line_rejected.txt)
 		const size_t ti = (size_t)(prim - sh.n_quads - sh.n_spheres - 6 * sh.n_boxes);
 		const float *T = sh.tris + ti * kTriStride;
 		s.p = vadd(o, vscale(d, t));

@@ -524,15 +524,20 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 		st_store(const_cast<uint4 *>(a.st_in), a, 0, tid, ray_o, (uint32_t)rng.state);
 		st_store(const_cast<uint4 *>(a.st_in), a, 1, tid, ray_d, (uint32_t)(rng.state >> 32));
 	} else if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
-		const uint4 q0 = a.carry_in[tid * 8 + 0], q1 = a.carry_in[tid * 8 + 1];
+		const bool want_cls = PG_SORT_CLASS_BIT && a.guided && a.bounce + 1 < a.max_depth; // (uniform)
+		uint4 q0, q1, q5 = make_uint4(0u, 0u, 0u, 0u);
+		// (Measured and removed, round 5: these three entries read by four lanes per record and handed over through the wave's
+		// stack columns, as k_wave_shade reads its PERMUTED records -- here the wave's records lie side by side, consecutive
+		// lanes ask for consecutive lines, and the detour through LDS cost 11.5 -> 12.8 ms per step:
+		// profiles/r05/ab_trace_coop_record_load_rejected.txt.)
+		q0 = a.carry_in[tid * 8 + 0]; q1 = a.carry_in[tid * 8 + 1];
+		if (want_cls && tid < (uint64_t)a.n_sort) q5 = a.carry_in[tid * 8 + 5];
 		ray_o = st_v3(q0);
 		ray_d = st_v3(q1);
 		// (the class bit of the sort key is made HERE, ahead of the walk, from the sampler state in the two entries just read: one
 		// register through the walk instead of the state's four)
-		if (PG_SORT_CLASS_BIT && a.guided && a.bounce + 1 < a.max_depth && tid < (uint64_t)a.n_sort) {
-			const uint4 q5 = a.carry_in[tid * 8 + 5];
+		if (want_cls && tid < (uint64_t)a.n_sort)
 			cls_ahead = (int)lane_class_ahead((uint64_t)q0.w | ((uint64_t)q1.w << 32), (uint64_t)q5.x | ((uint64_t)q5.y << 32), a.frac);
-		}
 	} else {
 		ray_o = st_v3(st_load(a.st_in, a, 0, tid));
 		ray_d = st_v3(st_load(a.st_in, a, 1, tid));
@@ -1006,7 +1011,7 @@ constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage *
 #endif
 static_assert(!PG_SHADE_COOP || 7 * kRBlock <= kShadeLdsQuads, "k_wave_shade: the records' seven entries per thread must fit the dynamic LDS");
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs a)
+__device__ __forceinline__ void shade_body(const RenderArgs &a)
 {
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	__shared__ uint32_t s_wave[kRBlock / 64];
@@ -1064,8 +1069,8 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 		HitRec h;
 		const bool from_rec = !kFirst && a.perm != nullptr; // a sorted bounce: the path's 128-byte record, through the permutation
 		uint32_t place = (uint32_t)tid; // (32-bit: a place in the live list; one register through the walks, not two)
-		if (coop) place = coop_place;
-		else if (from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
+		if (PG_SHADE_RELOAD && coop) place = coop_place;
+		else if (!coop && from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
 		if (from_rec) {
 			const uint4 *rec = a.carry_in + (uint64_t)place * 8;
 			uint4 q0, q1, q2, q3, q5, q6;
@@ -1192,6 +1197,20 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs
 	}
 	// (append_survivors' first barrier comes after every walk of the workgroup: from there on the stacks' bytes hold records)
 	append_survivors<kShadeStage>(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_dyn);
+}
+
+template <int kLevel, bool kFirst>
+__global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs a)
+{
+	shade_body<kLevel, kFirst>(a);
+}
+// Feature level 3 (torus: transmission, delta lobes, one-sided BSDFs) needs one register more than five waves per SIMD leave
+// (97 of 96); told the occupancy it is wanted at, the compiler finds an allocation of 95 without a byte of scratch.  (The
+// same hint makes the level-2 kernel spill 12 bytes per lane: it fits by itself and is left alone.)
+template <bool kFirst>
+__global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_wave_shade_l3(RenderArgs a)
+{
+	shade_body<3, kFirst>(a);
 }
 
 // See tail_checkpoint (pg_render_dev.hpp): launched before the launches of bounce a.bounce with a grid
@@ -1334,11 +1353,17 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 		if (!told && getenv("PGSD_TRACE_OCC")) { // (dev switch: how many workgroups of this kernel a compute unit holds)
 			told = true;
 			int nb = 0;
-			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wave_shade<kLevel, false>, kRBlock, lds);
+			if constexpr (kLevel == 3) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wave_shade_l3<false>, kRBlock, lds);
+			else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wave_shade<kLevel, false>, kRBlock, lds);
 			fprintf(stderr, "[pgsd] k_wave_shade<%d>: %d workgroups of %d threads per compute unit with %zu bytes of dynamic LDS\n", kLevel, nb, kRBlock, lds);
 		}
-		if (first) hipLaunchKernelGGL((k_wave_shade<kLevel, true>), grid, block, lds, s, a);
-		else hipLaunchKernelGGL((k_wave_shade<kLevel, false>), grid, block, lds, s, a);
+		if constexpr (kLevel == 3) {
+			if (first) hipLaunchKernelGGL((k_wave_shade_l3<true>), grid, block, lds, s, a);
+			else hipLaunchKernelGGL((k_wave_shade_l3<false>), grid, block, lds, s, a);
+		} else {
+			if (first) hipLaunchKernelGGL((k_wave_shade<kLevel, true>), grid, block, lds, s, a);
+			else hipLaunchKernelGGL((k_wave_shade<kLevel, false>), grid, block, lds, s, a);
+		}
 		break;
 	}
 	default: hipLaunchKernelGGL((k_wave_tail<kLevel>), grid, block, 0, s, a); break;
