@@ -164,7 +164,7 @@ void destroy_comm(pg_context *ctx);
 // pg_sort.hip
 size_t sort_pairs_temp_bytes(uint32_t n);
 hipError_t sort_places16(void *temp, size_t temp_bytes, const uint16_t *keys_in, uint16_t *keys_out, uint32_t *places_out, uint32_t n,
-                         hipStream_t s);
+                         const uint32_t *d_live, hipStream_t s);
 // helpers shared by pg_context.hip / pg_refine.hip
 int fail(pg_context *ctx, int code, const std::string &msg);
 int hip_fail(pg_context *ctx, hipError_t e, const char *what);

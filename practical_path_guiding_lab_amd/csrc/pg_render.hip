@@ -1074,7 +1074,8 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 				}
 				{
 					Timed t(r, s, 11);
-					PG_HIP(ctx, sort_places16(b.sort_tmp.p, b.sort_tmp_bytes, b.sort_key.p, b.sort_key_out.p, b.sort_perm.p, (uint32_t)n_sort, s));
+					PG_HIP(ctx, sort_places16(b.sort_tmp.p, b.sort_tmp_bytes, b.sort_key.p, b.sort_key_out.p, b.sort_perm.p, (uint32_t)n_sort,
+					                            a.live_count + (it - 1), s));
 				}
 				a.perm = b.sort_perm.p;
 				if (joint) {

@@ -18,11 +18,41 @@
 // That is all the order the shading needs (cells of the spatial sort are 2^-15 of the box; the results do not depend on the
 // order at all), and it is what makes the passes cheap: no decoupled look-back, no ranking by match-any, 27 KB of LDS.
 // The first pass reads no places (a pair's place is its index) and the second writes no keys.
+// Because the order inside a tile of the second pass is free, a place WITHOUT a path (key 0xffff) could come to stand in front
+// of a live one with key 0xfffe or 0xfffd.  The live list is dense -- places 0 .. live-1 hold paths, the rest of the n places
+// the host sized the sort for hold none -- so the kernels read the live count from device memory (`d_live`) and never look at
+// the places beyond it: places_out[0 .. live) is a permutation of 0 .. live-1, what lies behind it is not written.
 #include <stdint.h>
+
+#ifndef PG_SORT_ROCPRIM
+#define PG_SORT_ROCPRIM 0 // (A/B: 1 = rocPRIM's radix_sort_pairs, as rounds 3 and 4)
+#endif
+#if PG_SORT_ROCPRIM
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#endif
 
 #include "pg_context.hpp"
 
 namespace pg {
+
+#if PG_SORT_ROCPRIM
+size_t sort_pairs_temp_bytes(uint32_t n)
+{
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t *)nullptr, (uint16_t *)nullptr, rocprim::counting_iterator<uint32_t>(0),
+	                                (uint32_t *)nullptr, n, 0, 16, (hipStream_t) nullptr);
+	return bytes;
+}
+hipError_t sort_places16(void *temp, size_t temp_bytes, const uint16_t *keys_in, uint16_t *keys_out, uint32_t *places_out, uint32_t n,
+                         const uint32_t *, hipStream_t s)
+{
+	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), places_out, n, 0, 16, s);
+}
+#else
 
 namespace {
 
@@ -56,10 +86,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 }
 
 template <int kShift>
-__global__ __launch_bounds__(kSortBlock) void k_sort_hist(const uint16_t *__restrict__ keys, uint32_t n, uint32_t n_tiles,
-                                                          uint32_t *__restrict__ counts)
+__global__ __launch_bounds__(kSortBlock) void k_sort_hist(const uint16_t *__restrict__ keys, uint32_t n, const uint32_t *__restrict__ d_live,
+                                                          uint32_t n_tiles, uint32_t *__restrict__ counts)
 {
 	__shared__ uint32_t s_hist[256];
+	if (d_live != nullptr && *d_live < n) n = *d_live; // (uniform)
 	s_hist[threadIdx.x] = 0u;
 	__syncthreads();
 	const uint32_t first = blockIdx.x * kSortTile + threadIdx.x * kSortItems;
@@ -122,10 +153,12 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scan_sums(uint32_t *__restr
 // kFirst: the places are the pairs' indices (not read); kLast: the keys are not written
 template <int kShift, bool kFirst, bool kLast>
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const uint16_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                             uint32_t n, uint32_t n_tiles, const uint32_t *__restrict__ counts,
-                                                             const uint32_t *__restrict__ chunk_base, uint16_t *__restrict__ keys_out,
-                                                             uint32_t *__restrict__ vals_out)
+                                                             uint32_t n, const uint32_t *__restrict__ d_live, uint32_t n_tiles,
+                                                             const uint32_t *__restrict__ counts, const uint32_t *__restrict__ chunk_base,
+                                                             uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out)
 {
+	if (d_live != nullptr && *d_live < n) n = *d_live; // (uniform)
+	if (blockIdx.x * kSortTile >= n) return;           // a tile past the live list: nothing to place
 	__shared__ uint32_t s_cnt[256];   // the tile's count per digit, then where the digit's run starts in the tile
 	__shared__ uint32_t s_gbase[256]; // where the digit's run of this tile starts in the output
 	__shared__ uint32_t s_wave[4];
@@ -231,11 +264,12 @@ size_t sort_pairs_temp_bytes(uint32_t n)
 	return sort_plan(n ? n : 1u).bytes;
 }
 
-// places_out = a permutation of 0 .. n-1 in the order described at the top of this file (keys_out: the keys between the
-// two passes -- scratch of n entries); asynchronous on `s`.  n < 2^28 (4096 x 65536 tiles): pg_render_pass keeps the
-// lanes of a pass below that.
+// places_out[0 .. live) = a permutation of 0 .. live-1 in the order described at the top of this file, live = min(n, *d_live)
+// (d_live: the number of places that hold a path, in device memory; nullptr: all n do); keys_out: the keys between the two
+// passes -- scratch of n entries; asynchronous on `s`.  n < 2^28 (4096 x 65536 tiles): pg_render_pass keeps the lanes of a
+// pass below that.
 hipError_t sort_places16(void *temp, size_t temp_bytes, const uint16_t *keys_in, uint16_t *keys_out, uint32_t *places_out, uint32_t n,
-                         hipStream_t s)
+                         const uint32_t *d_live, hipStream_t s)
 {
 	if (n == 0) return hipSuccess;
 	const SortPlan p = sort_plan(n);
@@ -244,18 +278,19 @@ hipError_t sort_places16(void *temp, size_t temp_bytes, const uint16_t *keys_in,
 	uint32_t *sums = reinterpret_cast<uint32_t *>((char *)temp + p.off_sums);
 	uint32_t *vals = reinterpret_cast<uint32_t *>((char *)temp + p.off_vals);
 	// the low byte
-	hipLaunchKernelGGL(k_sort_hist<0>, dim3(p.n_tiles), dim3(kSortBlock), 0, s, keys_in, n, p.n_tiles, counts);
+	hipLaunchKernelGGL(k_sort_hist<0>, dim3(p.n_tiles), dim3(kSortBlock), 0, s, keys_in, n, d_live, p.n_tiles, counts);
 	hipLaunchKernelGGL(k_sort_scan_chunks, dim3(p.n_chunks), dim3(kSortBlock), 0, s, counts, p.m, sums);
 	hipLaunchKernelGGL(k_sort_scan_sums, dim3(1), dim3(kSortBlock), 0, s, sums, p.n_chunks);
-	hipLaunchKernelGGL((k_sort_scatter<0, true, false>), dim3(p.n_tiles), dim3(kSortBlock), 0, s, keys_in, (const uint32_t *)nullptr, n, p.n_tiles,
-	                   counts, sums, keys_out, vals);
+	hipLaunchKernelGGL((k_sort_scatter<0, true, false>), dim3(p.n_tiles), dim3(kSortBlock), 0, s, keys_in, (const uint32_t *)nullptr, n, d_live,
+	                   p.n_tiles, counts, sums, keys_out, vals);
 	// the high byte
-	hipLaunchKernelGGL(k_sort_hist<8>, dim3(p.n_tiles), dim3(kSortBlock), 0, s, (const uint16_t *)keys_out, n, p.n_tiles, counts);
+	hipLaunchKernelGGL(k_sort_hist<8>, dim3(p.n_tiles), dim3(kSortBlock), 0, s, (const uint16_t *)keys_out, n, d_live, p.n_tiles, counts);
 	hipLaunchKernelGGL(k_sort_scan_chunks, dim3(p.n_chunks), dim3(kSortBlock), 0, s, counts, p.m, sums);
 	hipLaunchKernelGGL(k_sort_scan_sums, dim3(1), dim3(kSortBlock), 0, s, sums, p.n_chunks);
 	hipLaunchKernelGGL((k_sort_scatter<8, false, true>), dim3(p.n_tiles), dim3(kSortBlock), 0, s, (const uint16_t *)keys_out, (const uint32_t *)vals, n,
-	                   p.n_tiles, counts, sums, (uint16_t *)nullptr, places_out);
+	                   d_live, p.n_tiles, counts, sums, (uint16_t *)nullptr, places_out);
 	return hipGetLastError();
 }
+#endif // PG_SORT_ROCPRIM
 
 } // namespace pg
