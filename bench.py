@@ -199,6 +199,17 @@ def traffic_for(kernel, key):
     return None
 
 
+def profiled_table_bits(key):
+    """(jump_bits, kd_grid_bits) of the forest the committed PMC figures of configuration `key` were taken of, or None."""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("configs", {}).get(key, {})
+        if "_jump_bits" in k:
+            return int(k["_jump_bits"]), int(k.get("_kd_grid_bits", -1))
+    except Exception:
+        pass
+    return None
+
+
 def spawn_ranks(cmd, n, env=None, relay=sys.stdout, grace_s=10.0):
     """Starts n rank processes of `cmd` (a list for subprocess.Popen) on this node, one per GPU, with the
     environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE,
@@ -703,6 +714,9 @@ def run_render(args):
                           "the six teapot shapes are absent: their mesh files are missing from the reference mount)"}[args.scene]
     tr_dom = traffic_for(dom, cfg_key)
     traffic = None if tr_dom is None else tr_dom["hi"]
+    # (the committed counters belong to a forest with these table resolutions: another one -- a different memory budget --
+    # moves other bytes)
+    prof_bits = profiled_table_bits(cfg_key)
     # every kernel against the HBM roofline by its COUNTER traffic (the committed PMC figures of this configuration and of
     # THIS code, profiles/pmc_traffic.json: as counted, and with the gfx950 FETCH correction, an upper bound) over the
     # duration measured in this run
@@ -715,13 +729,16 @@ def run_render(args):
             if all(t is not None for t in tr):
                 sec = kernels[name]["avg_us"] * 1e-6
                 hi = sum(t["hi"] for t in tr) / len(tr)
-                kernels[name]["pmc_hbm_bytes_per_launch"] = int(hi)
-                kernels[name]["pmc_hbm_GBps"] = round(hi / sec / 1e9, 1)
-                kernels[name]["pmc_frac_of_hbm_peak"] = round(hi / sec / 1e9 / HBM_PEAK_GBS, 3)
+                # pmc_frac_of_hbm_peak: the bytes AS COUNTED (FETCH_SIZE + WRITE_SIZE) over this run's launch time and the 8 TB/s
+                # peak; ..._fetch_x2: with the guide's x2 FETCH correction, which is calibrated for wide coalesced reads and is an
+                # upper bound for everything else -- for k_splat_list it gives more than the box's own copy rate
                 if all(t["lo"] is not None for t in tr):
                     lo = sum(t["lo"] for t in tr) / len(tr)
-                    kernels[name]["pmc_hbm_bytes_per_launch_uncorrected"] = int(lo)
-                    kernels[name]["pmc_frac_of_hbm_peak_uncorrected"] = round(lo / sec / 1e9 / HBM_PEAK_GBS, 3)
+                    kernels[name]["pmc_hbm_bytes_per_launch"] = int(lo)
+                    kernels[name]["pmc_hbm_GBps"] = round(lo / sec / 1e9, 1)
+                    kernels[name]["pmc_frac_of_hbm_peak"] = round(lo / sec / 1e9 / HBM_PEAK_GBS, 3)
+                kernels[name]["pmc_hbm_bytes_per_launch_fetch_x2"] = int(hi)
+                kernels[name]["pmc_frac_of_hbm_peak_fetch_x2"] = round(hi / sec / 1e9 / HBM_PEAK_GBS, 3)
                 if tr[0]["atomics"]:
                     kernels[name]["atomic_sector_updates_per_launch"] = int(tr[0]["atomics"])
                     kernels[name]["atomics_G_per_s"] = round(tr[0]["atomics"] / sec / 1e9, 2)
@@ -749,6 +766,8 @@ def run_render(args):
             "alg_bytes_per_launch": kernels[dom].get("alg_bytes_per_launch"),
             "avg_launch_us": kernels[dom]["avg_us"],
             "traffic": traffic,
+            "traffic_tables_match": None if (prof_bits is None or traffic is None) else bool(prof_bits[0] == int(stats.jump_bits)
+                                                                                                and prof_bits[1] in (-1, int(stats.kd_grid_bits))),
             # above 1 the algorithmic model is not a bandwidth at all: in a spatially sorted list (pg_render_sort) the lanes of a
             # wave walk the same KD leaves and quadtrees, their gathers meet in L1/L2 and the bytes the model prices per lane are
             # fetched once per wave -- frac_counter_* say what reaches HBM

@@ -14,7 +14,7 @@ src, dst, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 BOUNCES = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # k_bounce launches per pass = max_depth
 os.makedirs(dst, exist_ok=True)
 KERNELS = ("k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_shade", "k_wave_tail", "k_bounce", "k_splat_list",
-           "k_process_and_splat", "k_finish")  # (k_wave_shade after _a and _b: the first name found in a kernel's name counts)  # k_wave_cast = the persistent any-hit kernel of the shadow rays
+           "k_process_and_splat", "k_finish", "k_sort_scatter", "k_sort_hist", "k_sort_scan")  # (k_wave_shade after _a and _b: the first name found in a kernel's name counts)  # k_wave_cast = the persistent any-hit kernel of the shadow rays
 PER_BOUNCE = ("k_bounce", "k_wave_trace", "k_wave_shade_a", "k_wave_cast", "k_wave_guide", "k_wave_shade_b", "k_wave_shade")
 
 
@@ -132,5 +132,11 @@ traffic["configs"][cfg] = {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]
                                "atomic_sector_updates_per_launch": v.get("TCC_EA0_ATOMIC_sum")}
                            for k, v in out["kernels"].items()}
 traffic["configs"][cfg]["_source_hash"] = source_hash()
+try:  # the table resolutions of the forest the counters were taken of (bench.py flags a run whose forest has others)
+    bj = json.load(open(os.path.join(dst, "bench_under_rocprof.json")))
+    traffic["configs"][cfg]["_jump_bits"] = int(bj["config"]["jump_bits"])
+    traffic["configs"][cfg]["_kd_grid_bits"] = int(bj["config"]["kd_grid_bits"])
+except Exception:
+    pass
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps(out, indent=1))
