@@ -445,6 +445,12 @@ __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tma
 	return best;
 }
 
+// (Measured and removed, round 5: TWO closest-hit walks per lane -- a lane works on whichever of its two rays stands at a node
+// and sits out a node round only when both stand at a leaf; the walks change places in the registers, one v_swap each.  By the
+// counters 31 of 64 lanes are busy per vector cycle of k_wave_trace, and this fills the rounds -- but two walks are 118
+// registers, four waves per SIMD instead of seven, and the kernel went from 11.5 to 15.9 ms per step (torus 3.8 -> 5.1),
+// bit-exact: profiles/r05/ab_trace_two_rays_per_lane_rejected.txt.  What the walk lacks is not lanes but waves.)
+
 // scenes without meshes (feature levels 0 and 1): no stack
 template <int kGeneral, bool kAny = false>
 __device__ __forceinline__ int intersect(const Shapes &sh, v3 o, v3 d, float tmax, float &t_out)
