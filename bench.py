@@ -33,15 +33,21 @@ timed in a SECOND region of K steps that follows the K steps of `value` at once:
 pg_render_stages(2) -- by default a bounce's shading, SD-tree calls and shadow ray are ONE kernel, k_wave_shade, in which
 they cannot be timed apart; `roofline.region` says which region the figures are of).  Two byte models over its mean
 launch time (HIP events recorded by the library on the launch stream) and the 8 TB/s HBM peak:
-  frac         SURVEY.md 8d's ALGORITHMIC bytes: 16 B per KD level + 20 B per quadtree level of the REFERENCE's descents, levels
-               counted by an instrumented pass.  The jump grid and jump tables serve most of those levels with one gather
-               each, so this exceeds 1 on spatially sorted lists: not a bandwidth (model_applicable false).
-  frac_layout  the bytes the lanes of that pass GATHERED from the tables of the built layout (16 per KD grid entry / node below
-               it, 8 per tree head, 16 per jump-table entry, 32 per quadtree record of a pdf or sampling walk, 16 per record
-               of a leaf walk; pg_depth_counters.layout_bytes), nothing credited for lanes of a wave that share a line --
-               what the memory pipeline moves at least; <= 1 by construction.
-`traffic` = HBM bytes of the PMC counters per launch (profiles/pmc_traffic.json, refused unless taken of exactly this code).
-`kernels` lists every kernel of a step with its share and, from the committed PMC figures, its counter traffic per second.
+  frac / achieved   the bytes the lanes of an instrumented pass GATHERED from the tables of the built layout (16 per KD grid entry /
+               node below it, 8 per tree head, 16 per jump-table entry, 32 per quadtree record of a pdf or sampling walk, 16 per
+               record of a leaf walk; pg_depth_counters.layout_bytes), nothing credited for lanes of a wave that share a line --
+               what the memory pipeline moves at least; <= 1 by construction; recomputable from layout_bytes_per_launch and
+               avg_launch_us (the rocprofv3 summary of the same command under profiles/ has the same average).
+  frac_model_8d  SURVEY.md 8d's ALGORITHMIC bytes: 16 B per KD level + 20 B per quadtree level of the REFERENCE's descents, levels
+               counted by the same pass.  The jump grid and jump tables serve most of those levels with one gather each, so this
+               exceeds 1 on spatially sorted lists: not a bandwidth (model_applicable false).  (Rounds 1-4 had this under `frac`.)
+`traffic` = HBM bytes of the PMC counters per launch (profiles/pmc_traffic.json, refused unless taken of exactly this code;
+traffic_tables_match: the forest of this run has the table resolutions of the profiled one).
+`kernels` lists every kernel of a step with its share and, from the committed PMC figures, its counter traffic per second
+(pmc_frac_of_hbm_peak: as counted; ..._fetch_x2: with the guide's FETCH correction, an upper bound).
+`kernels_synthetic` / roofline.s1_* s2_* s3_*: the stand-alone entry points on SURVEY 8(d)'s S1 / S2 / S3 with the same two fractions and,
+from the cpu_baseline leg, the CPU restatement's rate on the same inputs (cpu_G_units_per_s, cpu_cores).
+config.c2_* / c3_* / c5_*: BASELINE configs[1], [2], [4] timed for a few steps in the same run (other_configs_leg).
 
 `--synthetic` runs the renderer-free hot-path workload instead (seeded synthetic surface points).
 Launch:  python bench.py [--gpus N]      (N > 1 without WORLD_SIZE in the environment: this process starts N fresh

@@ -21,6 +21,9 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef __int128 i128;
 typedef unsigned __int128 u128;
@@ -780,35 +783,54 @@ void pgo_add_data_propagate(pgo_tree *t, size_t m, const float *pos, const float
 {
 	KD *k = &t->kd;
 	/* several threads: the counts are exact integers and the irradiance sums exact 128-bit integers (acc_add), so the
-	 * records may be added in any order by any number of threads */
-	const int mt = pgo_threads_in_effect() > 1 && m > 1024;
+	 * records may be added in any order by any number of threads.  The KD counts go to a private array per thread first
+	 * (every record bumps the root and the nodes under it: one shared counter would be all the threads do), summed at the end;
+	 * the quadtree sums are added in place with carry-correct atomic adds. */
+	const int nth = pgo_threads_in_effect();
+	const int mt = nth > 1 && m > 1024;
+	uint64_t *part = NULL; /* [thread][node] */
+	if (mt && (size_t)nth * k->n * sizeof(uint64_t) <= ((size_t)256 << 20)) part = calloc((size_t)nth * k->n, sizeof(uint64_t));
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(pgo_threads_in_effect()) if (mt)
+#pragma omp parallel num_threads(nth) if (mt)
 #endif
-	for (size_t i = 0; i < m; ++i) {
-		float p[3] = { pos[i], pos[m + i], pos[2 * m + i] };
-		/* kdtree.py:185-217: vertCount += 1 on every visited node */
-		uint32_t node = 0;
-		int active = kd_contains(k, 0, p);
-		for (int guard = 0; active && guard < 64; ++guard) {
-			if (mt) __atomic_fetch_add(&k->count[node], 1, __ATOMIC_RELAXED);
-			else k->count[node] += 1;
-			if (k->isLeaf[node]) break;
-			uint32_t l = k->left[node], r = k->right[node], next = node;
-			if (kd_contains(k, l, p)) next = l;
-			if (kd_contains(k, r, p)) next = r;
-			if (next == node) break;
-			node = next;
+	{
+#ifdef _OPENMP
+		uint64_t *mine = part ? part + (size_t)omp_get_thread_num() * k->n : NULL;
+#pragma omp for schedule(static)
+#else
+		uint64_t *mine = NULL;
+#endif
+		for (size_t i = 0; i < m; ++i) {
+			float p[3] = { pos[i], pos[m + i], pos[2 * m + i] };
+			/* kdtree.py:185-217: vertCount += 1 on every visited node */
+			uint32_t node = 0;
+			int active = kd_contains(k, 0, p);
+			for (int guard = 0; active && guard < 64; ++guard) {
+				if (mine) mine[node] += 1;
+				else if (mt) __atomic_fetch_add(&k->count[node], 1, __ATOMIC_RELAXED);
+				else k->count[node] += 1;
+				if (k->isLeaf[node]) break;
+				uint32_t l = k->left[node], r = k->right[node], next = node;
+				if (kd_contains(k, l, p)) next = l;
+				if (kd_contains(k, r, p)) next = r;
+				if (next == node) break;
+				node = next;
+			}
+			/* kdtree.py:224-225: unmasked gather -> out-of-bbox records use node 0's tree */
+			uint32_t root = k->qroot[node];
+			float wp = woPdf[i];
+			float w = wp > 0.0f ? radiance[i] / wp : 0.0f;            /* quadtree.py:451 */
+			qt_add_one_mt(&t->qt, root, dir[i], dir[m + i], w, mt);
+			if (t->qt.storeNEE) {
+				float wn = wp > 0.0f ? radNeeLum[i] / wp : 0.0f;      /* quadtree.py:461-462 */
+				qt_add_one_mt(&t->qt, root, dirNee[i], dirNee[m + i], wn, mt);
+			}
 		}
-		/* kdtree.py:224-225: unmasked gather -> out-of-bbox records use node 0's tree */
-		uint32_t root = k->qroot[node];
-		float wp = woPdf[i];
-		float w = wp > 0.0f ? radiance[i] / wp : 0.0f;            /* quadtree.py:451 */
-		qt_add_one_mt(&t->qt, root, dir[i], dir[m + i], w, mt);
-		if (t->qt.storeNEE) {
-			float wn = wp > 0.0f ? radNeeLum[i] / wp : 0.0f;      /* quadtree.py:461-462 */
-			qt_add_one_mt(&t->qt, root, dirNee[i], dirNee[m + i], wn, mt);
-		}
+	}
+	if (part) {
+		for (int th = 0; th < nth; ++th)
+			for (size_t j = 0; j < k->n; ++j) k->count[j] += part[(size_t)th * k->n + j];
+		free(part);
 	}
 }
 
