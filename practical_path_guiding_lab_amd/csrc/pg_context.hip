@@ -371,6 +371,15 @@ int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t rese
 	if (getenv("PGSD_TRACE_SHADOW") && h.body_waves)
 		fprintf(stderr, "[pgsd] k_wave_shade: %llu waves ran the body, %llu of them walked shadow rays with %llu lanes (%.1f of 64 per walking wave)\n",
 		        h.body_waves, h.shadow_waves, h.shadow_lanes, h.shadow_waves ? (double)h.shadow_lanes / (double)h.shadow_waves : 0.0);
+	if (getenv("PGSD_TRACE_SHADOW") && h.body_waves) {
+		unsigned long long tot = 0;
+		for (int i = 0; i < 7; ++i) tot += h.phase[i];
+		if (tot) {
+			static const char *names[7] = {"records + staging", "stage_a1", "shadow walk", "stage_a2", "SD-tree calls", "stage_b", "append"};
+			fprintf(stderr, "[pgsd] k_wave_shade: a wave's %.0f cycles on average, by phase:", (double)tot / (double)h.body_waves);
+			for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f %%%s", names[i], 100.0 * (double)h.phase[i] / (double)tot, i < 6 ? "," : "\n");
+		}
+	}
 	if (reset) PG_HIP(ctx, hipMemset(ctx->dc, 0, sizeof(DepthCounters)));
 	return PG_OK;
 }

@@ -15,6 +15,9 @@ struct DepthCounters { // device-resident, optional
 	// (diagnostics of instrumented passes, printed by pg_read_depth_counters under $PGSD_TRACE_SHADOW: how full are the waves
 	// that walk shadow rays in k_wave_shade?)  waves that walked, their lanes with a ray, waves that ran the kernel's body
 	unsigned long long shadow_waves, shadow_lanes, body_waves;
+	// ... and where does a wave of k_wave_shade spend its life?  Clock cycles (s_memtime) summed over the waves, phase by phase:
+	// 0 the records + staging, 1 stage_a1, 2 the shadow walk, 3 stage_a2, 4 the SD-tree calls, 5 stage_b, 6 the survivors' append
+	unsigned long long phase[8];
 };
 
 // ---- queries (pg_kernels_query.hip) ----

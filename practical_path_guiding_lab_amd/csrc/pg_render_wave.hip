@@ -994,11 +994,6 @@ constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage *
 // (122 vector registers, four waves per SIMD, which is also what 33 KB of LDS per workgroup allow.  Measured: staging the
 // records 128 at a time -- 23 KB -- changes nothing by itself, and compiled for five waves on top of that the kernel spills
 // 31 registers: 35.2 -> 37.6 ms per step.)
-#ifdef PG_SHADE1_WAVES
-#define PG_SHADE1_OCC __attribute__((amdgpu_waves_per_eu(PG_SHADE1_WAVES)))
-#else
-#define PG_SHADE1_OCC
-#endif
 // The paths' 128-byte records of a sorted bounce are read THROUGH LDS by the wave as a whole (PG_SHADE_COOP): a lane that
 // gathers the seven 16-byte entries of its own record makes seven vector loads that each touch 64 different cache lines --
 // the compute unit's L1 looks up about one line per clock, so such a load holds the vector-memory path for 64 clocks however
@@ -1021,6 +1016,43 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	// Probe builds only (-DPG_SHADE_PHASES=1; the instrumented pass of such a build prints the shares under $PGSD_TRACE_SHADOW):
+	// where a wave spends its life, DepthCounters::phase.  NOT in the product: the seven s_memtime stamps, behind a uniform
+	// branch that is never taken in a timed pass, took k_wave_shade from 28.6 to 45-47 ms per step (profiles/r05/
+	// ab_shade_early_staging.txt: every variant of that run carries them).
+#ifndef PG_SHADE_PHASES
+#define PG_SHADE_PHASES 0
+#endif
+#if PG_SHADE_PHASES
+	unsigned long long t_phase = a.dc ? (unsigned long long)clock64() : 0ull;
+#define PG_PHASE(i)                                                                                                          \
+	if (a.dc) {                                                                                                              \
+		const unsigned long long t_now = (unsigned long long)clock64();                                                      \
+		if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) atomicAdd(&a.dc->phase[i], t_now - t_phase);     \
+		t_phase = t_now;                                                                                                     \
+	}
+#else
+#define PG_PHASE(i)
+#endif
+	// What the workgroup stages in LDS -- the KD grid's planes and the BVH's top -- is ASKED FOR first and written last: the loads
+	// are in flight while the records make their own two round trips (the permutation, then the entries), instead of being
+	// two more round trips behind them, each with a barrier of its own (an instrumented pass showed a quarter of a wave's life
+	// gone before stage_a1 began: profiles/r05/shade_phases.txt).
+#ifndef PG_SHADE_EARLY
+#define PG_SHADE_EARLY 1
+#endif
+	float pl_pre = 0.0f;
+	u32x4_t top_pre[2];
+	top_pre[0] = u32x4_t{0u, 0u, 0u, 0u};
+	top_pre[1] = top_pre[0];
+	const uint32_t n_top = a.shapes.n_bvh_nodes < kShadeTopNodes ? (uint32_t)a.shapes.n_bvh_nodes : (uint32_t)kShadeTopNodes;
+	static_assert(kShadeTopNodes * 8 <= 2 * kRBlock && 3 * kKdGridPlanes <= kRBlock, "k_wave_shade: the staging loads of one thread");
+#if PG_SHADE_EARLY
+	if (a.tree.kd_grid != nullptr && threadIdx.x < 3u * kKdGridPlanes) pl_pre = a.tree.kd_planes[threadIdx.x];
+#pragma unroll
+	for (int k = 0; k < 2; ++k)
+		if (threadIdx.x + k * kRBlock < n_top * 8u) top_pre[k] = reinterpret_cast<const u32x4_t *>(a.shapes.bvh)[threadIdx.x + k * kRBlock];
+#endif
 	uint4 cq0 = make_uint4(0u, 0u, 0u, 0u), cq1 = cq0, cq2 = cq0, cq3 = cq0, cq4 = cq0, cq5 = cq0, cq6 = cq0;
 	uint32_t coop_place = (uint32_t)tid;
 	const bool coop = PG_SHADE_COOP && !kFirst && a.perm != nullptr; // (uniform)
@@ -1040,11 +1072,22 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		cq6 = s_dyn[6 * kRBlock + threadIdx.x];
 		__syncthreads(); // every wave has its entries: the bytes become the BVH's top, the stacks and the stash
 	}
-	stage_kd_planes(s_planes, a.tree);
 	uint2 *s_stack = reinterpret_cast<uint2 *>(s_dyn);
 	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kShadeStack * kRBlock / 2;
 	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack, kShadeStack);
+#if PG_SHADE_EARLY
+	if (a.tree.kd_grid != nullptr && threadIdx.x < 3u * kKdGridPlanes) s_planes[threadIdx.x] = pl_pre;
+#pragma unroll
+	for (int k = 0; k < 2; ++k)
+		if (threadIdx.x + k * kRBlock < n_top * 8u) s_top[threadIdx.x + k * kRBlock] = top_pre[k];
+	__syncthreads();
+	stk.top = (const LdsQuad *)s_top;
+	stk.n_top = n_top;
+#else
+	(void)pl_pre; (void)top_pre; (void)n_top;
+	stage_kd_planes(s_planes, a.tree);
 	stage_bvh_top<kShadeTopNodes>(s_top, a, stk);
+#endif
 	bool cont = false;
 	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(1, 1, 1), L = V(0, 0, 0), p_here = V(0, 0, 0), prev_p = V(0, 0, 0);
 	float ior = 1.0f, prev_pdf = 1.0f;
@@ -1106,6 +1149,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 			h.t = wsf(a, WS_HIT_T, tid); h.u = wsf(a, WS_HIT_U, tid); h.v = wsf(a, WS_HIT_V, tid);
 		}
 		StageA A;
+		PG_PHASE(0)
 		stage_a1<kLevel>(a, rng, ray_o, ray_d, thr, prev_p, prev_pdf, prev_delta, h, (uint32_t)a.bounce, A);
 		// What stage_a1 leaves is PINNED here: every output is made now, so that its inputs die.  (Left alone the compiler
 		// sinks the last operations of a value that is only read behind the walk -- the emitted radiance's three products, the
@@ -1135,6 +1179,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		// bounce keeps were this kernel's register peak (123 with the walk at the end).  The walk draws no
 		// sample, so the sampler's order is untouched.
 		bool occluded = false;
+		PG_PHASE(1)
 		if (a.dc) { // (instrumented passes only: how full are the waves that walk?)
 			const unsigned long long m = __ballot((A.flags & F_NEED_SHADOW) != 0u);
 			if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) {
@@ -1146,6 +1191,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 			float th, bu, bv;
 			occluded = intersect<kLevel, true, PG_SHADE_SLIM != 0>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
 		}
+		PG_PHASE(2)
 #if PG_SHADE_PIN
 		// (the shading frame and the material row are functions of the normal and the material's number: made again from
 		// them behind the walk -- a dozen operations and two loads -- instead of being carried through it, which is what
@@ -1164,8 +1210,10 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
 		g.wo = A.wo;
+		PG_PHASE(3)
 		if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, (A.flags & F_SMP_TREE) ? V(0, 0, 0) : A.wo, A.flags, g);
 		if (a.record && (A.flags & F_VALID)) store_slots(a, rec_base + tid, g);
+		PG_PHASE(4)
 #if PG_SHADE_PIN
 		asm volatile("" : "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z), "+v"(A.mat)); // (the same behind the SD-tree walks, for stage_b's second BSDF evaluation)
 #endif
@@ -1194,19 +1242,22 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		p_here = A.p;
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
 		if (!cont) a.Lq[lane] = make_uint4(__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u); // the path ends here
+		PG_PHASE(5)
 	}
 	// (append_survivors' first barrier comes after every walk of the workgroup: from there on the stacks' bytes hold records)
 	append_survivors<kShadeStage>(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_dyn);
+	PG_PHASE(6)
+#undef PG_PHASE
 }
 
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) PG_SHADE1_OCC void k_wave_shade(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
 {
 	shade_body<kLevel, kFirst>(a);
 }
-// Feature level 3 (torus: transmission, delta lobes, one-sided BSDFs) needs one register more than five waves per SIMD leave
-// (97 of 96); told the occupancy it is wanted at, the compiler finds an allocation of 95 without a byte of scratch.  (The
-// same hint makes the level-2 kernel spill 12 bytes per lane: it fits by itself and is left alone.)
+// Feature level 3 (torus: transmission, delta lobes, one-sided BSDFs) needs three registers more than five waves per SIMD leave
+// (99 of 96); told the occupancy it is wanted at, the compiler finds an allocation of 96 without a byte of scratch.  (The
+// same hint makes the level-2 kernel, which fits by itself at 96, spill 12 bytes per lane: it is left alone.)
 template <bool kFirst>
 __global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_wave_shade_l3(RenderArgs a)
 {
