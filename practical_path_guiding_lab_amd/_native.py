@@ -117,7 +117,7 @@ EXPORTS = (
     "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_film_batched", "pg_film_batched_accumulate", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
     "pg_render_split_pipeline", "pg_comm_info", "pg_exchange_pack", "pg_exchange_unpack", "pg_exchange_pack_words",
-    "pg_exchange_unpack_words",
+    "pg_exchange_unpack_words", "pg_sort_places",
 )
 
 
@@ -217,6 +217,7 @@ def lib() -> C.CDLL:
     L.pg_exchange_unpack.argtypes = [V, V]
     L.pg_exchange_pack_words.argtypes = [V, U64, V]
     L.pg_exchange_unpack_words.argtypes = [V, U64, V]
+    L.pg_sort_places.argtypes = [V, U64, V, V, V, V]
     L.pg_render_reserve.argtypes = [V, U64]
     L.pg_render_split_pipeline.argtypes = [V, C.c_int32]
     for name in EXPORTS:

@@ -349,6 +349,24 @@ int pg_accumulators(pg_context *ctx, int64_t **d_buffer, uint64_t *count)
 	return PG_OK;
 }
 
+int pg_sort_places(pg_context *ctx, uint64_t n, const uint16_t *d_keys, const uint32_t *d_live, uint32_t *d_places_out, void *stream)
+{
+	if (!ctx) return PG_ERR_INVALID;
+	if (n == 0) return PG_OK;
+	if (!d_keys || !d_places_out) return fail(ctx, PG_ERR_INVALID, "pg_sort_places: NULL pointer");
+	if (n >= (1ull << 28)) return fail(ctx, PG_ERR_INVALID, "pg_sort_places: at most 2^28 - 1 places");
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+	DevBuf<char> tmp;
+	DevBuf<uint16_t> keys_mid;
+	const size_t bytes = sort_pairs_temp_bytes((uint32_t)n);
+	PG_HIP(ctx, tmp.ensure(bytes));
+	PG_HIP(ctx, keys_mid.ensure((size_t)n));
+	PG_HIP(ctx, sort_places16(tmp.p, bytes, d_keys, keys_mid.p, d_places_out, (uint32_t)n, d_live, s));
+	PG_HIP(ctx, hipStreamSynchronize(s)); // (the scratch buffers go out of scope)
+	return PG_OK;
+}
+
 int pg_enable_depth_counters(pg_context *ctx, int32_t on)
 {
 	if (!ctx) return PG_ERR_INVALID;

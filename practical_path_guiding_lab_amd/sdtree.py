@@ -277,6 +277,20 @@ class SDTree:
         self._ck(self._lib.pg_accumulators(self._h, C.byref(p), C.byref(n)))
         return _wrap_device_i64(p.value, n.value, self.device)
 
+    def sortPlaces(self, keys: torch.Tensor, live: Optional[int] = None) -> torch.Tensor:
+        """pg_sort_places: the ordering step of a sorted bounce by itself -- keys: uint16-valued places' keys (an int16 / uint16
+        tensor of n entries on this device); returns the uint32 places (as int32 bits) in key order for the first `live` places."""
+        n = int(keys.numel())
+        k = keys.contiguous()
+        if k.element_size() != 2:
+            raise TypeError("keys: a 16-bit tensor")
+        out = torch.full((n,), -1, dtype=torch.int32, device=self.device)
+        d_live = None
+        if live is not None:
+            d_live = torch.tensor([int(live)], dtype=torch.int32, device=self.device)
+        self._ck(self._lib.pg_sort_places(self._h, n, k.data_ptr(), None if d_live is None else d_live.data_ptr(), out.data_ptr(), _stream_ptr()))
+        return out
+
     def packAccumulators(self) -> torch.Tensor:
         """sdTree_current's accumulators in the 24-byte exchange format (pg_exchange_pack, on the current stream): the int64
         tensor a host-side collective sums instead of accumulators() -- a quarter fewer bytes; unpackAccumulators() writes

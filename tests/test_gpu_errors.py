@@ -25,6 +25,23 @@ def _msg(L, h):
     return L.pg_last_error(h).decode()
 
 
+def test_exchange_entry_points_before_their_preconditions(ctx):
+    """pg_exchange_pack / _unpack / pg_comm_info: a configured tree, a packed buffer, a communicator."""
+    N, L, h = ctx
+    p, n = C.c_void_p(), C.c_uint64()
+    assert L.pg_exchange_pack(h, C.byref(p), C.byref(n), None) < 0 and "pg_setup" in _msg(L, h)
+    assert L.pg_exchange_unpack(h, None) < 0
+    lo, hi = (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1)
+    assert L.pg_setup(h, lo, hi, 16, 4, 20, 20, 1, 0.5) == 0
+    assert L.pg_exchange_unpack(h, None) < 0 and "pg_exchange_pack first" in _msg(L, h)
+    assert L.pg_exchange_pack(h, None, C.byref(n), None) < 0
+    assert L.pg_exchange_pack(h, C.byref(p), C.byref(n), None) == 0 and n.value == 3 + 1 and p.value   # one tree: its root accumulator + fallback counter
+    assert L.pg_exchange_unpack(h, None) == 0
+    a, b = C.c_int32(), C.c_int32()
+    assert L.pg_comm_info(h, C.byref(a), C.byref(b)) < 0 and "pg_comm_init" in _msg(L, h)
+    assert L.pg_exchange_pack_words(None, 1, None) < 0 and L.pg_exchange_unpack_words(None, 1, None) < 0
+
+
 def test_calls_before_setup_and_bad_arguments(ctx):
     import torch
 

@@ -536,7 +536,16 @@ def _worker_drive_batched(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    img, tree, rows = _drive((rank, world, 4), spp_per_pass=1, training_passes_per_launch=5)
+    # (a caller-supplied exchange, as bench.py hands the driver libpgsd's own: it is given the accumulators in their 24-byte
+    # exchange format and is ORDERED ahead of the image collectives -- exchange_overlap stays off for it)
+    from practical_path_guiding_lab_amd.parallel import all_reduce_accumulators
+    seen = []
+
+    def exchange(acc):
+        seen.append(int(acc.numel()))
+        all_reduce_accumulators(acc)
+    img, tree, rows = _drive((rank, world, 4), spp_per_pass=1, training_passes_per_launch=5, all_reduce=exchange)
+    assert seen and all(n % 1 == 0 for n in seen)
     np.savez(out % rank, image=img, **{"rec_" + k: v for k, v in rows.items()}, **tree)
     dist.barrier()
     dist.destroy_process_group()
