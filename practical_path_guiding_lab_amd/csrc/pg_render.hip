@@ -568,7 +568,7 @@ struct PassBuf {
 	DevBuf<uint32_t> ray_of;
 	DevBuf<float> r_bsdf, r_tb, r_tr, r_nee, r_wp;
 	// pg_render_sort: keys of the places (written by k_wave_trace), the sorted keys, the identity, the places in sorted
-	// order, rocPRIM's temporary storage
+	// order, the sort's temporary storage (pg_sort.hip)
 	DevBuf<uint16_t> sort_key, sort_key_out;
 	DevBuf<uint32_t> sort_perm;
 	DevBuf<uint4> carry[2]; // the paths' 128-byte records of a sorted bounce (RenderArgs::carry_in), two sets swapped per bounce:
@@ -681,7 +681,7 @@ static int ensure_pass_buffers(pg_context *ctx, int slot, uint64_t N, bool recor
 	} else {
 		for (int k = 0; k < 2; ++k) { PG_HIP(ctx, b.st[k].ensure(5 * N)); PG_HIP(ctx, b.inc[k].ensure(N)); }
 		PG_HIP(ctx, b.Lq.ensure(N));
-		if (r->sort) { // pg_render_sort: keys, the sorted places, the paths' 128-byte records, rocPRIM's temporary storage
+		if (r->sort) { // pg_render_sort: keys, the sorted places, the paths' 128-byte records, the sort's temporary storage
 			if (N > 0xfffffff0ull) return fail(ctx, PG_ERR_INVALID, "pg_render_sort: more than 2^32 lanes in one pass");
 			PG_HIP(ctx, b.sort_key.ensure(N)); PG_HIP(ctx, b.sort_key_out.ensure(N)); PG_HIP(ctx, b.sort_perm.ensure(N));
 			PG_HIP(ctx, b.carry[0].ensure(8 * N)); PG_HIP(ctx, b.carry[1].ensure(8 * N));

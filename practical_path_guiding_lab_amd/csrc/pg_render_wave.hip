@@ -879,7 +879,6 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
-	const uint64_t N = a.n_lanes;
 	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
 	uint64_t rec_base = 0;
 	if (!kFirst) {
@@ -1281,7 +1280,6 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
 	stage_kd_planes(s_planes, a.tree);
 	bool alive = tid < live;
-	const uint64_t N = a.n_lanes;
 	uint64_t lane = 0;
 	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce
 	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
