@@ -68,7 +68,7 @@ t0 = time.perf_counter()
 g.refineAndPrepareSDTreeForNextIteration()
 torch.cuda.synchronize()
 refine_ms = (time.perf_counter() - t0) * 1e3
-acc_bytes = int(g.sdTree.accumulators().numel()) * 8
+acc_bytes = int(g.sdTree.packAccumulators().numel()) * 8  # (what travels since round 5: the 24-byte exchange format)
 steps = 128 // spp
 allreduce_ms = acc_bytes * 2.0 * (world - 1) / world / 153e9 * 1e3
 t1 = steps * full + refine_ms
