@@ -181,6 +181,8 @@ def make_scene(name, width, depth):
 
 
 ATOMIC_CEILING_GPS = 23.6  # G sector-updates/s chip-wide: tools/atomic_probe.hip on MI355X (round 1), scattered 64-bit adds
+RANDOM_GATHER_CEILING_GPS = 55.0  # G lanes/s, every lane its own 16 bytes of a table beyond every cache (268 MB - 1 GB): tools/gather_probe.hip
+#                                   on MI355X (profiles/r05/gather_probe.txt) = 0.88 TB/s of useful bytes, 0.11 of the 8 TB/s peak; 242 G/s from 4 MB (L2)
 
 
 def traffic_for(kernel, key):
@@ -979,8 +981,14 @@ def synthetic_kernels_leg(device, cpu=False):
         lay_pdf = dc.layout_bytes + 8 * dc.kd_queries
         # (a leaf lookup alone gathers the KD side of that launch: what pdf's walks add is 16 per table hit + 32 per record)
         ms_pdf = timed(lambda: tree.pdf(P, D))
-        put(tag + "_pg_pdf", tag.upper() + " pg_pdf", nq, ms_pdf, nq * (16.0 * d_kd + 20.0 * d_q), lay_pdf,
-            {"D_kd": round(d_kd, 3), "D_quad": round(d_q, 3)})
+        extra_pdf = {"D_kd": round(d_kd, 3), "D_quad": round(d_q, 3)}
+        if tag == "s1":
+            # S1's pdf walks end in the jump tables (64 KB per tree x 4096 trees = 268 MB: beyond every cache): ONE random 16-byte
+            # gather per lane from HBM, beside the KD grid's and the tree head's, which hit in L2 -- the chip's rate for that pattern
+            extra_pdf["hbm_random_gathers_per_lane"] = 1
+            extra_pdf["random_gather_ceiling_G_per_s"] = RANDOM_GATHER_CEILING_GPS
+            extra_pdf["frac_of_random_gather_ceiling"] = round(nq / ms_pdf / 1e6 / RANDOM_GATHER_CEILING_GPS, 3)
+        put(tag + "_pg_pdf", tag.upper() + " pg_pdf", nq, ms_pdf, nq * (16.0 * d_kd + 20.0 * d_q), lay_pdf, extra_pdf)
 
         def do_sample():
             tree.sample(P, smp)
