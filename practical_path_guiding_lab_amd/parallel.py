@@ -102,8 +102,9 @@ def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
     multi-node jobs are eligible).  Returns False on every rank when the ranks are not eligible or RCCL
     cannot be loaded on rank 0 -- the caller then exchanges through torch.distributed
     (all_reduce_accumulators), the same RCCL all-reduce issued by PyTorch.  Once the ranks have agreed to
-    join, a rank that fails raises: the process ends with a non-zero exit code and the launcher ends the
-    job.  There is no half-joined communicator and no fallback decided by one rank alone."""
+    join, a rank on which the join fails says so in a second collective vote and EVERY rank falls back to
+    torch.distributed; a rank whose peers never arrive is ended by the Watchdog (non-zero exit: the launcher ends
+    the job).  There is no half-joined communicator and no fallback decided by one rank alone."""
     if not dist.is_available() or not dist.is_initialized():
         return False
     import os
@@ -126,12 +127,29 @@ def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
     if ident[0] is None:
         return False
     # ncclCommInitRank blocks until every rank has joined: bounded (a rank whose peers never come exits non-zero and the
-    # launcher ends the job); raises on failure
+    # launcher ends the job).  A rank on which the call FAILS -- or on which RCCL then reports other numbers than the process
+    # group's (ncclCommCount / ncclCommUserRank read back) -- says so in a second vote: the library communicator is used by
+    # every rank or by none (the others let go of theirs, and everybody exchanges through torch.distributed instead).
+    ok, why = 1, ""
     with Watchdog(comm_init_timeout_s(), f"rank {rank}: ncclCommInitRank of libpgsd's communicator ({world} ranks)"):
-        tree.commInit(world, rank, ident[0])
-    n_seen, r_seen = tree.commInfo()  # what RCCL itself says (ncclCommCount / ncclCommUserRank)
-    if (n_seen, r_seen) != (world, rank):
-        raise RuntimeError(f"libpgsd communicator: RCCL reports {n_seen} ranks / rank {r_seen}, expected {world} / {rank}")
+        try:
+            tree.commInit(world, rank, ident[0])
+            n_seen, r_seen = tree.commInfo()
+            if (n_seen, r_seen) != (world, rank):
+                ok, why = 0, f"RCCL reports {n_seen} ranks / rank {r_seen}, expected {world} / {rank}"
+        except Exception as e:  # noqa: BLE001 (whatever the library raises: the vote below decides for everybody)
+            ok, why = 0, str(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=_flag_device(group))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        import warnings
+        if not ok:
+            warnings.warn(f"rank {rank}: libpgsd RCCL communicator not usable ({why}); every rank exchanges through torch.distributed")
+        try:
+            tree.commDestroy()
+        except Exception:  # noqa: BLE001
+            pass
+        return False
     return True
 
 

@@ -837,6 +837,17 @@ def _worker_nccl_one_rank(rank, world, port, out):
     t = max_over_ranks(0.25, device="cuda")
     if ok:
         g.commDestroy()
+    # a join that FAILS on a rank: the second vote sends every rank to the torch.distributed exchange, nobody raises or hangs
+    import warnings
+    g2 = SDTree(0)
+    g2.load(_base_tree())
+
+    def broken(*a_, **k_):
+        raise RuntimeError("ncclCommInitRank: simulated failure")
+    g2.commInit = broken
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ok = ok and (init_library_comm(g2) is False)
     dist.barrier()
     dist.destroy_process_group()
     np.save(out, np.array([ok, same, float(s1.sum()) == 24.0 and float(s2.sum()) == 48.0, lo == 7.0 and hi == 7.0, t == 0.25]))
