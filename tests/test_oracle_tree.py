@@ -466,3 +466,68 @@ def test_threaded_stand_alone_entry_points_equal_the_single_threaded_ones():
     for a, b in zip(out[1], out[7]):
         assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
     assert out[1][5][0] == 3 * (1 << 16) and int(np.abs(out[1][7]).max()) > 0   # the high halves are in use
+
+
+def test_the_scalar_oracle_equals_a_wavefront_restatement_of_the_reference():
+    """oracle/pg_oracle.c walks lane by lane; the reference is a masked wavefront program (masked gathers yield 0, masked
+    scatters overwrite in statement order).  tests/wavefront_model.py restates getLeafNodeIndex, pdfQuadTree, sampleQuadTree
+    and addIrradiancePropagate in THAT form on the 23-key columns: two independently structured programs must agree bit for
+    bit -- leaf indices (ties on split planes, points outside the box, NaN), pdfs (ties on cell boundaries take the first
+    child's energy and walk into the last), sampled directions and sampler states (three draws per visited node, the leaf
+    included), and the nodes a record adds to."""
+    import synth
+    import wavefront_model as wm
+    from oracle import pg_oracle as po
+
+    pair = synth.build_skewed(1 << 12, 4)
+    tree = pair.prev
+    t = tree.export()
+    n = 6000
+    p = synth.positions_uniform(n, 21, [0.0] * 3, [100.0] * 3)
+    # points ON split planes (ties go right), outside the box, NaN
+    kd_lo, kd_hi = t["kdtree_bbox_min"], t["kdtree_bbox_max"]
+    inner = np.nonzero(~t["kdtree_isLeaf"])[0]
+    for j, node in enumerate(inner[:40]):
+        right = t["kdtree_child_right_index"][node]
+        axis = int(t["kdtree_depth"][node]) % 3
+        q = (0.5 * (kd_lo[right].astype(np.float64) + kd_hi[right].astype(np.float64))).astype(np.float32)
+        q[axis] = kd_lo[right][axis]                      # the plane the two children share
+        p[:, j] = q
+    p[:, 100] = np.float32(1e9)
+    p[0, 101] = np.float32("nan")
+    np.testing.assert_array_equal(wm.kd_get_leaf_node_index(t, p.T.copy()), tree.get_leaf_node_index(p))
+    leaf = tree.get_leaf_node_index(p)
+    roots = t["kdtree_quadTreeRootIndex"][leaf].astype(np.uint32)
+    # directions: random, and canonical positions exactly on cell boundaries of every depth
+    d = synth.directions_uniform(n, 22)
+    c = synth.canonical_uniform(n, 23)
+    c[:, :2000] = np.floor(c[:, :2000] * np.float32(32)) / np.float32(32)     # multiples of 1/32: on the boundaries of levels <= 5
+    d[:, :3000] = po.canonical_to_dir(c)[:, :3000]
+    d[2, 3001] = np.float32("nan")
+    pdf_o = tree.pdf_quadtree(roots, d)
+    pdf_w = wm.quad_pdf(t, roots, d.T.copy())
+    np.testing.assert_array_equal(pdf_w.view(np.uint32), pdf_o.view(np.uint32))
+    assert (pdf_o > 0).sum() > n // 2
+    st_o, inc = po.rng_seed(n, 7)
+    st_w = st_o.copy()
+    dir_o = tree.sample_quadtree(roots, st_o, inc)
+    dir_w, _ = wm.quad_sample(t, roots, st_w, inc)
+    np.testing.assert_array_equal(dir_w.T.copy().view(np.uint32), dir_o.view(np.uint32))
+    np.testing.assert_array_equal(st_w, st_o)
+    # the nodes a record adds to (quadtree.py:398-441): every lane's path, node for node, against the oracle's accumulators
+    m = 3000
+    cur = po.OracleTree()
+    cur.copy_from(tree)
+    cur.reset()
+    pos2 = c[:, :m].T.copy()
+    pos2[5] = [np.float32(1.5), np.float32(0.2)]          # outside the unit square: adds to nothing
+    w = np.ones(m, np.float32)
+    zero2 = np.full((2, m), np.float32(2.0))             # (the NEE direction outside the square: no second add)
+    cur.add_data_propagate(p[:, :m], np.ascontiguousarray(pos2.T), w, w, zero2, np.zeros(m, np.float32))
+    got = cur.quad_column("acc_lo")
+    exp = np.zeros_like(got)
+    q1 = int(po.quantize(np.ones(1, np.float32))[0][0])
+    for lanes, nodes in wm.quad_add_propagate(t, roots[:m], pos2):
+        np.add.at(exp, nodes, np.uint64(q1))
+    np.testing.assert_array_equal(got, exp)
+    assert exp.sum() > 0 and (cur.quad_column("acc_hi") == 0).all()
