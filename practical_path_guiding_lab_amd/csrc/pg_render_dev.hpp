@@ -21,7 +21,10 @@
 
 namespace pg {
 
-constexpr int kRBlock = 256;
+#ifndef PG_RBLOCK
+#define PG_RBLOCK 256
+#endif
+constexpr int kRBlock = PG_RBLOCK; // threads of a workgroup in every render kernel
 constexpr float kInvPiF = 0.31830988618379067154f;
 constexpr float kRayEps = 1e-4f;
 constexpr float kShadowEps = 1e-3f;

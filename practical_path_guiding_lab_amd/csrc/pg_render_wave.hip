@@ -410,12 +410,37 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, P
 
 // which live-list entry does this thread serve, if any: false for a whole workgroup past the list or
 // when a tail launch is finishing the paths (both uniform over the workgroup)
-template <bool kFirst>
+// kXcd: workgroups b, b + 8, b + 16, ... (dealt to ONE of the chip's eight XCDs, MI355X_MICROARCH.md "Workgroup dispatch")
+// take CONSECUTIVE tiles of the list, so that an XCD's L2 serves one eighth of a sorted list -- one region of the scene --
+// instead of every eighth tile of all of it.  Speed only: any assignment of workgroups to tiles gives the same results.
+// (The grid is a multiple of eight workgroups: launch_wave_stage.)
+#ifndef PG_XCD_TRACE
+#define PG_XCD_TRACE 0
+#endif
+#ifndef PG_XCD_SHADE
+#define PG_XCD_SHADE 0
+#endif
+#ifndef PG_XCD_RUN
+#define PG_XCD_RUN 0
+#endif
+template <bool kFirst, bool kXcd = false>
 __device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, bool &alive)
 {
-	tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
-	if ((uint64_t)blockIdx.x * kRBlock >= live) return false;
+	uint32_t tile = blockIdx.x;
+	if (kXcd) {
+#if PG_XCD_RUN
+		// runs of PG_XCD_RUN consecutive tiles per XCD, the eight XCDs' runs side by side: all of them advance through the list together
+		const uint32_t g = blockIdx.x >> 3;
+		tile = ((g / (uint32_t)PG_XCD_RUN) * 8u + (blockIdx.x & 7u)) * (uint32_t)PG_XCD_RUN + g % (uint32_t)PG_XCD_RUN;
+#else
+		const uint32_t per = ((uint32_t)((live + kRBlock - 1) / kRBlock) + 7u) >> 3; // tiles of an XCD
+		if ((blockIdx.x >> 3) >= per) return false;
+		tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+#endif
+	}
+	tid = (uint64_t)tile * kRBlock + threadIdx.x;
+	if ((uint64_t)tile * kRBlock >= live) return false;
 	if (!kFirst && tail_took_over(a, a.bounce)) return false;
 	alive = tid < live;
 	return true;
@@ -489,7 +514,10 @@ __device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p, i
 // leaves beside the walks' stacks at seven workgroups per compute unit (16 KB of stack + 6 KB of nodes each).  Measured on
 // veach-ajar, ms per step: closest hits 12.7 / 11.8 / 11.6 with 16 / 32 / 48 nodes (15.1 with none); shadow rays 6.9 /
 // 6.6 / 6.6 with 32 / 64 / 80 at six waves per SIMD (7.9 with none), 6.5 / 6.4 with 32 / 48 at seven.
-constexpr int kBvhTopNodes = 48;
+#ifndef PG_TRACE_TOP
+#define PG_TRACE_TOP 48
+#endif
+constexpr int kBvhTopNodes = PG_TRACE_TOP;
 template <int kNodes>
 __device__ __forceinline__ void stage_bvh_top(u32x4_t *s_top, const RenderArgs &a, BvhStack &stk)
 {
@@ -509,7 +537,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	if (!wave_entry<kFirst, PG_XCD_TRACE != 0>(a, tid, alive)) return;
 	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
 	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
 	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
@@ -679,7 +707,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 	__shared__ float s_planes[kGuide ? 3 * kKdGridPlanes : 1];
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	if (!wave_entry<kFirst, false>(a, tid, alive)) return;
 	if (kGuide) stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
 	Pcg32 rng;
@@ -878,7 +906,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	extern __shared__ uint4 s_rec[]; // kRBlock * 8 entries when the next bounce is sorted (a.carry_out), else none
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	if (!wave_entry<kFirst, false>(a, tid, alive)) return;
 	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
 	uint64_t rec_base = 0;
 	if (!kFirst) {
@@ -1014,7 +1042,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	extern __shared__ uint4 s_dyn[]; // kShadeLdsQuads entries: [stacks kLdsStack * kRBlock * 8 B][BVH top][...], later the records
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	if (!wave_entry<kFirst, PG_XCD_SHADE != 0>(a, tid, alive)) return;
 	// Probe builds only (-DPG_SHADE_PHASES=1; the instrumented pass of such a build prints the shares under $PGSD_TRACE_SHADOW):
 	// where a wave spends its life, DepthCounters::phase.  NOT in the product: the seven s_memtime stamps, behind a uniform
 	// branch that is never taken in a timed pass, took k_wave_shade from 28.6 to 45-47 ms per step (profiles/r05/
@@ -1040,16 +1068,20 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 #ifndef PG_SHADE_EARLY
 #define PG_SHADE_EARLY 1
 #endif
-	float pl_pre = 0.0f;
-	u32x4_t top_pre[2];
-	top_pre[0] = u32x4_t{0u, 0u, 0u, 0u};
-	top_pre[1] = top_pre[0];
-	const uint32_t n_top = a.shapes.n_bvh_nodes < kShadeTopNodes ? (uint32_t)a.shapes.n_bvh_nodes : (uint32_t)kShadeTopNodes;
-	static_assert(kShadeTopNodes * 8 <= 2 * kRBlock && 3 * kKdGridPlanes <= kRBlock, "k_wave_shade: the staging loads of one thread");
-#if PG_SHADE_EARLY
-	if (a.tree.kd_grid != nullptr && threadIdx.x < 3u * kKdGridPlanes) pl_pre = a.tree.kd_planes[threadIdx.x];
+	constexpr int kPlaneLoads = 1, kTopLoads = (kShadeTopNodes * 8 + kRBlock - 1) / kRBlock;
+	float pl_pre[kPlaneLoads];
+	u32x4_t top_pre[kTopLoads];
 #pragma unroll
-	for (int k = 0; k < 2; ++k)
+	for (int k = 0; k < kPlaneLoads; ++k) pl_pre[k] = 0.0f;
+#pragma unroll
+	for (int k = 0; k < kTopLoads; ++k) top_pre[k] = u32x4_t{0u, 0u, 0u, 0u};
+	const uint32_t n_top = a.shapes.n_bvh_nodes < kShadeTopNodes ? (uint32_t)a.shapes.n_bvh_nodes : (uint32_t)kShadeTopNodes;
+#if PG_SHADE_EARLY
+#pragma unroll
+	for (int k = 0; k < kPlaneLoads; ++k)
+		if (a.tree.kd_grid != nullptr && threadIdx.x + k * kRBlock < 3u * kKdGridPlanes) pl_pre[k] = a.tree.kd_planes[threadIdx.x + k * kRBlock];
+#pragma unroll
+	for (int k = 0; k < kTopLoads; ++k)
 		if (threadIdx.x + k * kRBlock < n_top * 8u) top_pre[k] = reinterpret_cast<const u32x4_t *>(a.shapes.bvh)[threadIdx.x + k * kRBlock];
 #endif
 	uint4 cq0 = make_uint4(0u, 0u, 0u, 0u), cq1 = cq0, cq2 = cq0, cq3 = cq0, cq4 = cq0, cq5 = cq0, cq6 = cq0;
@@ -1075,9 +1107,13 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kShadeStack * kRBlock / 2;
 	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack, kShadeStack);
 #if PG_SHADE_EARLY
-	if (a.tree.kd_grid != nullptr && threadIdx.x < 3u * kKdGridPlanes) s_planes[threadIdx.x] = pl_pre;
 #pragma unroll
-	for (int k = 0; k < 2; ++k)
+	for (int k = 0; k < kPlaneLoads; ++k)
+		if (a.tree.kd_grid != nullptr && threadIdx.x + k * kRBlock < 3u * kKdGridPlanes) s_planes[threadIdx.x + k * kRBlock] = pl_pre[k];
+	if (a.tree.kd_grid != nullptr) // (a workgroup smaller than the planes' count -- variant builds -- takes the rest here)
+		for (uint32_t i = threadIdx.x + kPlaneLoads * kRBlock; i < 3u * kKdGridPlanes; i += kRBlock) s_planes[i] = a.tree.kd_planes[i];
+#pragma unroll
+	for (int k = 0; k < kTopLoads; ++k)
 		if (threadIdx.x + k * kRBlock < n_top * 8u) s_top[threadIdx.x + k * kRBlock] = top_pre[k];
 	__syncthreads();
 	stk.top = (const LdsQuad *)s_top;
@@ -1421,6 +1457,10 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 
 void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, unsigned n_cus, hipStream_t s)
 {
+	{ // (wave_entry's XCD mapping deals the tiles out by eights, or by eight runs; a workgroup past the list leaves at once)
+		const unsigned unit = 8u * (PG_XCD_RUN ? (unsigned)PG_XCD_RUN : 1u);
+		grid_blocks = (grid_blocks + unit - 1u) / unit * unit;
+	}
 	if (level >= 3) launch_stage_level<3>(stage, first, a, dim3(grid_blocks), n_cus, s);
 	else launch_stage_level<2>(stage, first, a, dim3(grid_blocks), n_cus, s);
 }
