@@ -41,8 +41,11 @@ launch time (HIP events recorded by the library on the launch stream) and the 8 
   frac_model_8d  SURVEY.md 8d's ALGORITHMIC bytes: 16 B per KD level + 20 B per quadtree level of the REFERENCE's descents, levels
                counted by the same pass.  The jump grid and jump tables serve most of those levels with one gather each, so this
                exceeds 1 on spatially sorted lists: not a bandwidth (model_applicable false).  (Rounds 1-4 had this under `frac`.)
-`traffic` = HBM bytes of the PMC counters per launch (profiles/pmc_traffic.json, refused unless taken of exactly this code;
-traffic_tables_match: the forest of this run has the table resolutions of the profiled one).
+`traffic` = HBM bytes of the PMC counters per launch.  The default one-GPU line MEASURES it in the run (traffic_source "in-run":
+behind the timed regions rank 0 starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` as two bounded child processes over
+three steps of the same configuration, measure_traffic_in_run; --pmc-in-run 0 to skip); otherwise, and whenever those passes
+fail, it is the committed figure (profiles/pmc_traffic.json, refused unless taken of exactly this code; traffic_tables_match: the
+forest of this run has the table resolutions of the profiled one), which the line also carries as traffic_committed.
 `kernels` lists every kernel of a step with its share and, from the committed PMC figures, its counter traffic per second
 (pmc_frac_of_hbm_peak: as counted; ..._fetch_x2: with the guide's FETCH correction, an upper bound).
 `kernels_synthetic` / roofline.s1_* s2_* s3_*: the stand-alone entry points on SURVEY 8(d)'s S1 / S2 / S3 with the same two fractions and,
@@ -126,6 +129,11 @@ def parse():
                          "report value_full_schedule_12it + the final image's MSE; default: 1 at N = 1, 0 otherwise")
     ap.add_argument("--spp1", type=int, default=1, help="0: skip the leg that times 1-spp passes (value_spp1)")
     ap.add_argument("--cpu", type=int, default=1, help="0: skip the cpu_baseline / MSE-equality leg")
+    ap.add_argument("--pmc-in-run", type=int, default=None,
+                    help="1: `roofline.traffic` is MEASURED in this run -- behind the timed regions, rank 0 starts two bounded child "
+                         "processes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, nothing traced) around three "
+                         "steps of the same configuration, and reads their counter tables; 0: the committed figures of "
+                         "profiles/pmc_traffic.json only (default: 1 for the default one-GPU line)")
     ap.add_argument("--other-configs", type=int, default=None,
                     help="1: also time BASELINE configs[1], [2], [4] (cornell-box 512x512, veach-mis 1280x720, torus 1920x1080 depth 32) for a "
                          "few steps each and put the figures into `config` (c2_/c3_/c5_*); default: 1 at N = 1 on the default scene")
@@ -161,6 +169,8 @@ def parse():
         args.synthetic_kernels = 1 if (args.gpus == 1 and not args.synthetic) else 0
     if args.other_configs is None:
         args.other_configs = 1 if (args.gpus == 1 and not args.synthetic and args.scene == "veach-ajar") else 0
+    if args.pmc_in_run is None:
+        args.pmc_in_run = 1 if (args.gpus == 1 and not args.synthetic and args.full_schedule) else 0
     if args.in_flight is None:
         args.in_flight = 2 if (args.gpus > 1 and args.shard == "tiles" and not args.synthetic) else 1
     return args
@@ -185,12 +195,91 @@ RANDOM_GATHER_CEILING_GPS = 55.0  # G lanes/s, every lane its own 16 bytes of a 
 #                                   on MI355X (profiles/r05/gather_probe.txt) = 0.88 TB/s of useful bytes, 0.11 of the 8 TB/s peak; 242 G/s from 4 MB (L2)
 
 
+IN_RUN_TRAFFIC = {}  # kernel -> {"hi", "lo", "atomics": None}: filled by measure_traffic_in_run, consulted first by traffic_for
+PMC_CHILD_STEPS = 3
+
+
+def measure_traffic_in_run(args, launches_per_step, timeout_s=240.0):
+    """HBM bytes per launch of the kernels that hold the SD-tree calls, measured NOW: two child processes, one counter each
+    (`rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` -- separate passes and nothing traced beside them, as
+    MI355X_MICROARCH.md's HBM section prescribes), each running this script for PMC_CHILD_STEPS steps of the same
+    configuration; the counter tables are read as tools/summarize_profile.py reads a committed profile: k_wave_guide over the
+    last steps' launches (the roofline region), k_wave_shade over the last launches before the first k_wave_guide (the
+    region `value` is quoted on).  `launches_per_step`: {kernel: launches per step}.  Returns (figures, note): figures =
+    {kernel: {"hi": (2 * FETCH + WRITE) bytes, "lo": as counted, "atomics": None}} or None with the reason in note.  The
+    children are fresh processes started with subprocess (nothing is exec'ed by this process, which has touched the GPU);
+    the program behind `--` is python3 itself."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    out = tempfile.mkdtemp(prefix="pgsd_pmc_", dir="/tmp")
+    child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.abspath(__file__),
+             "--scene", args.scene, "--res", str(args.res), "--depth", str(args.depth), "--spp-per-pass", str(args.spp_per_pass),
+             "--batched", str(args.batched), "--train-iters", str(args.train_iters), "--sort", str(args.sort),
+             "--in-flight", str(args.in_flight), "--steps", str(PMC_CHILD_STEPS), "--warmup", "1", "--cpu", "0", "--full-schedule", "0",
+             "--spp1", "0", "--other-configs", "0", "--synthetic-kernels", "0", "--pmc-in-run", "0"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [rp, "--pmc", counter, "--kernel-include-regex", "k_wave_guide|k_wave_shade", "--output-format", "csv", "-d", d, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not fs:
+                return None, f"rocprofv3 --pmc {counter} wrote no counter table"
+            rows = sorted((x for x in csv.DictReader(open(fs[0])) if x["Counter_Name"] == counter), key=lambda x: int(x["Dispatch_Id"]))
+
+            def short(n):
+                for k in ("k_wave_shade_a", "k_wave_shade_b", "k_wave_guide", "k_wave_shade"):
+                    if k in n:
+                        return k
+                return None
+            first_guide = min((int(x["Dispatch_Id"]) for x in rows if short(x["Kernel_Name"]) == "k_wave_guide"), default=None)
+            for k, per_step in launches_per_step.items():
+                v = [float(x["Counter_Value"]) for x in rows if short(x["Kernel_Name"]) == k
+                     and (k != "k_wave_shade" or first_guide is None or int(x["Dispatch_Id"]) < first_guide)]
+                n = int(round(per_step * PMC_CHILD_STEPS))
+                if n <= 0 or len(v) < n:
+                    return None, f"{counter}: {len(v)} launches of {k} in the child's table, {n} expected"
+                vals.setdefault(k, {})[counter] = sum(v[-n:]) / n  # KiB per launch over the child's timed steps
+    except subprocess.TimeoutExpired:
+        return None, f"a counter pass did not finish within {timeout_s:.0f} s"
+    except Exception as e:  # (a counter table of an unexpected shape: the committed figures serve)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    fig = {k: {"hi": int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "lo": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "atomics": None}
+           for k, c in vals.items()}
+    return fig, (f"measured in this run: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` as two child processes of {PMC_CHILD_STEPS} steps each "
+                 f"behind the timed regions ({time.perf_counter() - t0:.0f} s), KiB as reported, hi = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
+                 "(the gfx950 x2 FETCH correction of MI355X_MICROARCH.md, an upper bound for scattered reads), lo = as counted")
+
+
 def traffic_for(kernel, key):
     """Counter figures per launch of `kernel` from the committed PMC summary of the same configuration
     (profiles/pmc_traffic.json, tools/summarize_profile.py) -- {"hi": HBM bytes with the gfx950 x2 FETCH correction of
     MI355X_MICROARCH.md (an upper bound for scattered reads), "lo": as counted, "atomics": L2 atomic sector updates} --
     or None when none is committed or when it was taken of OTHER CODE: the summary records the hash of the library's
     sources, and a figure whose hash differs from the sources this run was built from is refused."""
+    if kernel in IN_RUN_TRAFFIC:
+        return IN_RUN_TRAFFIC[kernel]
+    return committed_traffic_for(kernel, key)
+
+
+def committed_traffic_for(kernel, key):
+    """traffic_for's committed source (see there)."""
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         from practical_path_guiding_lab_amd._native import source_hash
@@ -720,8 +809,20 @@ def run_render(args):
                           "mount, 4482 triangles with texture coordinates, and its three bitmap textures at full "
                           "resolution (the JPG files' bytes in the package data veach_ajar.npz, decoded with PIL as load_xml does); checkerboard GGX floor, Beckmann door handle; "
                           "the six teapot shapes are absent: their mesh files are missing from the reference mount)"}[args.scene]
+    # ---- `traffic`, measured in this run where that is possible (--pmc-in-run): the default line of one GPU, the wavefront
+    # pipeline with its roofline region; otherwise, and whenever the counter passes fail, the committed figures ----
+    traffic_source, traffic_in_run_note = "committed", None
+    if args.pmc_in_run and rank == 0 and world == 1 and wave and kt_roof is not None and "k_wave_shade" in kernels:
+        want = {"k_wave_guide": kernels["k_wave_guide"]["launches"] / max(args.steps, 1),
+                "k_wave_shade": kernels["k_wave_shade"]["launches"] / max(args.steps, 1)}
+        fig, traffic_in_run_note = measure_traffic_in_run(args, want)
+        if fig is not None:
+            IN_RUN_TRAFFIC.update(fig)
+            traffic_source = "in-run"
+        print(f"[bench] traffic: {traffic_in_run_note}", file=sys.stderr, flush=True)
     tr_dom = traffic_for(dom, cfg_key)
     traffic = None if tr_dom is None else tr_dom["hi"]
+    tr_committed = committed_traffic_for(dom, cfg_key)
     # (the committed counters belong to a forest with these table resolutions: another one -- a different memory budget --
     # moves other bytes)
     prof_bits = profiled_table_bits(cfg_key)
@@ -774,6 +875,8 @@ def run_render(args):
             "alg_bytes_per_launch": kernels[dom].get("alg_bytes_per_launch"),
             "avg_launch_us": kernels[dom]["avg_us"],
             "traffic": traffic,
+            "traffic_source": traffic_source if traffic is not None else None,
+            "traffic_committed": None if tr_committed is None else tr_committed["hi"],
             "traffic_tables_match": None if (prof_bits is None or traffic is None) else bool(prof_bits[0] == int(stats.jump_bits)
                                                                                                 and prof_bits[1] in (-1, int(stats.kd_grid_bits))),
             # above 1 the algorithmic model is not a bandwidth at all: in a spatially sorted list (pg_render_sort) the lanes of a
@@ -789,7 +892,11 @@ def run_render(args):
                            "query) that the KD jump grid replaces by ONE 16-byte gather for most queries, and the top six quadtree levels of "
                            "a pdf walk are one 16-byte jump-table gather: the kernel moves far fewer bytes than the model prices -- read "
                            "frac_counter_lo / frac_counter_hi for what it moves, and `limiter` for what it waits on"),
-            "traffic_note": ("traffic / frac_counter_*: PMC figures of this configuration taken of exactly this code (source hash checked)"
+            "traffic_note": ("traffic / frac_counter_*: " + traffic_in_run_note + "; traffic_committed: the figure of the same configuration "
+                             "and code in profiles/pmc_traffic.json (tools/profile_bench.sh), for comparison"
+                             if traffic_source == "in-run" else
+                             "traffic / frac_counter_*: PMC figures of this configuration taken of exactly this code (source hash checked)"
+                             + (f"; not measured in this run: {traffic_in_run_note}" if traffic_in_run_note else "")
                              if tr_dom is not None else
                              "traffic null: no PMC figures of this configuration taken of THIS code are committed (profiles/pmc_traffic.json "
                              "records the hash of the sources it was taken of; a mismatch is refused rather than paired with new timings)"),
@@ -811,8 +918,7 @@ def run_render(args):
                      "k_bounce is one whole bounce of the wavefront (ray casting, NEE incl. shadow ray, shading, SD-tree "
                      "queries, record store, state load/store); its algorithmic bytes count only the SD-tree descents "
                      "(16 B/KD level, 20 B/quadtree level, SURVEY 8d). ")
-                    + "The splat is bound by scattered L2 atomics, not HBM (DESIGN.md 5). `traffic` is not measured in this run: it "
-                      "is the PMC figure of the same configuration and code committed in profiles/pmc_traffic.json."}
+                    + "The splat is bound by scattered L2 atomics, not HBM (DESIGN.md 5). `traffic`: see traffic_source / traffic_note."}
     # ---- the same two fractions for the kernel that holds the SD-tree calls in the region `value` is quoted on (k_wave_shade:
     # also the slowest kernel of the step).  It runs every launch of a bounce in that region, so its launches see the same
     # algorithmic and layout bytes as k_wave_guide's; its time also covers the surface, the BSDFs, the shadow ray and the
@@ -837,7 +943,7 @@ def run_render(args):
             "value_region_note": ("value_region_*: the kernel that makes the SD-tree calls in the steps `value` is quoted on (k_wave_shade, one launch "
                                   "per bounce, the slowest kernel of the step) priced with the same gathered layout bytes (value_region_frac) and the "
                                   "same SURVEY 8(d) model bytes (value_region_frac_model_8d) as k_wave_guide above, over ITS average launch in the "
-                                  "timed region of `value`; value_region_traffic / _frac_counter_* are its committed PMC figures")})
+                                  "timed region of `value`; value_region_traffic / _frac_counter_* are its PMC figures (roofline.traffic_source)")})
         sh["alg_bytes_per_launch"] = int(sh_alg)
         sh["alg_GBps"] = round(sh_alg / sh_sec / 1e9, 2)
     cpu = None

@@ -863,3 +863,72 @@ def test_nccl_backend_code_paths_with_one_rank(tmp_path):
     mp.spawn(_worker_nccl_one_rank, args=(1, 29619, out), nprocs=1, join=True)
     res = np.load(out)
     assert res.all(), res
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's in-run counter passes (roofline.traffic): the parsing and the refusals, with a stand-in for rocprofv3
+# ---------------------------------------------------------------------------------------------
+_FAKE_ROCPROF = r'''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+assert "--" in a and os.path.basename(a[a.index("--") + 1]).startswith("python"), a    # the program itself behind `--`
+assert not any(x in a for x in ("--sys-trace", "--kernel-trace", "--stats", "-s", "-r")), a   # counters only, nothing traced
+if os.environ.get("FAKE_ROCPROF_FAIL") == counter:
+    sys.exit(3)
+os.makedirs(os.path.join(out, "host"), exist_ok=True)
+n_guide = int(os.environ.get("FAKE_ROCPROF_GUIDE", "12"))
+rows, did = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"], 0
+def put(name, v):
+    global did
+    did += 1
+    rows.append('%d,"%s",%s,%f' % (did, name, counter, v))
+base = 100.0 if counter == "FETCH_SIZE" else 10.0
+for i in range(8): put("void pg::k_wave_shade<2, false>(pg::RenderArgs)", 7.0)               # training / warm-up: not counted
+for i in range(12): put("void pg::k_wave_shade<2, false>(pg::RenderArgs)", base + i)           # 3 steps x 4 launches
+for i in range(20): put("void pg::k_wave_shade_a<2, false, false>(pg::RenderArgs)", 1e6)      # the roofline region's other kernels
+for i in range(4): put("pg::k_wave_guide(pg::RenderArgs)", 5.0)                                # its warm-up
+for i in range(n_guide): put("pg::k_wave_guide(pg::RenderArgs)", 2.0 * base + i)
+for i in range(3): put("void pg::k_wave_shade<2, false>(pg::RenderArgs)", 9e9)                 # behind the first k_wave_guide: not `value`'s region
+open(os.path.join(out, "host", "1_counter_collection.csv"), "w").write("\n".join(rows) + "\n")
+'''
+
+
+def test_bench_counter_passes_read_their_tables_and_refuse_what_they_cannot_use(tmp_path, monkeypatch):
+    """bench.measure_traffic_in_run: two counter passes (FETCH_SIZE, WRITE_SIZE), each a child process of `rocprofv3 --pmc`
+    with python3 itself behind `--` and nothing traced; k_wave_guide over the last steps' launches, k_wave_shade over the
+    last launches BEFORE the first k_wave_guide; hi = (2 FETCH + WRITE) KiB, lo as counted.  A pass that fails, a table
+    with too few launches and a run that is itself profiled give None and the reason (the committed figures then serve)."""
+    import argparse
+    B = _bench_module()
+    fake = tmp_path / "rocprofv3"
+    fake.write_text(_FAKE_ROCPROF)
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    args = argparse.Namespace(scene="veach-ajar", res=1920, depth=13, spp_per_pass=16, batched=1, train_iters=6, sort=1, in_flight=1)
+    want = {"k_wave_guide": 4.0, "k_wave_shade": 4.0}
+    fig, note = B.measure_traffic_in_run(args, want, timeout_s=60)
+    assert fig is not None, note
+    f_sh, w_sh = 100.0 + 5.5, 10.0 + 5.5            # means of base .. base + 11
+    f_g, w_g = 200.0 + 5.5, 20.0 + 5.5
+    assert fig["k_wave_shade"] == {"hi": int((2 * f_sh + w_sh) * 1024), "lo": int((f_sh + w_sh) * 1024), "atomics": None}
+    assert fig["k_wave_guide"] == {"hi": int((2 * f_g + w_g) * 1024), "lo": int((f_g + w_g) * 1024), "atomics": None}
+    assert "measured in this run" in note
+    # the override reaches traffic_for; without it the committed table answers (or None)
+    B.IN_RUN_TRAFFIC.update(fig)
+    assert B.traffic_for("k_wave_guide", "no such configuration") == fig["k_wave_guide"]
+    B.IN_RUN_TRAFFIC.clear()
+    assert B.traffic_for("k_wave_guide", "no such configuration") is None
+    monkeypatch.setenv("FAKE_ROCPROF_FAIL", "WRITE_SIZE")
+    fig, note = B.measure_traffic_in_run(args, want, timeout_s=60)
+    assert fig is None and "WRITE_SIZE exited 3" in note
+    monkeypatch.delenv("FAKE_ROCPROF_FAIL")
+    monkeypatch.setenv("FAKE_ROCPROF_GUIDE", "7")   # fewer launches than three steps hold
+    fig, note = B.measure_traffic_in_run(args, want, timeout_s=60)
+    assert fig is None and "11 launches of k_wave_guide" in note   # (4 of its warm-up + 7)
+    monkeypatch.delenv("FAKE_ROCPROF_GUIDE")
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+    fig, note = B.measure_traffic_in_run(args, want, timeout_s=60)
+    assert fig is None and "profiler" in note
