@@ -199,7 +199,7 @@ IN_RUN_TRAFFIC = {}  # kernel -> {"hi", "lo", "atomics": None}: filled by measur
 PMC_CHILD_STEPS = 3
 
 
-def measure_traffic_in_run(args, launches_per_step, timeout_s=240.0):
+def measure_traffic_in_run(args, launches_per_step, timeout_s=90.0):
     """HBM bytes per launch of the kernels that hold the SD-tree calls, measured NOW: two child processes, one counter each
     (`rocprofv3 --pmc FETCH_SIZE`, `--pmc WRITE_SIZE` -- separate passes and nothing traced beside them, as
     MI355X_MICROARCH.md's HBM section prescribes), each running this script for PMC_CHILD_STEPS steps of the same
@@ -212,6 +212,7 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=240.0):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
 
@@ -233,9 +234,19 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=240.0):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
             cmd = [rp, "--pmc", counter, "--kernel-include-regex", "k_wave_guide|k_wave_shade", "--output-format", "csv", "-d", d, "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+            # (its own session: on expiry the whole group goes -- the profiler AND the python3 it started -- by its exact id)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.communicate()
+                return None, f"the {counter} pass did not finish within {timeout_s:.0f} s (ended)"
+            if pr.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {pr.returncode}: {err.decode(errors='replace')[-300:]}"
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not fs:
                 return None, f"rocprofv3 --pmc {counter} wrote no counter table"
@@ -254,8 +265,6 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=240.0):
                 if n <= 0 or len(v) < n:
                     return None, f"{counter}: {len(v)} launches of {k} in the child's table, {n} expected"
                 vals.setdefault(k, {})[counter] = sum(v[-n:]) / n  # KiB per launch over the child's timed steps
-    except subprocess.TimeoutExpired:
-        return None, f"a counter pass did not finish within {timeout_s:.0f} s"
     except Exception as e:  # (a counter table of an unexpected shape: the committed figures serve)
         return None, f"{type(e).__name__}: {e}"
     finally:

@@ -876,6 +876,11 @@ assert "--" in a and os.path.basename(a[a.index("--") + 1]).startswith("python")
 assert not any(x in a for x in ("--sys-trace", "--kernel-trace", "--stats", "-s", "-r")), a   # counters only, nothing traced
 if os.environ.get("FAKE_ROCPROF_FAIL") == counter:
     sys.exit(3)
+if os.environ.get("FAKE_ROCPROF_HANG"):
+    import subprocess, time
+    kid = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])   # the profiled program, one level down
+    open(os.environ["FAKE_ROCPROF_HANG"], "w").write(str(kid.pid))
+    time.sleep(600)
 os.makedirs(os.path.join(out, "host"), exist_ok=True)
 n_guide = int(os.environ.get("FAKE_ROCPROF_GUIDE", "12"))
 rows, did = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"], 0
@@ -900,6 +905,7 @@ def test_bench_counter_passes_read_their_tables_and_refuse_what_they_cannot_use(
     last launches BEFORE the first k_wave_guide; hi = (2 FETCH + WRITE) KiB, lo as counted.  A pass that fails, a table
     with too few launches and a run that is itself profiled give None and the reason (the committed figures then serve)."""
     import argparse
+    import time
     B = _bench_module()
     fake = tmp_path / "rocprofv3"
     fake.write_text(_FAKE_ROCPROF)
@@ -929,6 +935,24 @@ def test_bench_counter_passes_read_their_tables_and_refuse_what_they_cannot_use(
     fig, note = B.measure_traffic_in_run(args, want, timeout_s=60)
     assert fig is None and "11 launches of k_wave_guide" in note   # (4 of its warm-up + 7)
     monkeypatch.delenv("FAKE_ROCPROF_GUIDE")
+    # a pass that hangs is ended with everything it started (its process group), and the reason is reported
+    pidfile = tmp_path / "kid.pid"
+    monkeypatch.setenv("FAKE_ROCPROF_HANG", str(pidfile))
+    fig, note = B.measure_traffic_in_run(args, want, timeout_s=3)
+    assert fig is None and "did not finish within 3 s" in note
+    kid = int(pidfile.read_text())
+    for _ in range(50):
+        try:
+            os.kill(kid, 0)
+        except ProcessLookupError:
+            break
+        st = open(f"/proc/{kid}/stat").read().split()[2] if os.path.exists(f"/proc/{kid}/stat") else "X"
+        if st in ("Z", "X"):
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the profiled program of a hung counter pass was left running")
+    monkeypatch.delenv("FAKE_ROCPROF_HANG")
     monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
     fig, note = B.measure_traffic_in_run(args, want, timeout_s=60)
     assert fig is None and "profiler" in note
