@@ -467,6 +467,33 @@ def test_render_returns_plausible_cornell_image():
     assert img[2:6, 28:36].mean() > 3.0 and 0.05 < img.mean() < 0.5
 
 
+@pytest.mark.parametrize("spp", [5, 24, 28])
+def test_both_film_kernels_match_the_oracle(spp):
+    """The film is developed by tiles with the samples' film positions staged in LDS (k_film_tiled) where those fit in 64 KB and
+    pixel by pixel (k_film) where they do not: 5 samples per pixel take the tiled kernel, 24 take it with more than 48 KB of
+    dynamic LDS (the attribute that allows it is set) for the tent filter and the pixel kernel for the gaussian, 28 take the
+    pixel kernel for both -- every one against pgo_film on a ragged film, bit for bit."""
+    import torch
+    from practical_path_guiding_lab_amd import _native as N
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+    from practical_path_guiding_lab_amd.scene import cornell_box
+
+    w, h, seed = 37, 23, 977 + spp
+    sc = cornell_box(w, h, 3, 8)
+    g = PathGuidingIntegrator({"max_depth": 3})
+    g.setup(w * h, sc.bbox_min - 1e-4, sc.bbox_max + 1e-4, 20, 20, True, 0.5)
+    g.setIteration(0, True)
+    L, _, _ = g.sample(WavefrontScene(sc), IndependentSampler(spp, seed))
+    t = g.sdTree
+    Lh = L.cpu().numpy()
+    for filt, name in ((0, "tent"), (1, "gaussian")):
+        img = torch.empty((3, w * h), dtype=torch.float32, device="cuda")
+        N.check(t._h, t._lib.pg_film(t._h, filt, seed, spp, L.data_ptr(), img.data_ptr(), None))
+        exp = po.film(name, seed, spp, w, h, Lh)
+        np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), exp.view(np.uint32), err_msg=f"{name} spp={spp}")
+
+
 @pytest.mark.parametrize("which", ["cornell-box", "veach-mis"])
 def test_fused_kernel_and_split_pipeline_are_two_implementations_of_one_bounce(which):
     """A quad scene runs the fused k_bounce by default and the split pipeline (the kernels of the mesh
