@@ -46,8 +46,9 @@ behind the timed regions rank 0 starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc W
 three steps of the same configuration, measure_traffic_in_run; --pmc-in-run 0 to skip); otherwise, and whenever those passes
 fail, it is the committed figure (profiles/pmc_traffic.json, refused unless taken of exactly this code; traffic_tables_match: the
 forest of this run has the table resolutions of the profiled one), which the line also carries as traffic_committed.
-`kernels` lists every kernel of a step with its share and, from the committed PMC figures, its counter traffic per second
-(pmc_frac_of_hbm_peak: as counted; ..._fetch_x2: with the guide's FETCH correction, an upper bound).
+`kernels` lists every kernel of a step with its share and, from the same counter passes (in-run for k_wave_guide, k_wave_shade,
+k_wave_trace, k_splat_list and k_finish; the committed figures otherwise, and for the atomic sector updates), its counter traffic
+per second (pmc_frac_of_hbm_peak: as counted; ..._fetch_x2: with the guide's FETCH correction, an upper bound).
 `kernels_synthetic` / roofline.s1_* s2_* s3_*: the stand-alone entry points on SURVEY 8(d)'s S1 / S2 / S3 with the same two fractions and,
 from the cpu_baseline leg, the CPU restatement's rate on the same inputs (cpu_G_units_per_s, cpu_cores).
 config.c2_* / c3_* / c5_*: BASELINE configs[1], [2], [4] timed for a few steps in the same run (other_configs_leg).
@@ -233,7 +234,7 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=90.0):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
-            cmd = [rp, "--pmc", counter, "--kernel-include-regex", "k_wave_guide|k_wave_shade", "--output-format", "csv", "-d", d, "--"] + child
+            cmd = [rp, "--pmc", counter, "--kernel-include-regex", "k_wave_|k_splat_list|k_finish", "--output-format", "csv", "-d", d, "--"] + child
             # (its own session: on expiry the whole group goes -- the profiler AND the python3 it started -- by its exact id)
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
             try:
@@ -253,14 +254,17 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=90.0):
             rows = sorted((x for x in csv.DictReader(open(fs[0])) if x["Counter_Name"] == counter), key=lambda x: int(x["Dispatch_Id"]))
 
             def short(n):
-                for k in ("k_wave_shade_a", "k_wave_shade_b", "k_wave_guide", "k_wave_shade"):
+                for k in ("k_wave_trace", "k_wave_shade_a", "k_wave_shade_b", "k_wave_guide", "k_wave_shade", "k_wave_cast", "k_wave_tail",
+                          "k_splat_list", "k_finish"):
                     if k in n:
                         return k
                 return None
             first_guide = min((int(x["Dispatch_Id"]) for x in rows if short(x["Kernel_Name"]) == "k_wave_guide"), default=None)
             for k, per_step in launches_per_step.items():
+                # (k_wave_guide: the roofline region, the run's last steps; every other kernel: the region `value` is quoted on,
+                # which ends where the first k_wave_guide starts)
                 v = [float(x["Counter_Value"]) for x in rows if short(x["Kernel_Name"]) == k
-                     and (k != "k_wave_shade" or first_guide is None or int(x["Dispatch_Id"]) < first_guide)]
+                     and (k == "k_wave_guide" or first_guide is None or int(x["Dispatch_Id"]) < first_guide)]
                 n = int(round(per_step * PMC_CHILD_STEPS))
                 if n <= 0 or len(v) < n:
                     return None, f"{counter}: {len(v)} launches of {k} in the child's table, {n} expected"
@@ -283,7 +287,11 @@ def traffic_for(kernel, key):
     or None when none is committed or when it was taken of OTHER CODE: the summary records the hash of the library's
     sources, and a figure whose hash differs from the sources this run was built from is refused."""
     if kernel in IN_RUN_TRAFFIC:
-        return IN_RUN_TRAFFIC[kernel]
+        e = dict(IN_RUN_TRAFFIC[kernel])
+        if e.get("atomics") is None:  # (the run's own passes count bytes; the atomic sector updates stay the committed pass's)
+            c = committed_traffic_for(kernel, key)
+            e["atomics"] = None if c is None else c.get("atomics")
+        return e
     return committed_traffic_for(kernel, key)
 
 
@@ -822,8 +830,8 @@ def run_render(args):
     # pipeline with its roofline region; otherwise, and whenever the counter passes fail, the committed figures ----
     traffic_source, traffic_in_run_note = "committed", None
     if args.pmc_in_run and rank == 0 and world == 1 and wave and kt_roof is not None and "k_wave_shade" in kernels:
-        want = {"k_wave_guide": kernels["k_wave_guide"]["launches"] / max(args.steps, 1),
-                "k_wave_shade": kernels["k_wave_shade"]["launches"] / max(args.steps, 1)}
+        want = {k_: kernels[k_]["launches"] / max(args.steps, 1)
+                for k_ in ("k_wave_guide", "k_wave_shade", "k_wave_trace", "k_splat_list", "k_finish") if k_ in kernels and kernels[k_]["launches"] > 0}
         fig, traffic_in_run_note = measure_traffic_in_run(args, want)
         if fig is not None:
             IN_RUN_TRAFFIC.update(fig)
