@@ -53,6 +53,11 @@ per second (pmc_frac_of_hbm_peak: as counted; ..._fetch_x2: with the guide's FET
 from the cpu_baseline leg, the CPU restatement's rate on the same inputs (cpu_G_units_per_s, cpu_cores).
 config.c2_* / c3_* / c5_*: BASELINE configs[1], [2], [4] timed for a few steps in the same run (other_configs_leg).
 
+OUTPUT: stdout carries exactly ONE line -- compact_record(): < 6 KB of strict JSON with the contract's keys, `roofline`, `cpu_baseline`,
+kernel name -> ms per step, and the flat figures named below; it is the last thing the process writes (the driver could not
+parse round 5's 22.9 KB line).  The FULL record (every note, the per-kernel counter tables, kernels_synthetic, schedule, full_schedule)
+goes to --detail (default gpurun_out/bench_detail.json); a builder-run copy of it is committed per round under profiles/.
+
 `--synthetic` runs the renderer-free hot-path workload instead (seeded synthetic surface points).
 Launch:  python bench.py [--gpus N]      (N > 1 without WORLD_SIZE in the environment: this process starts N fresh
                                           rank processes itself -- before anything touches the GPU -- and relays rank 0's line)
@@ -157,6 +162,9 @@ def parse():
                          "eighth of it leaves gaps between its small launches that a second pass fills: 7.72 -> 7.08 ms per step of a rank's share, "
                          "6.7x -> 7.3x of 8 by emulation on one GPU (tools/stripe_balance.py, profiles/r04/stripe_balance.txt)")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
+    ap.add_argument("--detail", default=None,
+                    help="file the FULL record is written to (default gpurun_out/bench_detail.json); stdout carries one compact line, "
+                         "< 6 KB of strict JSON, and nothing else")
     ap.add_argument("--no-compaction", action="store_true", help="(synthetic) mask dead lanes instead of compacting")
     args = ap.parse_args()
     w, _, d = SCENES[args.scene]
@@ -227,7 +235,7 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=90.0):
              "--scene", args.scene, "--res", str(args.res), "--depth", str(args.depth), "--spp-per-pass", str(args.spp_per_pass),
              "--batched", str(args.batched), "--train-iters", str(args.train_iters), "--sort", str(args.sort),
              "--in-flight", str(args.in_flight), "--steps", str(PMC_CHILD_STEPS), "--warmup", "1", "--cpu", "0", "--full-schedule", "0",
-             "--spp1", "0", "--other-configs", "0", "--synthetic-kernels", "0", "--pmc-in-run", "0"]
+             "--spp1", "0", "--other-configs", "0", "--synthetic-kernels", "0", "--pmc-in-run", "0", "--detail", os.devnull]
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.perf_counter()
     vals = {}
@@ -1556,6 +1564,127 @@ def run_synthetic(args):
     return out
 
 
+COMPACT_LINE_MAX = 6000  # bytes: the driver kept `parsed: null` for round 5's 22.9 KB line
+SCHEMA = 6               # of the compact line; round 5 and earlier printed the whole record as the one line
+
+
+def _finite(x):
+    """x with every non-finite float replaced by None, recursively (the line is STRICT JSON: no NaN / Infinity)."""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if hasattr(x, "item") and not isinstance(x, (str, bytes)):  # numpy / torch scalars
+        try:
+            return _finite(x.item())
+        except Exception:
+            return str(x)
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_record(out):
+    """The ONE line the driver parses: bench.py's contract keys plus the flat figures the judge reads, no prose -- everything
+    else (notes, per-kernel counter tables, kernels_synthetic, schedule, full_schedule) goes to the detail file only."""
+    cfg, roof, cpu = out.get("config") or {}, out.get("roofline") or {}, out.get("cpu_baseline")
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype")}
+    c["schema"] = SCHEMA
+    c["data"] = "synthetic: the reference's scene files packaged, seeded sampler streams, SD-tree trained in the run"
+    if out.get("data") == "synthetic":
+        c["data"] = "synthetic"
+    wl = str(cfg.get("workload", ""))
+    c["config"] = {"workload": wl if len(wl) <= 300 else wl[:297] + "..."}
+    c["config"].update(_pick(cfg, ("paths_per_step", "spp_per_pass", "passes_per_launch", "steps_per_launch", "kd_leaves", "quad_records", "measured_D_kd",
+                                   "measured_D_quad", "jump_bits", "kd_grid_bits", "bytes_jump_tables", "pixels_per_rank_min",
+                                   "pixels_per_rank_max", "value_one_launch_per_1spp_pass", "value_full_schedule_12it",
+                                   "mse_vs_gt_full_schedule", "mse_equal_device_vs_cpu")))
+    for k, v in cfg.items():  # BASELINE configs[1], [2], [4] timed in the same run
+        if k.startswith(("c2_", "c3_", "c5_")) and k.endswith(("_msamples_per_s", "_ms_per_step")):
+            c["config"][k] = v
+    for k in ("value_full_schedule", "mse_vs_gt", "mse_equal"):
+        if out.get(k) is not None:
+            c[k] = out[k]
+    r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "layout_bytes_per_launch",
+                     "alg_bytes_per_launch", "frac_model_8d", "traffic", "traffic_source", "frac_counter_lo", "frac_counter_hi",
+                     "value_region_kernel", "value_region_avg_launch_us", "value_region_frac", "value_region_frac_counter_lo",
+                     "value_region_sdtree_us", "value_region_sdtree_frac", "value_region_sdtree_share", "value_region_sdtree_probe_overhead",
+                     "s1_pg_sample_frac", "s1_pg_sample_frac_model_8d", "s1_pg_pdf_frac", "s1_pg_guide_bounce_frac", "s2_pg_sample_frac",
+                     "s3_pg_splat_frac", "device_copy_GBps"))
+    if r:
+        r["frac_basis"] = ("bytes the lanes gathered from the built layout per launch / avg_launch_us / peak; "
+                           "SURVEY 8d model bytes: frac_model_8d")[:120]
+    c["roofline"] = r or None
+    if isinstance(cpu, dict):
+        cc = _pick(cpu, ("value", "unit", "cores", "kind", "host_cores_usable", "mse_equal", "images_bit_identical_to_device", "config",
+                         "value_small", "seconds"))
+        cc["label"] = "CPU restatement (oracle/, OpenMP over the lanes), not the reference: Mitsuba/Dr.Jit absent"
+        s = str(cpu.get("sample", ""))
+        cc["sample"] = s if len(s) <= 240 else s[:237] + "..."
+        c["cpu_baseline"] = cc
+    else:
+        c["cpu_baseline"] = None
+    kern = out.get("kernels") or {}
+    c["kernels"] = {k: (round(v["ms_per_step"], 3) if isinstance(v, dict) and "ms_per_step" in v else
+                        (round(1e-3 * v["avg_us"] * v["launches"] / max(out.get("steps") or 1, 1), 3) if isinstance(v, dict) and "avg_us" in v else None))
+                    for k, v in kern.items()}
+    ex = out.get("extra") or {}
+    c["extra"] = _pick(ex, ("source_hash", "rccl_ranks", "exchange_bytes", "allreduce_ms", "refine_ms"))
+    e = str(ex.get("exchange", "none"))
+    c["extra"]["exchange"] = e if len(e) <= 80 else e[:77] + "..."
+    return _finite(c)
+
+
+def format_line(out):
+    """compact_record(out) as one line of strict JSON, shortened -- optional groups first -- until it fits COMPACT_LINE_MAX."""
+    c = compact_record(out)
+    line = json.dumps(c, allow_nan=False, separators=(", ", ": "))
+    for drop in (("extra", "allreduce_ms"), ("extra", "refine_ms"), ("kernels",), ("config", "workload")):
+        if len(line) < COMPACT_LINE_MAX:
+            break
+        d = c
+        for k in drop[:-1]:
+            d = d.get(k) or {}
+        if drop[-1] == "workload" and "workload" in d:
+            d["workload"] = d["workload"][:120]
+        else:
+            d.pop(drop[-1], None)
+        line = json.dumps(c, allow_nan=False, separators=(", ", ": "))
+    if len(line) >= COMPACT_LINE_MAX:
+        raise RuntimeError(f"bench line is {len(line)} bytes (limit {COMPACT_LINE_MAX})")
+    return line
+
+
+def detail_path():
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return os.path.join(d, "bench_detail.json")
+    except OSError:
+        return os.path.join("/tmp", "bench_detail.json")
+
+
+def emit(out, detail=None):
+    """The full record to the detail file (never to stdout: the line the driver parses must be the only JSON there), then the
+    compact line as the LAST thing this process writes -- nothing follows it on stdout or stderr."""
+    path = detail_path() if detail is None else detail
+    try:
+        with open(path, "w") as f:
+            json.dump(_finite(out), f, allow_nan=False)
+            f.write("\n")
+        print(f"[bench] full record: {path}", file=sys.stderr, flush=True)
+    except OSError as e:
+        print(f"[bench] full record not written ({e})", file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    sys.stdout.write(format_line(out) + "\n")
+    sys.stdout.flush()
+
+
 def main():
     # (the pool's host driver supports dmabuf IPC only: RCCL and CUDA-tensor sharing across processes fail without this, and the
     # HSA runtime reads it when it starts -- so it is set before anything here or in a rank can have touched the GPU)
@@ -1567,7 +1696,7 @@ def main():
         sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     out = run_synthetic(args) if args.synthetic else run_render(args)
     if out is not None:
-        print(json.dumps(out))
+        emit(out, args.detail)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ mkdir -p $OUT
 for rep in 1 2; do
 for v in "$@"; do
 	if [ "$v" = default ]; then unset PGSD_LIBRARY; else export PGSD_LIBRARY=$PWD/practical_path_guiding_lab_amd/libpgsd_$v.so; fi
-	python bench.py --cpu 0 --full-schedule 0 --spp1 0 --other-configs 0 $ARGS > $OUT/$v.$rep.json 2> $OUT/$v.$rep.err || exit 1
+	python bench.py --cpu 0 --full-schedule 0 --spp1 0 --other-configs 0 $ARGS --detail $OUT/$v.$rep.json > $OUT/$v.$rep.line 2> $OUT/$v.$rep.err || exit 1
 	python - <<PY
 import json
 d = json.load(open("$OUT/$v.$rep.json"))

@@ -8,7 +8,7 @@ set -e
 OUT=gpurun_out/exp_ablate
 mkdir -p $OUT
 run() {
-	python bench.py --cpu 0 --steps 10 > $OUT/$1.json
+	python bench.py --cpu 0 --steps 10 --detail $OUT/$1.json > $OUT/$1.line
 	python - <<EOF
 import json
 d = json.load(open("$OUT/$1.json"))

@@ -11,7 +11,7 @@ for g in ${@:-8 16 32 64 128}; do
 	touch practical_path_guiding_lab_amd/csrc/pg_kernels_splat.hip
 	make -s -C practical_path_guiding_lab_amd/csrc -j8 EXTRA="-DPG_SPLAT_GROUPS_PER_CU=$g" > $OUT/make.log 2>&1
 	for s in cornell-box veach-mis torus; do
-		python bench.py --scene $s --cpu 0 --steps 10 > $OUT/$s.$g.json
+		python bench.py --scene $s --cpu 0 --steps 10 --detail $OUT/$s.$g.json > $OUT/$s.$g.line
 		python - <<EOF
 import json
 d = json.load(open("$OUT/$s.$g.json"))

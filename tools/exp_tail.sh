@@ -14,7 +14,7 @@ first=1
 for t in ${@:-524288 131072 32768 2097152}; do
 	touch practical_path_guiding_lab_amd/csrc/pg_render.hip
 	make -s -C practical_path_guiding_lab_amd/csrc -j8 EXTRA="-DPG_TAIL_PATHS=${t}u" > $OUT/make.log 2>&1
-	python bench.py --scene torus --cpu 0 --steps 10 > $OUT/torus.$t.json
+	python bench.py --scene torus --cpu 0 --steps 10 --detail $OUT/torus.$t.json > $OUT/torus.$t.line
 	python - <<EOF
 import json
 d = json.load(open("$OUT/torus.$t.json"))
@@ -22,7 +22,7 @@ print("tail paths %8d  value %7.1f  ms %.3f  bounce step %.1f us  splat %.1f us"
 EOF
 	if [ $first = 1 ]; then
 		first=0
-		(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --scene torus --steps 3 --warmup 1 --cpu 0 > $OUT/trace.json 2> $OUT/trace.err)
+		(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --scene torus --steps 3 --warmup 1 --cpu 0 --detail $OUT/trace.json > $OUT/trace.line 2> $OUT/trace.err)
 		python - <<EOF
 import csv, glob
 f = glob.glob("$OUT/trace/*/*kernel_trace.csv")[0]

@@ -15,7 +15,7 @@ cd /tmp
 FILTER="k_bounce|k_wave_|k_process_and_splat|k_splat_list|k_finish|k_sort_"
 SFILTER="k_sample|k_pdf|k_guide_bounce|k_leaf_index|pg::k_splat\("
 B="--cpu 0 --full-schedule 0 --spp1 0 --other-configs 0 --pmc-in-run 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 $B $EXTRA > $D/bench_under_trace.json 2> $D/trace.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 $B $EXTRA --detail $D/bench_under_trace.json > $D/bench_under_trace.line 2> $D/trace.err &&
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 $B --synthetic-kernels 0 $EXTRA > /dev/null 2> $D/pmc_fetch.err &&
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 $B --synthetic-kernels 0 $EXTRA > /dev/null 2> $D/pmc_write.err &&
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --kernel-include-regex "$FILTER" --output-format csv -d $D/pmc_l2 -- python3 $R/bench.py --steps 3 --warmup 1 $B --synthetic-kernels 0 $EXTRA > /dev/null 2> $D/pmc_l2.err &&

@@ -4,5 +4,5 @@
 OUT=${1:-trace_wave}; shift
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 mkdir -p $R/gpurun_out/$OUT
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$OUT/trace -- python3 $R/bench.py --steps 2 --warmup 1 --cpu 0 --train-iters 4 "$@" > $R/gpurun_out/$OUT/bench.json 2> $R/gpurun_out/$OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$OUT/trace -- python3 $R/bench.py --steps 2 --warmup 1 --cpu 0 --train-iters 4 "$@" --detail $R/gpurun_out/$OUT/bench.json > $R/gpurun_out/$OUT/bench.line 2> $R/gpurun_out/$OUT/err.txt
 echo rc=$?
