@@ -35,7 +35,9 @@ extern "C" {
  * pg_pass_params.reserved2 became `batched` (same size); new entry points pg_film_batched, pg_film_batched_accumulate. */
 /* 5 (round 5): new entry points pg_comm_info, pg_exchange_pack, pg_exchange_unpack, pg_exchange_pack_words,
  * pg_exchange_unpack_words; pg_allreduce moves the accumulators in the 24-byte exchange format (same sums).  No struct changed. */
-#define PGSD_ABI_VERSION 5
+/* 6 (round 6): pg_refine_and_swap is a transaction (on any error both trees are exactly what they were; the context stays usable);
+ * new entry points pg_debug_fail_alloc, pg_debug_fail_alloc_pending (fault injection for the tests).  No struct changed. */
+#define PGSD_ABI_VERSION 6
 
 typedef struct pg_context pg_context;
 
@@ -181,8 +183,20 @@ int pg_process_and_splat(pg_context *ctx, uint64_t num_rays, int32_t max_depth,
 
 /* refineAndPrepareSDTreeForNextIteration (path_guiding_integrator.py:566-586) with the
  * iteration number given to pg_set_iteration: KD split, quadtree threshold/merge/split,
- * canonical re-layout, prev <- current, reset.  Synchronises `stream`. */
+ * canonical re-layout, prev <- current, reset.  Synchronises `stream`.
+ * A TRANSACTION, as the reference's allocate-new + copy growth is (common.py:161-189: its arrays are replaced, never edited, so
+ * sdTree_prev survives a failed split): the refined KD tree, the new quadtree forest and the next iteration's accumulators are
+ * built in spare buffers and committed by pointer swap.  On ANY error (PG_ERR_NOMEM from an allocation, a limit) sdTree_prev and
+ * sdTree_current -- topology, sampling values and the running iteration's accumulators -- are exactly what they were before the
+ * call: every query, pass and export answers bit for bit as before, and the call may simply be repeated. */
 int pg_refine_and_swap(pg_context *ctx, void *stream);
+
+/* Fault injection for the tests of that guarantee (tests/test_gpu_errors.py); process-wide, not for production use:
+ * after `successes_before_failure` further device allocations of the library have succeeded, the next one reports out of memory
+ * exactly as a refused hipMalloc does, and the hook disarms itself (-1 disarms it at once).  pg_debug_fail_alloc_pending
+ * returns 1 while a failure is armed and has not happened yet, 0 otherwise (the hook fired or was never armed). */
+int pg_debug_fail_alloc(int64_t successes_before_failure);
+int pg_debug_fail_alloc_pending(void);
 
 /* Views of sdTree_current's integer accumulators for the multi-GPU exchange: one contiguous
  * device buffer of `count` int64 that is element-wise summable across ranks (topology is
@@ -433,7 +447,11 @@ int pg_render_sort(pg_context *ctx, int32_t on);
 
 /* Allocates what pg_render_pass needs for passes of up to n_lanes lanes (pixels of the tile x spp) ahead
  * of time -- the reference allocates its numRays x max_depth record arrays in setup()
- * (path_guiding_integrator.py:93, 116); without this call the first pass of a size allocates them. */
+ * (path_guiding_integrator.py:93, 116); without this call the first pass of a size allocates them.
+ * After the pass buffers, for passes of >= 2^20 lanes and only while the device still has four times the jump tables' budget
+ * ($PGSD_JUMP_TABLE_MAX_BYTES, default 2 GiB) free, the tables' buffer is also taken at that budget, so that no refine of the
+ * training allocates it; $PGSD_JUMP_TABLE_RESERVE=0 switches that off.  It changes allocation times only, never a result, and
+ * a refused allocation of it is not an error. */
 int pg_render_reserve(pg_context *ctx, uint64_t n_lanes);
 
 /* Which kernels run a bounce.  Scenes of quads, boxes, spheres with diffuse / rough-conductor BSDFs run

@@ -105,7 +105,7 @@ class pg_depth_counters(C.Structure):
 
 
 # every symbol include/pgsd.h declares (checked by tests/test_abi.py)
-ABI_VERSION = 5  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
+ABI_VERSION = 6  # PGSD_ABI_VERSION of include/pgsd.h these bindings match
 
 EXPORTS = (
     "pg_create", "pg_destroy", "pg_last_error", "pg_abi_version", "pg_setup", "pg_set_iteration",
@@ -117,7 +117,7 @@ EXPORTS = (
     "pg_math_eval", "pg_scene_set_ex", "pg_film", "pg_film_stripes", "pg_film_batched", "pg_film_batched_accumulate", "pg_render_overlap", "pg_render_sort", "pg_render_stages",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
     "pg_render_split_pipeline", "pg_comm_info", "pg_exchange_pack", "pg_exchange_unpack", "pg_exchange_pack_words",
-    "pg_exchange_unpack_words", "pg_sort_places",
+    "pg_exchange_unpack_words", "pg_sort_places", "pg_debug_fail_alloc", "pg_debug_fail_alloc_pending",
 )
 
 
@@ -184,6 +184,8 @@ def lib() -> C.CDLL:
     L.pg_process_records.argtypes = [V, U64, I32, V, C.POINTER(pg_dense_records), C.POINTER(pg_records_out), V, V]
     L.pg_process_and_splat.argtypes = [V, U64, I32, V, C.POINTER(pg_dense_records), V]
     L.pg_refine_and_swap.argtypes = [V, V]
+    L.pg_debug_fail_alloc.argtypes = [C.c_int64]
+    L.pg_debug_fail_alloc_pending.argtypes = []
     L.pg_accumulators.argtypes = [V, C.POINTER(V), C.POINTER(U64)]
     L.pg_export_sizes.argtypes = [V, C.POINTER(pg_tree_sizes)]
     L.pg_export.argtypes = [V, C.POINTER(pg_tree_sizes), C.POINTER(pg_tree_columns)]

@@ -328,17 +328,17 @@ int pg_process_and_splat(pg_context *ctx, uint64_t num_rays, int32_t max_depth, 
 int pg_refine_and_swap(pg_context *ctx, void *stream)
 {
 	PG_READY(ctx);
-	const int rc = refine_and_swap(ctx, (hipStream_t)stream);
-	if (rc != PG_OK) {
-		// The refine changes the KD nodes in place before the new quadtree forest, heads and counts are
-		// committed: a failure in between (out of memory, a limit) leaves links that point past the old
-		// arrays.  Nothing may walk such a tree: the context goes back to "not set up" -- every later
-		// query, splat or pass is refused until pg_setup or pg_import gives it a whole tree again.
-		ctx->configured = false;
-		ctx->err += " (the SD-tree is no longer valid: call pg_setup or pg_import)";
-	}
-	return rc;
+	// (a transaction, pg_refine.hip: on any error sdTree_prev and sdTree_current are exactly what they were)
+	return refine_and_swap(ctx, (hipStream_t)stream);
 }
+
+int pg_debug_fail_alloc(int64_t successes_before_failure)
+{
+	g_alloc_fail_countdown = successes_before_failure < 0 ? -1 : (long long)successes_before_failure;
+	return PG_OK;
+}
+
+int pg_debug_fail_alloc_pending(void) { return g_alloc_fail_countdown >= 0 ? 1 : 0; }
 
 int pg_accumulators(pg_context *ctx, int64_t **d_buffer, uint64_t *count)
 {

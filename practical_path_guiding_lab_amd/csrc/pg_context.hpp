@@ -18,6 +18,11 @@ namespace pg {
 // asks for slack: a hipFree synchronises the whole device and a fresh hipMalloc of a gigabyte maps pages for tens of
 // milliseconds, so a buffer that follows a growing tree must not be reallocated every time the tree grows a little
 // (round 3's refine spent 20-190 ms per iteration there).
+// Fault injection for the tests (pg_debug_fail_alloc, include/pgsd.h): when >= 0, the number of device allocations that still
+// succeed -- the one after them reports hipErrorOutOfMemory exactly as a refused hipMalloc does (the buffer is left empty), and
+// the hook disarms itself.  One variable for the whole library (C++17 inline variable); -1 = off.
+inline long long g_alloc_fail_countdown = -1;
+
 template <class T> struct DevBuf {
 	T *p = nullptr;
 	size_t cap = 0;
@@ -38,6 +43,7 @@ template <class T> struct DevBuf {
 		size_t want = (size_t)((double)n * slack);
 		if (want < n) want = n;
 		if (want < 16) want = 16;
+		if (g_alloc_fail_countdown >= 0 && g_alloc_fail_countdown-- == 0) return hipErrorOutOfMemory; // (tests only; p is empty)
 		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
 		if (e != hipSuccess) { p = nullptr; return e; }
 		cap = want;
@@ -91,6 +97,11 @@ struct Forest {
 		DevBuf<uint32_t> tree_src, counts, cnt, pos, scan_sums, scan_total;
 		DevBuf<TreeHead> new_head;
 		DevBuf<QuadRec> new_rec;
+		// the refined KD tree and the next iteration's accumulators are built HERE and become the forest's by a pointer swap
+		// (pg_refine.hip: a refine is a transaction); what they replace becomes the next refine's scratch
+		DevBuf<KdNode> new_kd;
+		DevBuf<float> new_bmin, new_bmax, new_vc;
+		DevBuf<long long> new_acc;
 		DevBuf<unsigned char> pend_a, pend_b; // (Pending entries: the type lives in pg_refine.hip)
 		void *pinned = nullptr;             // 64 bytes of page-locked host memory for the counters a refine reads back
 		~RefineScratch() { if (pinned) (void)hipHostFree(pinned); }
@@ -124,8 +135,8 @@ struct pg_context {
 	pg::Forest f;
 	pg::DepthCounters *dc = nullptr; // device
 	bool dc_on = false;
-	// memory budget of the quadtree jump tables (bytes): $PGSD_JUMP_TABLE_MAX_BYTES at pg_create, default 2 GiB, and never
-	// more than a quarter of the device memory that is free when they are built
+	// memory budget of the quadtree jump tables (bytes): $PGSD_JUMP_TABLE_MAX_BYTES at pg_create, default 2 GiB.  The resolution a
+	// forest gets follows from the forest and this budget alone (pg_refine.hip: rebuild_jump)
 	uint64_t jump_budget = 2ull << 30;
 	void *comm = nullptr;            // ncclComm_t of the multi-GPU exchange (pg_comm.hip)
 	bool comm_owned = false;         // made by pg_comm_init (destroyed with the context) or attached by the caller

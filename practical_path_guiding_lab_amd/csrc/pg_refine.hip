@@ -15,6 +15,14 @@
 //   4. swap      the new forest becomes both sdTree_prev (values) and sdTree_current (zeroed
 //                accumulators)
 //
+// A refine is a TRANSACTION (round 6; the reference grows by allocate-new + copy, common.py:161-189, so its trees survive a
+// failed split): steps 1-3 read the forest and write only scratch buffers -- the split KD tree is made in a COPY of the node
+// arrays, the new records, heads and thresholds in their own buffers, the next iteration's accumulators in a spare one -- and
+// step 4 commits by swapping pointers and counts, which cannot fail.  Any error before the commit (an allocation, a limit)
+// returns with sdTree_prev and sdTree_current exactly as they were: every query, pass and export answers as before, and
+// the refine can be called again.  After the commit only the two accelerators are rebuilt (KD jump grid, quadtree jump
+// tables); if that fails the forest simply has none and every consumer walks from the roots (results are the same).
+//
 // Cloning a quadtree for the right child of a KD split (kdtree.py:316-323) commutes with the
 // per-tree refinement that follows (both copies start identical and see the same threshold), so
 // a clone is just a second level-0 entry pointing at the same source tree.
@@ -503,6 +511,7 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 	uint32_t *h_counts = reinterpret_cast<uint32_t *>(h_plan + 2);                   // [2]
 	uint32_t *h_total = h_counts + 2;                                                // [1]
 
+	// ======== A. everything that can fail: reads the forest, writes scratch only ========
 	// ---- 1. resolve --------------------------------------------------------------------------
 	PG_HIP(ctx, w.tot.ensure(f.n_rec, kGrow));
 	PG_HIP(ctx, w.cnt_tot.ensure(f.n_rec, kGrow));
@@ -521,33 +530,38 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 	hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, w.tree_count.p, w.kd_cnt.p, 0, 1);
 	for (int d = ctx->kd_max_depth - 1; d >= 0; --d)
 		hipLaunchKernelGGL(k_kd_counts, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, w.tree_count.p, w.kd_cnt.p, d, 0);
-	hipLaunchKernelGGL(k_kd_vcount, grid_for(f.n_kd), dim3(kBlk), 0, s, w.kd_cnt.p, f.kd_vcount.p, f.n_kd);
+	// (the vertCount column of the NEW sdTree_prev: the old one's stays in f.kd_vcount until the commit)
+	PG_HIP(ctx, w.new_vc.ensure(f.n_kd, kGrow));
+	hipLaunchKernelGGL(k_kd_vcount, grid_for(f.n_kd), dim3(kBlk), 0, s, w.kd_cnt.p, w.new_vc.p, f.n_kd);
 	PG_HIP(ctx, hipGetLastError());
 
 	tr.mark("resolve");
-	// ---- 2. KD refine ------------------------------------------------------------------------
-	ctx->kd_max_leaf_size = 12000.0 * sqrt(pow(2.0, (double)ctx->iteration)); // kdtree.py:327-330
-	const float kd_thr = (float)ctx->kd_max_leaf_size;
+	// ---- 2. KD refine, in a copy of the node arrays ------------------------------------------
+	const double kd_max_leaf_size = 12000.0 * sqrt(pow(2.0, (double)ctx->iteration)); // kdtree.py:327-330
+	const float kd_thr = (float)kd_max_leaf_size;
 	PG_HIP(ctx, w.plan.ensure(2));
 	PG_HIP(ctx, hipMemsetAsync(w.plan.p, 0, 2 * sizeof(unsigned long long), s));
-	hipLaunchKernelGGL(k_kd_plan, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, f.kd_vcount.p, kd_thr,
+	hipLaunchKernelGGL(k_kd_plan, grid_for(f.n_kd), dim3(kBlk), 0, s, f.kd.p, f.n_kd, w.new_vc.p, kd_thr,
 	                   ctx->kd_max_depth, w.plan.p);
 	PG_HIP(ctx, hipGetLastError());
 	PG_HIP(ctx, hipMemcpyAsync(h_plan, w.plan.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	PG_HIP(ctx, hipStreamSynchronize(s));
 	const uint64_t want_kd = (uint64_t)f.n_kd + h_plan[0], want_trees = (uint64_t)f.n_trees + h_plan[1];
 	if (want_kd > 0x7fffffffull) return fail(ctx, PG_ERR_NOMEM, "refine: KD tree would exceed 2^31 nodes");
-	PG_HIP(ctx, grow_preserve(f.kd, f.n_kd, want_kd, s));
-	PG_HIP(ctx, grow_preserve(f.kd_bmin, (size_t)f.n_kd * 3, want_kd * 3, s));
-	PG_HIP(ctx, grow_preserve(f.kd_bmax, (size_t)f.n_kd * 3, want_kd * 3, s));
-	PG_HIP(ctx, grow_preserve(f.kd_vcount, f.n_kd, want_kd, s));
+	PG_HIP(ctx, w.new_kd.ensure(want_kd, kGrow));
+	PG_HIP(ctx, w.new_bmin.ensure(want_kd * 3, kGrow));
+	PG_HIP(ctx, w.new_bmax.ensure(want_kd * 3, kGrow));
+	PG_HIP(ctx, grow_preserve(w.new_vc, f.n_kd, want_kd, s));
+	PG_HIP(ctx, hipMemcpyAsync(w.new_kd.p, f.kd.p, (size_t)f.n_kd * sizeof(KdNode), hipMemcpyDeviceToDevice, s));
+	PG_HIP(ctx, hipMemcpyAsync(w.new_bmin.p, f.kd_bmin.p, (size_t)f.n_kd * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+	PG_HIP(ctx, hipMemcpyAsync(w.new_bmax.p, f.kd_bmax.p, (size_t)f.n_kd * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
 	PG_HIP(ctx, w.tree_src.ensure(want_trees, kGrow));
 	PG_HIP(ctx, w.counts.ensure(2));
 	hipLaunchKernelGGL(k_iota, grid_for(f.n_trees), dim3(kBlk), 0, s, w.tree_src.p, f.n_trees);
 	uint32_t n_kd_new = f.n_kd, n_trees_new = f.n_trees;
 	if (h_plan[0]) {
 		KdRefineArgs a;
-		a.kd = f.kd.p; a.bmin = f.kd_bmin.p; a.bmax = f.kd_bmax.p; a.vc = f.kd_vcount.p;
+		a.kd = w.new_kd.p; a.bmin = w.new_bmin.p; a.bmax = w.new_bmax.p; a.vc = w.new_vc.p;
 		a.tree_src = w.tree_src.p; a.n_kd = f.n_kd; a.n_trees = f.n_trees; a.thr = kd_thr;
 		a.max_depth = ctx->kd_max_depth; a.out_counts = w.counts.p;
 		hipLaunchKernelGGL(k_kd_refine, dim3(1), dim3(1024), 0, s, a);
@@ -610,21 +624,39 @@ int refine_and_swap(pg_context *ctx, hipStream_t s)
 	}
 
 	tr.mark("quadtree rebuild");
-	// ---- 4. swap + reset ---------------------------------------------------------------------
-	PG_HIP(ctx, hipStreamSynchronize(s));
-	f.rec.swap(w.new_rec);     // (the old forest's buffers become the next refine's scratch)
+	// ---- the next iteration's accumulators (sdTree_current after the reset, path_guiding_integrator.py:583-586): zeroed in
+	// the spare buffer; the running iteration's stay in f.acc until the commit
+	const uint64_t new_acc_count = (uint64_t)off * 4 * kAccWords + (uint64_t)n_trees_new * kAccWords + n_trees_new;
+	PG_HIP(ctx, w.new_acc.ensure(new_acc_count, kGrow));
+	PG_HIP(ctx, hipMemsetAsync(w.new_acc.p, 0, new_acc_count * sizeof(long long), s));
+	PG_HIP(ctx, hipStreamSynchronize(s)); // (the last call of the transaction that can fail)
+
+	// ======== B. commit: pointer swaps and counts, nothing here can fail ========
+	f.kd.swap(w.new_kd);       // (what the forest held becomes the next refine's scratch)
+	f.kd_bmin.swap(w.new_bmin);
+	f.kd_bmax.swap(w.new_bmax);
+	f.kd_vcount.swap(w.new_vc);
+	f.rec.swap(w.new_rec);
 	f.head.swap(w.new_head);
 	f.tree_thr.swap(w.new_thr);
+	f.acc.swap(w.new_acc);
 	f.n_rec = (uint32_t)off;
 	f.n_trees = n_trees_new;
 	f.n_kd = n_kd_new;
-	f.level_off = new_level_off;
-	PG_HIP(ctx, f.acc.ensure(f.acc_count(), kGrow));
-	PG_HIP(ctx, hipMemsetAsync(f.acc.p, 0, f.acc_count() * sizeof(long long), s));
+	f.level_off.swap(new_level_off);
+	ctx->kd_max_leaf_size = kd_max_leaf_size;
 	tr.mark("swap + accumulators");
-	const int rc_jump = rebuild_jump(ctx, s);
-	if (rc_jump != PG_OK) return rc_jump;
-	PG_HIP(ctx, hipStreamSynchronize(s));
+
+	// ======== C. the accelerators of the new forest.  They are optional: a forest without them is walked from its roots by
+	// every consumer with the same results, so a failure here (it would be a device fault: their buffers were sized by
+	// setup / an earlier refine, or fall back by themselves) leaves a valid, slower forest and is not an error of the refine ========
+	const std::string err_keep = ctx->err;
+	if (rebuild_jump(ctx, s) != PG_OK || hipStreamSynchronize(s) != hipSuccess) {
+		(void)hipGetLastError();
+		f.jump_valid = false;
+		f.kd_grid_valid = false;
+		ctx->err = err_keep;
+	}
 	tr.mark("jump tables");
 	return PG_OK;
 }

@@ -1307,22 +1307,37 @@ int pg_render_reserve(pg_context *ctx, uint64_t n_lanes)
 	if (ctx->max_depth <= 0 || n_lanes == 0) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: max_depth and n_lanes must be > 0");
 	if (n_lanes * (uint64_t)ctx->max_depth > 0xffffffffull) return fail(ctx, PG_ERR_INVALID, "pg_render_reserve: more than 2^32 record slots in one pass");
 	PG_HIP(ctx, hipSetDevice(ctx->device));
-	// A pass of this size is a real render: the quadtree jump tables will grow to their memory budget while the SD-tree is
-	// trained (64 KB per quadtree, 1.4 GB at the veach-ajar bench tree), and a fresh allocation of hundreds of megabytes in the
-	// middle of a refine is the one thing that makes a 3 ms refine take 25 or 84 ms on some boxes (bench.py's
-	// exchange_refine_ms of a run on a slow-to-allocate box, round 5).  Reserving is what this call is for: the tables' buffer is
-	// taken at its budget now (the resolution a forest gets is a function of the forest and the budget alone, pg_refine.hip).
-	// A failed allocation here is no error: the refine falls back as it always did.
-	if (n_lanes >= (1ull << 20) && ctx->f.jump.cap * sizeof(QuadJump) < ctx->jump_budget) {
-		DevBuf<QuadJump> big;
-		if (big.ensure((size_t)(ctx->jump_budget / sizeof(QuadJump))) == hipSuccess) {
-			const size_t in_use = ctx->f.jump_valid ? ((size_t)ctx->f.n_trees << (2 * ctx->f.jump_bits)) : 0;
-			if (in_use) PG_HIP(ctx, hipMemcpy(big.p, ctx->f.jump.p, in_use * sizeof(QuadJump), hipMemcpyDeviceToDevice)); // (synchronous)
-			PG_HIP(ctx, hipDeviceSynchronize()); // (nothing in flight reads the old table any more: it is freed with `big`)
-			ctx->f.jump.swap(big);
+	// The pass buffers first: they are what this call is for, and what a pass cannot run without.
+	const int rc = ensure_pass_buffers(ctx, 0, n_lanes, true); // (a second set, pg_pass_params.slot 1, is allocated by its first pass)
+	if (rc != PG_OK) return rc;
+	// Then, where memory is plentiful, the quadtree jump tables' buffer at its budget: while the SD-tree of a real render is
+	// trained the tables grow towards it (64 KB per quadtree, 1.4 GB at the veach-ajar bench tree), and a fresh allocation of
+	// hundreds of megabytes in the middle of a refine is the one thing that makes a 3 ms refine take 25 or 84 ms on some boxes
+	// (bench.py's exchange_refine_ms on a slow-to-allocate box, round 5).  It is an OPTIMISATION of allocation time only -- the
+	// resolution a forest gets is a function of the forest and the budget alone (pg_refine.hip), with or without it -- so it is
+	// taken only
+	//   * for a pass of a real render (>= 2^20 lanes) and unless $PGSD_JUMP_TABLE_RESERVE is 0,
+	//   * AFTER the pass buffers, and only while the device still has four times the budget free: a context on a crowded
+	//     device (ranks of a rehearsal sharing one GPU, a small-memory configuration) leaves the memory alone and its refines
+	//     allocate what their forests need, as before round 5,
+	//   * without ever failing the call: a refused allocation changes nothing.
+	const char *rsv = getenv("PGSD_JUMP_TABLE_RESERVE");
+	const bool want_reserve = !(rsv && rsv[0] == '0');
+	if (want_reserve && n_lanes >= (1ull << 20) && ctx->f.jump.cap * sizeof(QuadJump) < ctx->jump_budget) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= 4ull * ctx->jump_budget) {
+			DevBuf<QuadJump> big;
+			if (big.ensure((size_t)(ctx->jump_budget / sizeof(QuadJump))) == hipSuccess) {
+				const size_t in_use = ctx->f.jump_valid ? ((size_t)ctx->f.n_trees << (2 * ctx->f.jump_bits)) : 0;
+				// (synchronous copy + device synchronisation: nothing in flight reads the old table when it is freed with `big`)
+				if ((in_use == 0 || hipMemcpy(big.p, ctx->f.jump.p, in_use * sizeof(QuadJump), hipMemcpyDeviceToDevice) == hipSuccess) &&
+				    hipDeviceSynchronize() == hipSuccess)
+					ctx->f.jump.swap(big);
+				else (void)hipGetLastError();
+			} else (void)hipGetLastError();
 		} else (void)hipGetLastError();
 	}
-	return ensure_pass_buffers(ctx, 0, n_lanes, true); // (a second set, pg_pass_params.slot 1, is allocated by its first pass)
+	return PG_OK;
 }
 
 int pg_film_tent(pg_context *ctx, uint32_t seed, int32_t spp, const float *L, float *image_out, void *stream)

@@ -32,7 +32,7 @@ def test_abi_version_and_loud_failure_without_gpu(native):
     L = native.lib()
     hdr = open(os.path.join(ROOT, "include", "pgsd.h")).read()
     declared = int(re.search(r"^#define PGSD_ABI_VERSION (\d+)", hdr, flags=re.M).group(1))
-    assert L.pg_abi_version() == declared == native.ABI_VERSION == 5   # header, library and bindings agree
+    assert L.pg_abi_version() == declared == native.ABI_VERSION == 6   # header, library and bindings agree
     import torch
 
     if torch.cuda.is_available():

@@ -47,14 +47,19 @@ def _trained(name="cornell-box"):
     return g, ws
 
 
-@pytest.mark.parametrize("name", ["veach-ajar", "torus"])
-def test_guided_pass_at_full_size_equals_the_oracle(name):
+@pytest.mark.parametrize("name,passes", [("cornell-box", 1), ("veach-mis", 1), ("veach-ajar", 2), ("torus", 1)])
+def test_guided_pass_at_full_size_equals_the_oracle(name, passes):
     """Device against ORACLE at BASELINE's full sizes, inside the suite (the lifecycle comparison at these sizes,
     tools/soak_parity.py, takes two minutes per scene): the SD-tree is trained on the device (three iterations),
-    exported (pg_export) and loaded into the oracle -- sdTree_prev and, zeroed, sdTree_current -- and then ONE guided
-    one-sample training pass (main.py:192) of the whole 1920x1080 film is traced on both: veach-ajar at max_depth 13,
-    torus at max_depth 32 (path_guiding_integrator.py:126-431; 2 M paths, seconds on the box's host cores).  Radiance per
-    lane, the valid flags, the per-pixel sums, every KD count and every accumulator limb of every node: bit for bit."""
+    exported (pg_export) and loaded into the oracle -- sdTree_prev and, zeroed, sdTree_current -- and then guided
+    one-sample training passes (main.py:192, seeded initial_seed + cumm_spp, :218) of the whole film are traced on both
+    (path_guiding_integrator.py:126-431; seconds on the box's host cores):
+      cornell-box 512x512 max_depth 8, veach-mis 1280x720 max_depth 3   the FUSED per-bounce kernels (k_bounce<*, 0/1>);
+      veach-ajar 1920x1080 max_depth 13   the split wavefront pipeline, as ONE BATCHED LAUNCH of two one-sample passes
+                                          (pg_pass_params.batched: the form bench.py's step launches, 4.1 M lanes) against the
+                                          oracle's two separate passes;
+      torus 1920x1080 max_depth 32        the split pipeline with its tail launch.
+    Radiance per lane, the valid flags, the per-pixel sums, every KD count and every accumulator limb of every node: bit for bit."""
     from oracle import pg_oracle as po
     from practical_path_guiding_lab_amd.render import IndependentSampler
 
@@ -70,16 +75,20 @@ def test_guided_pass_at_full_size_equals_the_oracle(name):
     pair.current.reset()
     g.setIteration(3, False)
     g.resetVarianceCounter()
-    Lg, vg, _ = g.sample(ws, IndependentSampler(1, 31337))
+    Lg, vg, _ = g.sample(ws, IndependentSampler(passes, 31337, batched=passes > 1))
+    Lg = Lg.cpu().numpy().reshape(3, npix, passes)       # lane = pixel * passes + pass
+    vg = vg.cpu().numpy().reshape(npix, passes)
     o_sumL, o_sumL2 = np.zeros((3, npix), np.float32), np.zeros((3, npix), np.float32)
     threads = po.set_threads(0)
     try:
-        Lo, vo = po.render_pass(pair, sc, sc.camera, depth, rr, 3, False, 31337, 1, True, 0.5, o_sumL, o_sumL2)
+        for s_ in range(passes):
+            Lo, vo = po.render_pass(pair, sc, sc.camera, depth, rr, 3, False, 31337 + s_, 1, True, 0.5, o_sumL, o_sumL2)
+            assert Lo.shape == (3, npix) and np.isfinite(Lo).all() and Lo.mean() > 0
+            np.testing.assert_array_equal(np.ascontiguousarray(Lg[:, :, s_]).view(np.uint32), Lo.view(np.uint32))
+            np.testing.assert_array_equal(vg[:, s_], vo)
     finally:
         po.set_threads(1)
-    assert threads >= 1 and Lo.shape == (3, npix) and np.isfinite(Lo).all() and Lo.mean() > 0
-    np.testing.assert_array_equal(Lg.cpu().numpy().view(np.uint32), Lo.view(np.uint32))
-    np.testing.assert_array_equal(vg.cpu().numpy(), vo)
+    assert threads >= 1
     np.testing.assert_array_equal(g.sumL.cpu().numpy().view(np.uint32), o_sumL.view(np.uint32))
     np.testing.assert_array_equal(g.sumL2.cpu().numpy().view(np.uint32), o_sumL2.view(np.uint32))
     kd, lo, hi = g.sdTree.exportAccumulators()
