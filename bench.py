@@ -162,6 +162,11 @@ def parse():
                          "eighth of it leaves gaps between its small launches that a second pass fills: 7.72 -> 7.08 ms per step of a rank's share, "
                          "6.7x -> 7.3x of 8 by emulation on one GPU (tools/stripe_balance.py, profiles/r04/stripe_balance.txt)")
     ap.add_argument("--synthetic", action="store_true", help="renderer-free SD-tree hot-path workload")
+    ap.add_argument("--phase-probe", type=int, default=None,
+                    help="1: behind the timed regions rank 0 runs the PROBE build of the library (libpgsd_phases.so, csrc/Makefile `probe`: "
+                         "k_wave_shade with wave-clock stamps at its phase boundaries) as a child process for three steps and reports the "
+                         "SD-tree calls' share of k_wave_shade in the region `value` is quoted on (roofline.value_region_sdtree_*); "
+                         "default: 1 for the default one-GPU line.  2: (internal) this process IS that child")
     ap.add_argument("--detail", default=None,
                     help="file the FULL record is written to (default gpurun_out/bench_detail.json); stdout carries one compact line, "
                          "< 6 KB of strict JSON, and nothing else")
@@ -180,6 +185,8 @@ def parse():
         args.other_configs = 1 if (args.gpus == 1 and not args.synthetic and args.scene == "veach-ajar") else 0
     if args.pmc_in_run is None:
         args.pmc_in_run = 1 if (args.gpus == 1 and not args.synthetic and args.full_schedule) else 0
+    if args.phase_probe is None:
+        args.phase_probe = 1 if (args.gpus == 1 and not args.synthetic and args.full_schedule) else 0
     if args.in_flight is None:
         args.in_flight = 2 if (args.gpus > 1 and args.shard == "tiles" and not args.synthetic) else 1
     return args
@@ -235,7 +242,7 @@ def measure_traffic_in_run(args, launches_per_step, timeout_s=90.0):
              "--scene", args.scene, "--res", str(args.res), "--depth", str(args.depth), "--spp-per-pass", str(args.spp_per_pass),
              "--batched", str(args.batched), "--train-iters", str(args.train_iters), "--sort", str(args.sort),
              "--in-flight", str(args.in_flight), "--steps", str(PMC_CHILD_STEPS), "--warmup", "1", "--cpu", "0", "--full-schedule", "0",
-             "--spp1", "0", "--other-configs", "0", "--synthetic-kernels", "0", "--pmc-in-run", "0", "--detail", os.devnull]
+             "--spp1", "0", "--other-configs", "0", "--synthetic-kernels", "0", "--pmc-in-run", "0", "--phase-probe", "0", "--detail", os.devnull]
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.perf_counter()
     vals = {}
@@ -560,6 +567,106 @@ def image_mse(sumL, spp, width, height, name):
     return masked_mse(img, gt, mask), note
 
 
+PROBE_LIBRARY = os.path.join(ROOT, "practical_path_guiding_lab_amd", "libpgsd_phases.so")
+PHASE_NAMES = ("records_staging", "stage_a1", "shadow_walk", "stage_a2", "sdtree_calls", "stage_b", "append")
+
+
+def run_phase_probe(args):
+    """--phase-probe 2: this process runs on the PROBE build ($PGSD_LIBRARY = libpgsd_phases.so): the same scene, training and
+    batched steps as the timed region of `value`, with k_wave_shade's phase stamps on and the depth counters OFF
+    (pg_enable_depth_counters(2): no atomics inside the SD-tree walks), and prints one small JSON line: the wave-clock cycles
+    of the seven phases summed over the waves of args.steps steps, k_wave_shade's average launch while stamping and -- the
+    same passes again with the stamps switched off -- while the compiled-in stamps idle."""
+    import numpy as np
+    import torch
+    from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+    from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+
+    sc = make_scene(args.scene, args.res, args.depth)
+    integ = PathGuidingIntegrator({"max_depth": args.depth, "rr_depth": 8}, device=0)
+    tree = integ.sdTree
+    npix = sc.camera.width * sc.camera.height
+    integ.setup(npix, sc.bbox_min - np.float32(1e-4), sc.bbox_max + np.float32(1e-4), 20, 20, True, 0.5)
+    ws = WavefrontScene(sc, in_flight=args.in_flight, sort=bool(args.sort), stages=args.stages)
+    ws.reserve(integ, args.spp_per_pass)
+    batched = bool(args.batched)
+    cumm = 0
+    for k in range(args.train_iters):
+        integ.setIteration(k, False)
+        iter_spp = 2 ** (k + 2)
+        chunk = max(1, min(args.spp_per_pass, iter_spp))
+        for i in range(iter_spp // chunk):
+            integ.sample(ws, IndependentSampler(chunk, cumm + i * chunk, batched=batched))
+        cumm += iter_spp
+        integ.refineAndPrepareSDTreeForNextIteration()
+    integ.setIteration(args.train_iters, False)
+    seed = [cumm]
+
+    def step():
+        integ.sample(ws, IndependentSampler(args.spp_per_pass, seed[0], batched=batched))
+        seed[0] += args.spp_per_pass
+
+    def region(mode):
+        tree.enableDepthCounters(mode)
+        step()
+        torch.cuda.synchronize()
+        tree.readShadePhases(reset=True)
+        tree.enableKernelTiming(True)
+        tree.readKernelTiming(reset=True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        kt = tree.readKernelTiming(reset=True)
+        tree.enableKernelTiming(False)
+        ph = tree.readShadePhases(reset=True)
+        tree.enableDepthCounters(False)
+        return kt, ph
+
+    kt_on, (compiled, waves, cycles) = region(2)
+    kt_off, _ = region(0)
+    return {"phase_probe": True, "compiled_in": compiled, "waves": waves, "cycles": cycles, "steps": args.steps,
+            "shade_launches": int(kt_on.bounce_launches), "shade_avg_us_stamping": 1e3 * kt_on.shade_ms / max(kt_on.bounce_launches, 1),
+            "shade_avg_us_stamps_idle": 1e3 * kt_off.shade_ms / max(kt_off.bounce_launches, 1)}
+
+
+def measure_sdtree_phase(args, timeout_s=120.0):
+    """The SD-tree calls INSIDE k_wave_shade, where `value` is quoted: a child process on the probe build
+    (run_phase_probe) -- a fresh process with $PGSD_LIBRARY set, nothing exec'ed by this one.  Returns (dict, note) or (None, why)."""
+    import signal
+    import subprocess
+
+    if not os.path.exists(PROBE_LIBRARY):
+        return None, "the probe build (libpgsd_phases.so: make -C practical_path_guiding_lab_amd/csrc probe) is not there"
+    child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.abspath(__file__),
+             "--scene", args.scene, "--res", str(args.res), "--depth", str(args.depth), "--spp-per-pass", str(args.spp_per_pass),
+             "--batched", str(args.batched), "--train-iters", str(args.train_iters), "--sort", str(args.sort),
+             "--in-flight", str(args.in_flight), "--stages", str(args.stages), "--steps", "3", "--phase-probe", "2"]
+    env = dict(os.environ, PGSD_LIBRARY=PROBE_LIBRARY)
+    pr = subprocess.Popen(child, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    try:
+        out, err = pr.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        pr.communicate()
+        return None, f"the probe process did not finish within {timeout_s:.0f} s (ended)"
+    if pr.returncode != 0:
+        return None, f"the probe process exited {pr.returncode}: {err.decode(errors='replace')[-300:]}"
+    for line in reversed(out.decode(errors="replace").splitlines()):
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if d.get("phase_probe"):
+                if not d.get("compiled_in") or sum(d["cycles"]) <= 0:
+                    return None, "the probe library has no phase stamps compiled in"
+                return d, "measured in this run: three steps on the probe build (libpgsd_phases.so), stamps on, depth counters off"
+    return None, "the probe process printed no result"
+
+
 # ------------------------------------------------------------------------------------------------
 def run_render(args):
     import numpy as np
@@ -690,6 +797,8 @@ def run_render(args):
         ws.set_stages(integ, args.stages)
     tree.enableKernelTiming(False)
 
+    # (the SD-tree `value` was quoted on, for the config-matched cpu_baseline: sdTree_prev's 23 columns on the host)
+    bench_tree_cols = tree.export() if (args.cpu and world == 1) else None
     # per-iteration exchange + refine (not part of `value`)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -971,10 +1080,37 @@ def run_render(args):
                                   "timed region of `value`; value_region_traffic / _frac_counter_* are its PMC figures (roofline.traffic_source)")})
         sh["alg_bytes_per_launch"] = int(sh_alg)
         sh["alg_GBps"] = round(sh_alg / sh_sec / 1e9, 2)
+        # ---- ... and the SD-tree calls' own share of that kernel, taken IN PLACE by the probe build:
+        # value_region_sdtree_us = that share of k_wave_shade's average launch in the timed region of `value` (the product
+        # build's time, not the probe's), value_region_sdtree_frac = the gathered layout bytes of a launch over it and the peak --
+        # the figure to put beside `frac` (k_wave_guide, the same calls as a kernel of their own in the second region) ----
+        if args.phase_probe == 1 and rank == 0 and world == 1:
+            pp, pp_note = measure_sdtree_phase(args)
+            print(f"[bench] phase probe: {pp_note}", file=sys.stderr, flush=True)
+            if pp is not None:
+                tot = float(sum(pp["cycles"]))
+                share = pp["cycles"][PHASE_NAMES.index("sdtree_calls")] / tot
+                sd_us = share * sh["avg_us"]
+                roof.update({
+                    "value_region_sdtree_share": round(share, 4), "value_region_sdtree_us": round(sd_us, 2),
+                    "value_region_sdtree_frac": round(sh_layout / (sd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "value_region_sdtree_frac_model_8d": round(sh_alg / (sd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "value_region_sdtree_probe_overhead": round(pp["shade_avg_us_stamping"] / sh["avg_us"], 3),
+                    # (the probe stamps the start, the two sides of the SD-tree calls and the end: three shares)
+                    "value_region_phase_shares": {"ahead_of_sdtree_calls": round(sum(pp["cycles"][:4]) / tot, 4), "sdtree_calls": round(share, 4),
+                                                  "stage_b_and_append": round(sum(pp["cycles"][5:]) / tot, 4)},
+                    "value_region_sdtree_note": (
+                        "the SD-tree calls of a bounce (path_guiding_integrator.py:244, 301, 307) timed IN PLACE, inside k_wave_shade: " + pp_note +
+                        f"; wave-clock cycles of the seven phases summed over {pp['waves']} waves of {pp['shade_launches']} launches; "
+                        "value_region_sdtree_us = the SD-tree phase's share x k_wave_shade's average launch in `value`'s region (this "
+                        f"build, {sh['avg_us']} us); the probe's k_wave_shade took {pp['shade_avg_us_stamping']:.1f} us per launch while "
+                        f"stamping and {pp['shade_avg_us_stamps_idle']:.1f} us with its stamps idle (value_region_sdtree_probe_overhead = "
+                        "stamping / this build)")})
     cpu = None
     mse_small = mse_small_cpu = None
     if args.cpu and world == 1:
-        cpu, mse_small, mse_small_cpu = cpu_leg(args)
+        cpu, mse_small, mse_small_cpu = cpu_leg(args, bench_tree=bench_tree_cols, iteration=k)
+        bench_tree_cols = None
     synth_detail = None
     if args.synthetic_kernels and world == 1:
         synth_flat, synth_detail = synthetic_kernels_leg(local_rank, cpu=bool(args.cpu))
@@ -1396,11 +1532,15 @@ def full_schedule_leg(args, integ, ws, shard, reduce_fn, W, H):
                     "mse_vs_gt = per-pixel mean of the final image's samples vs the ground truth" + (": " + note if note else "")}
 
 
-def cpu_leg(args, iters=4, width=320):
-    """The same 4-iteration schedule (4+8+16+32 spp, the last two guided) of the same scene on a
-    320-pixel-wide film, on the device and on the CPU oracle with all host cores: same seeds, so the
-    images -- and their MSEs against the ground truth -- must be identical; the oracle's guided
-    passes are the timed cpu_baseline sample."""
+def cpu_leg(args, iters=4, width=320, bench_tree=None, iteration=None, full_passes=3):
+    """cpu_baseline.  (1) CONFIG-MATCHED: `full_passes` guided ONE-sample training passes (main.py:192) of the
+    bench's own film (args.res wide, the config's max_depth) through the bench's own SD-tree -- `bench_tree`, the 23 columns
+    exported behind the timed steps, loaded into the oracle as sdTree_prev and, zeroed, as sdTree_current -- on all host cores:
+    cpu_baseline.value.  The first of those passes is also traced on the device through the same tree (a fresh context that
+    loads the columns): radiance bit-identical or images_bit_identical_to_device is false.
+    (2) The same 4-iteration schedule (4+8+16+32 spp, the last two guided) of the same scene on a 320-pixel-wide film, on the
+    device and on the oracle: same seeds, so the images -- and their MSEs against the ground truth -- must be identical
+    (mse_equal); its guided passes timed are cpu_baseline.value_small (round 5's `value`)."""
     import numpy as np
     from oracle import pg_oracle as po
     from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
@@ -1462,18 +1602,58 @@ def cpu_leg(args, iters=4, width=320):
         cumm += spp
         if k + 1 < iters:
             pair2.refine_and_prepare(k)
-    cpu = {"value": round(n_guided / t_guided / 1e6, 4), "unit": "Msamples/s", "cores": cores, "host_cores_usable": usable,
+    # ---- (1) the config-matched sample: the bench's film, the bench's tree ----
+    full = None
+    if bench_tree is not None:
+        import torch
+        scF = make_scene(args.scene, args.res, args.depth)
+        WF, HF = scF.camera.width, scF.camera.height
+        fmin, fmax = scF.bbox_min - np.float32(1e-4), scF.bbox_max + np.float32(1e-4)
+        pairF = po.OracleSDTreePair()
+        pairF.setup(fmin, fmax, 20, 20, True)
+        pairF.prev.load(bench_tree)
+        pairF.current.load(bench_tree)   # (same topology, path_guiding_integrator.py:582; a load leaves the accumulators at zero)
+        pairF.current.reset()
+        gF = PathGuidingIntegrator({"max_depth": args.depth, "rr_depth": 8})
+        gF.setup(WF * HF, fmin, fmax, 20, 20, True, 0.5)
+        gF.sdTree.load(bench_tree)
+        gF.setIteration(iteration, False)
+        wsF = WavefrontScene(scF)
+        seedF = 770000
+        Lg = gF.sample(wsF, IndependentSampler(1, seedF))[0].cpu().numpy()
+        del gF, wsF
+        torch.cuda.empty_cache()
+        tF, same_full = 0.0, None
+        for p_ in range(full_passes):
+            t0 = time.perf_counter()
+            Lo, _ = po.render_pass(pairF, scF, scF.camera, args.depth, 8, iteration, False, seedF + p_, 1, True, 0.5)
+            tF += time.perf_counter() - t0
+            if p_ == 0:
+                same_full = bool((Lg.view(np.uint32) == Lo.view(np.uint32)).all())
+        full = {"value": round(full_passes * WF * HF / tF / 1e6, 4), "seconds": round(tF, 2), "film": f"{WF}x{HF}", "passes": full_passes,
+                "same": same_full, "paths": full_passes * WF * HF}
+        del pairF, Lg
+    small_value = round(n_guided / t_guided / 1e6, 4)
+    cpu = {"value": small_value if full is None else full["value"], "unit": "Msamples/s", "cores": cores, "host_cores_usable": usable,
            "host_cores_shown": os.cpu_count(), "kind": "port",
+           "config": (f"same film ({full['film']}, max_depth {args.depth}), same SD-tree (the one `value` was quoted on), {full['passes']} guided "
+                      "one-sample passes" if full is not None else f"{W}x{H} film, 4-iteration schedule, guided iterations 2-3"),
+           "seconds": None if full is None else full["seconds"],
+           "value_small": small_value, "images_bit_identical_to_device_full_size": None if full is None else full["same"],
            "label": "CPU restatement: the build's own C restatement of the reference's Python (oracle/, OpenMP over the lanes), NOT the "
                     "reference -- its Python / Dr.Jit path cannot run on this box (Mitsuba 3 and Dr.Jit are absent: SURVEY 8c)",
-           "images_bit_identical_to_device": same,
+           "images_bit_identical_to_device": bool(same and (full is None or full["same"])),
            "mse_vs_gt_device": mse_g, "mse_vs_gt_cpu": mse_c, "mse_equal": bool(mse_g == mse_c),
            "value_one_sample_passes": round(n_guided_1 / t_guided_1 / 1e6, 4),
-           "sample": f"the guided passes (iterations 2-3, 16 + 32 spp) of a 4-iteration schedule of the same scene on a {W}x{H} "
+           "sample": (f"{full['passes']} guided one-sample passes (main.py:192) of the bench's own {full['film']} film, max_depth {args.depth}, through the "
+                      f"bench's own SD-tree: {full['paths']} paths in {full['seconds']} s on {cores} threads ({usable} usable cores); first pass "
+                      f"bit-identical to the device's: {full['same']}") if full is not None else
+                     f"the guided passes (iterations 2-3, 16 + 32 spp) of a 4-iteration schedule of the same scene on a {W}x{H} "
                      f"film ({n_guided} paths), C oracle with OpenMP over the lanes on {cores} threads (this process may use {usable} of the box's "
                      f"{os.cpu_count()} cores: its cgroup quota), {t_guided:.1f} s; "
                      f"value_one_sample_passes: the same samples as 48 separate one-sample passes ({t_guided_1:.1f} s), the leg the "
-                     "device's images are compared with"}
+                     "device's images are compared with",
+           "sample_small": f"value_small: guided iterations 2-3 (16 + 32 spp) of a 4-iteration schedule on a {W}x{H} film, {n_guided} paths, {t_guided:.1f} s"}
     return cpu, mse_g, mse_c
 
 
@@ -1621,8 +1801,8 @@ def compact_record(out):
                            "SURVEY 8d model bytes: frac_model_8d")[:120]
     c["roofline"] = r or None
     if isinstance(cpu, dict):
-        cc = _pick(cpu, ("value", "unit", "cores", "kind", "host_cores_usable", "mse_equal", "images_bit_identical_to_device", "config",
-                         "value_small", "seconds"))
+        cc = _pick(cpu, ("value", "unit", "cores", "kind", "host_cores_usable", "mse_equal", "images_bit_identical_to_device",
+                         "images_bit_identical_to_device_full_size", "config", "value_small", "seconds"))
         cc["label"] = "CPU restatement (oracle/, OpenMP over the lanes), not the reference: Mitsuba/Dr.Jit absent"
         s = str(cpu.get("sample", ""))
         cc["sample"] = s if len(s) <= 240 else s[:237] + "..."
@@ -1694,6 +1874,9 @@ def main():
         # the driver's plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing above has imported
         # torch or touched HIP, the children are fresh processes (no exec of a process that holds the GPU).
         sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.phase_probe == 2:  # (the probe child of measure_sdtree_phase: one small line, not a bench record)
+        print(json.dumps(run_phase_probe(args)))
+        return
     out = run_synthetic(args) if args.synthetic else run_render(args)
     if out is not None:
         emit(out, args.detail)

@@ -36,7 +36,8 @@ extern "C" {
 /* 5 (round 5): new entry points pg_comm_info, pg_exchange_pack, pg_exchange_unpack, pg_exchange_pack_words,
  * pg_exchange_unpack_words; pg_allreduce moves the accumulators in the 24-byte exchange format (same sums).  No struct changed. */
 /* 6 (round 6): pg_refine_and_swap is a transaction (on any error both trees are exactly what they were; the context stays usable);
- * new entry points pg_debug_fail_alloc, pg_debug_fail_alloc_pending (fault injection for the tests).  No struct changed. */
+ * new entry points pg_debug_fail_alloc, pg_debug_fail_alloc_pending (fault injection for the tests), pg_read_shade_phases (probe
+ * builds); pg_enable_depth_counters takes mode 2.  No struct changed. */
 #define PGSD_ABI_VERSION 6
 
 typedef struct pg_context pg_context;
@@ -565,6 +566,17 @@ typedef struct pg_depth_counters {
 } pg_depth_counters;
 int pg_enable_depth_counters(pg_context *ctx, int32_t on);
 int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t reset);
+
+/* Where a wave of k_wave_shade spends its life -- a PROBE BUILD's instrument (the library compiled with -DPG_SHADE_PHASES=1,
+ * csrc/Makefile target `probe`: libpgsd_phases.so; the product build has no stamps, h_out[0] = 0 and zeros): the kernel that makes
+ * the three SD-tree calls of a bounce (path_guiding_integrator.py:244, 301, 307) in the default pipeline also shades, walks the
+ * shadow ray and appends the survivors, so the calls cannot be timed apart by events; the probe stamps the wave clock at the
+ * seven phase boundaries.  pg_enable_depth_counters(ctx, 2) switches the stamps on WITHOUT the depth counters (no atomics in the
+ * walks themselves); pg_enable_depth_counters(ctx, 1) switches both on.  h_out[10]:
+ *   [0] 1 when the stamps are compiled in, [1] waves that ran the kernel's body,
+ *   [2..8] wave-clock cycles summed over those waves: records + staging, stage_a1, shadow walk, stage_a2, SD-tree calls,
+ *          stage_b, survivors' append;  [9] 0. */
+int pg_read_shade_phases(pg_context *ctx, uint64_t *h_out, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,7 @@ EXPORTS = (
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_attach", "pg_comm_destroy", "pg_allreduce", "pg_render_reserve",
     "pg_render_split_pipeline", "pg_comm_info", "pg_exchange_pack", "pg_exchange_unpack", "pg_exchange_pack_words",
     "pg_exchange_unpack_words", "pg_sort_places", "pg_debug_fail_alloc", "pg_debug_fail_alloc_pending",
+    "pg_read_shade_phases",
 )
 
 
@@ -185,6 +186,7 @@ def lib() -> C.CDLL:
     L.pg_process_and_splat.argtypes = [V, U64, I32, V, C.POINTER(pg_dense_records), V]
     L.pg_refine_and_swap.argtypes = [V, V]
     L.pg_debug_fail_alloc.argtypes = [C.c_int64]
+    L.pg_read_shade_phases.argtypes = [V, C.POINTER(C.c_uint64), I32]
     L.pg_debug_fail_alloc_pending.argtypes = []
     L.pg_accumulators.argtypes = [V, C.POINTER(V), C.POINTER(U64)]
     L.pg_export_sizes.argtypes = [V, C.POINTER(pg_tree_sizes)]

@@ -370,7 +370,16 @@ int pg_sort_places(pg_context *ctx, uint64_t n, const uint16_t *d_keys, const ui
 int pg_enable_depth_counters(pg_context *ctx, int32_t on)
 {
 	if (!ctx) return PG_ERR_INVALID;
-	ctx->dc_on = on != 0;
+	ctx->dc_on = on == 1;
+	ctx->ph_on = false;
+	if ((on == 1 || on == 2) && shade_phases_compiled_in()) { // (2: a probe build's phase stamps alone, without the counters' atomics)
+		PG_HIP(ctx, hipSetDevice(ctx->device));
+		if (!ctx->ph_buf.p) {
+			PG_HIP(ctx, ctx->ph_buf.ensure((size_t)kPhaseStripes * kPhaseWords));
+			PG_HIP(ctx, hipMemset(ctx->ph_buf.p, 0, (size_t)kPhaseStripes * kPhaseWords * sizeof(unsigned long long)));
+		}
+		ctx->ph_on = true;
+	}
 	return PG_OK;
 }
 
@@ -389,16 +398,32 @@ int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t rese
 	if (getenv("PGSD_TRACE_SHADOW") && h.body_waves)
 		fprintf(stderr, "[pgsd] k_wave_shade: %llu waves ran the body, %llu of them walked shadow rays with %llu lanes (%.1f of 64 per walking wave)\n",
 		        h.body_waves, h.shadow_waves, h.shadow_lanes, h.shadow_waves ? (double)h.shadow_lanes / (double)h.shadow_waves : 0.0);
-	if (getenv("PGSD_TRACE_SHADOW") && h.body_waves) {
-		unsigned long long tot = 0;
-		for (int i = 0; i < 7; ++i) tot += h.phase[i];
-		if (tot) {
-			static const char *names[7] = {"records + staging", "stage_a1", "shadow walk", "stage_a2", "SD-tree calls", "stage_b", "append"};
-			fprintf(stderr, "[pgsd] k_wave_shade: a wave's %.0f cycles on average, by phase:", (double)tot / (double)h.body_waves);
-			for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f %%%s", names[i], 100.0 * (double)h.phase[i] / (double)tot, i < 6 ? "," : "\n");
-		}
-	}
 	if (reset) PG_HIP(ctx, hipMemset(ctx->dc, 0, sizeof(DepthCounters)));
+	return PG_OK;
+}
+
+int pg_read_shade_phases(pg_context *ctx, uint64_t *h_out, int32_t reset)
+{
+	if (!ctx || !h_out) return PG_ERR_INVALID;
+	for (int i = 0; i < 10; ++i) h_out[i] = 0;
+	h_out[0] = shade_phases_compiled_in() ? 1u : 0u;
+	if (!ctx->ph_buf.p) return PG_OK; // (the product build, or never enabled)
+	PG_HIP(ctx, hipSetDevice(ctx->device));
+	PG_HIP(ctx, hipDeviceSynchronize());
+	std::vector<unsigned long long> h((size_t)kPhaseStripes * kPhaseWords);
+	PG_HIP(ctx, hipMemcpy(h.data(), ctx->ph_buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	for (int st = 0; st < kPhaseStripes; ++st) {
+		h_out[1] += h[(size_t)st * kPhaseWords + 7];
+		for (int i = 0; i < 7; ++i) h_out[2 + i] += h[(size_t)st * kPhaseWords + i];
+	}
+	if (getenv("PGSD_TRACE_SHADOW") && h_out[1]) {
+		unsigned long long tot = 0;
+		for (int i = 0; i < 7; ++i) tot += h_out[2 + i];
+		static const char *names[7] = {"records + staging", "stage_a1", "shadow walk", "stage_a2", "SD-tree calls", "stage_b", "append"};
+		fprintf(stderr, "[pgsd] k_wave_shade: a wave's %.0f cycles on average, by phase:", (double)tot / (double)h_out[1]);
+		for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f %%%s", names[i], 100.0 * (double)h_out[2 + i] / (double)(tot ? tot : 1), i < 6 ? "," : "\n");
+	}
+	if (reset) PG_HIP(ctx, hipMemset(ctx->ph_buf.p, 0, h.size() * sizeof(unsigned long long)));
 	return PG_OK;
 }
 

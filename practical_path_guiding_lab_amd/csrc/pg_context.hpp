@@ -135,6 +135,8 @@ struct pg_context {
 	pg::Forest f;
 	pg::DepthCounters *dc = nullptr; // device
 	bool dc_on = false;
+	bool ph_on = false;              // a probe build's phase stamps are on (pg_enable_depth_counters 1 or 2; never in the product build)
+	pg::DevBuf<unsigned long long> ph_buf; // their striped counters (kPhaseStripes x kPhaseWords), allocated by the first enable of a probe build
 	// memory budget of the quadtree jump tables (bytes): $PGSD_JUMP_TABLE_MAX_BYTES at pg_create, default 2 GiB.  The resolution a
 	// forest gets follows from the forest and this budget alone (pg_refine.hip: rebuild_jump)
 	uint64_t jump_budget = 2ull << 30;
@@ -170,6 +172,8 @@ int refine_and_swap(pg_context *ctx, hipStream_t s);
 int rebuild_jump(pg_context *ctx, hipStream_t s); // after every change of the quadtree records or heads
 // pg_render.hip
 void destroy_render_state(pg_context *ctx);
+// pg_render_wave.hip
+bool shade_phases_compiled_in();
 // pg_comm.hip
 void destroy_comm(pg_context *ctx);
 // pg_sort.hip

@@ -9,15 +9,19 @@
 
 namespace pg {
 
+// Probe builds (-DPG_SHADE_PHASES=1): where does a wave of k_wave_shade spend its life?  Wave-clock cycles (s_memtime), phase by phase
+// -- 0 the records + staging, 1 stage_a1, 2 the shadow walk, 3 stage_a2, 4 the SD-tree calls, 5 stage_b, 6 the survivors' append; word 7
+// counts the waves -- accumulated by each wave in LDS and flushed ONCE, by one eight-lane atomic, into one of kPhaseStripes lines of
+// kPhaseWords words (pg_read_shade_phases sums the stripes).  Round 5's probe added every stamp to ONE line of device memory: its
+// k_wave_shade ran eleven times slower than the product's, and the shares it reported were those of a kernel waiting for that line.
+constexpr int kPhaseStripes = 1024, kPhaseWords = 16;
+
 struct DepthCounters { // device-resident, optional
 	unsigned long long kd_levels, kd_queries, quad_levels, quad_queries;
 	unsigned long long layout_bytes; // bytes the lanes gathered from the built tables (stat_word, pg_descent.hpp); tree heads not included
 	// (diagnostics of instrumented passes, printed by pg_read_depth_counters under $PGSD_TRACE_SHADOW: how full are the waves
 	// that walk shadow rays in k_wave_shade?)  waves that walked, their lanes with a ray, waves that ran the kernel's body
 	unsigned long long shadow_waves, shadow_lanes, body_waves;
-	// ... and where does a wave of k_wave_shade spend its life?  Clock cycles (s_memtime) summed over the waves, phase by phase:
-	// 0 the records + staging, 1 stage_a1, 2 the shadow walk, 3 stage_a2, 4 the SD-tree calls, 5 stage_b, 6 the survivors' append
-	unsigned long long phase[8];
 };
 
 // ---- queries (pg_kernels_query.hip) ----

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	__shared__ uint32_t s_base;
 	__shared__ float s_stash[kBounceStash][kRBlock];
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
+	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)live_final(a, a.bounce - 1);
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
 	if (!kFirst && tail_took_over(a, a.bounce)) return;  // a tail launch is finishing these paths
 #ifdef PG_FUSED_LDS_KD
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	uint64_t rec_base = 0;
 	if (!kFirst) {
 		rec_base = a.n_lanes;
-		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 	}
 	bool cont = false;
 	if (alive) cont = bounce_lane<kFirst, kGeneral, true>(a, s_kd, lane, rec_base + tid, (uint32_t)a.bounce, (LdsFloat *)&s_stash[0][threadIdx.x]);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (bounce_lane's parameter: the staged table of whichever kind)
 #endif
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	const uint64_t live = (uint64_t)a.live_count[a.bounce - 1];
+	const uint64_t live = (uint64_t)live_final(a, a.bounce - 1);
 	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
 #ifdef PG_FUSED_LDS_KD
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 	bool alive = tid < live;
 	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
 	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce
-	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 	const uint64_t tail_base = rec_base + live; // behind the entries of bounce a.bounce
 	uint64_t slot = rec_base + tid;
 	const unsigned wl = threadIdx.x & 63u;
@@ -1087,6 +1087,7 @@ int pg_render_pass(pg_context *ctx, const pg_pass_params *prm, float *L_out, uin
 	a.seed = prm->seed;
 	a.batched = prm->batched ? 1 : 0;
 	a.dc = ctx->dc_on ? ctx->dc : nullptr;
+	a.ph = ctx->ph_on ? ctx->ph_buf.p : nullptr;
 	a.ray_d = b.ray_d.p; a.thr = b.thr.p; a.L = L_out; a.prev_p = b.prev_p.p;
 	a.prev_pdf = b.prev_pdf.p; a.prev_quad = b.prev_quad.p; a.hit0 = b.hit0.p;
 	a.rng_state = b.rng_state.p; a.rng_inc = b.rng_inc.p; a.live_count = b.live_count.p;

@@ -1188,6 +1188,7 @@ struct RenderArgs {
 	uint32_t seed;
 	int batched;               // pg_pass_params.batched: the spp samples of a pixel are spp one-sample passes seed, seed + 1, ...
 	DepthCounters *dc;
+	unsigned long long *ph; // probe builds (-DPG_SHADE_PHASES=1) only: the striped phase counters of k_wave_shade (pg_kernels.hpp: kPhaseStripes lines), on in instrumented passes and -- without the depth counters' atomics -- with pg_enable_depth_counters(2); never read by the product build
 	int bounce, last;          // index of this launch = path depth of every live lane; last launch of the pass
 	int fuse_guide;            // split pipeline: k_wave_shade_a also makes the SD-tree calls, no k_wave_guide launch
 	const uint32_t *order_in;  // live-ray list written by the previous bounce (unused by the first)
@@ -1256,6 +1257,26 @@ __host__ __device__ constexpr bool tail_checkpoint(int bounce, int max_depth)
 	return max_depth > 8 && bounce >= 4 && bounce + 1 < max_depth &&
 	       (bounce < 8 || (bounce < 16 && bounce % 2 == 0) || bounce % 4 == 0);
 }
+// The counters of EARLIER bounces are final when a launch of bounce b reads them (the launches of a pass are stream-ordered) and the
+// same for every lane: they are read as CONSTANTS -- address space 4, scalar loads (s_load, counted by lgkmcnt) -- whatever stands
+// around the read.  Left to the compiler this was a scalar load only by luck: with ANY instruction it cannot see through behind the
+// kernel's entry (one `s_nop`, a probe's stamp) the read of live_count[] became a vector load followed by `s_waitcnt vmcnt(0)` --
+// a wait for EVERY vector load in flight, among them the records' gathers and the staging loads k_wave_shade issues first so
+// that they overlap -- and k_wave_shade took 46 ms per step instead of 27.5 at identical registers, LDS and occupancy
+// (profiles/r06/phase_probe.txt: this, not the stamps, was round 5's "a never-taken branch costs 60 %").
+typedef const __attribute__((address_space(4))) uint32_t *ConstU32Ptr;
+__device__ __forceinline__ uint32_t live_final(const RenderArgs &a, int j)
+{
+	return reinterpret_cast<ConstU32Ptr>(reinterpret_cast<uintptr_t>(a.live_count))[j];
+}
+// entries of the record list ahead of bounce a.bounce's: the camera rays' and the earlier bounces' survivors
+__device__ __forceinline__ uint64_t records_before(const RenderArgs &a)
+{
+	uint64_t r = a.n_lanes;
+	for (int j = 0; j + 1 < a.bounce; ++j) r += live_final(a, j);
+	return r;
+}
+
 // Did a tail launch at a checkpoint <= bounce take the paths over?  live_count[c-1] is final when
 // checkpoint c is launched, and the first checkpoint that fires decides: the entries a tail launch
 // adds to afterwards are never looked at before one that already said yes.
@@ -1263,7 +1284,7 @@ __device__ __forceinline__ bool tail_took_over(const RenderArgs &a, int bounce)
 {
 	if (a.max_depth <= 8) return false;
 	for (int c = 4; c <= bounce; ++c)
-		if (tail_checkpoint(c, a.max_depth) && a.live_count[c - 1] <= kTailPaths) return true;
+		if (tail_checkpoint(c, a.max_depth) && live_final(a, c - 1) <= kTailPaths) return true;
 	return false;
 }
 

@@ -426,7 +426,7 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, P
 template <bool kFirst, bool kXcd = false>
 __device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, bool &alive)
 {
-	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)a.live_count[a.bounce - 1];
+	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)live_final(a, a.bounce - 1);
 	uint32_t tile = blockIdx.x;
 	if (kXcd) {
 #if PG_XCD_RUN
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(7))) vo
 {
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
 	if (!kFirst && tail_took_over(a, a.bounce)) return; // a tail launch is finishing these paths
-	const uint32_t total = kFirst ? (uint32_t)a.n_lanes : a.live_count[a.bounce - 1];
+	const uint32_t total = kFirst ? (uint32_t)a.n_lanes : live_final(a, a.bounce - 1);
 	const uint32_t gtid = blockIdx.x * kRBlock + threadIdx.x, n_static = gridDim.x * kRBlock;
 	if (blockIdx.x * kRBlock >= total) return; // (uniform) not even a first entry for this workgroup
 	const unsigned wl = threadIdx.x & 63u;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArg
 			uint64_t rec_base = 0;
 			if (!kFirst) {
 				rec_base = a.n_lanes;
-				for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+				for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 			}
 			store_slots(a, rec_base + tid, g);
 		}
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 		uint64_t rec_base = 0;
 		if (a.bounce > 0) {
 			rec_base = a.n_lanes;
-			for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+			for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 		}
 		store_slots(a, rec_base + tid, g);
 	}
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	uint64_t rec_base = 0;
 	if (!kFirst) {
 		rec_base = a.n_lanes;
-		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 	}
 	bool cont = false;
 	// what a survivor takes along to its place in the next list
@@ -1051,12 +1051,25 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 #define PG_SHADE_PHASES 0
 #endif
 #if PG_SHADE_PHASES
-	unsigned long long t_phase = a.dc ? (unsigned long long)clock64() : 0ull;
+	// A wave keeps its stamps in its own row of LDS (one lane, plain stores: LDS operations of a wave complete in order) and
+	// flushes the row once at the end, by one eight-lane atomic into its stripe.  (Round 5's probe added every stamp to ONE line
+	// of device memory: its k_wave_shade ran eleven times slower than the product's.  And what made a probe build 1.7 times
+	// slower even with its stamps idle was not the stamps at all: see live_final(), pg_render_dev.hpp.  With both repaired this
+	// build's k_wave_shade takes 27.7 ms per step against the product's 27.5, stamping or not: profiles/r06/phase_probe.txt.)
+	// PG_SHADE_PHASES 1: the start and three stamps -- slot 3 = everything ahead of the SD-tree calls, slot 4 = the calls, slot 6 =
+	// stage_b + the survivors' append.  PG_SHADE_PHASES 2: all seven (a breakdown).
+	__shared__ unsigned long long s_ph[kRBlock / 64][10]; // [0..6] the phases, [7] stamps taken, [8] the last stamp
+	if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) {
+		s_ph[threadIdx.x >> 6][8] = (unsigned long long)clock64();
+		s_ph[threadIdx.x >> 6][7] = 0ull;
+	}
 #define PG_PHASE(i)                                                                                                          \
-	if (a.dc) {                                                                                                              \
+	if ((PG_SHADE_PHASES >= 2 || (i) == 3 || (i) == 4 || (i) == 6) && a.ph && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) { \
 		const unsigned long long t_now = (unsigned long long)clock64();                                                      \
-		if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) atomicAdd(&a.dc->phase[i], t_now - t_phase);     \
-		t_phase = t_now;                                                                                                     \
+		unsigned long long *row = s_ph[threadIdx.x >> 6];                                                                    \
+		row[i] = t_now - row[8];                                                                                             \
+		row[8] = t_now;                                                                                                      \
+		row[7] |= 1ull << (i);                                                                                               \
 	}
 #else
 #define PG_PHASE(i)
@@ -1133,7 +1146,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	uint64_t rec_base = 0;
 	if (!kFirst) {
 		rec_base = a.n_lanes;
-		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+		for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 		// (the same number in every lane, but read by vector loads -- live_count is written by this very grid -- so the
 		// compiler keeps it in two vector registers through the whole kernel unless it is told that it is uniform)
 		rec_base = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec_base) |
@@ -1283,6 +1296,15 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	append_survivors<kShadeStage>(a, cont, ray_o, ray_d, thr, ior, delta, p_here, prev_pdf, L, lane, rng, s_wave, s_base, s_oct, s_dyn);
 	PG_PHASE(6)
 #undef PG_PHASE
+#if PG_SHADE_PHASES
+	if (a.ph && (threadIdx.x & 63u) < 8u) { // the wave's row, once: eight lanes, one line of the wave's stripe
+		const unsigned long long *row = s_ph[threadIdx.x >> 6];
+		const unsigned l = threadIdx.x & 63u;
+		// (a slot whose stamp this wave never passed -- a wave without a live lane skips the body -- holds nothing of this launch)
+		const unsigned long long v = l == 7u ? 1ull : ((row[7] >> l) & 1ull) ? row[l] : 0ull;
+		atomicAdd(&a.ph[(size_t)((blockIdx.x * (kRBlock / 64) + (threadIdx.x >> 6)) & (unsigned)(kPhaseStripes - 1)) * kPhaseWords + l], v);
+	}
+#endif
 }
 
 template <int kLevel, bool kFirst>
@@ -1311,14 +1333,14 @@ __global__ __launch_bounds__(kRBlock) void k_wave_tail(RenderArgs a)
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
-	const uint64_t live = (uint64_t)a.live_count[a.bounce - 1];
+	const uint64_t live = (uint64_t)live_final(a, a.bounce - 1);
 	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
 	stage_kd_planes(s_planes, a.tree);
 	bool alive = tid < live;
 	uint64_t lane = 0;
 	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce
-	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += a.live_count[j];
+	for (int j = 0; j + 1 < a.bounce; ++j) rec_base += live_final(a, j);
 	const uint64_t tail_base = rec_base + live; // behind the entries of bounce a.bounce
 	uint64_t slot = rec_base + tid;
 	const unsigned wl = threadIdx.x & 63u;
@@ -1466,5 +1488,7 @@ void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, un
 }
 
 int wave_workspace_planes() { return WS_COUNT; }
+
+bool shade_phases_compiled_in() { return PG_SHADE_PHASES != 0; }
 
 } // namespace pg

@@ -431,8 +431,16 @@ class SDTree:
         self._ck(self._lib.pg_render_live_counts(self._h, out, int(max_depth)))
         return [int(v) for v in out]
 
-    def enableDepthCounters(self, on: bool = True):
+    def enableDepthCounters(self, on=True):
+        """on: False / True, or 2 -- a probe build's phase stamps alone (pg_read_shade_phases), no counters' atomics."""
         self._ck(self._lib.pg_enable_depth_counters(self._h, int(on)))
+
+    def readShadePhases(self, reset: bool = True):
+        """pg_read_shade_phases: (compiled_in, waves, [cycles of the seven phases of k_wave_shade]) -- zeros unless the library
+        is the probe build (csrc/Makefile `probe`, libpgsd_phases.so)."""
+        out = (C.c_uint64 * 10)()
+        self._ck(self._lib.pg_read_shade_phases(self._h, out, int(reset)))
+        return bool(out[0]), int(out[1]), [int(out[2 + i]) for i in range(7)]
 
     def readDepthCounters(self, reset: bool = True) -> N.pg_depth_counters:
         dc = N.pg_depth_counters()
