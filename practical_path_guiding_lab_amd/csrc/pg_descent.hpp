@@ -60,58 +60,6 @@ __device__ __forceinline__ uint32_t kd_descend(const KdNode *kd, float x, float 
 	return node;
 }
 
-// The first kLdsKdNodes KD nodes (the top of the tree: split rounds append deeper nodes at the end,
-// kdtree.py:243-245) staged in LDS once per workgroup.  A fully divergent wave-load costs the CU's
-// vector-memory path one tag lookup per lane; the top levels are shared by every ray, so serving
-// them from LDS removes most of the KD descent's lookups.
-constexpr uint32_t kLdsKdNodes = 1024; // 16 KiB
-
-__device__ __forceinline__ void stage_kd_top(uint4 *s_kd, const KdNode *kd, uint32_t n_kd)
-{
-	const uint32_t n = n_kd < kLdsKdNodes ? n_kd : kLdsKdNodes;
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_kd[i] = reinterpret_cast<const uint4 *>(kd)[i];
-	__syncthreads();
-}
-
-// kd_descend with the top of the tree read from LDS (same result, kdtree.py:435-470).
-// Children always have larger indices than their parent, so a descent runs inside the staged
-// prefix first and in global memory afterwards: two loops keep the two address spaces apart
-// (a single `i < K ? lds : global` select makes hipcc emit slow flat_load instructions).
-__device__ __forceinline__ uint32_t kd_descend_lds(const KdNode *kd, const uint4 *s_kd, float x, float y,
-                                                   float z, bool search, KdNode &leaf, uint32_t &levels)
-{
-	uint32_t node = 0;
-	uint4 v = s_kd[0];
-	levels = 0;
-	if (search) {
-		int it = 0;
-		for (; it < kMaxLevels && v.x != 0; ++it) {
-			const uint32_t axis = v.z & 3u;
-			const float c = axis == 0 ? x : (axis == 1 ? y : z);
-			node = v.x + (c >= __uint_as_float(v.y) ? 1u : 0u);
-			++levels;
-			if (node >= kLdsKdNodes) break;
-			v = s_kd[node];
-		}
-		if (node >= kLdsKdNodes) {
-			v = gather16(kd + node);
-			for (++it; it < kMaxLevels && v.x != 0; ++it) {
-				const uint32_t axis = v.z & 3u;
-				const float c = axis == 0 ? x : (axis == 1 ? y : z);
-				node = v.x + (c >= __uint_as_float(v.y) ? 1u : 0u);
-				++levels;
-				v = gather16(kd + node);
-			}
-		}
-	}
-	levels = stat_word(levels, 16u * levels); // (an A/B form: the nodes read from LDS are priced like the others)
-	leaf.child = v.x;
-	leaf.split = __uint_as_float(v.y);
-	leaf.axis_depth = v.z;
-	leaf.tree = v.w;
-	return node;
-}
-
 // ---- the KD jump grid (pg_tree.hpp) ----
 // The planes of the grid staged in LDS once per workgroup (3 * kKdGridPlanes floats): every query reads six.
 __device__ __forceinline__ void stage_kd_planes(float *s_planes, const TreeView &t)

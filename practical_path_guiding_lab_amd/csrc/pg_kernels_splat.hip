@@ -54,11 +54,7 @@ __device__ __forceinline__ void plan_record(const TreeView &t, const AccumView &
 	const bool inside = inside_root(t, x, y, z);
 	KdNode leaf;
 	uint32_t lv;
-#ifdef PG_SPLAT_LDS_KD // (A/B switch: the KD top staged in LDS instead of the jump grid)
-	kd_descend_lds(t.kd, s_kd, x, y, z, inside, leaf, lv);
-#else
 	kd_descend_grid(t, reinterpret_cast<const float *>(s_kd), x, y, z, inside, leaf, lv);
-#endif
 	kd_lv += stat_levels(lv); // (statistics words, pg_descent.hpp: a thread may plan many records, so they are unpacked here)
 	bytes += stat_bytes(lv);
 	const uint32_t tree = leaf.tree; // outside the bbox: node 0's (stale) tree (kdtree.py:224)
@@ -169,19 +165,11 @@ __global__ __launch_bounds__(kBlock) void k_splat(TreeView t, AccumView a, int s
                                                   const float *__restrict__ nee_lum,
                                                   const uint32_t *__restrict__ d_count, DepthCounters *dc)
 {
-#ifdef PG_SPLAT_LDS_KD
-	__shared__ uint4 s_kd[kLdsKdNodes];
-#else
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (plan_record's parameter: the staged table of whichever kind)
-#endif
 	__shared__ long long s_val[kBlock * 4];
 	__shared__ unsigned long long s_ptr[kBlock];
-#ifdef PG_SPLAT_LDS_KD
-	stage_kd_top(s_kd, t.kd, t.n_kd);
-#else
 	stage_kd_planes(s_planes, t);
-#endif
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	const uint64_t valid = d_count ? (uint64_t)*d_count : m; // plane stride stays m
 	unsigned kd_lv = 0, q_lv = 0, q_q = 0, did = 0, st_bytes = 0;
@@ -281,21 +269,13 @@ __global__ __launch_bounds__(kBlock) void k_process_and_splat(TreeView t, AccumV
                                                               const float *__restrict__ l_final,
                                                               pg_dense_records r, DepthCounters *dc)
 {
-#ifdef PG_SPLAT_LDS_KD
-	__shared__ uint4 s_kd[kLdsKdNodes];
-#else
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (plan_record's parameter: the staged table of whichever kind)
-#endif
 	__shared__ long long s_val[kBlock * 4];
 	__shared__ unsigned long long s_ptr[kBlock];
 	const uint64_t S = num_rays * (uint64_t)max_depth;
 	const uint64_t total = S;
-#ifdef PG_SPLAT_LDS_KD
-	stage_kd_top(s_kd, t.kd, t.n_kd);
-#else
 	stage_kd_planes(s_planes, t);
-#endif
 	// First iteration: one KD leaf owning a single-leaf quadtree (kdtree.py:122, quadtree.py:355), so
 	// every record of the pass lands in the same accumulator.  One word takes ~11 ns per atomic;
 	// sum inside the workgroup and send four atomics per workgroup instead of two per record.
@@ -432,10 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_list(TreeView t, AccumView a, 
 	}
 }
 
-#ifndef PG_SPLAT_GROUPS_PER_CU
-#define PG_SPLAT_GROUPS_PER_CU 64 // measured (tools/exp_splat_grid.sh): 8 -> 847, 16 -> 798, 32 -> 746, 64 -> 726, 128 -> 755 us on cornell-box
-#endif
-constexpr unsigned kSplatGroupsPerCu = PG_SPLAT_GROUPS_PER_CU;
+constexpr unsigned kSplatGroupsPerCu = 64; // measured (round 2): 8 -> 847, 16 -> 798, 32 -> 746, 64 -> 726, 128 -> 755 us on cornell-box
 
 static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 

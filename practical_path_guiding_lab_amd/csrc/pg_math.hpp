@@ -22,9 +22,6 @@ constexpr int kClampLog2 = 48;     // PG_W_CLAMP_LOG2
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void sincos_f32(float phi, float &s_out, float &c_out)
 {
-#ifdef PG_ABLATE_TRIG // timing experiment only: hardware approximations instead of the exact series
-	s_out = __sinf(phi); c_out = __cosf(phi); return;
-#endif
 	const double x = (double)phi;
 	const double k = __builtin_rint(x * 0.63661977236758134308);
 	// pi/2 = hi + lo, hi has 33 significant bits: k*hi is exact for the k that occur
@@ -88,9 +85,6 @@ __device__ __forceinline__ double atan_unit(double t)
 
 __device__ __forceinline__ float atan2_f32(float yf, float xf)
 {
-#ifdef PG_ABLATE_TRIG
-	return atan2f(yf, xf);
-#endif
 	if (yf != yf || xf != xf) return yf + xf;
 	const double x = (double)xf, y = (double)yf;
 	const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);

@@ -19,7 +19,6 @@
 // (The microfacet helpers are inlined here too since round 5: kept out of line, every call cost the level-1 kernels a 32-byte
 // stack frame in scratch memory; inlined, k_bounce<*, 1> is 87 / 89 registers at five waves per SIMD with no scratch at
 // all -- veach-mis 2.33 -> 2.32 ms per pass, profiles/r05/ab_fused_kernel_helpers_inlined.txt.)
-#define PG_RENDER_INLINE_ALL
 #include "pg_render_dev.hpp"
 
 namespace pg {
@@ -144,11 +143,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	if (active_sd_em || do_record) {
 		KdNode leaf;
 		const bool inside = inside_root(a.tree, p.x, p.y, p.z);
-#ifdef PG_FUSED_LDS_KD // (A/B switch: the KD top staged in LDS instead of the jump grid)
-		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside, leaf, lv);
-#else
 		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside, leaf, lv);
-#endif
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
@@ -203,11 +198,7 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 	float sdtree_pdf = 1.0f;
 	if ((smp_tree || bsdf_mis) && !tree_known) {
 		KdNode leaf;
-#ifdef PG_FUSED_LDS_KD // (A/B switch: the KD top staged in LDS instead of the jump grid)
-		kd_descend_lds(a.tree.kd, s_kd, p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
-#else
 		kd_descend_grid(a.tree, reinterpret_cast<const float *>(s_kd), p.x, p.y, p.z, inside_root(a.tree, p.x, p.y, p.z), leaf, lv);
-#endif
 		c_kd += lv; ++c_kdq;
 		const uint2 hv = gather8(a.tree.head + leaf.tree);
 		head.root_rec = hv.x;
@@ -328,12 +319,8 @@ __device__ __forceinline__ bool bounce_lane(const RenderArgs &a, const uint4 *s_
 template <bool kFirst, int kGeneral>
 __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 {
-#ifdef PG_FUSED_LDS_KD
-	__shared__ uint4 s_kd[kLdsKdNodes];
-#else
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (bounce_lane's parameter: the staged table of whichever kind)
-#endif
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
 	__shared__ float s_stash[kBounceStash][kRBlock];
@@ -341,11 +328,7 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)live_final(a, a.bounce - 1);
 	if ((uint64_t)blockIdx.x * kRBlock >= live) return; // whole workgroup past the list
 	if (!kFirst && tail_took_over(a, a.bounce)) return;  // a tail launch is finishing these paths
-#ifdef PG_FUSED_LDS_KD
-	if (a.guided || a.record) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
-#else
 	if (a.guided || a.record) stage_kd_planes(s_planes, a.tree); // (a recorded vertex descends the KD tree too: its accumulators)
-#endif
 	const bool alive = tid < live;
 	const uint64_t lane = alive ? (kFirst ? tid : (uint64_t)a.order_in[tid]) : 0;
 	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
@@ -384,21 +367,13 @@ __global__ __launch_bounds__(kRBlock) void k_bounce(RenderArgs a)
 template <int kGeneral>
 __global__ __launch_bounds__(kRBlock) void k_bounce_tail(RenderArgs a)
 {
-#ifdef PG_FUSED_LDS_KD
-	__shared__ uint4 s_kd[kLdsKdNodes];
-#else
 	__shared__ float s_planes[3 * kKdGridPlanes];
 	const uint4 *s_kd = reinterpret_cast<const uint4 *>(s_planes); // (bounce_lane's parameter: the staged table of whichever kind)
-#endif
 	const uint64_t tid = (uint64_t)blockIdx.x * kRBlock + threadIdx.x;
 	const uint64_t live = (uint64_t)live_final(a, a.bounce - 1);
 	if (live > kTailPaths || (uint64_t)blockIdx.x * kRBlock >= live) return;
 	if (tail_took_over(a, a.bounce - 1)) return; // an earlier checkpoint already did
-#ifdef PG_FUSED_LDS_KD
-	if (a.guided || a.record) stage_kd_top(s_kd, a.tree.kd, a.tree.n_kd);
-#else
 	if (a.guided || a.record) stage_kd_planes(s_planes, a.tree); // (a recorded vertex descends the KD tree too: its accumulators)
-#endif
 	bool alive = tid < live;
 	const uint64_t lane = alive ? (uint64_t)a.order_in[tid] : 0;
 	uint64_t rec_base = a.n_lanes; // entries of the bounces before a.bounce

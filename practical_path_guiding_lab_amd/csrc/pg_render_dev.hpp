@@ -9,22 +9,14 @@
 #include "pg_descent.hpp"
 #include "pg_kernels.hpp"
 
-// The microfacet helpers are called from several places.  Both render translation units inline them
-// (PG_RENDER_INLINE_ALL): a call needs a stack frame in scratch memory, and no kernel of the library is to use any.
-// (Rounds 1-4 kept them out of line in the fused kernel of pg_render.hip: 32 bytes of scratch per lane in its level-1
-// instantiations.)
-#ifdef PG_RENDER_INLINE_ALL
+// The microfacet helpers are called from several places and inlined at every one of them: a call needs a stack frame in
+// scratch memory, and no kernel of the library is to use any.  (Rounds 1-4 kept them out of line in the fused kernel of
+// pg_render.hip: 32 bytes of scratch per lane in its level-1 instantiations.)
 #define PG_OUTLINE __forceinline__
-#else
-#define PG_OUTLINE __noinline__
-#endif
 
 namespace pg {
 
-#ifndef PG_RBLOCK
-#define PG_RBLOCK 256
-#endif
-constexpr int kRBlock = PG_RBLOCK; // threads of a workgroup in every render kernel
+constexpr int kRBlock = 256; // threads of a workgroup in every render kernel
 constexpr float kInvPiF = 0.31830988618379067154f;
 constexpr float kRayEps = 1e-4f;
 constexpr float kShadowEps = 1e-3f;
@@ -1062,11 +1054,7 @@ __device__ __forceinline__ void sample_emitter(const Shapes &sh, const DirLights
 		const float sdist = __builtin_sqrtf(dot3(sd, sd));
 		const v3 sdn = vdivs(sd, sdist);
 		float th;
-#ifdef PG_ABLATE_SHADOW // timing experiment only: no shadow rays
-		const bool occ = false; (void)th; (void)sdn;
-#else
 		const bool occ = intersect<kGeneral, true>(sh, so, sdn, sdist * (1.0f - kShadowEps), th) >= 0;
-#endif
 		if (!occ) em_weight = vscale(vdivs(radiance, pdf), count);
 	}
 }
@@ -1248,10 +1236,7 @@ struct RenderArgs {
 // launches k_bounce_tail: when no more than kTailPaths paths are alive it takes all of them over
 // and every lane follows its own path to its end in this one launch; the per-bounce launches after
 // it find that out from the same counts and retire.
-#ifndef PG_TAIL_PATHS
-#define PG_TAIL_PATHS (128u * 1024u) // torus (tools/exp_tail.sh): 32 Ki -> 12.9, 128 Ki -> 12.4, 512 Ki -> 13.2, 2 Mi -> 13.2 ms per pass
-#endif
-constexpr uint32_t kTailPaths = PG_TAIL_PATHS;
+constexpr uint32_t kTailPaths = 128u * 1024u; // torus (tools/exp_tail.sh): 32 Ki -> 12.9, 128 Ki -> 12.4, 512 Ki -> 13.2, 2 Mi -> 13.2 ms per pass
 __host__ __device__ constexpr bool tail_checkpoint(int bounce, int max_depth)
 {
 	return max_depth > 8 && bounce >= 4 && bounce + 1 < max_depth &&

@@ -31,7 +31,6 @@
 // hits and the sort still on their own.  What a path carries from bounce to bounce travels with its place in the
 // live list (st_load below).  Arithmetic and sampler draw order are those of oracle/pg_oracle_render.c, operation
 // by operation, in every form.
-#define PG_RENDER_INLINE_ALL
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -409,36 +408,17 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, uint64_t lane, P
 }
 
 // which live-list entry does this thread serve, if any: false for a whole workgroup past the list or
-// when a tail launch is finishing the paths (both uniform over the workgroup)
-// kXcd: workgroups b, b + 8, b + 16, ... (dealt to ONE of the chip's eight XCDs, MI355X_MICROARCH.md "Workgroup dispatch")
-// take CONSECUTIVE tiles of the list, so that an XCD's L2 serves one eighth of a sorted list -- one region of the scene --
-// instead of every eighth tile of all of it.  Speed only: any assignment of workgroups to tiles gives the same results.
-// (The grid is a multiple of eight workgroups: launch_wave_stage.)
-#ifndef PG_XCD_TRACE
-#define PG_XCD_TRACE 0
-#endif
-#ifndef PG_XCD_SHADE
-#define PG_XCD_SHADE 0
-#endif
-#ifndef PG_XCD_RUN
-#define PG_XCD_RUN 0
-#endif
-template <bool kFirst, bool kXcd = false>
+// when a tail launch is finishing the paths (both uniform over the workgroup).  Tile = workgroup: the hardware deals workgroups
+// b, b + 8, b + 16, ... to ONE of the chip's eight XCDs (MI355X_MICROARCH.md "Workgroup dispatch"), so every XCD's L2 sees every
+// eighth tile of the (sorted) list.  XCD-aware assignments were measured in round 5 and are not here any more: contiguous eighths
+// of the list per XCD lose 5 ms per step (the regions of a sorted list cost unequal amounts and a workgroup can only go to its own
+// XCD: seven wait for the eighth), runs of 4 / 16 / 160 tiles per XCD change nothing -- these kernels' time is not in L2 capacity
+// (profiles/r05/ab_xcd_tile_mapping_rejected.txt).
+template <bool kFirst>
 __device__ __forceinline__ bool wave_entry(const RenderArgs &a, uint64_t &tid, bool &alive)
 {
 	const uint64_t live = kFirst ? a.n_lanes : (uint64_t)live_final(a, a.bounce - 1);
-	uint32_t tile = blockIdx.x;
-	if (kXcd) {
-#if PG_XCD_RUN
-		// runs of PG_XCD_RUN consecutive tiles per XCD, the eight XCDs' runs side by side: all of them advance through the list together
-		const uint32_t g = blockIdx.x >> 3;
-		tile = ((g / (uint32_t)PG_XCD_RUN) * 8u + (blockIdx.x & 7u)) * (uint32_t)PG_XCD_RUN + g % (uint32_t)PG_XCD_RUN;
-#else
-		const uint32_t per = ((uint32_t)((live + kRBlock - 1) / kRBlock) + 7u) >> 3; // tiles of an XCD
-		if ((blockIdx.x >> 3) >= per) return false;
-		tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-#endif
-	}
+	const uint32_t tile = blockIdx.x;
 	tid = (uint64_t)tile * kRBlock + threadIdx.x;
 	if ((uint64_t)tile * kRBlock >= live) return false;
 	if (!kFirst && tail_took_over(a, a.bounce)) return false;
@@ -480,9 +460,6 @@ __device__ __forceinline__ uint32_t spread5(uint32_t v) // bits 0-4 -> bits 0, 3
 // lanes then stand class by class and most waves hold ONE class: the sampling walk and the second BSDF evaluation run on full
 // waves of "tree" lanes, the pdf walk on full waves of "BSDF" lanes, instead of every wave making all three for half its lanes
 // each.  A hint, not a contract: where the guess is wrong (a delta lobe, :283) only the order differs, and the order is free.
-#ifndef PG_SORT_CLASS_BIT
-#define PG_SORT_CLASS_BIT 1
-#endif
 __device__ __forceinline__ uint32_t lane_class_ahead(uint64_t state, uint64_t inc, float frac)
 {
 	Pcg32 r;
@@ -514,10 +491,7 @@ __device__ __forceinline__ uint32_t vertex_sort_key(const RenderArgs &a, v3 p, i
 // leaves beside the walks' stacks at seven workgroups per compute unit (16 KB of stack + 6 KB of nodes each).  Measured on
 // veach-ajar, ms per step: closest hits 12.7 / 11.8 / 11.6 with 16 / 32 / 48 nodes (15.1 with none); shadow rays 6.9 /
 // 6.6 / 6.6 with 32 / 64 / 80 at six waves per SIMD (7.9 with none), 6.5 / 6.4 with 32 / 48 at seven.
-#ifndef PG_TRACE_TOP
-#define PG_TRACE_TOP 48
-#endif
-constexpr int kBvhTopNodes = PG_TRACE_TOP;
+constexpr int kBvhTopNodes = 48;
 template <int kNodes>
 __device__ __forceinline__ void stage_bvh_top(u32x4_t *s_top, const RenderArgs &a, BvhStack &stk)
 {
@@ -537,7 +511,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	__shared__ uint2 s_stack[kLdsStack][kRBlock];
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst, PG_XCD_TRACE != 0>(a, tid, alive)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
 	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
 	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
@@ -552,7 +526,7 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 		st_store(const_cast<uint4 *>(a.st_in), a, 0, tid, ray_o, (uint32_t)rng.state);
 		st_store(const_cast<uint4 *>(a.st_in), a, 1, tid, ray_d, (uint32_t)(rng.state >> 32));
 	} else if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
-		const bool want_cls = PG_SORT_CLASS_BIT && a.guided && a.bounce + 1 < a.max_depth; // (uniform)
+		const bool want_cls = a.guided && a.bounce + 1 < a.max_depth; // (uniform)
 		uint4 q0, q1, q5 = make_uint4(0u, 0u, 0u, 0u);
 		// (Measured and removed, round 5: these three entries read by four lanes per record and handed over through the wave's
 		// stack columns, as k_wave_shade reads its PERMUTED records -- here the wave's records lie side by side, consecutive
@@ -595,14 +569,8 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 // measured on veach-ajar, the one-ray-per-lane form kept 14 % of the lanes of a wave busy.  Every ray
 // still takes exactly the steps intersect() takes for it, in the same order.  The rays are the entries
 // of the live list flagged F_NEED_SHADOW; WS_OCC receives 0 / 1.
-#ifndef PG_REFILL_IDLE
-#define PG_REFILL_IDLE 16
-#endif
-#ifndef PG_CAST_CHUNK
-#define PG_CAST_CHUNK 128
-#endif
-constexpr int kRefillIdle = PG_REFILL_IDLE;
-constexpr uint32_t kCastChunk = PG_CAST_CHUNK;
+constexpr int kRefillIdle = 16;
+constexpr uint32_t kCastChunk = 128;
 // (compiled for seven waves per SIMD -- 72 vector registers, none spilled; left alone the compiler takes 77 and six fit)
 template <int kLevel, bool kFirst>
 __global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(7))) void k_wave_cast(RenderArgs a)
@@ -692,22 +660,16 @@ __global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(7))) vo
 	}
 }
 
-// (A/B switch: waves per SIMD the two shading kernels are compiled for; default = what their registers allow)
-#ifdef PG_SHADE_WAVES
-#define PG_SHADE_OCC __attribute__((amdgpu_waves_per_eu(PG_SHADE_WAVES)))
-#else
-#define PG_SHADE_OCC
-#endif
 
 // ---- :189-220, 272-297 ----
 // kGuide: the SD-tree calls of the bounce (stage_guide, otherwise k_wave_guide's) follow in the same kernel
 template <int kLevel, bool kFirst, bool kGuide>
-__global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_a(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) void k_wave_shade_a(RenderArgs a)
 {
 	__shared__ float s_planes[kGuide ? 3 * kKdGridPlanes : 1];
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst, false>(a, tid, alive)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	if (kGuide) stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
 	Pcg32 rng;
@@ -898,7 +860,7 @@ __device__ __forceinline__ void append_survivors(const RenderArgs &a, bool cont,
 
 // ---- :247-261, 302-381 ----
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) void k_wave_shade_b(RenderArgs a)
 {
 	__shared__ uint32_t s_wave[kRBlock / 64];
 	__shared__ uint32_t s_base;
@@ -906,7 +868,7 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 	extern __shared__ uint4 s_rec[]; // kRBlock * 8 entries when the next bounce is sorted (a.carry_out), else none
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst, false>(a, tid, alive)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	// records of the earlier bounces: all paths for the first, the survivors of bounce j for bounce j+1
 	uint64_t rec_base = 0;
 	if (!kFirst) {
@@ -981,57 +943,29 @@ __global__ __launch_bounds__(kRBlock) PG_SHADE_OCC void k_wave_shade_b(RenderArg
 // rays as in k_wave_cast), and the tree walks run at the occupancy the shading's registers leave.  LDS: the walk's stacks
 // and the hottest BVH nodes, and -- over the same bytes, once every walk of the workgroup is done -- the survivors'
 // records of a sorted next bounce.
-#ifndef PG_SHADE_STAGE
-#define PG_SHADE_STAGE 128
-#endif
-constexpr int kShadeStage = PG_SHADE_STAGE; // survivors' records staged in LDS at a time
-#ifndef PG_SHADE_STASH
-#define PG_SHADE_STASH 1
-#endif
-// (A/B switches of the other register measures of k_wave_shade, each on by default: the second read of the path's state,
-// the walk that makes its row offsets at every node, the pinning of stage_a1's outputs)
-#ifndef PG_SHADE_RELOAD
-#define PG_SHADE_RELOAD 0
-#endif
-#ifndef PG_SHADE_SLIM
-#define PG_SHADE_SLIM 1
-#endif
-#ifndef PG_SHADE_PIN
-#define PG_SHADE_PIN 1
-#endif
-#ifndef PG_SHADE_TOP
-#define PG_SHADE_TOP 40
-#endif
-constexpr int kShadeTopNodes = PG_SHADE_STASH ? PG_SHADE_TOP : kBvhTopNodes; // (with the stash: what five workgroups per compute unit leave)
+constexpr int kShadeStage = 128; // survivors' records staged in LDS at a time (224 at a time: no gain, profiles/r05/ab_shade_stage224_rejected.txt)
+constexpr int kShadeTopNodes = 40; // BVH nodes kept in LDS beside the stash (the ray-casting kernels keep kBvhTopNodes): what five workgroups per compute unit leave
 // The walk's stack keeps kShadeStack entries per lane in LDS here (the ray-casting kernels keep kLdsStack = 8; deeper ones go
 // to the lane's overflow strip either way), which leaves room for the stash: kShadeStash values per lane that only stage_b
 // reads wait in LDS while the two walks run.
-#ifndef PG_SHADE_LDS_STACK
-#define PG_SHADE_LDS_STACK 6
-#endif
-constexpr int kShadeStack = PG_SHADE_LDS_STACK;
+constexpr int kShadeStack = 6;
 static_assert(kShadeStack >= kMinLdsStack && kShadeStack <= kLdsStack, "k_wave_shade: LDS stack depth");
-// (A/B: PG_SHADE_KEEP 1 / 2 / 3 keeps {ior, lane} / + L / + thr in registers instead -- room for a deeper LDS stack)
-#ifndef PG_SHADE_KEEP
-#define PG_SHADE_KEEP 2
-#endif
-constexpr int kShadeStash = PG_SHADE_STASH ? (PG_SHADE_RELOAD ? 9 : (PG_SHADE_KEEP >= 3 ? 9 : PG_SHADE_KEEP == 2 ? 12 : PG_SHADE_KEEP == 1 ? 15 : 17)) : 0;
+// (the stash: the nine values of stage_a1 that only stage_b reads and the path's throughput; the radiance so far, the index of
+// refraction and the lane stay in registers -- rounds 4-5 measured the other splits)
+constexpr int kShadeStash = 12;
 constexpr int kShadeWalkQuads = kShadeStack * kRBlock / 2 + kShadeTopNodes * 8 + kShadeStash * kRBlock / 4;
 constexpr int kShadeLdsQuads = kShadeStage * 8 > kShadeWalkQuads ? kShadeStage * 8 : kShadeWalkQuads;
 // (122 vector registers, four waves per SIMD, which is also what 33 KB of LDS per workgroup allow.  Measured: staging the
 // records 128 at a time -- 23 KB -- changes nothing by itself, and compiled for five waves on top of that the kernel spills
 // 31 registers: 35.2 -> 37.6 ms per step.)
-// The paths' 128-byte records of a sorted bounce are read THROUGH LDS by the wave as a whole (PG_SHADE_COOP): a lane that
+// The paths' 128-byte records of a sorted bounce are read THROUGH LDS by the wave as a whole: a lane that
 // gathers the seven 16-byte entries of its own record makes seven vector loads that each touch 64 different cache lines --
 // the compute unit's L1 looks up about one line per clock, so such a load holds the vector-memory path for 64 clocks however
 // few bytes it wants -- where eight lanes that read one record's eight entries side by side touch 8 lines per load: the same
 // 64 records in eight loads of 8 lines instead of seven of 64.  The entries cross to the lanes that own them through LDS
 // ([entry][thread] planes over the bytes the walks' stacks and the stash use later: one more workgroup barrier, ahead of the
 // staging of the BVH's top).
-#ifndef PG_SHADE_COOP
-#define PG_SHADE_COOP 1
-#endif
-static_assert(!PG_SHADE_COOP || 7 * kRBlock <= kShadeLdsQuads, "k_wave_shade: the records' seven entries per thread must fit the dynamic LDS");
+static_assert(7 * kRBlock <= kShadeLdsQuads, "k_wave_shade: the records' seven entries per thread must fit the dynamic LDS");
 template <int kLevel, bool kFirst>
 __device__ __forceinline__ void shade_body(const RenderArgs &a)
 {
@@ -1042,7 +976,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	extern __shared__ uint4 s_dyn[]; // kShadeLdsQuads entries: [stacks kLdsStack * kRBlock * 8 B][BVH top][...], later the records
 	uint64_t tid;
 	bool alive;
-	if (!wave_entry<kFirst, PG_XCD_SHADE != 0>(a, tid, alive)) return;
+	if (!wave_entry<kFirst>(a, tid, alive)) return;
 	// Probe builds only (-DPG_SHADE_PHASES=1; the instrumented pass of such a build prints the shares under $PGSD_TRACE_SHADOW):
 	// where a wave spends its life, DepthCounters::phase.  NOT in the product: the seven s_memtime stamps, behind a uniform
 	// branch that is never taken in a timed pass, took k_wave_shade from 28.6 to 45-47 ms per step (profiles/r05/
@@ -1078,9 +1012,6 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	// are in flight while the records make their own two round trips (the permutation, then the entries), instead of being
 	// two more round trips behind them, each with a barrier of its own (an instrumented pass showed a quarter of a wave's life
 	// gone before stage_a1 began: profiles/r05/shade_phases.txt).
-#ifndef PG_SHADE_EARLY
-#define PG_SHADE_EARLY 1
-#endif
 	constexpr int kPlaneLoads = 1, kTopLoads = (kShadeTopNodes * 8 + kRBlock - 1) / kRBlock;
 	float pl_pre[kPlaneLoads];
 	u32x4_t top_pre[kTopLoads];
@@ -1089,17 +1020,15 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 #pragma unroll
 	for (int k = 0; k < kTopLoads; ++k) top_pre[k] = u32x4_t{0u, 0u, 0u, 0u};
 	const uint32_t n_top = a.shapes.n_bvh_nodes < kShadeTopNodes ? (uint32_t)a.shapes.n_bvh_nodes : (uint32_t)kShadeTopNodes;
-#if PG_SHADE_EARLY
 #pragma unroll
 	for (int k = 0; k < kPlaneLoads; ++k)
 		if (a.tree.kd_grid != nullptr && threadIdx.x + k * kRBlock < 3u * kKdGridPlanes) pl_pre[k] = a.tree.kd_planes[threadIdx.x + k * kRBlock];
 #pragma unroll
 	for (int k = 0; k < kTopLoads; ++k)
 		if (threadIdx.x + k * kRBlock < n_top * 8u) top_pre[k] = reinterpret_cast<const u32x4_t *>(a.shapes.bvh)[threadIdx.x + k * kRBlock];
-#endif
 	uint4 cq0 = make_uint4(0u, 0u, 0u, 0u), cq1 = cq0, cq2 = cq0, cq3 = cq0, cq4 = cq0, cq5 = cq0, cq6 = cq0;
 	uint32_t coop_place = (uint32_t)tid;
-	const bool coop = PG_SHADE_COOP && !kFirst && a.perm != nullptr; // (uniform)
+	const bool coop = !kFirst && a.perm != nullptr; // (uniform)
 	if (coop) {
 		if (alive && tid < (uint64_t)a.n_sort) coop_place = a.perm[tid];
 		if (!alive) coop_place = 0u; // (a lane past the list still serves its wave's loads: any record that exists)
@@ -1119,7 +1048,6 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	uint2 *s_stack = reinterpret_cast<uint2 *>(s_dyn);
 	u32x4_t *s_top = reinterpret_cast<u32x4_t *>(s_dyn) + kShadeStack * kRBlock / 2;
 	BvhStack stk = bvh_stack(s_stack + threadIdx.x, a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack, kShadeStack);
-#if PG_SHADE_EARLY
 #pragma unroll
 	for (int k = 0; k < kPlaneLoads; ++k)
 		if (a.tree.kd_grid != nullptr && threadIdx.x + k * kRBlock < 3u * kKdGridPlanes) s_planes[threadIdx.x + k * kRBlock] = pl_pre[k];
@@ -1131,11 +1059,6 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	__syncthreads();
 	stk.top = (const LdsQuad *)s_top;
 	stk.n_top = n_top;
-#else
-	(void)pl_pre; (void)top_pre; (void)n_top;
-	stage_kd_planes(s_planes, a.tree);
-	stage_bvh_top<kShadeTopNodes>(s_top, a, stk);
-#endif
 	bool cont = false;
 	v3 ray_o = V(0, 0, 0), ray_d = V(0, 0, 1), thr = V(1, 1, 1), L = V(0, 0, 0), p_here = V(0, 0, 0), prev_p = V(0, 0, 0);
 	float ior = 1.0f, prev_pdf = 1.0f;
@@ -1153,15 +1076,14 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		           ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rec_base >> 32)) << 32);
 	}
 	if (alive) {
-		// What a path carries from bounce to bounce is READ TWICE: the ray, the sampler, the hit and the throughput (for the
-		// emitted radiance's share) now; the throughput again, the index of refraction, the radiance so far and the path's lane
-		// only where stage_b needs them, behind the two walks -- the second read comes from the cache line the first one
-		// fetched, and nine registers are not alive across the walks (PG_SHADE_RELOAD 0: kept in registers, as round 3 did).
+		// What a path carries from bounce to bounce is read ONCE, here: the ray, the sampler, the hit, the throughput, the index
+		// of refraction, the radiance so far and the path's lane.  (Reading the last four a second time behind the walks, to keep
+		// them out of the walks' registers, cost 1.25 ms per step -- two more gathers per lane; they wait in registers and, the
+		// throughput, in the LDS stash: DESIGN 5.7.)
 		HitRec h;
 		const bool from_rec = !kFirst && a.perm != nullptr; // a sorted bounce: the path's 128-byte record, through the permutation
 		uint32_t place = (uint32_t)tid; // (32-bit: a place in the live list; one register through the walks, not two)
-		if (PG_SHADE_RELOAD && coop) place = coop_place;
-		else if (!coop && from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
+		if (!coop && from_rec && tid < (uint64_t)a.n_sort) place = a.perm[tid];
 		if (from_rec) {
 			const uint4 *rec = a.carry_in + (uint64_t)place * 8;
 			uint4 q0, q1, q2, q3, q5, q6;
@@ -1171,9 +1093,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 			rng.inc = (uint64_t)q5.x | ((uint64_t)q5.y << 32);
 			ray_o = st_v3(q0); ray_d = st_v3(q1);
 			thr = st_v3(q2);
-#if !PG_SHADE_RELOAD
 			{ const uint4 q4 = coop ? cq4 : rec[4]; ior = __uint_as_float(q2.w & 0x7fffffffu); L = st_v3(q4); lane = q4.w; }
-#endif
 			prev_delta = (q2.w >> 31) != 0u;
 			prev_p = st_v3(q3);
 			prev_pdf = __uint_as_float(q3.w);
@@ -1186,9 +1106,7 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 			if (!kFirst) {
 				const uint4 q2 = st_load(a.st_in, a, 2, tid), q3 = st_load(a.st_in, a, 3, tid);
 				thr = st_v3(q2);
-#if !PG_SHADE_RELOAD
 				{ const uint4 q4 = st_load(a.st_in, a, 4, tid); ior = __uint_as_float(q2.w & 0x7fffffffu); L = st_v3(q4); lane = q4.w; }
-#endif
 				prev_delta = (q2.w >> 31) != 0u;
 				prev_p = st_v3(q3);
 				prev_pdf = __uint_as_float(q3.w);
@@ -1202,26 +1120,18 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		// What stage_a1 leaves is PINNED here: every output is made now, so that its inputs die.  (Left alone the compiler
 		// sinks the last operations of a value that is only read behind the walk -- the emitted radiance's three products, the
 		// flag word's bits -- below the walk, and carries their more numerous inputs through it instead.)
-#if PG_SHADE_PIN
 		asm volatile("" : "+v"(A.flags), "+v"(A.wi.x), "+v"(A.wi.y), "+v"(A.wi.z), "+v"(A.p.x), "+v"(A.p.y), "+v"(A.p.z),
 		                  "+v"(A.ng.x), "+v"(A.ng.y), "+v"(A.ng.z), "+v"(A.refl.x), "+v"(A.refl.y), "+v"(A.refl.z));
 		asm volatile("" : "+v"(A.ds_d.x), "+v"(A.ds_d.y), "+v"(A.ds_d.z), "+v"(A.ds_pdf), "+v"(A.bp_em), "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z));
-#endif
-#if PG_SHADE_STASH
 		// nine values only stage_b reads wait in LDS while the two walks run (column threadIdx.x of a [9][kRBlock] array)
 		float *stash = reinterpret_cast<float *>(s_dyn) + (kShadeStack * kRBlock * 2 + kShadeTopNodes * 32) + threadIdx.x;
 		stash[0 * kRBlock] = A.Le.x; stash[1 * kRBlock] = A.Le.y; stash[2 * kRBlock] = A.Le.z;
 		stash[3 * kRBlock] = A.bv_em.x; stash[4 * kRBlock] = A.bv_em.y; stash[5 * kRBlock] = A.bv_em.z;
 		stash[6 * kRBlock] = A.em_w.x; stash[7 * kRBlock] = A.em_w.y; stash[8 * kRBlock] = A.em_w.z;
-#if !PG_SHADE_RELOAD
 		// ... and with them what the path carries that only stage_b needs: throughput, radiance so far, index of refraction, lane
 		// (round-4 measurement: reading these a second time from the path's record cost 1.25 ms per step -- two more 16-byte
 		// gathers per lane in a kernel whose time follows its gathers -- where eight LDS words cost nothing)
-		if (PG_SHADE_KEEP < 3) { stash[9 * kRBlock] = thr.x; stash[10 * kRBlock] = thr.y; stash[11 * kRBlock] = thr.z; }
-		if (PG_SHADE_KEEP < 2) { stash[12 * kRBlock] = L.x; stash[13 * kRBlock] = L.y; stash[14 * kRBlock] = L.z; }
-		if (PG_SHADE_KEEP < 1) { stash[15 * kRBlock] = ior; stash[16 * kRBlock] = __uint_as_float((uint32_t)lane); }
-#endif
-#endif
+		stash[9 * kRBlock] = thr.x; stash[10 * kRBlock] = thr.y; stash[11 * kRBlock] = thr.z;
 		// The shadow ray is walked HERE, between the two halves of stage_a: the BSDF sample is not made yet and the SD-tree
 		// calls have no results yet, so neither is alive across the walk -- the walk's 50 registers on top of everything a
 		// bounce keeps were this kernel's register peak (123 with the walk at the end).  The walk draws no
@@ -1237,23 +1147,19 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		}
 		if (A.flags & F_NEED_SHADOW) { // :213 test_visibility
 			float th, bu, bv;
-			occluded = intersect<kLevel, true, PG_SHADE_SLIM != 0>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
+			occluded = intersect<kLevel, true, true>(a.shapes, A.sh_o, A.sh_d, A.sh_tmax, th, stk, bu, bv) >= 0;
 		}
 		PG_PHASE(2)
-#if PG_SHADE_PIN
 		// (the shading frame and the material row are functions of the normal and the material's number: made again from
 		// them behind the walk -- a dozen operations and two loads -- instead of being carried through it, which is what
 		// the compiler does unless it is told that these ARE new values)
 		asm volatile("" : "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z), "+v"(A.mat));
-#endif
 		stage_a2<kLevel>(a, rng, A);
-#if PG_SHADE_PIN
 		// (stage_a2's outputs pinned like stage_a1's: the nine products of to_world() were carried through the SD-tree walks
 		// instead of the three sums)
 		asm volatile("" : "+v"(A.wo.x), "+v"(A.wo.y), "+v"(A.wo.z), "+v"(A.bsdf_w.x), "+v"(A.bsdf_w.y), "+v"(A.bsdf_w.z),
 		                  "+v"(A.bsdf_pdf), "+v"(A.flags));
 		if (kLevel >= 3) asm volatile("" : "+v"(A.eta));
-#endif
 		GuideOut g;
 		g.nee_cx = 0.0f; g.nee_cy = 0.0f; g.wo_cx = 0.0f; g.wo_cy = 0.0f; g.pdf_nee = 1.0f; g.pdf_tree = 1.0f;
 		g.slot_path = kSlotNone; g.slot_nee = kSlotNone; g.tree_flags = 0u;
@@ -1262,30 +1168,11 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		if (guide_has_work(a, A.flags)) stage_guide(a, s_planes, rng, A.p, A.ds_d, (A.flags & F_SMP_TREE) ? V(0, 0, 0) : A.wo, A.flags, g);
 		if (a.record && (A.flags & F_VALID)) store_slots(a, rec_base + tid, g);
 		PG_PHASE(4)
-#if PG_SHADE_PIN
 		asm volatile("" : "+v"(A.n.x), "+v"(A.n.y), "+v"(A.n.z), "+v"(A.mat)); // (the same behind the SD-tree walks, for stage_b's second BSDF evaluation)
-#endif
-#if PG_SHADE_STASH
 		A.Le = V(stash[0 * kRBlock], stash[1 * kRBlock], stash[2 * kRBlock]);
 		A.bv_em = V(stash[3 * kRBlock], stash[4 * kRBlock], stash[5 * kRBlock]);
 		A.em_w = V(stash[6 * kRBlock], stash[7 * kRBlock], stash[8 * kRBlock]);
-#if !PG_SHADE_RELOAD
-		if (PG_SHADE_KEEP < 3) thr = V(stash[9 * kRBlock], stash[10 * kRBlock], stash[11 * kRBlock]);
-		if (PG_SHADE_KEEP < 2) L = V(stash[12 * kRBlock], stash[13 * kRBlock], stash[14 * kRBlock]);
-		if (PG_SHADE_KEEP < 1) { ior = stash[15 * kRBlock]; lane = (uint64_t)__float_as_uint(stash[16 * kRBlock]); }
-#endif
-#endif
-		// the second read (see above): throughput, index of refraction, radiance so far, lane
-		if (PG_SHADE_RELOAD && !kFirst) {
-			asm volatile("" : "+v"(place)); // (not the first read's value kept in registers: a load of its own)
-			uint4 q2, q4;
-			if (from_rec) { const uint4 *rec = a.carry_in + (uint64_t)place * 8; q2 = rec[2]; q4 = rec[4]; }
-			else { q2 = st_load(a.st_in, a, 2, place); q4 = st_load(a.st_in, a, 4, place); }
-			thr = st_v3(q2);
-			ior = __uint_as_float(q2.w & 0x7fffffffu);
-			L = st_v3(q4);
-			lane = q4.w;
-		}
+		thr = V(stash[9 * kRBlock], stash[10 * kRBlock], stash[11 * kRBlock]);
 		cont = stage_b<kLevel>(a, rng, thr, L, ior, A, g, occluded, lane, rec_base + tid, (uint32_t)a.bounce, ray_o, ray_d, prev_pdf, delta);
 		p_here = A.p;
 		if (kFirst) a.hit0[lane] = (A.flags & F_VALID) ? 1 : 0;
@@ -1479,10 +1366,6 @@ static void launch_stage_level(int stage, bool first, const RenderArgs &a, dim3 
 
 void launch_wave_stage(int stage, int level, bool first, const RenderArgs &a, unsigned grid_blocks, unsigned n_cus, hipStream_t s)
 {
-	{ // (wave_entry's XCD mapping deals the tiles out by eights, or by eight runs; a workgroup past the list leaves at once)
-		const unsigned unit = 8u * (PG_XCD_RUN ? (unsigned)PG_XCD_RUN : 1u);
-		grid_blocks = (grid_blocks + unit - 1u) / unit * unit;
-	}
 	if (level >= 3) launch_stage_level<3>(stage, first, a, dim3(grid_blocks), n_cus, s);
 	else launch_stage_level<2>(stage, first, a, dim3(grid_blocks), n_cus, s);
 }

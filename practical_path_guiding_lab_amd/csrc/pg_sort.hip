@@ -24,35 +24,11 @@
 // the places beyond it: places_out[0 .. live) is a permutation of 0 .. live-1, what lies behind it is not written.
 #include <stdint.h>
 
-#ifndef PG_SORT_ROCPRIM
-#define PG_SORT_ROCPRIM 0 // (A/B: 1 = rocPRIM's radix_sort_pairs, as rounds 3 and 4)
-#endif
-#if PG_SORT_ROCPRIM
-#include <cstring>
-#include <string.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#endif
 
 #include "pg_context.hpp"
 
 namespace pg {
 
-#if PG_SORT_ROCPRIM
-size_t sort_pairs_temp_bytes(uint32_t n)
-{
-	size_t bytes = 0;
-	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t *)nullptr, (uint16_t *)nullptr, rocprim::counting_iterator<uint32_t>(0),
-	                                (uint32_t *)nullptr, n, 0, 16, (hipStream_t) nullptr);
-	return bytes;
-}
-hipError_t sort_places16(void *temp, size_t temp_bytes, const uint16_t *keys_in, uint16_t *keys_out, uint32_t *places_out, uint32_t n,
-                         const uint32_t *, hipStream_t s)
-{
-	return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), places_out, n, 0, 16, s);
-}
-#else
 
 namespace {
 
@@ -291,6 +267,5 @@ hipError_t sort_places16(void *temp, size_t temp_bytes, const uint16_t *keys_in,
 	                   d_live, p.n_tiles, counts, sums, (uint16_t *)nullptr, places_out);
 	return hipGetLastError();
 }
-#endif // PG_SORT_ROCPRIM
 
 } // namespace pg

@@ -69,10 +69,7 @@ struct alignas(8) TreeHead {
 // points on a cell boundary or outside the unit square take the loop from the root.
 // (measured on the veach-ajar bench, ms per step: 3 bits 57.5, 4 bits 56.9, 5 bits 56.4, 6 bits 56.3 -- the quadtrees' leaves
 // lie 4.6 levels deep on average, so a 64 x 64 table ends most walks in its one gather; it costs 64 KB per quadtree)
-#ifndef PG_JUMP_BITS
-#define PG_JUMP_BITS 6
-#endif
-constexpr int kJumpBits = PG_JUMP_BITS; // the finest table.  A forest takes fewer bits when its tables would not fit their
+constexpr int kJumpBits = 6; // the finest table.  A forest takes fewer bits when its tables would not fit their
                                         // memory budget (pg_refine.hip: rebuild_jump): 4^bits entries per tree, the same for
                                         // every tree of a forest, a number the kernels read from the view (uniform)
 constexpr uint32_t kJumpCells = 1u << (2 * kJumpBits); // entries per tree of the finest table
@@ -106,10 +103,7 @@ struct JumpRef {
 // The resolution follows the tree: 2^bits cells per axis with bits = ceil(log2(leaves) / 3) + 1, at most
 // kKdGridBits (a table much finer than the tree only spreads the queries over more cache lines: uniform
 // random queries into a depth-12 tree ran 15 % slower on a 64^3 table than on a 32^3 one).
-#ifndef PG_KD_GRID_BITS
-#define PG_KD_GRID_BITS 6
-#endif
-constexpr int kKdGridBits = PG_KD_GRID_BITS; // the finest grid
+constexpr int kKdGridBits = 6; // the finest grid
 constexpr uint32_t kKdGridCells = 1u << (3 * kKdGridBits);
 // Behind the 8^grid_bits cells the table holds two entries for the ROOT: [cells] = node 0 as a searching
 // lane that lies in no cell (on a cell face) starts from it, [cells + 1] = node 0 as a lane that does not
