@@ -1039,7 +1039,12 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 			const uint32_t pj = (uint32_t)__shfl((int)coop_place, (int)j, 64);
 			if (q < 7u) s_dyn[q * kRBlock + wbase + j] = gather16(a.carry_in + (uint64_t)pj * 8 + q); // (entry 7 of a record is unused)
 		}
-		// (written and read by the same wave, LDS operations of a wave complete in order: no barrier between the two)
+		// (written and read by the same wave: its LDS operations complete in order, so no workgroup barrier -- but the lanes read
+		// entries OTHER lanes wrote, which the memory model only orders through a release / acquire pair at wavefront scope; the
+		// fences and the wave barrier emit no instruction, they pin the order for the compiler: ADVICE r5)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		cq0 = s_dyn[0 * kRBlock + threadIdx.x]; cq1 = s_dyn[1 * kRBlock + threadIdx.x]; cq2 = s_dyn[2 * kRBlock + threadIdx.x];
 		cq3 = s_dyn[3 * kRBlock + threadIdx.x]; cq4 = s_dyn[4 * kRBlock + threadIdx.x]; cq5 = s_dyn[5 * kRBlock + threadIdx.x];
 		cq6 = s_dyn[6 * kRBlock + threadIdx.x];

@@ -97,41 +97,49 @@ def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
     host without PyTorch would use.
 
     Whether the library communicator is used at all is decided COLLECTIVELY before anyone joins (one MIN
-    all-reduce of a flag, no early return ahead of it): it needs the nccl backend and a GPU of its own for
-    every rank of this node (RCCL refuses two ranks on one device; the check uses the LOCAL world size, so
-    multi-node jobs are eligible).  Returns False on every rank when the ranks are not eligible or RCCL
-    cannot be loaded on rank 0 -- the caller then exchanges through torch.distributed
-    (all_reduce_accumulators), the same RCCL all-reduce issued by PyTorch.  Once the ranks have agreed to
-    join, a rank on which the join fails says so in a second collective vote and EVERY rank falls back to
-    torch.distributed; a rank whose peers never arrive is ended by the Watchdog (non-zero exit: the launcher ends
-    the job).  There is no half-joined communicator and no fallback decided by one rank alone."""
+    all-reduce of a flag, no early return ahead of it).  A rank votes yes when the backend is nccl, every rank
+    of this node has a GPU of its own (RCCL refuses two ranks on one device; the check uses the LOCAL world
+    size, so multi-node jobs are eligible) AND libpgsd can load RCCL and find its symbols on THIS rank -- every
+    rank tries it (ncclGetUniqueId through pg_comm_unique_id; the ids of ranks other than 0 are thrown away), so
+    a rank with a broken RCCL installation is known before any rank blocks in ncclCommInitRank (round
+    5 checked rank 0 only).  Returns False on every rank when the vote fails -- the caller then exchanges
+    through torch.distributed (all_reduce_accumulators), the same RCCL all-reduce issued by PyTorch.
+    Once the ranks have agreed to join: a rank on which ncclCommInitRank RETURNS an error (or on which RCCL then
+    reports other numbers than the process group's) says so in a second vote and EVERY rank falls back to
+    torch.distributed.  A rank that DIES or never arrives before it has joined cannot vote: its peers are blocked
+    in ncclCommInitRank and are ended by the Watchdog after comm_init_timeout_s() (exit code 75: the launcher
+    ends the job) -- a pre-join failure ends the job, it does not fall back.  The second vote and the letting
+    go of a half-agreed communicator run under the same Watchdog.  There is no half-joined communicator and no
+    fallback decided by one rank alone."""
     if not dist.is_available() or not dist.is_initialized():
         return False
     import os
+    import warnings
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     mine = 1 if (dist.get_backend(group) == "nccl" and torch.cuda.is_available()
                  and local_world <= torch.cuda.device_count()) else 0
+    ident = [None]
+    if mine:
+        try:  # (loads RCCL and resolves its symbols on this rank; only rank 0's id is used)
+            my_id = tree.commUniqueId()
+            if rank == 0:
+                ident[0] = my_id
+        except Exception as e:  # noqa: BLE001
+            warnings.warn(f"rank {rank}: libpgsd RCCL communicator not available: {e}")
+            mine = 0
     flag = torch.tensor([mine], dtype=torch.int32, device=_flag_device(group))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if int(flag.item()) != 1:
         return False
-    ident = [None]
-    if rank == 0:
-        try:
-            ident[0] = tree.commUniqueId()
-        except Exception as e:  # RCCL cannot be loaded: every rank learns it from the broadcast below
-            import warnings
-            warnings.warn(f"libpgsd RCCL communicator not available: {e}")
     dist.broadcast_object_list(ident, src=0, group=group)
     if ident[0] is None:
         return False
-    # ncclCommInitRank blocks until every rank has joined: bounded (a rank whose peers never come exits non-zero and the
-    # launcher ends the job).  A rank on which the call FAILS -- or on which RCCL then reports other numbers than the process
-    # group's (ncclCommCount / ncclCommUserRank read back) -- says so in a second vote: the library communicator is used by
-    # every rank or by none (the others let go of theirs, and everybody exchanges through torch.distributed instead).
+    # ncclCommInitRank blocks until every rank has joined: bounded (see above).  A rank on which the call FAILS -- or on which
+    # RCCL then reports other numbers than the process group's (ncclCommCount / ncclCommUserRank read back) -- says so in the
+    # second vote: the library communicator is used by every rank or by none (the others let go of theirs).
     ok, why = 1, ""
-    with Watchdog(comm_init_timeout_s(), f"rank {rank}: ncclCommInitRank of libpgsd's communicator ({world} ranks)"):
+    with Watchdog(comm_init_timeout_s(), f"rank {rank}: ncclCommInitRank of libpgsd's communicator ({world} ranks), the vote on it"):
         try:
             tree.commInit(world, rank, ident[0])
             n_seen, r_seen = tree.commInfo()
@@ -139,16 +147,17 @@ def init_library_comm(tree, group: Optional[dist.ProcessGroup] = None) -> bool:
                 ok, why = 0, f"RCCL reports {n_seen} ranks / rank {r_seen}, expected {world} / {rank}"
         except Exception as e:  # noqa: BLE001 (whatever the library raises: the vote below decides for everybody)
             ok, why = 0, str(e)
-    flag = torch.tensor([ok], dtype=torch.int32, device=_flag_device(group))
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
-        import warnings
-        if not ok:
-            warnings.warn(f"rank {rank}: libpgsd RCCL communicator not usable ({why}); every rank exchanges through torch.distributed")
-        try:
-            tree.commDestroy()
-        except Exception:  # noqa: BLE001
-            pass
+        flag = torch.tensor([ok], dtype=torch.int32, device=_flag_device(group))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        agreed = int(flag.item()) == 1
+        if not agreed:
+            if not ok:
+                warnings.warn(f"rank {rank}: libpgsd RCCL communicator not usable ({why}); every rank exchanges through torch.distributed")
+            try:
+                tree.commDestroy()
+            except Exception:  # noqa: BLE001
+                pass
+    if not agreed:
         return False
     return True
 

@@ -848,6 +848,15 @@ def _worker_nccl_one_rank(rank, world, port, out):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ok = ok and (init_library_comm(g2) is False)
+    # a rank on which RCCL cannot even be LOADED says so in the first vote, before anybody could block in a join
+    g3 = SDTree(0)
+    g3.load(_base_tree())
+    joined = []
+    g3.commUniqueId = broken
+    g3.commInit = lambda *a_, **k_: joined.append(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ok = ok and (init_library_comm(g3) is False) and not joined
     dist.barrier()
     dist.destroy_process_group()
     np.save(out, np.array([ok, same, float(s1.sum()) == 24.0 and float(s2.sum()) == 48.0, lo == 7.0 and hi == 7.0, t == 0.25]))
