@@ -507,9 +507,10 @@ int pg_film_batched_accumulate(pg_context *ctx, int32_t filter, uint32_t seed, i
 int pg_math_eval(pg_context *ctx, int32_t which, uint64_t n, const float *x, float *out, void *stream);
 
 /* The ordering step of a sorted bounce (pg_render_sort) by itself, for tests: d_places_out[0 .. live) becomes a permutation of
- * the places 0 .. live-1 in the order of their 16-bit keys' HIGH byte and, inside one high byte, of the low byte up to pairs whose
- * low bytes are equal or adjacent (csrc/pg_sort.hip: two unstable counting passes; the renderer's results do not depend on the
- * order at all).  live = min(n, *d_live) -- the places that hold a path, read from device memory; d_live NULL: all n.  Entries of
+ * the places 0 .. live-1 in the order of their 16-bit keys' HIGH byte -- for every n -- and, inside one high byte, in the order of
+ * the low byte only as far as one 4096-pair tile of the second pass allows: equal or adjacent low bytes for n >= 2^21, coarser
+ * below, none for n < 2^20 (csrc/pg_sort.hip: two unstable counting passes; the permutation differs from run to run; the
+ * renderer's results do not depend on the order at all).  live = min(n, *d_live) -- the places that hold a path, read from device memory; d_live NULL: all n.  Entries of
  * d_places_out behind `live` are not written.  d_keys: uint16[n], d_places_out: uint32[n], device pointers.  Synchronises. */
 int pg_sort_places(pg_context *ctx, uint64_t n, const uint16_t *d_keys, const uint32_t *d_live, uint32_t *d_places_out, void *stream);
 

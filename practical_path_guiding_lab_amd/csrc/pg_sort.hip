@@ -14,9 +14,17 @@
 //                   LDS and leaves as runs of consecutive addresses
 // Neither pass is stable, and the result is not a sort: it is a permutation in which the places are in the order of the
 // key's HIGH byte, and inside one value of it in the order of the low byte up to the pairs of ONE tile of the second pass --
-// 4096 consecutive pairs of a sequence sorted by the low byte, i.e. pairs whose low bytes are equal or next to each other.
+// 4096 consecutive pairs of a sequence sorted by the low byte.  How much low-byte order that is DEPENDS ON n:
+// a tile of the second pass spans 4096 * 256 / n values of the low byte on average -- equal or adjacent low bytes from about
+// 2^21 places up (the 33 M lanes of the bench's step: an eighth of one value), 4 values at 2^18, and NO low-byte order at all
+// below 2^12 * 2^8 = 2^20 places, where one tile holds every low byte: the one or two million lanes of a cornell-box pass or
+// of a late bounce are ordered by the 8 high bits of the Morton key (and the class bit, bit 0, is not grouped there).
+// The permutation also differs from run to run (LDS atomics; and the list it is applied to was appended by atomics).
 // That is all the order the shading needs (cells of the spatial sort are 2^-15 of the box; the results do not depend on the
 // order at all), and it is what makes the passes cheap: no decoupled look-back, no ranking by match-any, 27 KB of LDS.
+// Measured against the stable form (ballot-match ranking, the true LSD sort: the same answer as numpy's stable argsort): the
+// full 16 bits are worth 2-3 % of the two SD-tree-walking kernels on lists of a million lanes and nothing on long ones, and
+// cost the sort 25 % -- a net loss of 1-2 % of the step at every size but the torus' (profiles/r06/ab_sort_stable_rejected.txt).
 // The first pass reads no places (a pair's place is its index) and the second writes no keys.
 // Because the order inside a tile of the second pass is free, a place WITHOUT a path (key 0xffff) could come to stand in front
 // of a live one with key 0xfffe or 0xfffd.  The live list is dense -- places 0 .. live-1 hold paths, the rest of the n places
