@@ -393,3 +393,60 @@ def test_reserve_then_pass_with_a_small_jump_table_budget_and_with_refused_alloc
     g1.setIteration(0, False)
     assert torch.equal(g1.sample(w1, IndependentSampler(spp, 10))[0].view(torch.int32), ref[0].view(torch.int32))
     L.pg_debug_fail_alloc(-1)
+
+
+def test_the_probe_build_renders_the_same_image_and_stamps_its_phases(tmp_path):
+    """The probe build (csrc/Makefile `probe`, -DPG_SHADE_PHASES=1: libpgsd_phases.so, what bench.py runs for
+    roofline.value_region_sdtree_*) is the product's code plus stamps: in a process of its own ($PGSD_LIBRARY) a guided
+    veach-ajar pass gives the ORACLE's radiance bit for bit, with the stamps on (pg_enable_depth_counters(2)) and off, and
+    pg_read_shade_phases reports one wave count and three non-empty phases -- ahead of the SD-tree calls, the calls, behind them.
+    The product build has no stamps: compiled_in false, zeros."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from practical_path_guiding_lab_amd import _native as N
+    from practical_path_guiding_lab_amd.sdtree import SDTree
+
+    t = SDTree(0)
+    t.setup([0, 0, 0], [1, 1, 1], 16, 4, 20, 20, True, 0.5)
+    t.enableDepthCounters(2)
+    assert t.readShadePhases() == (False, 0, [0] * 7)       # the product: nothing compiled in, nothing counted
+    t.enableDepthCounters(False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = os.path.join(os.path.dirname(N.LIB_PATH), "libpgsd_phases.so")
+    assert os.path.exists(probe), "make -C practical_path_guiding_lab_amd/csrc probe (__graft_entry__.build() does)"
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import pg_oracle as po
+from practical_path_guiding_lab_amd import _native as N
+from practical_path_guiding_lab_amd.integrator import PathGuidingIntegrator
+from practical_path_guiding_lab_amd.render import IndependentSampler, WavefrontScene
+from practical_path_guiding_lab_amd.scene import veach_ajar
+assert N.LIB_PATH.endswith("libpgsd_phases.so")
+sa = veach_ajar(64, 36)
+amin, amax = sa.bbox_min - np.float32(1e-4), sa.bbox_max + np.float32(1e-4)
+ao = po.OracleSDTreePair(); ao.setup(amin, amax, 20, 20, True)
+ag = PathGuidingIntegrator({"max_depth": 13, "rr_depth": 8}); ag.setup(64 * 36, amin, amax, 20, 20, True, 0.5)
+wa = WavefrontScene(sa)
+same, phases = True, None
+for k in range(4):
+    ag.setIteration(k, False)
+    ag.sdTree.enableDepthCounters(2 if k >= 2 else 0)      # guided iterations with the stamps on
+    Lo, _ = po.render_pass(ao, sa, sa.camera, 13, 8, k, False, 90 + k, 4, True, 0.5)
+    Lg = ag.sample(wa, IndependentSampler(4, 90 + k))[0].cpu().numpy()
+    same = same and bool((Lg.view(np.uint32) == Lo.view(np.uint32)).all())
+    ao.refine_and_prepare(k); ag.refineAndPrepareSDTreeForNextIteration()
+phases = ag.sdTree.readShadePhases()
+print(json.dumps({"same": same, "phases": phases}))
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, PGSD_LIBRARY=probe)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["same"] is True
+    compiled, waves, cyc = out["phases"]
+    assert compiled is True and waves > 0
+    assert cyc[3] > 0 and cyc[4] > 0 and cyc[6] > 0 and cyc[0] == cyc[1] == cyc[2] == cyc[5] == 0    # the three stamps of PG_SHADE_PHASES=1
+    assert 0.05 < cyc[4] / sum(cyc) < 0.6                                                         # the SD-tree calls: a share, not everything
