@@ -1096,9 +1096,7 @@ def run_render(args):
                     "value_region_sdtree_frac": round(sh_layout / (sd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "value_region_sdtree_frac_model_8d": round(sh_alg / (sd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "value_region_sdtree_probe_overhead": round(pp["shade_avg_us_stamping"] / sh["avg_us"], 3),
-                    # (the probe stamps the start, the two sides of the SD-tree calls and the end: three shares)
-                    "value_region_phase_shares": {"ahead_of_sdtree_calls": round(sum(pp["cycles"][:4]) / tot, 4), "sdtree_calls": round(share, 4),
-                                                  "stage_b_and_append": round(sum(pp["cycles"][5:]) / tot, 4)},
+                    "value_region_phase_shares": {n: round(c / tot, 4) for n, c in zip(PHASE_NAMES, pp["cycles"])},
                     "value_region_sdtree_note": (
                         "the SD-tree calls of a bounce (path_guiding_integrator.py:244, 301, 307) timed IN PLACE, inside k_wave_shade: " + pp_note +
                         f"; wave-clock cycles of the seven phases summed over {pp['waves']} waves of {pp['shade_launches']} launches; "

@@ -572,7 +572,8 @@ int pg_read_depth_counters(pg_context *ctx, pg_depth_counters *out, int32_t rese
  * csrc/Makefile target `probe`: libpgsd_phases.so; the product build has no stamps, h_out[0] = 0 and zeros): the kernel that makes
  * the three SD-tree calls of a bounce (path_guiding_integrator.py:244, 301, 307) in the default pipeline also shades, walks the
  * shadow ray and appends the survivors, so the calls cannot be timed apart by events; the probe stamps the wave clock at the
- * seven phase boundaries.  pg_enable_depth_counters(ctx, 2) switches the stamps on WITHOUT the depth counters (no atomics in the
+ * kernel's start and at its seven phase boundaries (a wave's stamps wait in LDS and leave in one striped atomic: the probe's
+ * kernel takes the product's time, profiles/r06/phase_probe.txt).  pg_enable_depth_counters(ctx, 2) switches the stamps on WITHOUT the depth counters (no atomics in the
  * walks themselves); pg_enable_depth_counters(ctx, 1) switches both on.  h_out[10]:
  *   [0] 1 when the stamps are compiled in, [1] waves that ran the kernel's body,
  *   [2..8] wave-clock cycles summed over those waves: records + staging, stage_a1, shadow walk, stage_a2, SD-tree calls,

@@ -990,15 +990,15 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 	// of device memory: its k_wave_shade ran eleven times slower than the product's.  And what made a probe build 1.7 times
 	// slower even with its stamps idle was not the stamps at all: see live_final(), pg_render_dev.hpp.  With both repaired this
 	// build's k_wave_shade takes 27.7 ms per step against the product's 27.5, stamping or not: profiles/r06/phase_probe.txt.)
-	// PG_SHADE_PHASES 1: the start and three stamps -- slot 3 = everything ahead of the SD-tree calls, slot 4 = the calls, slot 6 =
-	// stage_b + the survivors' append.  PG_SHADE_PHASES 2: all seven (a breakdown).
+	// Seven stamps behind the start: 0 the records + staging, 1 stage_a1, 2 the shadow walk, 3 stage_a2, 4 the SD-tree calls, 5 stage_b,
+	// 6 the survivors' append (pg_kernels.hpp).
 	__shared__ unsigned long long s_ph[kRBlock / 64][10]; // [0..6] the phases, [7] stamps taken, [8] the last stamp
 	if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) {
 		s_ph[threadIdx.x >> 6][8] = (unsigned long long)clock64();
 		s_ph[threadIdx.x >> 6][7] = 0ull;
 	}
 #define PG_PHASE(i)                                                                                                          \
-	if ((PG_SHADE_PHASES >= 2 || (i) == 3 || (i) == 4 || (i) == 6) && a.ph && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) { \
+	if (a.ph && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))) {                                            \
 		const unsigned long long t_now = (unsigned long long)clock64();                                                      \
 		unsigned long long *row = s_ph[threadIdx.x >> 6];                                                                    \
 		row[i] = t_now - row[8];                                                                                             \

@@ -399,7 +399,7 @@ def test_the_probe_build_renders_the_same_image_and_stamps_its_phases(tmp_path):
     """The probe build (csrc/Makefile `probe`, -DPG_SHADE_PHASES=1: libpgsd_phases.so, what bench.py runs for
     roofline.value_region_sdtree_*) is the product's code plus stamps: in a process of its own ($PGSD_LIBRARY) a guided
     veach-ajar pass gives the ORACLE's radiance bit for bit, with the stamps on (pg_enable_depth_counters(2)) and off, and
-    pg_read_shade_phases reports one wave count and three non-empty phases -- ahead of the SD-tree calls, the calls, behind them.
+    pg_read_shade_phases reports one wave count and seven non-empty phases.
     The product build has no stamps: compiled_in false, zeros."""
     import json
     import os
@@ -448,5 +448,5 @@ print(json.dumps({"same": same, "phases": phases}))
     assert out["same"] is True
     compiled, waves, cyc = out["phases"]
     assert compiled is True and waves > 0
-    assert cyc[3] > 0 and cyc[4] > 0 and cyc[6] > 0 and cyc[0] == cyc[1] == cyc[2] == cyc[5] == 0    # the three stamps of PG_SHADE_PHASES=1
+    assert all(c > 0 for c in cyc)                                                                # seven phases, every one passed
     assert 0.05 < cyc[4] / sum(cyc) < 0.6                                                         # the SD-tree calls: a share, not everything
