@@ -1033,12 +1033,21 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 		if (alive && tid < (uint64_t)a.n_sort) coop_place = a.perm[tid];
 		if (!alive) coop_place = 0u; // (a lane past the list still serves its wave's loads: any record that exists)
 		const uint32_t l = threadIdx.x & 63u, wbase = threadIdx.x & ~63u, q = l & 7u;
+		// ALL EIGHT gathers are issued before the first of them is waited for (round 6).  Written as one loop -- gather, then store
+		// under `q < 7` -- every round was a basic block of its own: permute, wait, gather, WAIT, store, eight round trips one
+		// after the other at the head of every wave (the ISA showed it: eight `s_waitcnt vmcnt(0)` in a row).  The gather is
+		// unconditional now (entry 7 of a record is its unused tail, in the same 128-byte line as the rest: loaded, not kept),
+		// so nothing splits the loop, and the stores follow in a loop of their own.
+		uint4 g[8];
 #pragma unroll
 		for (uint32_t k = 0; k < 8u; ++k) {
 			const uint32_t j = k * 8u + (l >> 3);
 			const uint32_t pj = (uint32_t)__shfl((int)coop_place, (int)j, 64);
-			if (q < 7u) s_dyn[q * kRBlock + wbase + j] = gather16(a.carry_in + (uint64_t)pj * 8 + q); // (entry 7 of a record is unused)
+			g[k] = gather16(a.carry_in + (uint64_t)pj * 8 + q);
 		}
+#pragma unroll
+		for (uint32_t k = 0; k < 8u; ++k)
+			if (q < 7u) s_dyn[q * kRBlock + wbase + k * 8u + (l >> 3)] = g[k];
 		// (written and read by the same wave: its LDS operations complete in order, so no workgroup barrier -- but the lanes read
 		// entries OTHER lanes wrote, which the memory model only orders through a release / acquire pair at wavefront scope; the
 		// fences and the wave barrier emit no instruction, they pin the order for the compiler: ADVICE r5)
