@@ -512,6 +512,23 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	uint64_t tid;
 	bool alive;
 	if (!wave_entry<kFirst>(a, tid, alive)) return;
+	// The ray is ASKED FOR ahead of the staging of the BVH's top (round 6): the staging ends in a workgroup barrier no load
+	// moves across, and the ray's round trip used to begin behind it.
+	const bool want_cls = !kFirst && a.carry_in && a.guided && a.bounce + 1 < a.max_depth; // (uniform)
+	uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q5 = q0;
+	if (!kFirst && alive) {
+		if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
+			// (Measured and removed, round 5: these three entries read by four lanes per record and handed over through the wave's
+			// stack columns, as k_wave_shade reads its PERMUTED records -- here the wave's records lie side by side, consecutive
+			// lanes ask for consecutive lines, and the detour through LDS cost 11.5 -> 12.8 ms per step:
+			// profiles/r05/ab_trace_coop_record_load_rejected.txt.)
+			q0 = a.carry_in[tid * 8 + 0]; q1 = a.carry_in[tid * 8 + 1];
+			if (want_cls && tid < (uint64_t)a.n_sort) q5 = a.carry_in[tid * 8 + 5];
+		} else {
+			q0 = st_load(a.st_in, a, 0, tid);
+			q1 = st_load(a.st_in, a, 1, tid);
+		}
+	}
 	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
 	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
 	stage_bvh_top<kBvhTopNodes>(s_top, a, stk);
@@ -525,24 +542,13 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 		const_cast<uint64_t *>(a.inc_in)[tid] = rng.inc;
 		st_store(const_cast<uint4 *>(a.st_in), a, 0, tid, ray_o, (uint32_t)rng.state);
 		st_store(const_cast<uint4 *>(a.st_in), a, 1, tid, ray_d, (uint32_t)(rng.state >> 32));
-	} else if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
-		const bool want_cls = a.guided && a.bounce + 1 < a.max_depth; // (uniform)
-		uint4 q0, q1, q5 = make_uint4(0u, 0u, 0u, 0u);
-		// (Measured and removed, round 5: these three entries read by four lanes per record and handed over through the wave's
-		// stack columns, as k_wave_shade reads its PERMUTED records -- here the wave's records lie side by side, consecutive
-		// lanes ask for consecutive lines, and the detour through LDS cost 11.5 -> 12.8 ms per step:
-		// profiles/r05/ab_trace_coop_record_load_rejected.txt.)
-		q0 = a.carry_in[tid * 8 + 0]; q1 = a.carry_in[tid * 8 + 1];
-		if (want_cls && tid < (uint64_t)a.n_sort) q5 = a.carry_in[tid * 8 + 5];
+	} else {
 		ray_o = st_v3(q0);
 		ray_d = st_v3(q1);
 		// (the class bit of the sort key is made HERE, ahead of the walk, from the sampler state in the two entries just read: one
 		// register through the walk instead of the state's four)
 		if (want_cls && tid < (uint64_t)a.n_sort)
 			cls_ahead = (int)lane_class_ahead((uint64_t)q0.w | ((uint64_t)q1.w << 32), (uint64_t)q5.x | ((uint64_t)q5.y << 32), a.frac);
-	} else {
-		ray_o = st_v3(st_load(a.st_in, a, 0, tid));
-		ray_d = st_v3(st_load(a.st_in, a, 1, tid));
 	}
 	HitRec h;
 	h.u = 0.0f; h.v = 0.0f;
@@ -757,17 +763,29 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	bool alive;
 	if (a.bounce == 0) { if (!wave_entry<true>(a, tid, alive)) return; }
 	else if (!wave_entry<false>(a, tid, alive)) return;
+	// The lane's inputs are ASKED FOR first -- together with its flags and ahead of the staging of the KD planes (round 6: the
+	// listing showed staging -> barrier -> flags -> wait -> branch -> inputs -> wait, three round trips at the head of every
+	// wave where one does): the planes hold a value for every live place, a lane without work throws its copies away.  (The
+	// empty asm behind the barrier keeps the loads where they are written; the compiler would sink them into the branch.)
+	uint32_t flags = 0u, rng_lo = 0u, rng_hi = 0u;
+	v3 p_in = V(0, 0, 0), ds_in = V(0, 0, 0), u_in = V(0, 0, 0);
+	if (alive) {
+		flags = wsu(a, WS_FLAGS, tid);
+		p_in = ws3(a, WS_P, tid); ds_in = ws3(a, WS_DS_D, tid); u_in = ws3(a, WS_U, tid);
+		rng_lo = wsu(a, WS_RNG_LO, tid); rng_hi = wsu(a, WS_RNG_HI, tid);
+	}
 	stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
-	const uint32_t flags = wsu(a, WS_FLAGS, tid);
+	asm volatile("" : "+v"(p_in.x), "+v"(p_in.y), "+v"(p_in.z), "+v"(ds_in.x), "+v"(ds_in.y), "+v"(ds_in.z), "+v"(u_in.x), "+v"(u_in.y),
+	                  "+v"(u_in.z), "+v"(rng_lo), "+v"(rng_hi));
 	if (!guide_has_work(a, flags)) return;
 	Pcg32 rng;
-	rng.state = (uint64_t)wsu(a, WS_RNG_LO, tid) | ((uint64_t)wsu(a, WS_RNG_HI, tid) << 32);
+	rng.state = (uint64_t)rng_lo | ((uint64_t)rng_hi << 32);
 	rng.inc = a.perm ? ((uint64_t)wsu(a, WS_FWD + 8, tid) | ((uint64_t)wsu(a, WS_FWD + 9, tid) << 32)) : a.inc_in[tid];
 	GuideOut g;
 	// (the BSDF-sampled direction of a lane that keeps it; a lane that samples the tree has none to evaluate)
-	const v3 wo_in = (flags & F_SMP_TREE) ? V(0, 0, 0) : ws3(a, WS_U, tid);
-	stage_guide(a, s_planes, rng, ws3(a, WS_P, tid), ws3(a, WS_DS_D, tid), wo_in, flags, g);
+	const v3 wo_in = (flags & F_SMP_TREE) ? V(0, 0, 0) : u_in;
+	stage_guide(a, s_planes, rng, p_in, ds_in, wo_in, flags, g);
 	if (a.record && (flags & F_VALID)) { // the entry k_wave_shade_b fills for this vertex
 		uint64_t rec_base = 0;
 		if (a.bounce > 0) {
