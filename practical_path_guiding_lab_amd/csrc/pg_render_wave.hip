@@ -1226,8 +1226,16 @@ __device__ __forceinline__ void shade_body(const RenderArgs &a)
 #endif
 }
 
+// (The probe build's stamps cost the level-2 kernel one register more than five waves per SIMD leave -- 97: four waves, and the
+// kernel 15 % -- so it is told the occupancy, as the level-3 kernel below is: 96 registers and a few spilled bytes.  A probe
+// must run at the product's occupancy to say anything about the product.)
+#if PG_SHADE_PHASES
+#define PG_PROBE_WAVES __attribute__((amdgpu_waves_per_eu(5)))
+#else
+#define PG_PROBE_WAVES
+#endif
 template <int kLevel, bool kFirst>
-__global__ __launch_bounds__(kRBlock) void k_wave_shade(RenderArgs a)
+__global__ __launch_bounds__(kRBlock) PG_PROBE_WAVES void k_wave_shade(RenderArgs a)
 {
 	shade_body<kLevel, kFirst>(a);
 }
