@@ -390,7 +390,12 @@ __device__ __forceinline__ void bvh_leaf_step(BvhWalk &w, const Shapes &sh, int 
 	const uint32_t first = w.next & 0x0fffffffu, count = ((w.next >> 28) & 7u) + 1u;
 	for (uint32_t i = first; i < first + count; ++i) {
 		const float *T = sh.tris + (size_t)i * kTriStride;
-		bvh_tri_test(w, ld3(T), ld3(T + 3), ld3(T + 6), tri_base + (int)i);
+		v3 v0 = ld3(T);
+		const v3 e1 = ld3(T + 3), e2 = ld3(T + 6);
+		// (the triangle's nine floats are asked for TOGETHER: left alone the compiler sinks the load of v0 behind the test of the
+		// determinant, which only e1 and e2 enter -- two round trips per triangle where one does; round 6, from the listing)
+		asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z));
+		bvh_tri_test(w, v0, e1, e2, tri_base + (int)i);
 	}
 }
 

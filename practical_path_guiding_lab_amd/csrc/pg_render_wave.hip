@@ -496,7 +496,22 @@ template <int kNodes>
 __device__ __forceinline__ void stage_bvh_top(u32x4_t *s_top, const RenderArgs &a, BvhStack &stk)
 {
 	const uint32_t n = a.shapes.n_bvh_nodes < kNodes ? (uint32_t)a.shapes.n_bvh_nodes : (uint32_t)kNodes;
-	for (uint32_t i = threadIdx.x; i < n * 8u; i += kRBlock) s_top[i] = reinterpret_cast<const u32x4_t *>(a.shapes.bvh)[i];
+	// (every load of a thread is asked for before the first is stored: as a loop -- load, wait, store, again -- the second
+	// 16 bytes of a thread began their round trip when the first had ended)
+	constexpr int kLoads = (kNodes * 8 + kRBlock - 1) / kRBlock;
+	if (n) { // (uniform; a scene without meshes has no table: nothing is read)
+		u32x4_t v[kLoads];
+#pragma unroll
+		for (int k = 0; k < kLoads; ++k) { // (unconditional, so that nothing ties a load to its store: a lane past the nodes reads entry 0)
+			const uint32_t i = threadIdx.x + (uint32_t)k * kRBlock;
+			v[k] = reinterpret_cast<const u32x4_t *>(a.shapes.bvh)[i < n * 8u ? i : 0u];
+		}
+#pragma unroll
+		for (int k = 0; k < kLoads; ++k) {
+			const uint32_t i = threadIdx.x + (uint32_t)k * kRBlock;
+			if (i < n * 8u) s_top[i] = v[k];
+		}
+	}
 	__syncthreads();
 	stk.top = (const LdsQuad *)s_top;
 	stk.n_top = n;
@@ -516,18 +531,20 @@ __global__ __launch_bounds__(kRBlock) void k_wave_trace(RenderArgs a)
 	// moves across, and the ray's round trip used to begin behind it.
 	const bool want_cls = !kFirst && a.carry_in && a.guided && a.bounce + 1 < a.max_depth; // (uniform)
 	uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q5 = q0;
-	if (!kFirst && alive) {
-		if (a.carry_in) { // a sorted bounce: the state is in the paths' 128-byte records only
-			// (Measured and removed, round 5: these three entries read by four lanes per record and handed over through the wave's
-			// stack columns, as k_wave_shade reads its PERMUTED records -- here the wave's records lie side by side, consecutive
-			// lanes ask for consecutive lines, and the detour through LDS cost 11.5 -> 12.8 ms per step:
-			// profiles/r05/ab_trace_coop_record_load_rejected.txt.)
-			q0 = a.carry_in[tid * 8 + 0]; q1 = a.carry_in[tid * 8 + 1];
-			if (want_cls && tid < (uint64_t)a.n_sort) q5 = a.carry_in[tid * 8 + 5];
-		} else {
-			q0 = st_load(a.st_in, a, 0, tid);
-			q1 = st_load(a.st_in, a, 1, tid);
-		}
+	if (!kFirst) {
+		// a sorted bounce: the state is in the paths' 128-byte records only; else in the planes of the state set.  ONE
+		// unconditional load site per entry: a load under a per-lane condition is merged with its zero behind the branch, and
+		// that merge waits for the load -- so a lane past the list reads place 0's entries (the list is not empty: this
+		// workgroup runs) and drops them, and the entry of the sort key's class bit is read whether or not it is used.
+		// (Measured and removed, round 5: these three entries read by four lanes per record and handed over through the wave's
+		// stack columns, as k_wave_shade reads its PERMUTED records -- here the wave's records lie side by side, consecutive
+		// lanes ask for consecutive lines, and the detour through LDS cost 11.5 -> 12.8 ms per step:
+		// profiles/r05/ab_trace_coop_record_load_rejected.txt.)
+		const uint64_t it = alive ? tid : 0;
+		const uint4 *p0 = a.carry_in ? a.carry_in + it * 8 : a.st_in + it;
+		const uint4 *p1 = a.carry_in ? a.carry_in + it * 8 + 1 : a.st_in + a.n_lanes + it;
+		const uint4 *p5 = a.carry_in ? a.carry_in + it * 8 + 5 : p0;
+		q0 = *p0; q1 = *p1; q5 = *p5;
 	}
 	__shared__ u32x4_t s_top[kBvhTopNodes * 8];
 	BvhStack stk = bvh_stack(&s_stack[0][threadIdx.x], a.bvh_ovf, (uint32_t)tid * (uint32_t)kOvfStack);
@@ -767,13 +784,12 @@ __global__ __launch_bounds__(kRBlock) void k_wave_guide(RenderArgs a)
 	// listing showed staging -> barrier -> flags -> wait -> branch -> inputs -> wait, three round trips at the head of every
 	// wave where one does): the planes hold a value for every live place, a lane without work throws its copies away.  (The
 	// empty asm behind the barrier keeps the loads where they are written; the compiler would sink them into the branch.)
-	uint32_t flags = 0u, rng_lo = 0u, rng_hi = 0u;
-	v3 p_in = V(0, 0, 0), ds_in = V(0, 0, 0), u_in = V(0, 0, 0);
-	if (alive) {
-		flags = wsu(a, WS_FLAGS, tid);
-		p_in = ws3(a, WS_P, tid); ds_in = ws3(a, WS_DS_D, tid); u_in = ws3(a, WS_U, tid);
-		rng_lo = wsu(a, WS_RNG_LO, tid); rng_hi = wsu(a, WS_RNG_HI, tid);
-	}
+	// (unconditional: a load under a per-lane condition is merged with its default behind the branch, and that merge waits for
+	// the load -- a lane past the list reads place 0's values, the list is not empty, and leaves below)
+	const uint64_t it = alive ? tid : 0;
+	const uint32_t flags = wsu(a, WS_FLAGS, it);
+	v3 p_in = ws3(a, WS_P, it), ds_in = ws3(a, WS_DS_D, it), u_in = ws3(a, WS_U, it);
+	uint32_t rng_lo = wsu(a, WS_RNG_LO, it), rng_hi = wsu(a, WS_RNG_HI, it);
 	stage_kd_planes(s_planes, a.tree);
 	if (!alive) return;
 	asm volatile("" : "+v"(p_in.x), "+v"(p_in.y), "+v"(p_in.z), "+v"(ds_in.x), "+v"(ds_in.y), "+v"(ds_in.z), "+v"(u_in.x), "+v"(u_in.y),
