@@ -62,10 +62,14 @@ __device__ __forceinline__ uint32_t kd_descend(const KdNode *kd, float x, float 
 
 // ---- the KD jump grid (pg_tree.hpp) ----
 // The planes of the grid staged in LDS once per workgroup (3 * kKdGridPlanes floats): every query reads six.
+// Every kernel that stages them runs workgroups of kStageThreads threads (kBlock / kRBlock: static_asserts beside the callers), so a
+// thread copies ONE plane (195 of 256 threads) -- written with `i += blockDim.x` the copy compiled to three loops (a vectorised
+// one, its two remainders), each load -> wait -> store, at the head of every kernel that walks the KD tree (round 6, from the listings).
+constexpr int kStageThreads = 256;
 __device__ __forceinline__ void stage_kd_planes(float *s_planes, const TreeView &t)
 {
-	if (t.kd_grid != nullptr)
-		for (uint32_t i = threadIdx.x; i < 3u * kKdGridPlanes; i += blockDim.x) s_planes[i] = t.kd_planes[i];
+	static_assert(3 * kKdGridPlanes <= kStageThreads, "one plane per thread");
+	if (t.kd_grid != nullptr && threadIdx.x < 3u * kKdGridPlanes) s_planes[threadIdx.x] = t.kd_planes[threadIdx.x];
 	__syncthreads();
 }
 

@@ -8,6 +8,7 @@
 namespace pg {
 
 constexpr int kBlock = 256;
+static_assert(kBlock == kStageThreads, "stage_kd_planes copies one plane per thread");
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {

@@ -17,6 +17,7 @@
 namespace pg {
 
 constexpr int kBlock = 256;
+static_assert(kBlock == kStageThreads, "stage_kd_planes copies one plane per thread");
 
 __device__ __forceinline__ TreeHead load_head_s(const TreeHead *h, uint32_t t)
 {

@@ -17,6 +17,7 @@
 namespace pg {
 
 constexpr int kRBlock = 256; // threads of a workgroup in every render kernel
+static_assert(kRBlock == kStageThreads, "stage_kd_planes copies one plane per thread");
 constexpr float kInvPiF = 0.31830988618379067154f;
 constexpr float kRayEps = 1e-4f;
 constexpr float kShadowEps = 1e-3f;
