@@ -1795,8 +1795,9 @@ def compact_record(out):
                      "s1_pg_sample_frac", "s1_pg_sample_frac_model_8d", "s1_pg_pdf_frac", "s1_pg_guide_bounce_frac", "s2_pg_sample_frac",
                      "s3_pg_splat_frac", "device_copy_GBps"))
     if r:
-        r["frac_basis"] = ("bytes the lanes gathered from the built layout per launch / avg_launch_us / peak; "
-                           "SURVEY 8d model bytes: frac_model_8d")[:120]
+        r["frac_basis"] = (("bytes the lanes gathered from the built layout per launch / avg_launch_us / peak; "
+                            "SURVEY 8d model bytes: frac_model_8d") if "layout_bytes_per_launch" in r else
+                           "SURVEY 8d algorithmic bytes per launch / launch time / peak")[:120]
     c["roofline"] = r or None
     if isinstance(cpu, dict):
         cc = _pick(cpu, ("value", "unit", "cores", "kind", "host_cores_usable", "mse_equal", "images_bit_identical_to_device",
