@@ -106,25 +106,30 @@ __device__ __forceinline__ void coop_add(const SlotAdd &s, long long *s_val, uns
 	s_ptr[t] = mine;
 	wave_lds_sync();
 	const unsigned lane = t & 63u, wbase = t & ~63u, word = lane & 3u;
-	// Neighbouring lanes hold neighbouring path vertices, which often add to the same accumulator
-	// (the NEE direction of a delta light is the same for a whole surface; coarse quadtree cells):
-	// the first lane of a run of equal targets sums the run (exact, integer) and the others drop
-	// out -- one update instead of a run of same-address updates, which the memory side serialises.
-	const bool follower = mine != 0 && lane != 0 && s_ptr[t - 1] == mine;
-	if (mine != 0 && !follower && lane != 63u && s_ptr[t + 1] == mine) {
-		long long a0 = s.w0, a1 = s.w1, a2 = s.w2, a3 = s.w3;
-		for (unsigned j = t + 1; j < wbase + 64u && s_ptr[j] == mine; ++j) {
-			a0 += s_val[4 * j + 0];
-			a1 += s_val[4 * j + 1];
-			a2 += s_val[4 * j + 2];
-			a3 += s_val[4 * j + 3];
-		}
-		s_val[4 * t + 0] = a0;
-		s_val[4 * t + 1] = a1;
-		s_val[4 * t + 2] = a2;
-		s_val[4 * t + 3] = a3;
+	// Lanes of a wave often add to the SAME accumulator (the NEE direction of a small light is the same for a whole surface;
+	// coarse quadtree cells) -- and not only neighbouring lanes: a sorted bounce puts the vertices of one spatial cell side by
+	// side, in no order inside the cell, so the same target comes back every few lanes.  Every lane finds the LOWEST lane of
+	// its wave with its target (eight ballots on a hash of the address pick the candidates, the candidate's address is
+	// compared: a collision of the hash only loses a merge), adds its four words to that lane's in LDS (64-bit integer adds:
+	// exact, any order) and drops out -- one update per distinct target of the wave instead of one per run of neighbours
+	// (rounds 1-5), which the memory side serialises.
+	const unsigned hkey = (unsigned)((mine >> 5) ^ (mine >> 13) ^ (mine >> 21)) & 255u;
+	unsigned long long peers = __ballot(mine != 0);
+#pragma unroll
+	for (int b = 0; b < 8; ++b) {
+		const unsigned long long m = __ballot(mine != 0 && ((hkey >> b) & 1u));
+		peers &= ((hkey >> b) & 1u) ? m : ~m;
 	}
-	wave_lds_sync(); // every run has been read
+	const unsigned leader = mine != 0 ? (unsigned)__builtin_ctzll(peers) : lane; // (a lane with a target is its own peer)
+	const bool follower = mine != 0 && leader != lane && s_ptr[wbase + leader] == mine;
+	if (follower) {
+		unsigned long long *dst = reinterpret_cast<unsigned long long *>(s_val + 4 * (wbase + leader));
+		if (s.w0) atomicAdd(dst + 0, (unsigned long long)s.w0);
+		if (s.w1) atomicAdd(dst + 1, (unsigned long long)s.w1);
+		if (s.w2) atomicAdd(dst + 2, (unsigned long long)s.w2);
+		if (s.w3) atomicAdd(dst + 3, (unsigned long long)s.w3);
+	}
+	wave_lds_sync(); // every follower has added
 	if (follower) s_ptr[t] = 0;
 	wave_lds_sync();
 #pragma unroll
