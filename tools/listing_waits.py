@@ -53,7 +53,7 @@ def main():
         ks = kernels(open(out).read())
     names = subprocess.run(["c++filt"] + list(ks), capture_output=True, text=True).stdout.split("\n")
     for mangled, dem in zip(ks, names):
-        short = re.sub(r"\(.*", "", dem).replace("void ", "").replace("pg::", "")
+        short = re.sub(r"\(.*", "", dem.replace("(anonymous namespace)::", "")).replace("void ", "").replace("pg::", "")
         if a.kernel and a.kernel.replace(" ", "") not in short.replace(" ", ""):
             continue
         n, ev, rows = 0, [], []
